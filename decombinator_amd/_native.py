@@ -1,0 +1,477 @@
+"""ctypes binding of libdcrx.so (include/dcrx.h, include/dcrx_synth.h).
+
+The HIP library IS the product: there is no Python or CPU implementation of the
+hot path behind this module.  Importing it fails loudly when the shared object
+has not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C decombinator_amd/csrc`), and every decombine call raises DcrxError
+when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdcrx.so")
+
+N_COUNTERS = 32
+ABI_VERSION = 1
+
+# enum dcrx_counter order; the strings are the reference's Counter keys
+# (reference decombine.py:598 and the increments cited in include/dcrx_codes.h)
+COUNTER_NAMES = [
+    "multiple_v_matches", "verr2", "foundv1notv2", "verr1", "foundv2notv1",
+    "no_vtags_found", "multiple_j_matches", "jerr2", "foundj1notj2", "jerr1",
+    "no_j_assigned", "dcrfilter_intertagN", "dcrfilter_toolong_intertag",
+    "dcrfilter_imposs_deletion", "dcrfilter_tag_overlap", "VJ_assignment_failed",
+    "v_del_failed_tag_at_end", "v_del_failed", "j_del_failed", "vj_count",
+    "read_count", "foundj2notj1", "frame_forward",
+]
+
+STATUS_NAMES = [
+    "OK", "V_MULTI", "V_WALK_FAIL_AT_END", "V_WALK_FAIL", "V_HALF1_EXHAUSTED", "V_HALF2_EXHAUSTED",
+    "V_NONE", "J_MULTI", "J_WALK_FAIL", "J_HALF1_EXHAUSTED", "J_HALF2_EXHAUSTED", "J_NONE",
+    "F_INTERTAG_N", "F_TOOLONG", "F_IMPOSS_DEL", "F_OVERLAP",
+]
+
+ORIENTATIONS = {"reverse": 0, "forward": 1, "both": 2}
+F_FORCE_SLOW_READER = 1
+
+RECORD_DTYPE = np.dtype([
+    ("v", "<u2"), ("j", "<u2"), ("v_start", "<u2"), ("j_end", "<u2"),
+    ("ins_start", "<u2"), ("ins_len", "<u2"), ("vdel", "u1"), ("jdel", "u1"),
+    ("status", "u1"), ("frame", "u1"),
+])
+assert RECORD_DTYPE.itemsize == 16
+
+
+class DcrxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"dcrx error {code}: {msg}")
+        self.code = code
+
+
+class TagSetC(C.Structure):
+    _fields_ = [
+        ("n_v", C.c_uint32), ("v_tags", C.POINTER(C.c_char_p)), ("v_jumps", C.POINTER(C.c_int32)),
+        ("v_regions", C.POINTER(C.c_char_p)),
+        ("n_j", C.c_uint32), ("j_tags", C.POINTER(C.c_char_p)), ("j_jumps", C.POINTER(C.c_int32)),
+        ("j_regions", C.POINTER(C.c_char_p)),
+        ("v_half_split", C.c_int32), ("j_half_split", C.c_int32),
+    ]
+
+
+class TablesInfoC(C.Structure):
+    _fields_ = [
+        ("n_v", C.c_uint32), ("n_j", C.c_uint32), ("n_states", C.c_uint32), ("dfa_bytes", C.c_uint32),
+        ("n_keywords", C.c_uint32 * 6), ("max_tag_len", C.c_uint32), ("tables_in_lds", C.c_uint32),
+        ("equal_len_per_automaton", C.c_uint32),
+    ]
+
+
+class CfgC(C.Structure):
+    _fields_ = [("orientation", C.c_int32), ("allow_ns", C.c_int32), ("lenthreshold", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class BatchC(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64), ("packed", C.c_void_p), ("stride", C.c_uint32), ("read_len", C.c_uint32),
+        ("lens", C.c_void_p), ("n_exc", C.c_uint64), ("exc_read", C.c_void_p), ("exc_pos", C.c_void_p),
+        ("exc_chr", C.c_void_p),
+    ]
+
+
+class SynthCfgC(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_rearranged", C.c_float),
+                ("sub_rate", C.c_float), ("n_rate", C.c_float)]
+
+
+# every symbol include/dcrx.h and include/dcrx_synth.h declare
+EXPORTS = [
+    "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_unpack_reads",
+    "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
+    "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
+    "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
+    "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
+    "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImportError with build instructions when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for the decombine hot path.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "dcrx_tables_create": (i32, [C.POINTER(TagSetC), C.POINTER(vp)]),
+        "dcrx_tables_destroy": (None, [vp]),
+        "dcrx_tables_info": (i32, [vp, C.POINTER(TablesInfoC)]),
+        "dcrx_pack_reads": (C.c_int64, [vp, vp, u64, u32, vp, vp, vp, vp, vp, u64]),
+        "dcrx_unpack_reads": (i32, [C.POINTER(BatchC), vp, vp]),
+        "dcrx_decombine": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp]),
+        "dcrx_decombine_device": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp, vp]),
+        "dcrx_set_timing_events": (i32, [vp, vp, vp]),
+        "dcrx_reserve_device": (i32, [vp, u64]),
+        "dcrx_compact_hits_device": (i32, [vp, u64, u64, vp, vp, vp, vp]),
+        "dcrx_device_count": (i32, []),
+        "dcrx_set_device": (i32, [i32]),
+        "dcrx_device_name": (i32, [C.c_char_p, C.c_size_t]),
+        "dcrx_malloc_device": (i32, [C.POINTER(vp), C.c_size_t]),
+        "dcrx_free_device": (i32, [vp]),
+        "dcrx_memcpy_h2d": (i32, [vp, vp, C.c_size_t]),
+        "dcrx_memcpy_d2h": (i32, [vp, vp, C.c_size_t]),
+        "dcrx_memset_device": (i32, [vp, i32, C.c_size_t]),
+        "dcrx_synchronize": (i32, []),
+        "dcrx_event_create": (i32, [C.POINTER(vp)]),
+        "dcrx_event_destroy": (i32, [vp]),
+        "dcrx_event_record": (i32, [vp, vp]),
+        "dcrx_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
+        "dcrx_abi_version": (i32, []),
+        "dcrx_last_error": (C.c_char_p, []),
+        "dcrx_build_info": (C.c_char_p, []),
+        "dcrx_synth_reads_host": (i32, [vp, C.POINTER(SynthCfgC), u64, u64, u32, vp]),
+        "dcrx_synth_reads_device": (i32, [vp, C.POINTER(SynthCfgC), u64, u64, u32, vp, vp]),
+        "dcrx_synth_exceptions_host": (C.c_int64, [vp, C.POINTER(SynthCfgC), u64, u64, vp, vp, vp, u64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the .so does not match include/dcrx.h
+        fn.restype = res
+        fn.argtypes = args
+    if L.dcrx_abi_version() != ABI_VERSION:
+        raise ImportError(f"libdcrx.so ABI {L.dcrx_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise DcrxError(rc, lib().dcrx_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _strs(xs):
+    arr = (C.c_char_p * max(1, len(xs)))()
+    for i, x in enumerate(xs):
+        arr[i] = x.encode("ascii") if isinstance(x, str) else bytes(x)
+    return arr
+
+
+class Tables:
+    """Opaque dcrx_tables_t: replaces import_tcr_info's module globals
+    (reference decombine.py:593-746) for one chain."""
+
+    def __init__(self, v_tags, v_jumps, v_regions, j_tags, j_jumps, j_regions,
+                 v_half_split: int, j_half_split: int):
+        if not (len(v_tags) == len(v_jumps) == len(v_regions)):
+            raise ValueError("V tags, jumps and regions differ in length")
+        if not (len(j_tags) == len(j_jumps) == len(j_regions)):
+            raise ValueError("J tags, jumps and regions differ in length")
+        self._keep = (_strs(v_tags), (C.c_int32 * max(1, len(v_jumps)))(*[int(x) for x in v_jumps]),
+                      _strs(v_regions), _strs(j_tags),
+                      (C.c_int32 * max(1, len(j_jumps)))(*[int(x) for x in j_jumps]), _strs(j_regions))
+        ts = TagSetC(len(v_tags), self._keep[0], self._keep[1], self._keep[2],
+                     len(j_tags), self._keep[3], self._keep[4], self._keep[5],
+                     int(v_half_split), int(j_half_split))
+        h = C.c_void_p()
+        self._h = None
+        check(lib().dcrx_tables_create(C.byref(ts), C.byref(h)))
+        self._h = h
+        self.n_v, self.n_j = len(v_tags), len(j_tags)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self) -> dict:
+        inf = TablesInfoC()
+        check(lib().dcrx_tables_info(self._h, C.byref(inf)))
+        return {"n_v": inf.n_v, "n_j": inf.n_j, "n_states": inf.n_states, "dfa_bytes": inf.dfa_bytes,
+                "n_keywords": list(inf.n_keywords), "max_tag_len": inf.max_tag_len,
+                "tables_in_lds": bool(inf.tables_in_lds),
+                "equal_len_per_automaton": bool(inf.equal_len_per_automaton)}
+
+    def close(self):
+        if self._h is not None:
+            lib().dcrx_tables_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def stride_for(max_len: int) -> int:
+    """Smallest legal stride (multiple of 8 bytes) for reads of up to max_len nt."""
+    return max(8, ((max_len + 3) // 4 + 7) // 8 * 8)
+
+
+class PackedBatch:
+    """Host-side packed reads (what dcrx_pack_reads produces)."""
+
+    def __init__(self, packed, stride, read_len, lens, exc_read, exc_pos, exc_chr):
+        self.packed = packed
+        self.stride = int(stride)
+        self.read_len = int(read_len)
+        self.lens = lens
+        self.exc_read, self.exc_pos, self.exc_chr = exc_read, exc_pos, exc_chr
+
+    @property
+    def n_reads(self) -> int:
+        return self.packed.shape[0]
+
+    def as_c(self) -> BatchC:
+        b = BatchC()
+        b.n_reads = self.n_reads
+        b.packed = self.packed.ctypes.data
+        b.stride = self.stride
+        b.read_len = self.read_len
+        b.lens = self.lens.ctypes.data if self.lens is not None else None
+        b.n_exc = len(self.exc_read)
+        b.exc_read = self.exc_read.ctypes.data if len(self.exc_read) else None
+        b.exc_pos = self.exc_pos.ctypes.data if len(self.exc_read) else None
+        b.exc_chr = self.exc_chr.ctypes.data if len(self.exc_read) else None
+        return b
+
+
+def pack_reads(reads, stride: int | None = None) -> PackedBatch:
+    """Packs a list of str/bytes reads (or a (buffer, offsets) pair) 2 bits per base."""
+    if isinstance(reads, tuple):
+        buf, offsets = reads
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    else:
+        bs = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in reads]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        buf = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, dtype=np.uint8)
+    n = len(offsets) - 1
+    lens64 = np.diff(offsets.astype(np.int64)) if n else np.zeros(0, dtype=np.int64)
+    max_len = int(lens64.max()) if n else 0
+    if stride is None:
+        stride = stride_for(max_len)
+    packed = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    cap = 1024
+    while True:
+        er = np.zeros(cap, dtype=np.uint32)
+        ep = np.zeros(cap, dtype=np.uint16)
+        ec = np.zeros(cap, dtype=np.uint8)
+        got = lib().dcrx_pack_reads(buf.ctypes.data if len(buf) else None, offsets.ctypes.data, n, stride,
+                                    packed.ctypes.data if n else None, lens.ctypes.data, er.ctypes.data,
+                                    ep.ctypes.data, ec.ctypes.data, cap)
+        check(int(got))
+        if got <= cap:
+            break
+        cap = int(got)
+    uniform = n > 0 and bool((lens64 == lens64[0]).all())
+    return PackedBatch(packed, stride, int(lens64[0]) if uniform else 0, None if uniform else lens,
+                       er[:got].copy(), ep[:got].copy(), ec[:got].copy())
+
+
+def unpack_reads(batch: PackedBatch):
+    """Inverse of pack_reads: list of str."""
+    n = batch.n_reads
+    lens = batch.lens.astype(np.uint64) if batch.lens is not None else np.full(n, batch.read_len, dtype=np.uint64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    out = np.zeros(int(offsets[-1]) + 1, dtype=np.uint8)
+    b = batch.as_c()
+    check(lib().dcrx_unpack_reads(C.byref(b), offsets.ctypes.data, out.ctypes.data))
+    raw = out.tobytes()
+    return [raw[int(offsets[i]):int(offsets[i + 1])].decode("latin-1") for i in range(n)]
+
+
+def make_cfg(orientation="reverse", allow_ns=False, lenthreshold=130, flags=0) -> CfgC:
+    o = ORIENTATIONS[orientation] if isinstance(orientation, str) else int(orientation)
+    return CfgC(o, int(bool(allow_ns)), int(lenthreshold), int(flags))
+
+
+def decombine(tables: Tables, batch: PackedBatch, orientation="reverse", allow_ns=False,
+              lenthreshold=130, flags=0):
+    """dcrx_decombine on host buffers.  Returns (records[RECORD_DTYPE], counters uint64[32])."""
+    cfg = make_cfg(orientation, allow_ns, lenthreshold, flags)
+    rec = np.zeros(batch.n_reads, dtype=RECORD_DTYPE)
+    cnt = np.zeros(N_COUNTERS, dtype=np.uint64)
+    b = batch.as_c()
+    check(lib().dcrx_decombine(tables.handle, C.byref(cfg), C.byref(b),
+                               rec.ctypes.data if batch.n_reads else None, cnt.ctypes.data))
+    return rec, cnt
+
+
+def synth_cfg(seed: int, read_len: int = 150, p_rearranged: float = 0.45, sub_rate: float = 0.005,
+              n_rate: float = 0.0005) -> SynthCfgC:
+    return SynthCfgC(int(seed), int(read_len), float(p_rearranged), float(sub_rate), float(n_rate))
+
+
+def synth_reads_host(tables: Tables, cfg: SynthCfgC, first: int, n: int, stride: int | None = None) -> PackedBatch:
+    """Seeded synthetic reads [first, first+n) generated by the library on the host."""
+    if stride is None:
+        stride = stride_for(cfg.read_len)
+    packed = np.zeros((n, stride), dtype=np.uint8)
+    check(lib().dcrx_synth_reads_host(tables.handle, C.byref(cfg), first, n, stride,
+                                      packed.ctypes.data if n else None))
+    er, ep, ec = synth_exceptions_host(tables, cfg, first, n)
+    return PackedBatch(packed, stride, cfg.read_len, None, er, ep, ec)
+
+
+def synth_exceptions_host(tables: Tables, cfg: SynthCfgC, first: int, n: int):
+    cap = max(16, int(n * cfg.n_rate * 2) + 64)
+    while True:
+        er = np.zeros(cap, dtype=np.uint32)
+        ep = np.zeros(cap, dtype=np.uint16)
+        ec = np.zeros(cap, dtype=np.uint8)
+        got = int(lib().dcrx_synth_exceptions_host(tables.handle, C.byref(cfg), first, n, er.ctypes.data,
+                                                   ep.ctypes.data, ec.ctypes.data, cap))
+        check(got)
+        if got <= cap:
+            return er[:got].copy(), ep[:got].copy(), ec[:got].copy()
+        cap = got
+
+
+def device_count() -> int:
+    return int(lib().dcrx_device_count())
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().dcrx_device_name(buf, 256))
+    return buf.value.decode()
+
+
+# ---- device-resident path (no torch needed: the library owns the HIP calls) ----
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned through the C ABI."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib().dcrx_malloc_device(C.byref(p), int(nbytes)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    @classmethod
+    def from_host(cls, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        buf = cls(max(arr.nbytes, 16))
+        if arr.nbytes:
+            check(lib().dcrx_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes))
+        return buf
+
+    def to_host(self, dtype, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=dtype)
+        if out.nbytes:
+            check(lib().dcrx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().dcrx_free_device(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBatch:
+    """Packed reads resident in HBM (the buffers dcrx_decombine_device reads)."""
+
+    def __init__(self, n_reads: int, stride: int, read_len: int, packed: DeviceBuffer,
+                 lens: DeviceBuffer | None = None, exc=None):
+        self.n_reads, self.stride, self.read_len = int(n_reads), int(stride), int(read_len)
+        self.packed, self.lens = packed, lens
+        self.exc = exc  # (n_exc, DeviceBuffer read, DeviceBuffer pos, DeviceBuffer chr) or None
+
+    @classmethod
+    def from_host(cls, b: PackedBatch) -> "DeviceBatch":
+        exc = None
+        if len(b.exc_read):
+            exc = (len(b.exc_read), DeviceBuffer.from_host(b.exc_read), DeviceBuffer.from_host(b.exc_pos),
+                   DeviceBuffer.from_host(b.exc_chr))
+        # 16 spare bytes after the last read (word-pair loads of the final read)
+        packed = DeviceBuffer(b.packed.nbytes + 16)
+        if b.packed.nbytes:
+            check(lib().dcrx_memcpy_h2d(packed.ptr, b.packed.ctypes.data, b.packed.nbytes))
+        return cls(b.n_reads, b.stride, b.read_len, packed,
+                   DeviceBuffer.from_host(b.lens) if b.lens is not None else None, exc)
+
+    def as_c(self) -> BatchC:
+        b = BatchC()
+        b.n_reads, b.packed, b.stride, b.read_len = self.n_reads, self.packed.ptr, self.stride, self.read_len
+        b.lens = self.lens.ptr if self.lens is not None else None
+        if self.exc:
+            b.n_exc, b.exc_read, b.exc_pos, b.exc_chr = self.exc[0], self.exc[1].ptr, self.exc[2].ptr, self.exc[3].ptr
+        else:
+            b.n_exc, b.exc_read, b.exc_pos, b.exc_chr = 0, None, None, None
+        return b
+
+
+def synth_reads_device(tables: Tables, cfg: SynthCfgC, first: int, n: int, stride: int | None = None,
+                       stream=None) -> DeviceBatch:
+    """Same reads as synth_reads_host, generated in HBM by the library's kernel."""
+    if stride is None:
+        stride = stride_for(cfg.read_len)
+    packed = DeviceBuffer(n * stride + 16)
+    check(lib().dcrx_synth_reads_device(tables.handle, C.byref(cfg), first, n, stride, packed.ptr, stream))
+    er, ep, ec = synth_exceptions_host(tables, cfg, first, n)
+    exc = None
+    if len(er):
+        exc = (len(er), DeviceBuffer.from_host(er), DeviceBuffer.from_host(ep), DeviceBuffer.from_host(ec))
+    return DeviceBatch(n, stride, cfg.read_len, packed, None, exc)
+
+
+def decombine_device(tables: Tables, batch: DeviceBatch, d_records: DeviceBuffer, d_counters: DeviceBuffer,
+                     orientation="reverse", allow_ns=False, lenthreshold=130, flags=0, stream=None):
+    """Asynchronous launch on `stream` (None = default); results stay in HBM."""
+    cfg = make_cfg(orientation, allow_ns, lenthreshold, flags)
+    b = batch.as_c()
+    check(lib().dcrx_decombine_device(tables.handle, C.byref(cfg), C.byref(b), d_records.ptr, d_counters.ptr, stream))
+
+
+def synchronize():
+    check(lib().dcrx_synchronize())
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().dcrx_event_create(C.byref(p)))
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(lib().dcrx_event_record(self.ptr, stream))
+
+    def elapsed_ms(self, later: "Event") -> float:
+        ms = C.c_float()
+        check(lib().dcrx_event_elapsed_ms(self.ptr, later.ptr, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dcrx_event_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+def compact_hits_device(d_records: DeviceBuffer, n_reads: int, first_index: int, d_hits: DeviceBuffer,
+                        d_hit_index: DeviceBuffer, d_n_hits: DeviceBuffer, stream=None):
+    check(lib().dcrx_compact_hits_device(d_records.ptr, n_reads, first_index, d_hits.ptr, d_hit_index.ptr,
+                                         d_n_hits.ptr, stream))

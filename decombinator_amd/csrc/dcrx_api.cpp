@@ -1,0 +1,422 @@
+// dcrx_api.cpp — the C ABI declared in include/dcrx.h and include/dcrx_synth.h.
+//
+// Host side of the boundary: validates arguments, owns the table handle and its
+// per-device workspace, launches the kernels of dcrx_kernels.hip.  There is no
+// CPU implementation of the hot path in this library: every decombine entry
+// point needs a GPU and fails with DCRX_E_NOGPU / DCRX_E_HIP without one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dcrx.h"
+#include "../../include/dcrx_synth.h"
+#include "dcrx_launch.h"
+#include "dcrx_synth_core.h"
+#include "dcrx_tables.h"
+
+namespace dcrx {
+hipError_t launch_synth(const DevTables &T, const SynthParams &P, uint64_t first, uint64_t n, uint32_t stride,
+                        uint8_t *d_packed, hipStream_t s);
+}
+
+using namespace dcrx;
+
+static thread_local std::string g_err;
+
+static int set_err(int code, const std::string &m) { g_err = m; return code; }
+static int hip_err(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? DCRX_E_NOGPU : DCRX_E_HIP;
+}
+#define HIP_TRY(call)                                   \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_err(e_, #call);    \
+  } while (0)
+
+struct dcrx_tables {
+  HostTables host;
+  // state on the device the tables were last used on
+  int device = -1;
+  uint8_t *d_blob = nullptr;
+  DevTables dev{};
+  LaunchPlan plan{};
+  uint32_t *d_block_counts = nullptr;
+  uint32_t *d_exc_flag = nullptr;
+  uint64_t exc_flag_reads = 0;
+  uint32_t *d_tile_count = nullptr;
+  uint64_t *d_tile_off = nullptr;
+  uint64_t compact_reads = 0;
+  // staging for the host-buffer entry point
+  uint8_t *d_stage = nullptr;
+  size_t stage_bytes = 0;
+  bool constants_ready = false;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+static void free_device_state(dcrx_tables *t) {
+  if (t->device < 0) return;
+  (void)hipFree(t->d_blob); (void)hipFree(t->d_block_counts); (void)hipFree(t->d_exc_flag);
+  (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
+  t->d_blob = nullptr; t->d_block_counts = nullptr; t->d_exc_flag = nullptr;
+  t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
+  t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
+}
+
+extern "C" {
+
+int dcrx_abi_version(void) { return DCRX_ABI_VERSION; }
+const char *dcrx_last_error(void) { return g_err.c_str(); }
+const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; block " "512" "; fast-scan reads <= 320 nt"; }
+
+int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
+  if (!out) return set_err(DCRX_E_INVALID, "out is null");
+  *out = nullptr;
+  dcrx_tables *t = new (std::nothrow) dcrx_tables();
+  if (!t) return set_err(DCRX_E_NOMEM, "out of memory");
+  std::string err;
+  int rc = compile_tables(tagset, &t->host, &err);
+  if (rc != DCRX_OK) { delete t; return set_err(rc, err); }
+  *out = t;
+  return DCRX_OK;
+}
+
+void dcrx_tables_destroy(dcrx_tables_t *t) {
+  if (!t) return;
+  if (t->device >= 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) {
+      if (cur != t->device) (void)hipSetDevice(t->device);
+      free_device_state(t);
+      if (cur != t->device && cur >= 0) (void)hipSetDevice(cur);
+    }
+  }
+  delete t;
+}
+
+int dcrx_tables_info(const dcrx_tables_t *t, dcrx_tables_info_t *info) {
+  if (!t || !info) return set_err(DCRX_E_INVALID, "null argument");
+  std::memset(info, 0, sizeof *info);
+  info->n_v = t->host.g[0].n; info->n_j = t->host.g[1].n;
+  info->n_states = t->host.n_states; info->dfa_bytes = t->host.dfa_bytes;
+  for (int c = 0; c < 6; c++) info->n_keywords[c] = t->host.n_keywords[c];
+  info->max_tag_len = t->host.max_tag_len;
+  info->tables_in_lds = t->host.dfa_bytes + 128 <= 144 * 1024;
+  info->equal_len_per_automaton = t->host.equal_len_per_automaton ? 1 : 0;
+  return DCRX_OK;
+}
+
+// ---- device plumbing ------------------------------------------------------------
+int dcrx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int dcrx_set_device(int device) { HIP_TRY(hipSetDevice(device)); return DCRX_OK; }
+int dcrx_device_name(char *buf, size_t cap) {
+  if (!buf || !cap) return set_err(DCRX_E_INVALID, "null buffer");
+  int dev = 0; HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t p; HIP_TRY(hipGetDeviceProperties(&p, dev));
+  std::snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return DCRX_OK;
+}
+int dcrx_malloc_device(void **ptr, size_t bytes) {
+  if (!ptr) return set_err(DCRX_E_INVALID, "null ptr");
+  HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16)); return DCRX_OK;
+}
+int dcrx_free_device(void *ptr) { HIP_TRY(hipFree(ptr)); return DCRX_OK; }
+int dcrx_memcpy_h2d(void *d, const void *h, size_t bytes) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return DCRX_OK; }
+int dcrx_memcpy_d2h(void *h, const void *d, size_t bytes) { HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return DCRX_OK; }
+int dcrx_memset_device(void *d, int value, size_t bytes) { HIP_TRY(hipMemset(d, value, bytes)); return DCRX_OK; }
+int dcrx_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return DCRX_OK; }
+int dcrx_event_create(void **ev) {
+  if (!ev) return set_err(DCRX_E_INVALID, "null event");
+  hipEvent_t e; HIP_TRY(hipEventCreate(&e)); *ev = e; return DCRX_OK;
+}
+int dcrx_event_destroy(void *ev) { HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return DCRX_OK; }
+int dcrx_event_record(void *ev, void *stream) { HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return DCRX_OK; }
+int dcrx_event_elapsed_ms(void *a, void *b, float *ms) {
+  if (!ms) return set_err(DCRX_E_INVALID, "null ms");
+  HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return DCRX_OK;
+}
+
+}  // extern "C"
+
+// ---- per-device state -------------------------------------------------------------
+static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (t->device != dev) {
+    if (t->device >= 0) {  // tables move with the caller's current device
+      int old = t->device;
+      (void)hipSetDevice(old); free_device_state(t); (void)hipSetDevice(dev);
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    HIP_TRY(hipMalloc(&t->d_blob, t->host.blob.size()));
+    HIP_TRY(hipMemcpy(t->d_blob, t->host.blob.data(), t->host.blob.size(), hipMemcpyHostToDevice));
+    t->dev = t->host.resolve(t->d_blob);
+    // launch plan: persistent blocks of DCRX_BLOCK threads, the DFA resident in LDS
+    const uint32_t lds_cap = 160 * 1024;
+    const uint32_t want = t->host.dfa_bytes + DCRX_N_COUNTERS * 4;
+    LaunchPlan P;
+    P.table_in_lds = want <= 144 * 1024;
+    P.lds_bytes = P.table_in_lds ? want : DCRX_N_COUNTERS * 4;
+    uint32_t per_cu = std::min<uint32_t>(2048 / DCRX_BLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
+    P.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+    t->plan = P;
+    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)P.grid * DCRX_N_COUNTERS * 4));
+    t->device = dev;
+  }
+  if (max_reads > t->exc_flag_reads) {
+    (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
+    HIP_TRY(hipMalloc(&t->d_exc_flag, ((max_reads + 31) / 32) * 4 + 16));
+    t->exc_flag_reads = max_reads;
+  }
+  if (max_reads > t->compact_reads) {
+    (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off);
+    t->d_tile_count = nullptr; t->d_tile_off = nullptr;
+    const size_t tiles = compact_tiles(max_reads) + 1024;
+    HIP_TRY(hipMalloc(&t->d_tile_count, tiles * 4));
+    HIP_TRY(hipMalloc(&t->d_tile_off, tiles * 8));
+    t->compact_reads = max_reads;
+  }
+  return DCRX_OK;
+}
+
+static int check_batch(const dcrx_batch_t *b) {
+  if (!b) return set_err(DCRX_E_INVALID, "batch is null");
+  if (b->n_reads >= (1ull << 32)) return set_err(DCRX_E_INVALID, "more than 2^32-1 reads in one call");
+  if (b->stride == 0 || (b->stride & 7u)) return set_err(DCRX_E_INVALID, "stride must be a positive multiple of 8");
+  if (b->stride > 4 * DCRX_NWMAX) return set_err(DCRX_E_UNSUPPORTED, "stride > 80 bytes: reads longer than 320 nt are not supported");
+  if (!b->lens && b->read_len > 4 * b->stride) return set_err(DCRX_E_INVALID, "read_len exceeds 4*stride");
+  if (b->n_reads && !b->packed) return set_err(DCRX_E_INVALID, "packed is null");
+  if (b->n_exc && (!b->exc_read || !b->exc_pos || !b->exc_chr)) return set_err(DCRX_E_INVALID, "exception arrays are null");
+  return DCRX_OK;
+}
+
+extern "C" {
+
+int dcrx_set_timing_events(dcrx_tables_t *t, void *start_event, void *stop_event) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  t->ev_start = (hipEvent_t)start_event; t->ev_stop = (hipEvent_t)stop_event;
+  return DCRX_OK;
+}
+
+int dcrx_reserve_device(dcrx_tables_t *t, uint64_t max_reads) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  return ensure_device(t, max_reads);
+}
+
+int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *b, dcrx_record_t *d_records,
+                          uint64_t *d_counters, void *stream) {
+  if (!t || !cfg || !d_counters) return set_err(DCRX_E_INVALID, "null argument");
+  int rc = check_batch(b);
+  if (rc) return rc;
+  if (b->n_reads && !d_records) return set_err(DCRX_E_INVALID, "d_records is null");
+  if (cfg->orientation < 0 || cfg->orientation > 2) return set_err(DCRX_E_INVALID, "orientation must be 0, 1 or 2");
+  rc = ensure_device(t, b->n_reads);
+  if (rc) return rc;
+  BatchDev B;
+  B.packed = b->packed; B.stride = b->stride; B.read_len = b->read_len; B.lens = b->lens;
+  B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
+  B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
+  CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
+  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, d_counters, (hipStream_t)stream,
+                           t->ev_start, t->ev_stop));
+  return DCRX_OK;
+}
+
+int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *hb, dcrx_record_t *records,
+                   uint64_t *counters) {
+  if (!t || !cfg || !counters) return set_err(DCRX_E_INVALID, "null argument");
+  int rc = check_batch(hb);
+  if (rc) return rc;
+  const uint64_t n = hb->n_reads;
+  if (n && !records) return set_err(DCRX_E_INVALID, "records is null");
+  // host-side validation the device entry cannot afford
+  if (hb->lens)
+    for (uint64_t r = 0; r < n; r++)
+      if (hb->lens[r] > 4 * hb->stride) return set_err(DCRX_E_INVALID, "a read is longer than 4*stride");
+  for (uint64_t i = 0; i < hb->n_exc; i++) {
+    const uint8_t c = hb->exc_chr[i];
+    if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return set_err(DCRX_E_INVALID, "exception byte is one of ACGT");
+    if (hb->exc_read[i] >= n) return set_err(DCRX_E_INVALID, "exception read index out of range");
+    if (i && (hb->exc_read[i] < hb->exc_read[i - 1] ||
+              (hb->exc_read[i] == hb->exc_read[i - 1] && hb->exc_pos[i] <= hb->exc_pos[i - 1])))
+      return set_err(DCRX_E_INVALID, "exceptions are not sorted by (read, pos)");
+    const uint32_t len = hb->lens ? hb->lens[hb->exc_read[i]] : hb->read_len;
+    if (hb->exc_pos[i] >= len) return set_err(DCRX_E_INVALID, "exception position beyond the read");
+  }
+  rc = ensure_device(t, n);
+  if (rc) return rc;
+  // one staging allocation: packed | lens | exc_read | exc_pos | exc_chr | records | counters
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_packed = 0;
+  const size_t o_lens = o_packed + al(n * hb->stride + 16);
+  const size_t o_er = o_lens + al(hb->lens ? n * 2 : 0);
+  const size_t o_ep = o_er + al(hb->n_exc * 4);
+  const size_t o_ec = o_ep + al(hb->n_exc * 2);
+  const size_t o_rec = o_ec + al(hb->n_exc);
+  const size_t o_cnt = o_rec + al(n * sizeof(dcrx_record_t));
+  const size_t total = o_cnt + al(DCRX_N_COUNTERS * 8);
+  if (total > t->stage_bytes) {
+    (void)hipFree(t->d_stage); t->d_stage = nullptr; t->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&t->d_stage, total));
+    t->stage_bytes = total;
+  }
+  uint8_t *d = t->d_stage;
+  if (n) HIP_TRY(hipMemcpy(d + o_packed, hb->packed, n * hb->stride, hipMemcpyHostToDevice));
+  if (hb->lens && n) HIP_TRY(hipMemcpy(d + o_lens, hb->lens, n * 2, hipMemcpyHostToDevice));
+  if (hb->n_exc) {
+    HIP_TRY(hipMemcpy(d + o_er, hb->exc_read, hb->n_exc * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d + o_ep, hb->exc_pos, hb->n_exc * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d + o_ec, hb->exc_chr, hb->n_exc, hipMemcpyHostToDevice));
+  }
+  dcrx_batch_t db = *hb;
+  db.packed = d + o_packed;
+  db.lens = hb->lens ? reinterpret_cast<const uint16_t *>(d + o_lens) : nullptr;
+  db.exc_read = reinterpret_cast<const uint32_t *>(d + o_er);
+  db.exc_pos = reinterpret_cast<const uint16_t *>(d + o_ep);
+  db.exc_chr = d + o_ec;
+  rc = dcrx_decombine_device(t, cfg, &db, reinterpret_cast<dcrx_record_t *>(d + o_rec),
+                             reinterpret_cast<uint64_t *>(d + o_cnt), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (n) HIP_TRY(hipMemcpy(records, d + o_rec, n * sizeof(dcrx_record_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(counters, d + o_cnt, DCRX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
+  return DCRX_OK;
+}
+
+int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
+                             dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits, void *stream) {
+  // workspace lives in a process-wide slot keyed by device: compaction does not need tables
+  static thread_local struct { int dev = -1; uint32_t *tc = nullptr; uint64_t *to = nullptr; uint64_t cap = 0; } ws;
+  if (!d_n_hits || (n_reads && (!d_records || !d_hits || !d_hit_index))) return set_err(DCRX_E_INVALID, "null argument");
+  int dev = -1; HIP_TRY(hipGetDevice(&dev));
+  if (ws.dev != dev || n_reads > ws.cap) {
+    if (ws.dev == dev) { (void)hipFree(ws.tc); (void)hipFree(ws.to); }
+    const size_t tiles = compact_tiles(n_reads) + 1024;
+    HIP_TRY(hipMalloc(&ws.tc, tiles * 4));
+    HIP_TRY(hipMalloc(&ws.to, tiles * 8));
+    ws.dev = dev; ws.cap = n_reads;
+  }
+  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_n_hits, ws.tc, ws.to, (hipStream_t)stream));
+  return DCRX_OK;
+}
+
+// ---- host-side packing --------------------------------------------------------------
+int64_t dcrx_pack_reads(const char *ascii, const uint64_t *offsets, uint64_t n_reads, uint32_t stride,
+                        uint8_t *packed, uint16_t *lens, uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
+                        uint64_t exc_cap) {
+  if ((n_reads && (!ascii || !offsets || !packed)) || stride == 0 || (stride & 7u))
+    return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads");
+  static int8_t code[256];
+  static bool code_ready = false;
+  if (!code_ready) {
+    for (int c = 0; c < 256; c++) code[c] = -1;
+    code[(int)'A'] = 0; code[(int)'C'] = 1; code[(int)'G'] = 2; code[(int)'T'] = 3;
+    code_ready = true;
+  }
+  uint64_t n_exc = 0;
+  for (uint64_t r = 0; r < n_reads; r++) {
+    const uint64_t len = offsets[r + 1] - offsets[r];
+    if (len > 4ull * stride || len > 65535) return set_err(DCRX_E_INVALID, "read longer than 4*stride");
+    if (lens) lens[r] = (uint16_t)len;
+    const uint8_t *s = reinterpret_cast<const uint8_t *>(ascii) + offsets[r];
+    uint8_t *out = packed + r * (uint64_t)stride;
+    std::memset(out, 0, stride);
+    for (uint64_t i = 0; i < len; i++) {
+      int c = code[s[i]];
+      if (c < 0) {
+        if (n_exc < exc_cap && exc_read) { exc_read[n_exc] = (uint32_t)r; exc_pos[n_exc] = (uint16_t)i; exc_chr[n_exc] = s[i]; }
+        n_exc++;
+        c = 0;
+      }
+      out[i >> 2] |= (uint8_t)(c << (2 * (i & 3)));
+    }
+  }
+  return (int64_t)n_exc;
+}
+
+int dcrx_unpack_reads(const dcrx_batch_t *b, const uint64_t *offsets, char *ascii) {
+  if (!b || !offsets || !ascii) return set_err(DCRX_E_INVALID, "null argument");
+  for (uint64_t r = 0; r < b->n_reads; r++) {
+    const uint32_t len = b->lens ? b->lens[r] : b->read_len;
+    const uint8_t *in = b->packed + r * (uint64_t)b->stride;
+    char *o = ascii + offsets[r];
+    for (uint32_t i = 0; i < len; i++) o[i] = "ACGT"[(in[i >> 2] >> (2 * (i & 3))) & 3];
+  }
+  for (uint64_t i = 0; i < b->n_exc; i++) ascii[offsets[b->exc_read[i]] + b->exc_pos[i]] = (char)b->exc_chr[i];
+  return DCRX_OK;
+}
+
+// ---- synthetic reads ------------------------------------------------------------------
+static SynthParams synth_params(const dcrx_synth_cfg_t *c) {
+  SynthParams P;
+  P.seed = c->seed; P.read_len = c->read_len;
+  auto clamp01 = [](double x) { return x < 0 ? 0.0 : (x > 1 ? 1.0 : x); };
+  P.p_rearr_u16 = (uint32_t)(clamp01(c->p_rearranged) * 65536.0 + 0.5);
+  P.sub_u16 = (uint32_t)(clamp01(c->sub_rate) * 65536.0 + 0.5);
+  double nr = clamp01(c->n_rate) * 4294967296.0;
+  P.n_u32 = nr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(nr + 0.5);
+  return P;
+}
+
+static int check_synth(const dcrx_tables_t *t, const dcrx_synth_cfg_t *c, uint32_t stride) {
+  if (!t || !c) return set_err(DCRX_E_INVALID, "null argument");
+  if (stride == 0 || (stride & 7u) || c->read_len > 4 * stride) return set_err(DCRX_E_INVALID, "bad stride for read_len");
+  if (c->read_len > 65535) return set_err(DCRX_E_INVALID, "read_len too large");
+  return DCRX_OK;
+}
+
+int dcrx_synth_reads_host(const dcrx_tables_t *t, const dcrx_synth_cfg_t *c, uint64_t first, uint64_t n,
+                          uint32_t stride, uint8_t *packed) {
+  int rc = check_synth(t, c, stride);
+  if (rc) return rc;
+  if (n && !packed) return set_err(DCRX_E_INVALID, "packed is null");
+  const DevTables T = t->host.resolve(t->host.blob.data());
+  const SynthParams P = synth_params(c);
+  for (uint64_t i = 0; i < n; i++)
+    synth_read(T.g[0], T.g[1], P, first + i, reinterpret_cast<uint32_t *>(packed + i * (uint64_t)stride), stride / 4);
+  return DCRX_OK;
+}
+
+int64_t dcrx_synth_exceptions_host(const dcrx_tables_t *t, const dcrx_synth_cfg_t *c, uint64_t first, uint64_t n,
+                                   uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr, uint64_t cap) {
+  if (!t || !c) return set_err(DCRX_E_INVALID, "null argument");
+  const SynthParams P = synth_params(c);
+  uint64_t cnt = 0;
+  if (P.n_u32 == 0 || P.read_len == 0) return 0;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t key = synth_mix64(P.seed ^ synth_mix64(first + i));
+    const uint64_t dn = synth_draw(key, 8);
+    if ((uint32_t)(dn & 0xFFFFFFFFu) < P.n_u32) {
+      if (cnt < cap && exc_read) {
+        exc_read[cnt] = (uint32_t)i; exc_pos[cnt] = (uint16_t)((dn >> 32) % (uint64_t)P.read_len); exc_chr[cnt] = 'N';
+      }
+      cnt++;
+    }
+  }
+  return (int64_t)cnt;
+}
+
+int dcrx_synth_reads_device(dcrx_tables_t *t, const dcrx_synth_cfg_t *c, uint64_t first, uint64_t n, uint32_t stride,
+                            uint8_t *d_packed, void *stream) {
+  int rc = check_synth(t, c, stride);
+  if (rc) return rc;
+  if (n && !d_packed) return set_err(DCRX_E_INVALID, "d_packed is null");
+  rc = ensure_device(t, 0);
+  if (rc) return rc;
+  HIP_TRY(launch_synth(t->dev, synth_params(c), first, n, stride, d_packed, (hipStream_t)stream));
+  return DCRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,518 @@
+// dcrx_dcr_device.h — the per-read device code of the decombine hot path: the
+// DFA scan, the half-tag rescue, the germline-end walks and the filters.
+// Included by dcrx_kernels.hip (device build) and by tests/host_emul/ (a
+// test-only host build of the very same functions, used to debug and to run
+// sanitizers without a GPU; it is never linked into libdcrx.so).
+#pragma once
+
+#include <cstdint>
+
+#include "../../include/dcrx.h"
+#include "dcrx_device.h"
+#include "dcrx_launch_types.h"
+
+#ifndef DCRX_HOST_EMUL
+#define DCRX_DEV __device__ __forceinline__
+#define DCRX_DEVNI __device__
+DCRX_DEV uint32_t dcrx_funnel_r(uint32_t lo, uint32_t hi, uint32_t sh) { return __funnelshift_r(lo, hi, sh); }
+DCRX_DEV int dcrx_sbfe(int v, uint32_t off, uint32_t w) { return __builtin_amdgcn_sbfe(v, off, w); }
+DCRX_DEV uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+DCRX_DEV void dcrx_atomic_inc(uint32_t *p) { atomicAdd(p, 1u); }
+DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
+  *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
+}
+using ::min;
+using ::max;
+#else
+#include <algorithm>
+#define DCRX_DEV inline
+#define DCRX_DEVNI inline
+inline uint32_t dcrx_funnel_r(uint32_t lo, uint32_t hi, uint32_t sh) {
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return (uint32_t)(v >> (sh & 31));
+}
+inline int dcrx_sbfe(int v, uint32_t off, uint32_t w) { return (int)((uint32_t)v << (32 - off - w)) >> (32 - w); }
+inline uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
+inline void dcrx_atomic_inc(uint32_t *p) { ++*p; }
+inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
+struct uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+#define __align__(n) alignas(n)
+using std::min;
+using std::max;
+#endif
+
+namespace dcrx {
+
+// ------------------------------------------------------------------------------
+// accumulator layout for a full-tag class: count | state<<9 | end_pos<<23.
+// Summed over hits; when count == 1 the upper fields are that hit's state and
+// end position, otherwise they are not read.
+// ------------------------------------------------------------------------------
+constexpr uint32_t ACC_CNT_MASK = 0x1FFu;
+constexpr int ACC_STATE_SHIFT = 9;
+constexpr int ACC_POS_SHIFT = 23;
+
+struct Counters {
+  uint32_t *lds;  // [DCRX_N_COUNTERS] block-local
+  DCRX_DEV void add(int idx) const { dcrx_atomic_inc(&lds[idx]); }
+};
+
+// ------------------------------------------------------------------------------
+// One read seen in one frame.  Frame position i is forward position n-1-i with
+// complemented bases when REV.
+// ------------------------------------------------------------------------------
+struct ReadView {
+  const uint8_t *comp;    // 256-entry complement table (Biopython's, decombine.py:184)
+  const uint32_t *words;  // this read's packed words (global memory)
+  int n;
+  int e0, e1;             // this read's slice of the exception list (e0 == e1: none)
+  const uint16_t *exc_pos;
+  const uint8_t *exc_chr;
+};
+
+template <bool REV>
+struct Frame {
+  const ReadView &r;
+  DCRX_DEVNI explicit Frame(const ReadView &rv) : r(rv) {}
+  DCRX_DEV int n() const { return r.n; }
+  DCRX_DEV int fpos(int i) const { return REV ? r.n - 1 - i : i; }
+  DCRX_DEV int code(int i) const {
+    int m = fpos(i);
+    uint32_t w = r.words[m >> 4];
+    int c = (int)((w >> ((m & 15) * 2)) & 3u);
+    return REV ? (c ^ 3) : c;
+  }
+  DCRX_DEVNI int exc_index(int i) const {
+    int m = fpos(i);
+    for (int x = r.e0; x < r.e1; x++)
+      if ((int)r.exc_pos[x] == m) return x;
+    return -1;
+  }
+  DCRX_DEV bool has_exc() const { return r.e1 > r.e0; }
+  // the character str(read)[i] the reference would see
+  DCRX_DEVNI uint8_t chr(int i) const {
+    if (has_exc()) {
+      int x = exc_index(i);
+      if (x >= 0) { uint8_t b = r.exc_chr[x]; return REV ? r.comp[b] : b; }
+    }
+    return (uint8_t)("ACGT"[code(i)]);
+  }
+  // 2*len bits of the packed forward read covering frame positions [a, a+len);
+  // caller guarantees 0 <= a, a+len <= n, len <= 16, no exception inside.
+  DCRX_DEV uint32_t window(int a, int len) const {
+    int lo = REV ? r.n - a - len : a;
+    int bit = lo * 2;
+    uint32_t w0 = r.words[bit >> 5];
+    int sh = bit & 31;
+    uint32_t w1 = (sh + 2 * len > 32) ? r.words[(bit >> 5) + 1] : 0u;
+    uint32_t v = dcrx_funnel_r(w0, w1, sh);
+    return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
+  }
+};
+
+// Python s[a:b] bounds on a sequence of length n
+DCRX_DEV void pyslice(int n, int a, int b, int &lo, int &hi) {
+  if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
+  if (b < 0) { b += n; if (b < 0) b = 0; } else if (b > n) b = n;
+  if (b < a) b = a;
+  lo = a; hi = b;
+}
+
+DCRX_DEV uint32_t packed_window(const uint32_t *pk, int base_pos, int len) {
+  int bit = base_pos * 2;
+  uint32_t w0 = pk[bit >> 5];
+  uint32_t w1 = pk[(bit >> 5) + 1];  // regions carry a spare word
+  uint32_t v = dcrx_funnel_r(w0, w1, bit & 31);
+  return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
+}
+
+// G[ga:gb] == read[ra:rb] with Python slice semantics (the comparisons at
+// decombine.py:769-772 and :802-805).
+template <bool REV>
+DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const Frame<REV> &F, int ra, int rb) {
+  const int Lg = (int)G.reg_len[g];
+  const int n = F.n();
+  // fast path: both slices are whole 10-mers inside their sequences, nothing but ACGT involved
+  if (ga >= 0 && gb <= Lg && gb - ga == rb - ra && ra >= 0 && rb <= n && gb - ga <= 16 && gb > ga &&
+      !F.has_exc() && G.reg_clean[g]) {
+    int len = gb - ga;
+    uint32_t rw = F.window(ra, len);
+    uint32_t gw = REV ? packed_window(G.reg_pk_rc + G.reg_pk_off[g], Lg - ga - len, len)
+                      : packed_window(G.reg_pk + G.reg_pk_off[g], ga, len);
+    return rw == gw;
+  }
+  int glo, ghi, rlo, rhi;
+  pyslice(Lg, ga, gb, glo, ghi);
+  pyslice(n, ra, rb, rlo, rhi);
+  if (ghi - glo != rhi - rlo) return false;
+  const uint8_t *gs = G.reg_bytes + G.reg_off[g];
+  for (int k = 0; k < ghi - glo; k++)
+    if (gs[glo + k] != F.chr(rlo + k)) return false;
+  return true;
+}
+
+// get_v_deletions — decombine.py:749-785
+template <bool REV>
+DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v_match, int temp_end_v,
+                                int &end_v, int &deletions_v, const Counters &C) {
+  const int n = F.n();
+  int f = temp_end_v;                                       // :753
+  const int Lg = (int)G.reg_len[v_match];
+  int pos = Lg - 10;                                        // :754-756
+  if (f >= n) { C.add(DCRX_C_V_DEL_FAILED_TAG_AT_END); return false; }  // :760-762
+  f += 1;                                                   // :764
+  int num_del = 0;                                          // :765
+  while (0 <= f && f < n) {                                 // :767
+    if (slice_eq<REV>(G, v_match, pos, pos + 10, F, f - 10, f)) {  // :769-772
+      deletions_v = num_del;                                // :774
+      end_v = temp_end_v - num_del;                         // :775
+      return true;
+    }
+    pos -= 1; num_del += 1; f -= 1;                         // :777-779
+  }
+  C.add(DCRX_C_V_DEL_FAILED);                               // :784
+  return false;
+}
+
+// get_j_deletions — decombine.py:788-817
+template <bool REV>
+DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j_match, int temp_start_j,
+                                int end_of_v, int &start_j, int &deletions_j, const Counters &C) {
+  const int n = F.n();
+  int f = temp_start_j;                                     // :792
+  int pos = 0;                                              // :793
+  while (0 <= f + 2 && f + 2 < n) {                         // :795
+    if (f < end_of_v) { pos += 1; f += 1; }                 // :798-800
+    else if (slice_eq<REV>(G, j_match, pos, pos + 10, F, f, f + 10)) {  // :802-805
+      deletions_j = pos; start_j = f;                       // :807-808
+      return true;
+    } else { pos += 1; f += 1; }                            // :810-811
+  }
+  C.add(DCRX_C_J_DEL_FAILED);                               // :816
+  return false;
+}
+
+// Levenshtein.hamming(tag k, read[lo:hi]) <= 1 (decombine.py:308-317 and siblings);
+// a length difference counts like rapidfuzz's padding.
+template <bool REV>
+DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const Frame<REV> &F, int lo, int hi) {
+  const int Lt = (int)G.tag_len[k];
+  const uint8_t *t = G.tag_ascii + k * 32;
+  int m = min(Lt, hi - lo);
+  int d = max(Lt, hi - lo) - m;
+  for (int x = 0; x < m && d <= 1; x++) d += (t[x] != F.chr(lo + x));
+  return d <= 1;
+}
+
+struct XDat { int match, pos, dels, tagpos; };  // (v_match,end_v,v_dels,v_seq_start) / (j_match,start_j,j_dels,j_seq_end)
+
+template <bool TABLE_LDS>
+DCRX_DEV uint32_t trans_at(const uint32_t *lds_trans, const DevTables &T, uint32_t byte_addr) {
+  if (TABLE_LDS) return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_trans) + byte_addr);
+  return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.trans) + byte_addr);
+}
+
+// ------------------------------------------------------------------------------
+// Half-tag rescue: the `else` branches of vanalysis (:292-394) and janalysis
+// (:420-531).  Re-scans the frame and, at every state where a keyword of class
+// CLS ends, walks that keyword's candidate tags in ascending index order — the
+// same order as iterating findall()'s list and the `indices` comprehension.
+// GENE 0 = V, 1 = J; HALF 1 or 2.  Returns true with `out` filled on success;
+// otherwise the caller bumps the "found half not other half" counter.
+// ------------------------------------------------------------------------------
+template <bool REV, bool TABLE_LDS, int GENE, int HALF>
+DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, int end_of_v,
+                       XDat &out, const Counters &C) {
+  constexpr int CLS = (GENE == 0) ? (HALF == 1 ? K_VH1 : K_VH2) : (HALF == 1 ? K_JH1 : K_JH2);
+  constexpr int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
+  const GeneDevPtrs &G = T.g[GENE];
+  const int n = F.n();
+  const int split = G.split;
+  uint32_t e = 0;
+  for (int i = 0; i < n; i++) {
+    if (F.has_exc() && F.exc_index(i) >= 0) { e = 0; continue; }  // unknown byte: machine back to the root
+    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + 4u * (uint32_t)F.code(i));
+    if (!((e >> BIT) & 1u)) continue;
+    const uint32_t st = (e & TE_ROW_MASK) >> 4;
+    for (uint32_t o = T.st_out[st];; o++) {
+      const uint32_t ent = T.outs[o];
+      if ((int)(ent & 7u) == CLS) {
+        const int hlen = (int)((ent >> 3) & 63u);
+        const uint32_t gk = T.kw_base[CLS] + ((ent >> 9) & 0xFFFFu);
+        const int p = i + 1 - hlen;                          // hold_x[i][1]
+        const int k0 = (int)T.kw_first[gk];                  // half_seqs.index(...)
+        const int L0 = (int)G.tag_len[k0];
+        for (uint32_t x = T.kw_begin[gk]; x < T.kw_begin[gk + 1]; x++) {
+          const int k = (int)T.kw_tags[x];                   // indices, ascending
+          const int Lk = (int)G.tag_len[k];
+          const int q = (HALF == 1) ? p : p - split;         // window start
+          int lo, hi;
+          pyslice(n, q, q + L0, lo, hi);                     // :302-307 / :348-357 / :429-434 / :482-491
+          if (Lk != hi - lo) continue;
+          pyslice(n, q, (HALF == 1) ? p + Lk : p + Lk - split, lo, hi);  // :311-314 / :361-366
+          if (!hamming_le1<REV>(G, k, F, lo, hi)) continue;
+          if (GENE == 0) {
+            C.add(HALF == 1 ? DCRX_C_VERR2 : DCRX_C_VERR1);  // :318 / :370
+            const int te = (HALF == 1) ? p + G.jump[k] - 1 : p + G.jump[k] - split - 1;  // :320-322 / :372-377
+            int end_v, dels;
+            if (get_v_deletions<REV>(G, F, k, te, end_v, dels, C)) {
+              out.match = k; out.pos = end_v; out.dels = dels; out.tagpos = q;  // :327-333 / :382-388
+              return true;
+            }
+          } else {
+            C.add(HALF == 1 ? DCRX_C_JERR2 : DCRX_C_JERR1);  // :445 / :504
+            const int ts = (HALF == 1) ? p - G.jump[k] : p - G.jump[k] - split;  // :447-449 / :506-510
+            const int jend = (HALF == 1) ? p + hlen + split : p + hlen;          // :450-454 / :511
+            int start_j, dels;
+            if (get_j_deletions<REV>(G, F, k, ts, end_of_v, start_j, dels, C)) {
+              out.match = k; out.pos = start_j; out.dels = dels; out.tagpos = jend;  // :463-468 / :520-525
+              return true;
+            }
+          }
+        }
+      }
+      if (ent >> 31) break;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------
+// The scan.  STEP consumes one symbol: one LDS look-up, flags OR-ed into `acc`,
+// full-tag hits added into vacc / jacc.
+// ------------------------------------------------------------------------------
+struct ScanOut { uint32_t acc, vacc, jacc; };
+
+#define DCRX_STEP(CODE)                                                                         \
+  do {                                                                                          \
+    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));         \
+    acc |= e;                                                                                   \
+    const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
+    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                      \
+    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                      \
+    it += (1u << ACC_POS_SHIFT);                                                                \
+  } while (0)
+
+// Fast scan: no exceptions in this read.  w[] holds the read's first nw words.
+template <bool REV, bool TABLE_LDS>
+DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
+                                             const uint32_t (&w)[DCRX_NWMAX], const uint32_t *words, int n) {
+  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  if (n > 0) {
+    const int top = (n - 1) >> 4;           // index of the last (possibly partial) word
+    const int cnt = ((n - 1) & 15) + 1;     // bases in it
+    if (REV) {
+      // the frame starts at the read's last base: partial word first, from its top base down
+      uint32_t wp = ~words[top] << (2 * (16 - cnt));
+      for (int k = 0; k < cnt; k++) { DCRX_STEP(wp >> 30); wp <<= 2; }
+#pragma unroll
+      for (int kk = DCRX_NWMAX - 1; kk >= 0; kk--) {
+        if (kk < top) {
+          const uint32_t wv = ~w[kk];
+#pragma unroll
+          for (int j = 15; j >= 0; j--) DCRX_STEP(dcrx_ubfe(wv, 2 * j, 2));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < DCRX_NWMAX; kk++) {
+        if (kk < top) {
+          const uint32_t wv = w[kk];
+#pragma unroll
+          for (int j = 0; j < 16; j++) DCRX_STEP(dcrx_ubfe(wv, 2 * j, 2));
+        }
+      }
+      uint32_t wp = words[top];
+      for (int k = 0; k < cnt; k++) { DCRX_STEP(wp & 3u); wp >>= 2; }
+    }
+  }
+  return ScanOut{acc, vacc, jacc};
+}
+
+// Slow scan: any read (exception bytes reset the machine, like acora on a
+// character outside its keywords).
+template <bool REV, bool TABLE_LDS>
+DCRX_DEVNI ScanOut scan_slow(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F) {
+  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  const int n = F.n();
+  for (int i = 0; i < n; i++) {
+    if (F.has_exc() && F.exc_index(i) >= 0) { e = 0; it += (1u << ACC_POS_SHIFT); continue; }
+    DCRX_STEP(F.code(i));
+  }
+  return ScanOut{acc, vacc, jacc};
+}
+
+// ------------------------------------------------------------------------------
+// dcr() for one frame — decombine.py:534-585 with vanalysis :273-394 and
+// janalysis :397-531 folded around the single scan.  Returns the status and
+// fills `rec` on DCRX_S_OK.
+// ------------------------------------------------------------------------------
+template <bool REV, bool TABLE_LDS>
+DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, const ScanOut &so,
+                         const dcrx::CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
+  const Frame<REV> F(rv);
+  const int n = rv.n;
+  const GeneDevPtrs &GV = T.g[0];
+  const GeneDevPtrs &GJ = T.g[1];
+  XDat vdat, jdat;
+
+  // ---- vanalysis ---------------------------------------------------------------
+  {
+    uint32_t vcount = so.vacc & ACC_CNT_MASK;
+    if ((so.acc >> TE_VMULTI_BIT) & 1u) vcount = 2;          // two tags ended at one position
+    if (vcount > 1) { C.add(DCRX_C_MULTIPLE_V_MATCHES); return DCRX_S_V_MULTI; }  // :278-280
+    if (vcount == 1) {
+      const uint32_t st = (so.vacc >> ACC_STATE_SHIFT) & 0x3FFFu;
+      const int iend = (int)(so.vacc >> ACC_POS_SHIFT);
+      const int v = (int)(T.st_full[st] & 0xFFFFu);          // v_seqs.index(tag) :282
+      const int p = iend + 1 - (int)GV.tag_len[v];           // hold_v[0][1]
+      const int te = p + GV.jump[v] - 1;                     // :283-285
+      int end_v, dels;
+      if (!get_v_deletions<REV>(GV, F, v, te, end_v, dels, C))                      // :288-290
+        return (te >= n) ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;         // :760-762 / :783-785
+      vdat = XDat{v, end_v, dels, p};
+    } else if ((so.acc >> TE_VH1_BIT) & 1u) {                // :294-335
+      if (!rescue<REV, TABLE_LDS, 0, 1>(T, lds_trans, F, 0, vdat, C)) {
+        C.add(DCRX_C_FOUNDV1NOTV2); return DCRX_S_V_HALF1_EXHAUSTED;
+      }
+    } else if ((so.acc >> TE_VH2_BIT) & 1u) {                // :339-390
+      if (!rescue<REV, TABLE_LDS, 0, 2>(T, lds_trans, F, 0, vdat, C)) {
+        C.add(DCRX_C_FOUNDV2NOTV1); return DCRX_S_V_HALF2_EXHAUSTED;
+      }
+    } else {
+      C.add(DCRX_C_NO_VTAGS_FOUND); return DCRX_S_V_NONE;    // :393-394
+    }
+  }
+  const int end_of_v = vdat.pos + 1;                         // :547
+
+  // ---- janalysis ---------------------------------------------------------------
+  int jstatus = DCRX_S_OK;
+  {
+    uint32_t jcount = so.jacc & ACC_CNT_MASK;
+    if ((so.acc >> TE_JMULTI_BIT) & 1u) jcount = 2;
+    if (jcount > 1) { C.add(DCRX_C_MULTIPLE_J_MATCHES); jstatus = DCRX_S_J_MULTI; }  // :402-404
+    else if (jcount == 1) {
+      const uint32_t st = (so.jacc >> ACC_STATE_SHIFT) & 0x3FFFu;
+      const int iend = (int)(so.jacc >> ACC_POS_SHIFT);
+      const int j = (int)(T.st_full[st] >> 16);              // j_seqs.index(tag) :406
+      const int Lj = (int)GJ.tag_len[j];
+      const int p = iend + 1 - Lj;
+      const int ts = p - GJ.jump[j];                         // :407-409
+      int start_j, dels;
+      if (get_j_deletions<REV>(GJ, F, j, ts, end_of_v, start_j, dels, C)) jdat = XDat{j, start_j, dels, p + Lj};  // :411-418
+      else jstatus = DCRX_S_J_WALK_FAIL;
+    } else if ((so.acc >> TE_JH1_BIT) & 1u) {                // :422-470
+      if (!rescue<REV, TABLE_LDS, 1, 1>(T, lds_trans, F, end_of_v, jdat, C)) {
+        C.add(DCRX_C_FOUNDJ1NOTJ2); jstatus = DCRX_S_J_HALF1_EXHAUSTED;
+      }
+    } else if ((so.acc >> TE_JH2_BIT) & 1u) {                // :473-527
+      if (!rescue<REV, TABLE_LDS, 1, 2>(T, lds_trans, F, end_of_v, jdat, C)) {
+        C.add(DCRX_C_FOUNDV2NOTV1); jstatus = DCRX_S_J_HALF2_EXHAUSTED;  // :526 bumps the V key
+      }
+    } else {
+      C.add(DCRX_C_NO_J_ASSIGNED); jstatus = DCRX_S_J_NONE;  // :530-531
+    }
+  }
+  if (jstatus != DCRX_S_OK) { C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); return jstatus; }  // :583-585
+
+  // ---- filters :553-569 --------------------------------------------------------
+  if (F.has_exc() && !cfg.allow_ns) {
+    int lo, hi;
+    pyslice(n, vdat.tagpos, jdat.tagpos, lo, hi);            // "N" in read[vdat[3]:jdat[3]]
+    bool hasN = false;
+    for (int x = rv.e0; x < rv.e1; x++) {
+      const int i = REV ? n - 1 - (int)rv.exc_pos[x] : (int)rv.exc_pos[x];
+      const uint8_t b = REV ? rv.comp[rv.exc_chr[x]] : rv.exc_chr[x];
+      if (i >= lo && i < hi && b == (uint8_t)'N') hasN = true;
+    }
+    if (hasN) { C.add(DCRX_C_DCRFILTER_INTERTAGN); return DCRX_S_F_INTERTAG_N; }
+  }
+  if ((vdat.tagpos - jdat.tagpos) >= cfg.lenthreshold) {     // :557-560
+    C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG); return DCRX_S_F_TOOLONG;
+  }
+  if (vdat.dels > (GV.jump[vdat.match] - (int)GV.tag_len[vdat.match]) || jdat.dels > GJ.jump[jdat.match]) {  // :561-565
+    C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION); return DCRX_S_F_IMPOSS_DEL;
+  }
+  if ((vdat.tagpos + (int)GV.tag_len[vdat.match]) > (jdat.tagpos + (int)GJ.tag_len[jdat.match])) {  // :566-569
+    C.add(DCRX_C_DCRFILTER_TAG_OVERLAP); return DCRX_S_F_OVERLAP;
+  }
+  int lo, hi;
+  pyslice(n, vdat.pos + 1, jdat.pos, lo, hi);                // read[vdat[1]+1 : jdat[1]] :577
+  rec.v = (uint16_t)vdat.match; rec.j = (uint16_t)jdat.match;
+  rec.v_start = (uint16_t)vdat.tagpos; rec.j_end = (uint16_t)jdat.tagpos;
+  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
+  rec.vdel = (uint8_t)vdat.dels; rec.jdel = (uint8_t)jdat.dels;
+  return DCRX_S_OK;
+}
+
+// One frame of one read: scan (fast or slow reader) then dcr_frame.
+template <bool REV, bool TABLE_LDS>
+DCRX_DEV int attempt(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv,
+                                       const uint32_t (&w)[DCRX_NWMAX], bool slow, const CfgDev &cfg,
+                                       const Counters &C, dcrx_record_t &rec) {
+  ScanOut so;
+  if (!slow) so = scan_fast<REV, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+  else so = scan_slow<REV, TABLE_LDS>(T, lds_trans, Frame<REV>(rv));
+  return dcr_frame<REV, TABLE_LDS>(T, lds_trans, rv, so, cfg, C, rec);
+}
+
+
+// ------------------------------------------------------------------------------
+// One read through the orientation dispatch of the reference's read loop
+// (decombine.py:991, :998-1013) and out as a 16-byte record.
+// ------------------------------------------------------------------------------
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg,
+                            uint64_t r, uint32_t nw, const Counters &C, dcrx_record_t *records) {
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  bool slow = (cfg.flags & DCRX_F_FORCE_SLOW_READER) != 0;
+  if (B.n_exc) {
+    if ((B.exc_flag[r >> 5] >> (r & 31)) & 1u) {
+      // binary search of this read's slice in the sorted exception list
+      uint64_t lo = 0, hi = B.n_exc;
+      while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
+      rv.e0 = (int)lo;
+      while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
+      rv.e1 = (int)lo;
+      slow = true;
+    }
+  }
+  // the read's words, for the register-resident fast scan
+  uint32_t w[DCRX_NWMAX];
+  {
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
+#pragma unroll
+    for (int k = 0; k < DCRX_NWMAX / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw) t = wp2[k];
+      w[2 * k] = t.x; w[2 * k + 1] = t.y;
+    }
+  }
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
+    status = attempt<false, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 1;
+  } else {                                                            // :999-1001, :1005-1007
+    status = attempt<true, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 0;
+    if (cfg.orientation == DCRX_ORIENT_BOTH && status != DCRX_S_OK) {  // :1008-1010
+      status = attempt<false, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 1;
+    }
+  }
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+}
+
+}  // namespace dcrx

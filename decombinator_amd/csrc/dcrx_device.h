@@ -1,0 +1,61 @@
+// dcrx_device.h — the table image as the kernels see it: resolved device
+// pointers into the single blob that dcrx::compile_tables laid out.
+#pragma once
+
+#include <cstdint>
+
+namespace dcrx {
+
+// output classes of the merged automaton (one per reference automaton)
+enum KwClass { K_VFULL = 0, K_JFULL = 1, K_VH1 = 2, K_VH2 = 3, K_JH1 = 4, K_JH2 = 5, K_NCLASS = 6 };
+
+// ---- transition entry layout (uint32) -------------------------------------
+// bits 0..17  byte offset of the target state's row (state * 16)
+// bit  18     >=1 V tag ends at the target state          (v_key.findall hit)
+// bit  19     >=1 J tag ends there                         (j_key)
+// bit  20..23 a V half1 / V half2 / J half1 / J half2 keyword ends there
+// bit  24     >=2 V tags end there (unequal-length tag sets only)
+// bit  25     >=2 J tags end there
+constexpr uint32_t TE_ROW_MASK = 0x3FFFFu;
+constexpr int TE_VFULL_BIT = 18, TE_JFULL_BIT = 19;
+constexpr int TE_VH1_BIT = 20, TE_VH2_BIT = 21, TE_JH1_BIT = 22, TE_JH2_BIT = 23;
+constexpr int TE_VMULTI_BIT = 24, TE_JMULTI_BIT = 25;
+constexpr uint32_t MAX_STATES = 16383;
+constexpr uint32_t MAX_TAG_LEN = 32;
+
+// entry of the per-state output list: class | len<<3 | kw<<9 | last<<31
+inline uint32_t out_pack(int cls, int len, int kw, bool last) {
+  return (uint32_t)cls | ((uint32_t)len << 3) | ((uint32_t)kw << 9) | (last ? 0x80000000u : 0u);
+}
+
+struct GeneDevPtrs {
+  uint32_t n;
+  int32_t split;               // v_half_split / j_half_split (decombine.py:657-661)
+  const uint8_t *tag_len;      // len(v_seqs[k])
+  const int32_t *jump;         // jump_to_end_v[k] / jump_to_start_j[k]
+  const uint8_t *tag_ascii;    // [k*32], the tag's characters
+  const uint32_t *reg_off;     // byte offset of region k inside reg_bytes
+  const uint32_t *reg_len;     // len(v_regions[k])
+  const uint8_t *reg_bytes;    // upper-cased germline characters
+  const uint32_t *reg_pk_off;  // word offset of region k inside reg_pk / reg_pk_rc
+  const uint32_t *reg_pk;      // 2-bit packed region (base i at bits 2(i%16) of word i/16)
+  const uint32_t *reg_pk_rc;   // 2-bit packed reverse complement of the region
+  const uint8_t *reg_clean;    // 1 when the region is pure ACGT (packed compare allowed)
+};
+
+struct DevTables {
+  uint32_t n_states;
+  uint32_t dfa_bytes;
+  const uint32_t *trans;      // [n_states*4] transition entries (dcrx_tables.h)
+  const uint32_t *st_full;    // [n_states] V tag | J tag << 16 ending at the state (0xFFFF none)
+  const uint32_t *st_out;     // [n_states+1] CSR into outs
+  const uint32_t *outs;       // per-state output list, longest keyword first
+  const uint32_t *kw_base;    // [K_NCLASS] first global keyword id of each class
+  const uint32_t *kw_first;   // [n_kw_total] first tag index holding the keyword (list.index)
+  const uint32_t *kw_begin;   // [n_kw_total+1] CSR into kw_tags
+  const uint32_t *kw_tags;    // tag indices holding the keyword, ascending
+  const uint8_t *comp;        // [256] Biopython ambiguous-DNA complement, both cases (decombine.py:184)
+  GeneDevPtrs g[2];           // 0 = V, 1 = J
+};
+
+}  // namespace dcrx

@@ -1,0 +1,218 @@
+// dcrx_kernels.hip — the `decombine` hot path as HIP kernels for gfx950 (CDNA4).
+//
+// One read per lane.  The merged Aho-Corasick automaton (V tags, J tags and the
+// four half-tag sets: the six acora automata of reference
+// src/decombinator/decombine.py:722-746) lives in LDS as a goto-only DFA whose
+// entries carry the output classes of their target state.  Reads arrive 2-bit
+// packed (A0 C1 G2 T3) and are never reverse-complemented in memory: the
+// `reverse` frame (decombine.py:1000, revcomp :182-184) is read by walking the
+// packed words backwards and inverting the bits, and germline windows are
+// compared against a pre-reverse-complemented packed copy of the region.
+//
+// Per read (decombine.py:534-585, dcr()):
+//   scan    one pass of the DFA over the frame: V/J full-tag hit count, the
+//           single hit's (state, position), and "any half-tag hit" flags
+//           (replaces the findall() calls at :275, :399 and tells whether the
+//           ones at :294, :339, :422, :473 would be non-empty)
+//   V       full hit -> get_v_deletions walk (:749-785); no hit -> half-tag
+//           rescue by re-scanning and testing candidates in findall order with
+//           Hamming <= 1 (:294-390)
+//   J       same (:397-531, walk :788-817), only when V succeeded (:544-548)
+//   filters :553-569, then the 16-byte record
+//
+// Integer/byte work only; no MFMA.  Bound: LDS look-ups and VALU issue for the
+// scan, HBM for the packed reads (40 B) and records (16 B).
+#include <hip/hip_runtime.h>
+
+#include "../../include/dcrx.h"
+#include "dcrx_device.h"
+#include "dcrx_launch.h"
+#include "dcrx_dcr_device.h"
+
+namespace dcrx {
+
+// ------------------------------------------------------------------------------
+// Main kernel: persistent blocks, each stages the DFA into LDS once and then
+// strides over tiles of blockDim reads.
+// ------------------------------------------------------------------------------
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+__global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, BatchDev B, CfgDev cfg,
+                                                               dcrx_record_t *__restrict__ records,
+                                                               uint32_t *__restrict__ block_counts) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
+  uint32_t *lds_trans = smem + DCRX_N_COUNTERS;       // [n_states*4] when TABLE_LDS
+  const int tid = threadIdx.x;
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  if (TABLE_LDS) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(T.trans);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
+    for (uint32_t i = tid; i < T.n_states; i += DCRX_BLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Counters C{lds_counts};
+  const uint32_t nw = B.stride >> 2;
+
+  for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
+    const uint64_t r = tile * DCRX_BLOCK + tid;
+    if (r >= B.n_reads) continue;
+    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+  }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
+}
+
+// Sums the per-block tallies into the caller's uint64[DCRX_N_COUNTERS].
+__global__ void reduce_counts_kernel(const uint32_t *__restrict__ block_counts, int n_blocks,
+                                     uint64_t *__restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= DCRX_N_COUNTERS) return;
+  uint64_t s = 0;
+  for (int b = 0; b < n_blocks; b++) s += block_counts[(size_t)b * DCRX_N_COUNTERS + c];
+  out[c] = s;
+}
+
+// Marks reads that own at least one exception.
+__global__ void mark_exceptions_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc,
+                                       uint32_t *__restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_exc) { const uint32_t r = exc_read[i]; atomicOr(&flag[r >> 5], 1u << (r & 31)); }
+}
+
+// ------------------------------------------------------------------------------
+// Order-preserving compaction of the decombined (status OK) records: the DCR
+// tuples that leave the GPU (gathered to rank 0 in the sharded run).
+// ------------------------------------------------------------------------------
+constexpr int CP_BLOCK = 256;
+constexpr int CP_PER_THREAD = 4;
+constexpr int CP_TILE = CP_BLOCK * CP_PER_THREAD;
+
+__global__ __launch_bounds__(CP_BLOCK) void compact_count_kernel(const dcrx_record_t *__restrict__ rec, uint64_t n,
+                                                                  uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * CP_TILE;
+  uint32_t c = 0;
+  for (int k = 0; k < CP_PER_THREAD; k++) {
+    const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
+    const bool ok = i < n && rec[i].status == DCRX_S_OK;
+    c += (uint32_t)__popcll(__ballot(ok));
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = s_cnt;
+}
+
+// Exclusive scan of the tile counts by one block; writes the grand total.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ tile_count, uint32_t n_tiles,
+                                                             uint64_t *__restrict__ tile_off,
+                                                             uint64_t *__restrict__ total) {
+  __shared__ uint64_t s_part[1024];
+  const uint32_t per = (n_tiles + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per;
+  uint64_t sum = 0;
+  for (uint32_t i = b; i < b + per && i < n_tiles; i++) sum += tile_count[i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < 1024; i++) { uint64_t t = s_part[i]; s_part[i] = run; run += t; }
+    *total = run;
+  }
+  __syncthreads();
+  uint64_t run = s_part[threadIdx.x];
+  for (uint32_t i = b; i < b + per && i < n_tiles; i++) { tile_off[i] = run; run += tile_count[i]; }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_record_t *__restrict__ rec, uint64_t n,
+                                                                    uint64_t first_index,
+                                                                    const uint64_t *__restrict__ tile_off,
+                                                                    dcrx_record_t *__restrict__ hits,
+                                                                    uint64_t *__restrict__ hit_index) {
+  __shared__ uint32_t s_wave[CP_PER_THREAD][CP_BLOCK / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CP_TILE;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  bool ok[CP_PER_THREAD];
+  uint32_t rank[CP_PER_THREAD];
+  for (int k = 0; k < CP_PER_THREAD; k++) {
+    const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
+    ok[k] = i < n && rec[i].status == DCRX_S_OK;
+    const unsigned long long m = __ballot(ok[k]);
+    rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[k][wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  uint64_t off = tile_off[blockIdx.x];
+  for (int k = 0; k < CP_PER_THREAD; k++) {
+    uint32_t before = 0;
+    for (int kk = 0; kk < k; kk++)
+      for (int wv = 0; wv < CP_BLOCK / 64; wv++) before += s_wave[kk][wv];
+    for (int wv = 0; wv < wave; wv++) before += s_wave[k][wv];
+    if (ok[k]) {
+      const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
+      const uint64_t dst = off + before + rank[k];
+      reinterpret_cast<uint4 *>(hits)[dst] = reinterpret_cast<const uint4 *>(rec)[i];
+      hit_index[dst] = first_index + i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// launchers (called from dcrx_api.cpp)
+// ------------------------------------------------------------------------------
+template <bool TABLE_LDS, bool UNIFORM>
+static hipError_t launch_one(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
+                             dcrx_record_t *rec, uint32_t *block_counts, hipStream_t s) {
+  auto kfn = decombine_kernel<TABLE_LDS, UNIFORM>;
+  if (P.lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kfn, dim3(P.grid), dim3(DCRX_BLOCK), P.lds_bytes, s, T, B, cfg, rec, block_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
+                            dcrx_record_t *rec, uint32_t *block_counts, uint64_t *d_counters, hipStream_t s,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  hipError_t e;
+  if (B.n_exc) {
+    e = hipMemsetAsync(const_cast<uint32_t *>(B.exc_flag), 0, ((B.n_reads + 31) / 32) * 4, s);
+    if (e != hipSuccess) return e;
+    const uint32_t g = (uint32_t)((B.n_exc + 255) / 256);
+    hipLaunchKernelGGL(mark_exceptions_kernel, dim3(g), dim3(256), 0, s, B.exc_read, B.n_exc,
+                       const_cast<uint32_t *>(B.exc_flag));
+  }
+  const bool uniform = B.lens == nullptr;
+  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
+  if (P.table_in_lds) {
+    e = uniform ? launch_one<true, true>(P, T, B, cfg, rec, block_counts, s)
+                : launch_one<true, false>(P, T, B, cfg, rec, block_counts, s);
+  } else {
+    e = uniform ? launch_one<false, true>(P, T, B, cfg, rec, block_counts, s)
+                : launch_one<false, false>(P, T, B, cfg, rec, block_counts, s);
+  }
+  if (e != hipSuccess) return e;
+  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(64), 0, s, block_counts, (int)P.grid, d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
+                          uint64_t *hit_index, uint64_t *d_total, uint32_t *tile_count, uint64_t *tile_off,
+                          hipStream_t s) {
+  const uint32_t n_tiles = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
+  if (n_tiles)
+    hipLaunchKernelGGL(compact_count_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, tile_count);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, n_tiles, tile_off, d_total);
+  if (n_tiles)
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, first_index, tile_off,
+                       hits, hit_index);
+  return hipGetLastError();
+}
+
+uint32_t compact_tiles(uint64_t n) { return (uint32_t)((n + CP_TILE - 1) / CP_TILE); }
+
+}  // namespace dcrx

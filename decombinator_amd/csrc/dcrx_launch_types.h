@@ -1,0 +1,32 @@
+// dcrx_launch_types.h — plain structs shared by host launch code, kernels and
+// the test-only host emulation (no HIP headers needed).
+#pragma once
+
+#include <cstdint>
+
+// words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
+#define DCRX_NWMAX 20
+#define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
+#define DCRX_BLOCK 512
+
+namespace dcrx {
+
+struct BatchDev {
+  const uint8_t *packed;
+  uint32_t stride;
+  uint32_t read_len;
+  const uint16_t *lens;
+  uint64_t n_reads;
+  uint64_t n_exc;
+  const uint32_t *exc_read;
+  const uint16_t *exc_pos;
+  const uint8_t *exc_chr;
+  const uint32_t *exc_flag;  // workspace bitmap: read owns >= 1 exception
+};
+
+struct CfgDev {
+  int32_t orientation, allow_ns, lenthreshold;
+  uint32_t flags;
+};
+
+}  // namespace dcrx

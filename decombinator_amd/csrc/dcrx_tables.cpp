@@ -1,0 +1,322 @@
+// dcrx_tables.cpp — compiles one chain's tag set into the device image.
+//
+// Host-only (no HIP calls).  Follows what the reference builds at
+// src/decombinator/decombine.py:657-661 (half splits), :690-696 (regions,
+// upper-cased), :820-866 (tags, jumps, half tags) and :722-746 (six acora
+// automata), but merges the six automata into one goto-only DFA: Aho-Corasick
+// reports every occurrence of every keyword independently of which other
+// keywords share the machine, so the per-class hit lists of the merged machine
+// are exactly the six findall() results.
+#include "dcrx_tables.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <queue>
+
+namespace dcrx {
+
+namespace {
+
+int base_code(char c) {
+  switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+  }
+}
+
+// Python s[a:b]
+std::string pyslice(const std::string &s, long a, long b) {
+  long n = (long)s.size();
+  if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
+  if (b < 0) { b += n; if (b < 0) b = 0; } else if (b > n) b = n;
+  if (b < a) b = a;
+  return s.substr((size_t)a, (size_t)(b - a));
+}
+
+struct Blob {
+  std::vector<uint8_t> bytes;
+  uint64_t reserve(size_t n) {  // 16-byte aligned
+    size_t off = (bytes.size() + 15) & ~(size_t)15;
+    bytes.resize(off + n, 0);
+    return off;
+  }
+  template <typename T>
+  uint64_t put(const std::vector<T> &v) {
+    uint64_t off = reserve(v.size() * sizeof(T) + 16);  // +16: tail padding for word-pair loads
+    if (!v.empty()) std::memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
+template <typename T>
+const T *as_off(uint64_t off) { return reinterpret_cast<const T *>(static_cast<uintptr_t>(off)); }
+
+void pack_region(const std::string &s, bool rc, std::vector<uint32_t> *out) {
+  size_t n = s.size();
+  size_t words = n / 16 + 2;  // one spare word for the funnel-shift pair load
+  size_t base = out->size();
+  out->resize(base + words, 0);
+  for (size_t i = 0; i < n; i++) {
+    int c;
+    if (!rc) c = base_code(s[i]);
+    else { c = base_code(s[n - 1 - i]); if (c >= 0) c ^= 3; }
+    if (c < 0) c = 0;
+    (*out)[base + i / 16] |= (uint32_t)c << (2 * (i % 16));
+  }
+}
+
+}  // namespace
+
+DevTables HostTables::resolve(const uint8_t *base) const {
+  DevTables d = rel;
+  auto fix = [&](auto &p) {
+    using P = std::remove_reference_t<decltype(p)>;
+    p = reinterpret_cast<P>(base + reinterpret_cast<uintptr_t>(p));
+  };
+  fix(d.trans); fix(d.st_full); fix(d.st_out); fix(d.outs);
+  fix(d.kw_base); fix(d.kw_first); fix(d.kw_begin); fix(d.kw_tags); fix(d.comp);
+  for (int g = 0; g < 2; g++) {
+    fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].reg_off);
+    fix(d.g[g].reg_len); fix(d.g[g].reg_bytes); fix(d.g[g].reg_pk_off); fix(d.g[g].reg_pk);
+    fix(d.g[g].reg_pk_rc); fix(d.g[g].reg_clean);
+  }
+  return d;
+}
+
+int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
+  auto fail = [&](int code, const std::string &m) { *err = m; return code; };
+  if (!ts || !out) return fail(DCRX_E_INVALID, "null tag set");
+  if (ts->n_v == 0 || ts->n_j == 0) return fail(DCRX_E_INVALID, "empty V or J tag list");
+  if (ts->n_v > 65534 || ts->n_j > 65534) return fail(DCRX_E_UNSUPPORTED, "more than 65534 genes");
+
+  HostTables &H = *out;
+  H = HostTables();
+  const char *const *tags_in[2] = {ts->v_tags, ts->j_tags};
+  const int32_t *jumps_in[2] = {ts->v_jumps, ts->j_jumps};
+  const char *const *regs_in[2] = {ts->v_regions, ts->j_regions};
+  const uint32_t n_in[2] = {ts->n_v, ts->n_j};
+  const int split_in[2] = {ts->v_half_split, ts->j_half_split};
+  const char *gname[2] = {"V", "J"};
+
+  for (int g = 0; g < 2; g++) {
+    GeneHost &G = H.g[g];
+    G.n = n_in[g];
+    G.split = split_in[g];
+    if (!tags_in[g] || !jumps_in[g] || !regs_in[g]) return fail(DCRX_E_INVALID, "null tag/jump/region array");
+    for (uint32_t k = 0; k < G.n; k++) {
+      if (!tags_in[g][k] || !regs_in[g][k]) return fail(DCRX_E_INVALID, "null tag or region string");
+      std::string t = tags_in[g][k];
+      if (t.empty() || t.size() > MAX_TAG_LEN)
+        return fail(DCRX_E_UNSUPPORTED, std::string(gname[g]) + " tag " + std::to_string(k) + ": length must be 1..32");
+      for (char c : t)
+        if (base_code(c) < 0)
+          return fail(DCRX_E_UNSUPPORTED, std::string(gname[g]) + " tag " + std::to_string(k) + " has a character outside ACGT");
+      if (G.split <= 0 || (size_t)G.split >= t.size())
+        return fail(DCRX_E_UNSUPPORTED, std::string(gname[g]) + " tag " + std::to_string(k) + ": half split leaves an empty half tag");
+      int32_t jump = jumps_in[g][k];
+      if (jump < -32768 || jump > 32767) return fail(DCRX_E_UNSUPPORTED, "jump outside int16 range");
+      // a decombined read reports vdel <= jump_v - len(tag) and jdel <= jump_j (decombine.py:561-565) in a byte
+      if (g == 0 && jump - (int)t.size() > 255) return fail(DCRX_E_UNSUPPORTED, "V jump - tag length > 255");
+      if (g == 1 && jump > 255) return fail(DCRX_E_UNSUPPORTED, "J jump > 255");
+      std::string r = regs_in[g][k];
+      if (r.size() > 65535) return fail(DCRX_E_UNSUPPORTED, "region longer than 65535");
+      for (char &c : r) if (c >= 'a' && c <= 'z') c = (char)(c - 32);  // .seq.upper(), decombine.py:695
+      G.tags.push_back(t);
+      G.half1.push_back(pyslice(t, 0, G.split));                 // :841 / :863
+      G.half2.push_back(pyslice(t, G.split, (long)t.size()));    // :842 / :864
+      G.jumps.push_back(jump);
+      G.regions.push_back(r);
+      H.max_tag_len = std::max<uint32_t>(H.max_tag_len, (uint32_t)t.size());
+    }
+  }
+
+  // ---- distinct keywords per class (AcoraBuilder keeps a set) ----------------
+  // kw_strings[c][i], kw_tags[c][i] = ascending tag indices holding that string
+  std::vector<std::string> kw_str[K_NCLASS];
+  std::vector<std::vector<uint32_t>> kw_idx[K_NCLASS];
+  auto add_class = [&](int cls, const std::vector<std::string> &list) {
+    std::map<std::string, int> seen;
+    for (uint32_t k = 0; k < list.size(); k++) {
+      auto it = seen.find(list[k]);
+      if (it == seen.end()) {
+        seen[list[k]] = (int)kw_str[cls].size();
+        kw_str[cls].push_back(list[k]);
+        kw_idx[cls].push_back({k});
+      } else {
+        kw_idx[cls][it->second].push_back(k);
+      }
+    }
+    H.n_keywords[cls] = (uint32_t)kw_str[cls].size();
+    for (auto &s : kw_str[cls])
+      if (s.size() != kw_str[cls][0].size()) H.equal_len_per_automaton = false;
+  };
+  add_class(K_VFULL, H.g[0].tags); add_class(K_JFULL, H.g[1].tags);
+  add_class(K_VH1, H.g[0].half1);  add_class(K_VH2, H.g[0].half2);
+  add_class(K_JH1, H.g[1].half1);  add_class(K_JH2, H.g[1].half2);
+
+  // ---- trie ---------------------------------------------------------------------
+  struct Node { int next[4] = {-1, -1, -1, -1}; int fail = 0; int out_link = -1; int depth = 0;
+                std::vector<std::pair<int, int>> own; };  // own: (class, kw) ending exactly here
+  std::vector<Node> nodes(1);
+  for (int cls = 0; cls < K_NCLASS; cls++) {
+    for (size_t i = 0; i < kw_str[cls].size(); i++) {
+      int s = 0;
+      for (char ch : kw_str[cls][i]) {
+        int c = base_code(ch);
+        if (nodes[s].next[c] < 0) {
+          nodes[s].next[c] = (int)nodes.size();
+          Node nn; nn.depth = nodes[s].depth + 1;
+          nodes.push_back(nn);
+        }
+        s = nodes[s].next[c];
+      }
+      nodes[s].own.push_back({cls, (int)i});
+    }
+  }
+  if (nodes.size() > MAX_STATES)
+    return fail(DCRX_E_UNSUPPORTED, "merged automaton needs " + std::to_string(nodes.size()) + " states (limit 16383)");
+  const uint32_t S = (uint32_t)nodes.size();
+  H.n_states = S;
+
+  // BFS: failure links, output links, full goto function
+  std::vector<int> delta(S * 4, 0);
+  {
+    std::queue<int> q;
+    for (int c = 0; c < 4; c++) {
+      int t = nodes[0].next[c];
+      if (t >= 0) { delta[c] = t; nodes[t].fail = 0; q.push(t); } else delta[c] = 0;
+    }
+    while (!q.empty()) {
+      int s = q.front(); q.pop();
+      int f = nodes[s].fail;
+      nodes[s].out_link = !nodes[f].own.empty() ? f : nodes[f].out_link;
+      for (int c = 0; c < 4; c++) {
+        int t = nodes[s].next[c];
+        if (t >= 0) { delta[s * 4 + c] = t; nodes[t].fail = delta[f * 4 + c]; q.push(t); }
+        else delta[s * 4 + c] = delta[f * 4 + c];
+      }
+    }
+  }
+
+  // per-state output lists (own keywords, then the out_link chain: longest first)
+  std::vector<uint32_t> kw_base(K_NCLASS + 1, 0);
+  for (int c = 0; c < K_NCLASS; c++) kw_base[c + 1] = kw_base[c] + (uint32_t)kw_str[c].size();
+  std::vector<uint32_t> st_out(S + 1, 0), outs, st_full(S, 0xFFFFFFFFu), st_flags(S, 0);
+  for (uint32_t s = 0; s < S; s++) {
+    st_out[s] = (uint32_t)outs.size();
+    int cnt[K_NCLASS] = {0, 0, 0, 0, 0, 0};
+    uint32_t vfull = 0xFFFF, jfull = 0xFFFF;
+    for (int t = nodes[s].own.empty() ? nodes[s].out_link : (int)s; t >= 0; t = nodes[t].out_link) {
+      // within one node order classes deterministically; only same-class order matters
+      auto own = nodes[t].own;
+      std::sort(own.begin(), own.end());
+      for (auto &o : own) {
+        outs.push_back(out_pack(o.first, nodes[t].depth, o.second, false));
+        if (o.first == K_VFULL && cnt[K_VFULL] == 0) vfull = kw_idx[K_VFULL][o.second][0];  // v_seqs.index(tag), :282
+        if (o.first == K_JFULL && cnt[K_JFULL] == 0) jfull = kw_idx[K_JFULL][o.second][0];  // j_seqs.index(tag), :406
+        cnt[o.first]++;
+      }
+    }
+    if (outs.size() > st_out[s]) outs.back() |= 0x80000000u;
+    st_full[s] = vfull | (jfull << 16);
+    uint32_t fl = 0;
+    if (cnt[K_VFULL] >= 1) fl |= 1u << TE_VFULL_BIT;
+    if (cnt[K_JFULL] >= 1) fl |= 1u << TE_JFULL_BIT;
+    if (cnt[K_VH1]) fl |= 1u << TE_VH1_BIT;
+    if (cnt[K_VH2]) fl |= 1u << TE_VH2_BIT;
+    if (cnt[K_JH1]) fl |= 1u << TE_JH1_BIT;
+    if (cnt[K_JH2]) fl |= 1u << TE_JH2_BIT;
+    if (cnt[K_VFULL] >= 2) fl |= 1u << TE_VMULTI_BIT;
+    if (cnt[K_JFULL] >= 2) fl |= 1u << TE_JMULTI_BIT;
+    st_flags[s] = fl;
+  }
+  st_out[S] = (uint32_t)outs.size();
+  for (auto &o : outs) {
+    if (((o >> 9) & 0x3FFFFF) > 0xFFFF) return fail(DCRX_E_UNSUPPORTED, "keyword id overflow");
+  }
+
+  std::vector<uint32_t> trans(S * 4);
+  for (uint32_t s = 0; s < S; s++)
+    for (int c = 0; c < 4; c++) {
+      uint32_t t = (uint32_t)delta[s * 4 + c];
+      trans[s * 4 + c] = (t * 16u) | st_flags[t];
+    }
+  H.dfa_bytes = S * 16u;
+
+  // keyword -> tags tables (global keyword id = kw_base[class] + kw)
+  std::vector<uint32_t> kw_first, kw_begin, kw_tags;
+  for (int c = 0; c < K_NCLASS; c++)
+    for (size_t i = 0; i < kw_str[c].size(); i++) {
+      kw_first.push_back(kw_idx[c][i][0]);
+      kw_begin.push_back((uint32_t)kw_tags.size());
+      for (uint32_t k : kw_idx[c][i]) kw_tags.push_back(k);
+    }
+  kw_begin.push_back((uint32_t)kw_tags.size());
+
+  // ---- blob ---------------------------------------------------------------------
+  Blob B;
+  DevTables &R = H.rel;
+  R.n_states = S;
+  R.dfa_bytes = H.dfa_bytes;
+  R.trans = as_off<uint32_t>(B.put(trans));
+  R.st_full = as_off<uint32_t>(B.put(st_full));
+  R.st_out = as_off<uint32_t>(B.put(st_out));
+  R.outs = as_off<uint32_t>(B.put(outs));
+  R.kw_base = as_off<uint32_t>(B.put(kw_base));
+  R.kw_first = as_off<uint32_t>(B.put(kw_first));
+  R.kw_begin = as_off<uint32_t>(B.put(kw_begin));
+  R.kw_tags = as_off<uint32_t>(B.put(kw_tags));
+  {
+    // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged
+    std::vector<uint8_t> comp(256);
+    for (int c = 0; c < 256; c++) comp[c] = (uint8_t)c;
+    const char *ck = "ACGTMRWSYKVHDBXNU", *cv = "TGCAKYWSRMBDHVXNA";
+    for (int i = 0; ck[i]; i++) {
+      comp[(uint8_t)ck[i]] = (uint8_t)cv[i];
+      comp[(uint8_t)(ck[i] + 32)] = (uint8_t)(cv[i] + 32);
+    }
+    R.comp = as_off<uint8_t>(B.put(comp));
+  }
+  for (int g = 0; g < 2; g++) {
+    const GeneHost &G = H.g[g];
+    std::vector<uint8_t> tag_len(G.n), tag_ascii(G.n * 32, 0), reg_bytes, reg_clean(G.n);
+    std::vector<int32_t> jump(G.n);
+    std::vector<uint32_t> reg_off(G.n), reg_len(G.n), reg_pk_off(G.n), reg_pk, reg_pk_rc;
+    for (uint32_t k = 0; k < G.n; k++) {
+      tag_len[k] = (uint8_t)G.tags[k].size();
+      std::memcpy(&tag_ascii[k * 32], G.tags[k].data(), G.tags[k].size());
+      jump[k] = G.jumps[k];
+      reg_off[k] = (uint32_t)reg_bytes.size();
+      reg_len[k] = (uint32_t)G.regions[k].size();
+      reg_bytes.insert(reg_bytes.end(), G.regions[k].begin(), G.regions[k].end());
+      bool clean = true;
+      for (char c : G.regions[k]) if (base_code(c) < 0) clean = false;
+      reg_clean[k] = clean ? 1 : 0;
+      reg_pk_off[k] = (uint32_t)reg_pk.size();
+      pack_region(G.regions[k], false, &reg_pk);
+      pack_region(G.regions[k], true, &reg_pk_rc);
+    }
+    GeneDevPtrs &P = R.g[g];
+    P.n = G.n;
+    P.split = G.split;
+    P.tag_len = as_off<uint8_t>(B.put(tag_len));
+    P.jump = as_off<int32_t>(B.put(jump));
+    P.tag_ascii = as_off<uint8_t>(B.put(tag_ascii));
+    P.reg_off = as_off<uint32_t>(B.put(reg_off));
+    P.reg_len = as_off<uint32_t>(B.put(reg_len));
+    P.reg_bytes = as_off<uint8_t>(B.put(reg_bytes));
+    P.reg_pk_off = as_off<uint32_t>(B.put(reg_pk_off));
+    P.reg_pk = as_off<uint32_t>(B.put(reg_pk));
+    P.reg_pk_rc = as_off<uint32_t>(B.put(reg_pk_rc));
+    P.reg_clean = as_off<uint8_t>(B.put(reg_clean));
+  }
+  B.reserve(64);
+  H.blob.swap(B.bytes);
+  return DCRX_OK;
+}
+
+}  // namespace dcrx

@@ -1,0 +1,112 @@
+"""Multi-GPU sharding of the decombine hot path: one process per GPU, reads split
+into contiguous ranges by rank, a final gather of the DCR tuples on rank 0 and a
+sum of the counters (torch.distributed; backend "nccl" is RCCL over xGMI on
+ROCm, "gloo" in the CPU tests).
+
+The reference is single-process: nothing here mirrors reference
+code.  Each read's result depends only on that read and the replicated tables
+(reference decombine.py:534-585 has no cross-read state but the additive
+Counter, :598), so the only exchange is the final one:
+
+  * contiguous shards, so that concatenating the ranks' outputs in rank order
+    reproduces the reference's input-order `.n12` (outdata.append, :1039);
+  * DCR tuples = the status-OK 16-byte records + their global read indices,
+    compacted on the device (dcrx_compact_hits_device);
+  * counters: all_reduce(sum) of the uint64[32] block.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
+    """[lo, hi) of the reads rank `rank` owns."""
+    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+
+
+def reduce_counters(counters: torch.Tensor) -> torch.Tensor:
+    """Sum of every rank's int64[32] counter block, on every rank."""
+    out = counters.clone()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
+
+
+def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
+    """Gathers each rank's (k_r, 16) uint8 tuple block and (k_r,) int64 index block on
+    `dst`, concatenated in rank order.  Sizes are exchanged first (one small
+    all_gather), then one padded gather per array.  Returns (hits, index) on dst and
+    (None, None) elsewhere."""
+    assert hits.dtype == torch.uint8 and hits.dim() == 2 and hits.shape[1] == 16
+    assert index.dtype == torch.int64 and index.shape[0] == hits.shape[0]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return hits, index
+    world, rank = dist.get_world_size(), dist.get_rank()
+    k = torch.tensor([hits.shape[0]], dtype=torch.int64, device=hits.device)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k)
+    counts = [int(x.item()) for x in ks]
+    kmax = max(counts) if counts else 0
+    pad_h = torch.zeros((kmax, 16), dtype=torch.uint8, device=hits.device)
+    pad_i = torch.zeros((kmax,), dtype=torch.int64, device=hits.device)
+    pad_h[:hits.shape[0]] = hits
+    pad_i[:index.shape[0]] = index
+    if rank == dst:
+        gh = [torch.empty_like(pad_h) for _ in range(world)]
+        gi = [torch.empty_like(pad_i) for _ in range(world)]
+        dist.gather(pad_h, gh, dst=dst)
+        dist.gather(pad_i, gi, dst=dst)
+        return (torch.cat([g[:c] for g, c in zip(gh, counts)]),
+                torch.cat([g[:c] for g, c in zip(gi, counts)]))
+    dist.gather(pad_h, None, dst=dst)
+    dist.gather(pad_i, None, dst=dst)
+    return None, None
+
+
+class TupleGather:
+    """Per-step fixed-capacity gather for the benchmark loop: no host sync inside
+    the timed region.  Every rank compacts its step's tuples on the device and
+    sends the first `cap` of them (cap = reads/2 covers the synthetic mixture's
+    ~42 % decombined reads; `check` verifies that after the run)."""
+
+    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5):
+        from . import _native as nat
+        self.nat = nat
+        self.world, self.rank = world, rank
+        self.cap = int(n_reads * cap_fraction) + 1024
+        self.d_hits = torch.empty(n_reads * 16, dtype=torch.uint8, device=device)
+        self.d_idx = torch.empty(n_reads, dtype=torch.int64, device=device)
+        self.d_n = torch.zeros(1, dtype=torch.int64, device=device)
+        if rank == 0:
+            self.g_hits = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
+            self.g_idx = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(world)]
+            self.g_n = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+
+    def step(self, d_rec: torch.Tensor, n_reads: int, first_index: int, stream_ptr) -> None:
+        nat = self.nat
+        nat.check(nat.lib().dcrx_compact_hits_device(d_rec.data_ptr(), n_reads, first_index,
+                                                     self.d_hits.data_ptr(), self.d_idx.data_ptr(),
+                                                     self.d_n.data_ptr(), stream_ptr))
+        h, i = self.d_hits[:self.cap * 16], self.d_idx[:self.cap]
+        if self.rank == 0:
+            dist.gather(self.d_n, self.g_n, dst=0)
+            dist.gather(h, self.g_hits, dst=0)
+            dist.gather(i, self.g_idx, dst=0)
+        else:
+            dist.gather(self.d_n, None, dst=0)
+            dist.gather(h, None, dst=0)
+            dist.gather(i, None, dst=0)
+
+    def check(self, n_hits_local: int) -> None:
+        if n_hits_local > self.cap:
+            raise RuntimeError(f"rank {self.rank}: {n_hits_local} tuples exceed the gather capacity {self.cap}")
+        if self.rank == 0:
+            got = [int(x.item()) for x in self.g_n]
+            if got[0] != n_hits_local or any(g <= 0 or g > self.cap for g in got):
+                raise RuntimeError(f"gathered tuple counts look wrong: {got}")
+            # rank order = read order: every rank's indices lie in its own shard, ascending
+            for r in range(self.world):
+                idx = self.g_idx[r][:got[r]]
+                if got[r] > 1 and not bool((idx[1:] > idx[:-1]).all()):
+                    raise RuntimeError(f"tuples of rank {r} are not in read order")

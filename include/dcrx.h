@@ -1,0 +1,209 @@
+/*
+ * dcrx.h — C ABI of the MI355X-native `decombine` hot path.
+ *
+ * The reference (innate2adaptive/decombinator, pure Python) has no FFI or plugin
+ * interface; its narrowest seam around this path is
+ *
+ *     decombine.import_tcr_info(inputargs)      src/decombinator/decombine.py:593-746
+ *     decombine.dcr(read, inputargs) -> 7-list  src/decombinator/decombine.py:534-585
+ *     the per-read driver loop                  src/decombinator/decombine.py:963-1050
+ *
+ * Each entry point below names the reference code it replaces.  A maintainer
+ * binds this library with ctypes (INTEGRATION.md shows the stub); all pointers
+ * are plain buffers owned by the caller, the only library-owned object is the
+ * opaque dcrx_tables_t handle.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative dcrx_error; the text of
+ *     the last failure on the calling thread is dcrx_last_error();
+ *   - nothing throws, aborts or prints;
+ *   - a dcrx_tables_t is not thread-safe: serialise calls that share one;
+ *   - "device" pointers are HIP device memory on the current device
+ *     (dcrx_set_device), "host" pointers ordinary process memory.
+ */
+#ifndef DCRX_H
+#define DCRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dcrx_codes.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCRX_ABI_VERSION 1
+
+enum dcrx_error {
+  DCRX_OK = 0,
+  DCRX_E_INVALID = -1,      /* bad argument */
+  DCRX_E_UNSUPPORTED = -2,  /* tag set outside what the device tables can express (see dcrx_tables_create) */
+  DCRX_E_NOMEM = -3,
+  DCRX_E_HIP = -4,          /* a HIP runtime call failed (no GPU, launch failure, ...) */
+  DCRX_E_NOGPU = -5
+};
+
+/* ---- tables: replaces import_tcr_info's module globals (decombine.py:593-746) ---- */
+
+/* What get_v_tags/get_j_tags (decombine.py:820-866) and SeqIO.parse (:683-696)
+ * produce for one chain.  Strings are NUL-terminated; regions may be any case
+ * (the library upper-cases them like `.seq.upper()`, :695). */
+typedef struct dcrx_tagset {
+  uint32_t n_v;
+  const char *const *v_tags;    /* v_seqs */
+  const int32_t *v_jumps;       /* jump_to_end_v */
+  const char *const *v_regions; /* v_regions */
+  uint32_t n_j;
+  const char *const *j_tags;    /* j_seqs */
+  const int32_t *j_jumps;       /* jump_to_start_j */
+  const char *const *j_regions; /* j_regions */
+  int32_t v_half_split;         /* decombine.py:657-661 */
+  int32_t j_half_split;
+} dcrx_tagset_t;
+
+typedef struct dcrx_tables dcrx_tables_t;
+
+typedef struct dcrx_tables_info {
+  uint32_t n_v, n_j;
+  uint32_t n_states;        /* states of the merged V/J/half-tag automaton */
+  uint32_t dfa_bytes;       /* bytes of the LDS-resident transition table */
+  uint32_t n_keywords[6];   /* distinct keywords: V, J, V half1, V half2, J half1, J half2 */
+  uint32_t max_tag_len;
+  uint32_t tables_in_lds;   /* 1 when the transition table fits the LDS budget */
+  uint32_t equal_len_per_automaton; /* 1 when every automaton's keywords share one length (acora tie order then irrelevant) */
+} dcrx_tables_info_t;
+
+/* Compiles the six Aho-Corasick automata of decombine.py:722-746 into one merged
+ * DFA plus the per-tag side tables.  Pure host work: needs no GPU.
+ * DCRX_E_UNSUPPORTED when a tag is empty, longer than 32 nt, has a character
+ * outside ACGT, a half split outside (0, len), a jump outside [-32768, 32767],
+ * or the automaton needs more than 16383 states. */
+int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out);
+void dcrx_tables_destroy(dcrx_tables_t *tables);
+int dcrx_tables_info(const dcrx_tables_t *tables, dcrx_tables_info_t *info);
+
+/* ---- per-read results: replaces dcr()'s return value (decombine.py:572-581) ---- */
+
+/* 16 bytes per read.  When status == DCRX_S_OK:
+ *   [v, j, vdel, jdel, frame_read[ins_start : ins_start+ins_len], v_start, j_end]
+ * is exactly dcr()'s 7-list, with frame_read = revcomp(read) when frame == 0 and
+ * read itself when frame == 1 (decombine.py:1015-1020).  Otherwise every field
+ * but status/frame is 0 and status names the exit path (dcrx_codes.h). */
+typedef struct dcrx_record {
+  uint16_t v, j;
+  uint16_t v_start, j_end;
+  uint16_t ins_start, ins_len;
+  uint8_t vdel, jdel;
+  uint8_t status; /* enum dcrx_status */
+  uint8_t frame;  /* 0 reverse, 1 forward */
+} dcrx_record_t;
+
+/* inputargs keys read on the path: orientation (:999-1010), allowNs (:554),
+ * lenthreshold (:557) */
+typedef struct dcrx_cfg {
+  int32_t orientation; /* enum dcrx_orientation */
+  int32_t allow_ns;
+  int32_t lenthreshold;
+  uint32_t flags;      /* DCRX_F_* */
+} dcrx_cfg_t;
+
+#define DCRX_F_NONE 0u
+#define DCRX_F_FORCE_SLOW_READER 1u /* tests: route every read through the exception-aware reader */
+
+/* A batch of reads, 2-bit packed: base i of read r is bits [2(i%4), 2(i%4)+1] of
+ * byte packed[r*stride + i/4]; A=0 C=1 G=2 T=3.  Bytes of the FASTQ sequence that
+ * are not one of "ACGT" (N, IUPAC codes, lower case) are packed as 0 and listed
+ * as exceptions sorted by (read, pos); the device treats them exactly as the
+ * reference treats the original byte.  stride is a multiple of
+ * 8 with 4*stride >= the longest read and stride <= 80: reads of up to 320 nt
+ * (DCRX_E_UNSUPPORTED beyond). */
+typedef struct dcrx_batch {
+  uint64_t n_reads;         /* < 2^32 per call */
+  const uint8_t *packed;
+  uint32_t stride;
+  uint32_t read_len;        /* length of every read when lens == NULL */
+  const uint16_t *lens;     /* optional per-read lengths */
+  uint64_t n_exc;
+  const uint32_t *exc_read; /* read index, ascending */
+  const uint16_t *exc_pos;  /* position in the read as stored (FASTQ frame), ascending within a read */
+  const uint8_t *exc_chr;   /* the original byte; never one of "ACGT" */
+} dcrx_batch_t;
+
+/* ---- host-side packing (the reads come from readfq, decombine.py:228-265) ---- */
+
+/* Packs n_reads ASCII sequences (concatenated in `ascii`, read r at
+ * [offsets[r], offsets[r+1])) into `packed` (n_reads*stride bytes) and `lens`.
+ * Exceptions go to exc_* (capacity exc_cap).  Returns the number of exceptions
+ * found (which may exceed exc_cap: call again with larger buffers), or a
+ * negative dcrx_error. */
+int64_t dcrx_pack_reads(const char *ascii, const uint64_t *offsets, uint64_t n_reads,
+                        uint32_t stride, uint8_t *packed, uint16_t *lens,
+                        uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
+                        uint64_t exc_cap);
+
+/* Inverse of dcrx_pack_reads: writes lens[r] (or read_len) ASCII bytes of read r
+ * to ascii + offsets[r], exception bytes restored. */
+int dcrx_unpack_reads(const dcrx_batch_t *host_batch, const uint64_t *offsets, char *ascii);
+
+/* ---- the hot path: replaces the body of the read loop, decombine.py:998-1013 ---- */
+
+/* Host buffers in, host buffers out (H2D copy, kernels, D2H copy, synchronous).
+ * records: n_reads entries; counters: DCRX_N_COUNTERS uint64, OVERWRITTEN with
+ * this batch's tallies (the caller adds them into its Counter). */
+int dcrx_decombine(dcrx_tables_t *tables, const dcrx_cfg_t *cfg, const dcrx_batch_t *host_batch,
+                   dcrx_record_t *records, uint64_t *counters);
+
+/* Device buffers in, device buffers out, asynchronous on `hip_stream`
+ * (a hipStream_t, NULL = default stream).  Every pointer inside `device_batch`,
+ * d_records and d_counters (DCRX_N_COUNTERS uint64, overwritten) are device
+ * memory.  No allocation and no synchronisation happens inside once the tables
+ * have been used on this device with a batch at least this large
+ * (dcrx_reserve_device does that up front). */
+int dcrx_decombine_device(dcrx_tables_t *tables, const dcrx_cfg_t *cfg,
+                          const dcrx_batch_t *device_batch, dcrx_record_t *d_records,
+                          uint64_t *d_counters, void *hip_stream);
+
+/* Profiling aid: the following dcrx_decombine_device calls on `tables` record
+ * start_event right before and stop_event right after the main decombine kernel,
+ * on the stream that kernel is launched on (hipEvent_t handles, e.g. from
+ * dcrx_event_create).  NULL, NULL switches it off. */
+int dcrx_set_timing_events(dcrx_tables_t *tables, void *start_event, void *stop_event);
+
+/* Uploads the tables to the current device and sizes the per-launch workspace
+ * for batches of up to max_reads reads. */
+int dcrx_reserve_device(dcrx_tables_t *tables, uint64_t max_reads);
+
+/* Compacts the status==OK records of a batch (the DCR tuples that are gathered
+ * across GPUs): d_hits gets the records in input order, d_hit_index their read
+ * indices (first_index + position), d_n_hits (one uint64) the count. */
+int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
+                             dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits,
+                             void *hip_stream);
+
+/* ---- device plumbing for callers without a HIP binding of their own ---- */
+int dcrx_device_count(void);
+int dcrx_set_device(int device);
+int dcrx_device_name(char *buf, size_t cap);
+int dcrx_malloc_device(void **ptr, size_t bytes);
+int dcrx_free_device(void *ptr);
+int dcrx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
+int dcrx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
+int dcrx_memset_device(void *dst_device, int value, size_t bytes);
+int dcrx_synchronize(void);
+/* HIP events on a stream, for timing the launches above where they run */
+int dcrx_event_create(void **event);
+int dcrx_event_destroy(void *event);
+int dcrx_event_record(void *event, void *hip_stream);
+int dcrx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+int dcrx_abi_version(void);
+const char *dcrx_last_error(void);
+/* 1 when the HIP kernels are compiled in (always, in this library), and the
+ * gfx target they were built for */
+const char *dcrx_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCRX_H */

@@ -1,0 +1,44 @@
+// emul.cpp — TEST-ONLY host build of the per-read device code
+// (decombinator_amd/csrc/dcrx_dcr_device.h) so that the exact functions the HIP
+// kernel runs can be checked against the oracle, and run under ASan/UBSan,
+// without a GPU.  It is never linked into libdcrx.so and nothing under
+// decombinator_amd/ refers to it.  It does NOT replace the GPU parity tests:
+// the kernel's launch geometry, LDS staging, counter reduction and the real
+// ISA are only exercised by `pytest -m gpu`.
+#define DCRX_HOST_EMUL 1
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../decombinator_amd/csrc/dcrx_dcr_device.h"
+#include "../../decombinator_amd/csrc/dcrx_tables.h"
+
+using namespace dcrx;
+
+extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
+                              dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
+  HostTables H;
+  std::string e;
+  int rc = compile_tables(ts, &H, &e);
+  if (rc) { std::strncpy(err, e.c_str(), (size_t)err_cap - 1); err[err_cap - 1] = 0; return rc; }
+  const DevTables T = H.resolve(H.blob.data());
+  std::vector<uint32_t> flag((b->n_reads + 31) / 32 + 1, 0);
+  for (uint64_t i = 0; i < b->n_exc; i++) flag[b->exc_read[i] >> 5] |= 1u << (b->exc_read[i] & 31);
+  // reads are copied with a padded tail so that the word-pair loads stay in bounds
+  std::vector<uint8_t> packed(b->n_reads * (size_t)b->stride + 4 * DCRX_NWMAX + 16, 0);
+  std::memcpy(packed.data(), b->packed, b->n_reads * (size_t)b->stride);
+  BatchDev B;
+  B.packed = packed.data(); B.stride = b->stride; B.read_len = b->read_len; B.lens = b->lens;
+  B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
+  B.exc_chr = b->exc_chr; B.exc_flag = flag.data();
+  CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
+  uint32_t counts[DCRX_N_COUNTERS] = {0};
+  Counters CC{counts};
+  for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
+  for (uint64_t r = 0; r < b->n_reads; r++) {
+    if (b->lens) decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+    else decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+    for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
+  }
+  return 0;
+}

@@ -1,0 +1,182 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libdcrx.so),
+against (1) the golden vectors captured from the reference, (2) the CPU oracle
+on seeded synthetic reads, and (3) size-independent properties at
+BASELINE.json's full size.  Bit-exact: every field of every 16-byte record and
+every counter."""
+import numpy as np
+import pytest
+
+from decombinator_amd import _native as nat
+from decombinator_amd import synth
+from oracle import oracle as orc
+from tests import golden_util as gu
+from tests import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(ts):
+    vs, js = ts.half_splits
+    t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, vs, js)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], vs, js)
+    return t, ot
+
+
+def test_gpu_present_and_native_library_loaded():
+    assert nat.device_count() >= 1
+    assert "gfx950" in nat.device_name()
+
+
+@pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
+@pytest.mark.parametrize("flags", [0, nat.F_FORCE_SLOW_READER], ids=["fast", "slowreader"])
+def test_hip_matches_golden_and_oracle(path, flags):
+    assert pu.check_fixture("hip", path, flags) > 500
+
+
+@pytest.mark.parametrize("config,seed,sub,n", [(2, 2, 0.005, 1_000_000), (5, 5, 0.02, 300_000)])
+def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n):
+    ts = synth.config_tagset(config)
+    t, ot = _tables(ts)
+    cfg = nat.synth_cfg(seed=seed, sub_rate=sub, n_rate=0.0005)
+    hb = nat.synth_reads_host(t, cfg, 0, n)
+    rec, cnt = nat.decombine(t, hb)
+    reads = nat.unpack_reads(hb)
+    orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+    pu.assert_records_equal(rec, orec, reads, f"config {config}")
+    pu.assert_counters_equal(cnt, ocnt, f"config {config}")
+    assert 0.3 < int(cnt[19]) / n < 0.46
+
+
+def test_config3_both_chains_bit_exact_vs_oracle():
+    n = 300_000
+    for ts, seed in zip(synth.config3_tagsets(), (3, 33)):
+        t, ot = _tables(ts)
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=seed), 0, n)
+        rec, cnt = nat.decombine(t, hb)
+        reads = nat.unpack_reads(hb)
+        orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(rec, orec, reads, ts.chain)
+        pu.assert_counters_equal(cnt, ocnt, ts.chain)
+
+
+def test_device_generator_equals_host_generator():
+    ts = synth.config_tagset(2)
+    t, _ = _tables(ts)
+    cfg = nat.synth_cfg(seed=2)
+    n = 200_000
+    hb = nat.synth_reads_host(t, cfg, 12345, n)
+    db = nat.synth_reads_device(t, cfg, 12345, n)
+    nat.synchronize()
+    got = db.packed.to_host(np.uint8, n * db.stride).reshape(n, db.stride)
+    assert (got == hb.packed).all()
+
+
+@pytest.mark.parametrize("orientation", ["forward", "both"])
+def test_orientations_on_mixed_strands(orientation):
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=7, n_rate=0.002), 0, 200_000)
+    reads = nat.unpack_reads(hb)
+    # flip every other read to the sense strand so both frames see rearrangements
+    reads = [orc.revcomp(r) if i % 2 else r for i, r in enumerate(reads)]
+    b = nat.pack_reads(reads)
+    rec, cnt = nat.decombine(t, b, orientation=orientation)
+    orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+    pu.assert_records_equal(rec, orec, reads, orientation)
+    pu.assert_counters_equal(cnt, ocnt, orientation)
+    assert int(cnt[22]) > 10_000  # frame_forward
+
+
+def test_ragged_lengths_and_empty_reads():
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    rng = np.random.default_rng(11)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=9, read_len=320, n_rate=0.01), 0, 60_000, stride=80)
+    reads = nat.unpack_reads(hb)
+    cut = rng.integers(0, 321, size=len(reads))
+    start = rng.integers(0, 120, size=len(reads))
+    reads = [r[s:s + c] if i % 3 else r[:c] for i, (r, s, c) in enumerate(zip(reads, start, cut))]
+    reads[0] = ""
+    reads[-1] = ""
+    b = nat.pack_reads(reads, stride=80)
+    assert b.lens is not None
+    for allow in (False, True):
+        rec, cnt = nat.decombine(t, b, allow_ns=allow)
+        orec, ocnt = pu.oracle_records(ot, reads, "reverse", allow, 130)
+        pu.assert_records_equal(rec, orec, reads, "ragged")
+        pu.assert_counters_equal(cnt, ocnt, "ragged")
+
+
+def test_empty_batch_and_single_read():
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    rec, cnt = nat.decombine(t, nat.pack_reads([]))
+    assert len(rec) == 0 and int(cnt.sum()) == 0
+    rec, cnt = nat.decombine(t, nat.pack_reads(["ACGT" * 37 + "AC"]))
+    assert len(rec) == 1 and int(cnt[20]) == 1
+
+
+def test_full_size_10M_properties_and_sampled_blocks():
+    """BASELINE config 2 at full size, device-resident: counters equal the status
+    histogram, chunked runs add up to the whole (linearity), and 16 sampled
+    64k-read blocks are bit-exact against the oracle."""
+    n = 10_000_000
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    cfg = nat.synth_cfg(seed=2)
+    db = nat.synth_reads_device(t, cfg, 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    rec = d_rec.to_host(nat.RECORD_DTYPE, n)
+    cnt = d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+    hist = np.bincount(rec["status"], minlength=16)
+    assert int(cnt[20]) == n and int(hist.sum()) == n
+    assert int(cnt[19]) == int(hist[0])
+    assert int(cnt[5]) == int(hist[6])           # no_vtags_found == V_NONE exits
+    assert int(cnt[15]) == int(hist[7:12].sum())  # VJ_assignment_failed == all J exits
+    assert 0.38 < hist[0] / n < 0.45
+    # linearity: four quarter-size launches on sub-ranges reproduce records and counters
+    q = n // 4
+    tot = np.zeros(nat.N_COUNTERS, dtype=np.uint64)
+    for k in range(4):
+        sub = nat.synth_reads_device(t, cfg, k * q, q)
+        d_r = nat.DeviceBuffer(q * 16)
+        d_c = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+        nat.decombine_device(t, sub, d_r, d_c)
+        nat.synchronize()
+        assert d_r.to_host(nat.RECORD_DTYPE, q).tobytes() == rec[k * q:(k + 1) * q].tobytes()
+        tot += d_c.to_host(np.uint64, nat.N_COUNTERS)
+    assert (tot == cnt).all()
+    # sampled blocks against the oracle
+    rng = np.random.default_rng(1)
+    blk = 65_536
+    for b0 in rng.integers(0, n // blk, size=16):
+        first = int(b0) * blk
+        hb = nat.synth_reads_host(t, cfg, first, blk)
+        reads = nat.unpack_reads(hb)
+        orec, _ = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(rec[first:first + blk], orec, reads, f"block {b0}")
+
+
+def test_compact_hits_matches_numpy():
+    n = 1_000_003
+    ts = synth.config_tagset(2)
+    t, _ = _tables(ts)
+    db = nat.synth_reads_device(t, nat.synth_cfg(seed=4), 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec, d_cnt)
+    d_hits = nat.DeviceBuffer(n * 16)
+    d_idx = nat.DeviceBuffer(n * 8)
+    d_n = nat.DeviceBuffer(8)
+    nat.compact_hits_device(d_rec, n, 5_000_000, d_hits, d_idx, d_n)
+    nat.synchronize()
+    rec = d_rec.to_host(nat.RECORD_DTYPE, n)
+    k = int(d_n.to_host(np.uint64, 1)[0])
+    ok = np.nonzero(rec["status"] == 0)[0]
+    assert k == len(ok)
+    assert d_hits.to_host(nat.RECORD_DTYPE, k).tobytes() == rec[ok].tobytes()
+    assert (d_idx.to_host(np.uint64, k) == ok.astype(np.uint64) + 5_000_000).all()
