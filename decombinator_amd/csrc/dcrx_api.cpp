@@ -49,6 +49,7 @@ struct dcrx_tables {
   uint32_t *d_block_counts = nullptr;
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
+  uint32_t *d_queue = nullptr;  // [exc_flag_reads + 1]: slot 0 = count, then read indices
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
   uint64_t compact_reads = 0;
@@ -61,9 +62,9 @@ struct dcrx_tables {
 
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
-  (void)hipFree(t->d_blob); (void)hipFree(t->d_block_counts); (void)hipFree(t->d_exc_flag);
+  (void)hipFree(t->d_blob); (void)hipFree(t->d_block_counts); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue);
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
-  t->d_blob = nullptr; t->d_block_counts = nullptr; t->d_exc_flag = nullptr;
+  t->d_blob = nullptr; t->d_block_counts = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
   t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
 }
@@ -167,17 +168,22 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     const uint32_t lds_cap = 160 * 1024;
     const uint32_t want = t->host.dfa_bytes + DCRX_N_COUNTERS * 4;
     LaunchPlan P;
+    P.n_cu = (uint32_t)prop.multiProcessorCount;
     P.table_in_lds = want <= 144 * 1024;
     P.lds_bytes = P.table_in_lds ? want : DCRX_N_COUNTERS * 4;
     uint32_t per_cu = std::min<uint32_t>(2048 / DCRX_BLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+    const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
+    P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
     t->plan = P;
-    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)P.grid * DCRX_N_COUNTERS * 4));
+    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid) * DCRX_N_COUNTERS * 4));
     t->device = dev;
   }
   if (max_reads > t->exc_flag_reads) {
     (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
+    (void)hipFree(t->d_queue); t->d_queue = nullptr;
     HIP_TRY(hipMalloc(&t->d_exc_flag, ((max_reads + 31) / 32) * 4 + 16));
+    HIP_TRY(hipMalloc(&t->d_queue, (max_reads + 4) * 4));
     t->exc_flag_reads = max_reads;
   }
   if (max_reads > t->compact_reads) {
@@ -229,7 +235,8 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
-  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, d_counters, (hipStream_t)stream,
+  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, t->d_queue + 4, t->d_queue, d_counters,
+                           (hipStream_t)stream,
                            t->ev_start, t->ev_stop));
   return DCRX_OK;
 }

@@ -18,6 +18,8 @@ DCRX_DEV uint32_t dcrx_funnel_r(uint32_t lo, uint32_t hi, uint32_t sh) { return 
 DCRX_DEV int dcrx_sbfe(int v, uint32_t off, uint32_t w) { return __builtin_amdgcn_sbfe(v, off, w); }
 DCRX_DEV uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
 DCRX_DEV void dcrx_atomic_inc(uint32_t *p) { atomicAdd(p, 1u); }
+DCRX_DEV int dcrx_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }
+DCRX_DEV int dcrx_clz64(uint64_t v) { return __clzll((long long)v); }
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
 }
@@ -34,6 +36,8 @@ inline uint32_t dcrx_funnel_r(uint32_t lo, uint32_t hi, uint32_t sh) {
 inline int dcrx_sbfe(int v, uint32_t off, uint32_t w) { return (int)((uint32_t)v << (32 - off - w)) >> (32 - w); }
 inline uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
 inline void dcrx_atomic_inc(uint32_t *p) { ++*p; }
+inline int dcrx_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
 struct uint2 { uint32_t x, y; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
@@ -109,7 +113,48 @@ struct Frame {
     uint32_t v = dcrx_funnel_r(w0, w1, sh);
     return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
   }
+  // 32 bases of the packed FORWARD read starting at forward position b (slot y = base b+y);
+  // caller guarantees 0 <= b and b+32 <= n.
+  DCRX_DEV uint64_t load64(int b) const {
+    const int bit = b * 2, i = bit >> 5, sh = bit & 31;
+    const uint32_t w0 = r.words[i], w1 = r.words[i + 1];
+    const uint32_t w2 = sh ? r.words[i + 2] : 0u;
+    return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+  }
 };
+
+// ---- bit-parallel 10-mer window search over 32-base words -------------------------
+// One bit per base slot (at bit 2*slot): set where two 2-bit-packed words differ.
+DCRX_DEV uint64_t mismatch_slots(uint64_t a, uint64_t b) {
+  const uint64_t x = a ^ b;
+  return (x | (x >> 1)) & 0x5555555555555555ull;
+}
+// bit 2t = OR of slots t..t+9 (meaningful for t <= 22)
+DCRX_DEV uint64_t or10_up(uint64_t y) {
+  const uint64_t a2 = y | (y >> 2), a4 = a2 | (a2 >> 4), a8 = a4 | (a4 >> 8);
+  return a8 | (a2 >> 16);
+}
+// bit 2t = OR of slots t-9..t (meaningful for t >= 9)
+DCRX_DEV uint64_t or10_down(uint64_t y) {
+  const uint64_t a2 = y | (y << 2), a4 = a2 | (a2 << 4), a8 = a4 | (a4 << 8);
+  return a8 | (a2 << 16);
+}
+// smallest k in [k0, 22] whose window is mismatch-free, or -1.
+// UP: window k = slots k..k+9 (z = or10_up);  DOWN: window k = slots 22-k..31-k (z = or10_down)
+DCRX_DEV int first_clean_up(uint64_t z, int k0) {
+  if (k0 > 22) return -1;
+  const uint64_t allowed = (0x5555555555555555ull >> (2 * k0) << (2 * k0)) & ((1ull << 46) - 1ull);
+  const uint64_t cand = ~z & allowed;
+  return cand ? (dcrx_ctz64(cand) >> 1) : -1;
+}
+DCRX_DEV int first_clean_down(uint64_t z, int k0) {
+  if (k0 > 22) return -1;
+  // slots 9 .. 31-k0
+  const uint64_t upto = (k0 == 0) ? ~0ull : ((1ull << (2 * (32 - k0))) - 1ull);
+  const uint64_t allowed = 0x5555555555555555ull & upto & ~((1ull << 18) - 1ull);
+  const uint64_t cand = ~z & allowed;
+  return cand ? 31 - ((63 - dcrx_clz64(cand)) >> 1) : -1;
+}
 
 // Python s[a:b] bounds on a sequence of length n
 DCRX_DEV void pyslice(int n, int a, int b, int &lo, int &hi) {
@@ -162,6 +207,14 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v
   int pos = Lg - 10;                                        // :754-756
   if (f >= n) { C.add(DCRX_C_V_DEL_FAILED_TAG_AT_END); return false; }  // :760-762
   f += 1;                                                   // :764
+  // Bit-parallel form of the loop below for the common geometry: the first 23 iterations
+  // only touch read[f-32:f] and the last 32 germline bases, all whole 10-mers of pure ACGT.
+  if (f >= 32 && f < n && !F.has_exc() && G.w64_ok[v_match]) {
+    const uint64_t rw = REV ? F.load64(n - f) : F.load64(f - 32);
+    const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[v_match] : G.w64_fwd[v_match]);
+    const int k = REV ? first_clean_up(or10_up(y), 0) : first_clean_down(or10_down(y), 0);
+    if (k >= 0) { deletions_v = k; end_v = temp_end_v - k; return true; }
+  }
   int num_del = 0;                                          // :765
   while (0 <= f && f < n) {                                 // :767
     if (slice_eq<REV>(G, v_match, pos, pos + 10, F, f - 10, f)) {  // :769-772
@@ -182,6 +235,15 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j
   const int n = F.n();
   int f = temp_start_j;                                     // :792
   int pos = 0;                                              // :793
+  // Bit-parallel form of the loop below while it stays inside read[ts:ts+32] and the first
+  // 32 germline bases: skipped steps (f < end_of_v, :798-800) only raise the first position tried.
+  if (f >= 0 && f + 32 <= n && !F.has_exc() && G.w64_ok[j_match]) {
+    const int k0 = end_of_v > f ? end_of_v - f : 0;
+    const uint64_t rw = REV ? F.load64(n - f - 32) : F.load64(f);
+    const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[j_match] : G.w64_fwd[j_match]);
+    const int k = REV ? first_clean_down(or10_down(y), k0) : first_clean_up(or10_up(y), k0);
+    if (k >= 0) { deletions_j = k; start_j = f + k; return true; }
+  }
   while (0 <= f + 2 && f + 2 < n) {                         // :795
     if (f < end_of_v) { pos += 1; f += 1; }                 // :798-800
     else if (slice_eq<REV>(G, j_match, pos, pos + 10, F, f, f + 10)) {  // :802-805
@@ -218,14 +280,15 @@ DCRX_DEV uint32_t trans_at(const uint32_t *lds_trans, const DevTables &T, uint32
 // (:420-531).  Re-scans the frame and, at every state where a keyword of class
 // CLS ends, walks that keyword's candidate tags in ascending index order — the
 // same order as iterating findall()'s list and the `indices` comprehension.
-// GENE 0 = V, 1 = J; HALF 1 or 2.  Returns true with `out` filled on success;
+// GENE 0 = V, 1 = J; HALF 1 or 2 are run-time values so that the lanes of a wave can
+// rescue different classes side by side.  Returns true with `out` filled on success;
 // otherwise the caller bumps the "found half not other half" counter.
 // ------------------------------------------------------------------------------
-template <bool REV, bool TABLE_LDS, int GENE, int HALF>
-DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, int end_of_v,
-                       XDat &out, const Counters &C) {
-  constexpr int CLS = (GENE == 0) ? (HALF == 1 ? K_VH1 : K_VH2) : (HALF == 1 ? K_JH1 : K_JH2);
-  constexpr int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
+template <bool REV, bool TABLE_LDS>
+DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, const int GENE,
+                       const int HALF, int end_of_v, XDat &out, const Counters &C) {
+  const int CLS = (GENE == 0) ? (HALF == 1 ? K_VH1 : K_VH2) : (HALF == 1 ? K_JH1 : K_JH2);
+  const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
   const GeneDevPtrs &G = T.g[GENE];
   const int n = F.n();
   const int split = G.split;
@@ -348,7 +411,11 @@ DCRX_DEVNI ScanOut scan_slow(const DevTables &T, const uint32_t *lds_trans, cons
 // janalysis :397-531 folded around the single scan.  Returns the status and
 // fills `rec` on DCRX_S_OK.
 // ------------------------------------------------------------------------------
-template <bool REV, bool TABLE_LDS>
+// DEFER: return DCRX_S_DEFER instead of entering a half-tag rescue (the fast kernel hands
+// such reads to the queue kernel); a deferred read has touched no counter.
+constexpr int DCRX_S_DEFER = 255;
+
+template <bool REV, bool TABLE_LDS, bool DEFER>
 DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, const ScanOut &so,
                          const dcrx::CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
   const Frame<REV> F(rv);
@@ -372,13 +439,12 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
       if (!get_v_deletions<REV>(GV, F, v, te, end_v, dels, C))                      // :288-290
         return (te >= n) ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;         // :760-762 / :783-785
       vdat = XDat{v, end_v, dels, p};
-    } else if ((so.acc >> TE_VH1_BIT) & 1u) {                // :294-335
-      if (!rescue<REV, TABLE_LDS, 0, 1>(T, lds_trans, F, 0, vdat, C)) {
-        C.add(DCRX_C_FOUNDV1NOTV2); return DCRX_S_V_HALF1_EXHAUSTED;
-      }
-    } else if ((so.acc >> TE_VH2_BIT) & 1u) {                // :339-390
-      if (!rescue<REV, TABLE_LDS, 0, 2>(T, lds_trans, F, 0, vdat, C)) {
-        C.add(DCRX_C_FOUNDV2NOTV1); return DCRX_S_V_HALF2_EXHAUSTED;
+    } else if ((so.acc >> TE_VH1_BIT) & 3u) {                // a V half1 (:294-335) or half2 (:339-390) keyword occurs
+      if (DEFER) return DCRX_S_DEFER;
+      const int half = ((so.acc >> TE_VH1_BIT) & 1u) ? 1 : 2;  // half2 is tried only when no half1 hit exists
+      if (!rescue<REV, TABLE_LDS>(T, lds_trans, F, 0, half, 0, vdat, C)) {
+        C.add(half == 1 ? DCRX_C_FOUNDV1NOTV2 : DCRX_C_FOUNDV2NOTV1);       // :334 / :389
+        return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : DCRX_S_V_HALF2_EXHAUSTED;
       }
     } else {
       C.add(DCRX_C_NO_VTAGS_FOUND); return DCRX_S_V_NONE;    // :393-394
@@ -402,13 +468,12 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
       int start_j, dels;
       if (get_j_deletions<REV>(GJ, F, j, ts, end_of_v, start_j, dels, C)) jdat = XDat{j, start_j, dels, p + Lj};  // :411-418
       else jstatus = DCRX_S_J_WALK_FAIL;
-    } else if ((so.acc >> TE_JH1_BIT) & 1u) {                // :422-470
-      if (!rescue<REV, TABLE_LDS, 1, 1>(T, lds_trans, F, end_of_v, jdat, C)) {
-        C.add(DCRX_C_FOUNDJ1NOTJ2); jstatus = DCRX_S_J_HALF1_EXHAUSTED;
-      }
-    } else if ((so.acc >> TE_JH2_BIT) & 1u) {                // :473-527
-      if (!rescue<REV, TABLE_LDS, 1, 2>(T, lds_trans, F, end_of_v, jdat, C)) {
-        C.add(DCRX_C_FOUNDV2NOTV1); jstatus = DCRX_S_J_HALF2_EXHAUSTED;  // :526 bumps the V key
+    } else if ((so.acc >> TE_JH1_BIT) & 3u) {                // a J half1 (:422-470) or half2 (:473-527) keyword occurs
+      if (DEFER) return DCRX_S_DEFER;                        // nothing has been counted for this read yet
+      const int half = ((so.acc >> TE_JH1_BIT) & 1u) ? 1 : 2;
+      if (!rescue<REV, TABLE_LDS>(T, lds_trans, F, 1, half, end_of_v, jdat, C)) {
+        C.add(half == 1 ? DCRX_C_FOUNDJ1NOTJ2 : DCRX_C_FOUNDV2NOTV1);       // :469 / :526 (the reference bumps the V key)
+        jstatus = half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : DCRX_S_J_HALF2_EXHAUSTED;
       }
     } else {
       C.add(DCRX_C_NO_J_ASSIGNED); jstatus = DCRX_S_J_NONE;  // :530-531
@@ -454,7 +519,7 @@ DCRX_DEV int attempt(const DevTables &T, const uint32_t *lds_trans, const ReadVi
   ScanOut so;
   if (!slow) so = scan_fast<REV, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
   else so = scan_slow<REV, TABLE_LDS>(T, lds_trans, Frame<REV>(rv));
-  return dcr_frame<REV, TABLE_LDS>(T, lds_trans, rv, so, cfg, C, rec);
+  return dcr_frame<REV, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec);
 }
 
 
@@ -513,6 +578,56 @@ DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const
   }
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
   dcrx_store_record(records + r, rec);
+}
+
+// ------------------------------------------------------------------------------
+// Fast-kernel form of decombine_one: clean reads (no exception bytes), one frame,
+// no half-tag rescue.  Returns false — having touched neither counters nor the
+// record — when the read needs the general path (decombine_one, run by the queue
+// kernel): exception bytes, orientation `both`, or a half-tag rescue.
+// ------------------------------------------------------------------------------
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+DCRX_DEV bool decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
+                                 const CfgDev &cfg, uint64_t r, uint32_t nw, const Counters &C,
+                                 dcrx_record_t *records) {
+  if (cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER)) return false;
+  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) return false;
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  uint32_t w[DCRX_NWMAX];
+  {
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
+#pragma unroll
+    for (int k = 0; k < DCRX_NWMAX / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw) t = wp2[k];
+      w[2 * k] = t.x; w[2 * k + 1] = t.y;
+    }
+  }
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
+    const ScanOut so = scan_fast<false, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+    status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1;
+  } else {                                                            // :999-1001
+    const ScanOut so = scan_fast<true, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+    status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0;
+  }
+  if (status == DCRX_S_DEFER) return false;
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+  return true;
 }
 
 }  // namespace dcrx

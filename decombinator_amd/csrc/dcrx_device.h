@@ -41,6 +41,13 @@ struct GeneDevPtrs {
   const uint32_t *reg_pk;      // 2-bit packed region (base i at bits 2(i%16) of word i/16)
   const uint32_t *reg_pk_rc;   // 2-bit packed reverse complement of the region
   const uint8_t *reg_clean;    // 1 when the region is pure ACGT (packed compare allowed)
+  // 32-base window at the end the walk starts from (V: last 32 nt, J: first 32 nt), for
+  // the bit-parallel walk: w64_fwd slot s (bits 2s..2s+1) = window base s; w64_rc slot y =
+  // complement of window base 31-y (the window as the packed FORWARD read shows it when the
+  // frame is the reverse complement); w64_ok = region has >= 32 nt and the window is pure ACGT
+  const uint64_t *w64_fwd;
+  const uint64_t *w64_rc;
+  const uint8_t *w64_ok;
 };
 
 struct DevTables {

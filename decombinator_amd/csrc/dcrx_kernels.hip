@@ -24,6 +24,8 @@
 // scan, HBM for the packed reads (40 B) and records (16 B).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/dcrx.h"
 #include "dcrx_device.h"
 #include "dcrx_launch.h"
@@ -32,13 +34,18 @@
 namespace dcrx {
 
 // ------------------------------------------------------------------------------
-// Main kernel: persistent blocks, each stages the DFA into LDS once and then
-// strides over tiles of blockDim reads.
+// Fast kernel: persistent blocks, each stages the DFA into LDS once and then
+// strides over tiles of DCRX_BLOCK reads.  Reads that need the general path
+// (half-tag rescue, exception bytes, orientation `both`) are compacted with a
+// wavefront ballot into a queue of read indices for the queue kernel, so that the
+// rare, long, divergent work runs in dense waves instead of stalling this one.
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, BatchDev B, CfgDev cfg,
                                                                dcrx_record_t *__restrict__ records,
-                                                               uint32_t *__restrict__ block_counts) {
+                                                               uint32_t *__restrict__ block_counts,
+                                                               uint32_t *__restrict__ queue,
+                                                               uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_trans = smem + DCRX_N_COUNTERS;       // [n_states*4] when TABLE_LDS
@@ -52,12 +59,52 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
   __syncthreads();
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
+  const int lane = tid & 63;
 
   for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
     const uint64_t r = tile * DCRX_BLOCK + tid;
-    if (r >= B.n_reads) continue;
-    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    bool defer = false;
+    if (r < B.n_reads) defer = !decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    const unsigned long long m = __ballot(defer);
+    if (m) {
+      const int leader = __ffsll(m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(queue_count, (uint32_t)__popcll(m));
+      base = __shfl(base, leader);
+      if (defer) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+    }
   }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
+}
+
+// Queue kernel: the general per-read path (decombine_one) over the compacted queue.
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables T, BatchDev B, CfgDev cfg,
+                                                                      dcrx_record_t *__restrict__ records,
+                                                                      uint32_t *__restrict__ block_counts,
+                                                                      const uint32_t *__restrict__ queue,
+                                                                      const uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_trans = smem + DCRX_N_COUNTERS;
+  const int tid = threadIdx.x;
+  const uint32_t n_queued = *queue_count;
+  if ((uint64_t)blockIdx.x * DCRX_QBLOCK >= n_queued) {  // nothing for this block: its tallies are zero
+    if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
+    return;
+  }
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  if (TABLE_LDS) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(T.trans);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
+    for (uint32_t i = tid; i < T.n_states; i += DCRX_QBLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Counters C{lds_counts};
+  const uint32_t nw = B.stride >> 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK)
+    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], nw, C, records);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
@@ -162,21 +209,57 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM>
-static hipError_t launch_one(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                             dcrx_record_t *rec, uint32_t *block_counts, hipStream_t s) {
-  auto kfn = decombine_kernel<TABLE_LDS, UNIFORM>;
+static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
+                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *queue_count,
+                              hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
+  auto kqueue = decombine_queue_kernel<TABLE_LDS, UNIFORM>;
   if (P.lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kqueue), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)P.lds_bytes);
+    if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kfn, dim3(P.grid), dim3(DCRX_BLOCK), P.lds_bytes, s, T, B, cfg, rec, block_counts);
-  return hipGetLastError();
+  hipError_t e;
+  // persistent grids: exactly as many blocks as are resident at once (a larger grid would run in
+  // two rounds and leave the tiles of the late blocks for the end)
+  static int occ_fast = 0, occ_queue = 0;
+  if (!occ_fast) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, DCRX_BLOCK, P.lds_bytes);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_queue, kqueue, DCRX_QBLOCK, P.lds_bytes);
+    if (e != hipSuccess) return e;
+    if (occ_fast < 1) occ_fast = 1;
+    if (occ_queue < 1) occ_queue = 1;
+  }
+  const uint32_t grid = std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
+  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_queue);
+  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), P.lds_bytes, s, T, B, cfg, rec, block_counts, queue,
+                     queue_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(kqueue, dim3(qgrid), dim3(DCRX_QBLOCK), P.lds_bytes, s, T, B, cfg, rec,
+                     block_counts + (size_t)P.grid * DCRX_N_COUNTERS, queue, queue_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // blocks that were not launched contribute zero tallies
+  if (grid < P.grid) {
+    e = hipMemsetAsync(block_counts + (size_t)grid * DCRX_N_COUNTERS, 0, (size_t)(P.grid - grid) * DCRX_N_COUNTERS * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  if (qgrid < P.qgrid)
+    e = hipMemsetAsync(block_counts + (size_t)(P.grid + qgrid) * DCRX_N_COUNTERS, 0,
+                       (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
+  return e;
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                            dcrx_record_t *rec, uint32_t *block_counts, uint64_t *d_counters, hipStream_t s,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *queue_count,
+                            uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   hipError_t e;
   if (B.n_exc) {
     e = hipMemsetAsync(const_cast<uint32_t *>(B.exc_flag), 0, ((B.n_reads + 31) / 32) * 4, s);
@@ -185,18 +268,18 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
     hipLaunchKernelGGL(mark_exceptions_kernel, dim3(g), dim3(256), 0, s, B.exc_read, B.n_exc,
                        const_cast<uint32_t *>(B.exc_flag));
   }
+  e = hipMemsetAsync(queue_count, 0, 4, s);
+  if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
-  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (P.table_in_lds) {
-    e = uniform ? launch_one<true, true>(P, T, B, cfg, rec, block_counts, s)
-                : launch_one<true, false>(P, T, B, cfg, rec, block_counts, s);
+    e = uniform ? launch_pair<true, true>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop)
+                : launch_pair<true, false>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop);
   } else {
-    e = uniform ? launch_one<false, true>(P, T, B, cfg, rec, block_counts, s)
-                : launch_one<false, false>(P, T, B, cfg, rec, block_counts, s);
+    e = uniform ? launch_pair<false, true>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop)
+                : launch_pair<false, false>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop);
   }
   if (e != hipSuccess) return e;
-  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(64), 0, s, block_counts, (int)P.grid, d_counters);
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(64), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
   return hipGetLastError();
 }
 

@@ -7,7 +7,8 @@
 // words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
 #define DCRX_NWMAX 20
 #define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
-#define DCRX_BLOCK 512
+#define DCRX_BLOCK 512   /* fast kernel */
+#define DCRX_QBLOCK 256  /* queue kernel */
 
 namespace dcrx {
 

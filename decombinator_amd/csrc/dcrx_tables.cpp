@@ -82,7 +82,7 @@ DevTables HostTables::resolve(const uint8_t *base) const {
   for (int g = 0; g < 2; g++) {
     fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].reg_off);
     fix(d.g[g].reg_len); fix(d.g[g].reg_bytes); fix(d.g[g].reg_pk_off); fix(d.g[g].reg_pk);
-    fix(d.g[g].reg_pk_rc); fix(d.g[g].reg_clean);
+    fix(d.g[g].reg_pk_rc); fix(d.g[g].reg_clean); fix(d.g[g].w64_fwd); fix(d.g[g].w64_rc); fix(d.g[g].w64_ok);
   }
   return d;
 }
@@ -286,6 +286,8 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     std::vector<uint8_t> tag_len(G.n), tag_ascii(G.n * 32, 0), reg_bytes, reg_clean(G.n);
     std::vector<int32_t> jump(G.n);
     std::vector<uint32_t> reg_off(G.n), reg_len(G.n), reg_pk_off(G.n), reg_pk, reg_pk_rc;
+    std::vector<uint64_t> w64_fwd(G.n, 0), w64_rc(G.n, 0);
+    std::vector<uint8_t> w64_ok(G.n, 0);
     for (uint32_t k = 0; k < G.n; k++) {
       tag_len[k] = (uint8_t)G.tags[k].size();
       std::memcpy(&tag_ascii[k * 32], G.tags[k].data(), G.tags[k].size());
@@ -299,6 +301,20 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
       reg_pk_off[k] = (uint32_t)reg_pk.size();
       pack_region(G.regions[k], false, &reg_pk);
       pack_region(G.regions[k], true, &reg_pk_rc);
+      // walk window: V = last 32 nt (get_v_deletions starts at the 3' end, :754), J = first 32 nt (:793)
+      const std::string &r = G.regions[k];
+      if (r.size() >= 32) {
+        const size_t w0 = (g == 0) ? r.size() - 32 : 0;
+        bool ok = true;
+        uint64_t f = 0, rcw = 0;
+        for (int s = 0; s < 32; s++) {
+          int c = base_code(r[w0 + s]);
+          if (c < 0) { ok = false; break; }
+          f |= (uint64_t)c << (2 * s);
+          rcw |= (uint64_t)(c ^ 3) << (2 * (31 - s));
+        }
+        if (ok) { w64_fwd[k] = f; w64_rc[k] = rcw; w64_ok[k] = 1; }
+      }
     }
     GeneDevPtrs &P = R.g[g];
     P.n = G.n;
@@ -313,6 +329,9 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     P.reg_pk = as_off<uint32_t>(B.put(reg_pk));
     P.reg_pk_rc = as_off<uint32_t>(B.put(reg_pk_rc));
     P.reg_clean = as_off<uint8_t>(B.put(reg_clean));
+    P.w64_fwd = as_off<uint64_t>(B.put(w64_fwd));
+    P.w64_rc = as_off<uint64_t>(B.put(w64_rc));
+    P.w64_ok = as_off<uint8_t>(B.put(w64_ok));
   }
   B.reserve(64);
   H.blob.swap(B.bytes);

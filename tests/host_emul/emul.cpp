@@ -36,8 +36,14 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
   Counters CC{counts};
   for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
   for (uint64_t r = 0; r < b->n_reads; r++) {
-    if (b->lens) decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
-    else decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+    // fast kernel first; what it defers goes through the general path (queue kernel)
+    if (b->lens) {
+      if (!decombine_fast_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records))
+        decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+    } else {
+      if (!decombine_fast_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records))
+        decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+    }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
   }
   return 0;
