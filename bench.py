@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg-flags", type=int, default=0, help="profiling only: DCRX_F_* bits (results are then not checked)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +143,7 @@ def main():
     batch.n_reads, batch.packed, batch.stride, batch.read_len, batch.lens = n, d_packed.data_ptr(), stride, READ_LEN, None
     batch.n_exc = len(er)
     batch.exc_read, batch.exc_pos, batch.exc_chr = (d_er.data_ptr(), d_ep.data_ptr(), d_ec.data_ptr()) if len(er) else (None, None, None)
-    cfg = nat.make_cfg("reverse", False, 130)
+    cfg = nat.make_cfg("reverse", False, 130, args.cfg_flags)
     nat.check(nat.lib().dcrx_reserve_device(tables.handle, n))
     gather = sharded.TupleGather(n, world, rank, dev) if world > 1 else None
 
@@ -180,7 +181,7 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     counters = d_cnt.cpu().numpy().astype(np.uint64)
     n_hits = int(counters[nat.COUNTER_NAMES.index("vj_count")])
-    assert int(counters[nat.COUNTER_NAMES.index("read_count")]) == n
+    assert args.cfg_flags or int(counters[nat.COUNTER_NAMES.index("read_count")]) == n
     if gather is not None:
         gather.check(n_hits)
 

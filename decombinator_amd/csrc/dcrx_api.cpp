@@ -179,6 +179,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid) * DCRX_N_COUNTERS * 4));
     t->device = dev;
   }
+  if (max_reads < 4096) max_reads = 4096;  // workspace exists even for empty batches
   if (max_reads > t->exc_flag_reads) {
     (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
     (void)hipFree(t->d_queue); t->d_queue = nullptr;

@@ -20,6 +20,8 @@ DCRX_DEV uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __bui
 DCRX_DEV void dcrx_atomic_inc(uint32_t *p) { atomicAdd(p, 1u); }
 DCRX_DEV int dcrx_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }
 DCRX_DEV int dcrx_clz64(uint64_t v) { return __clzll((long long)v); }
+DCRX_DEV int dcrx_popc64(uint64_t v) { return __popcll((unsigned long long)v); }
+DCRX_DEV int dcrx_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
 }
@@ -38,6 +40,8 @@ inline uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> o
 inline void dcrx_atomic_inc(uint32_t *p) { ++*p; }
 inline int dcrx_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
+inline int dcrx_popc64(uint64_t v) { return __builtin_popcountll(v); }
+inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
 struct uint2 { uint32_t x, y; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
@@ -260,6 +264,16 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j
 template <bool REV>
 DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const Frame<REV> &F, int lo, int hi) {
   const int Lt = (int)G.tag_len[k];
+  const int n = F.n();
+  // packed form: the slice is the whole tag-long window, pure ACGT, and a 32-base load covers it
+  if (hi - lo == Lt && !F.has_exc()) {
+    const int b = REV ? n - lo - Lt : lo;           // forward position of the window's first stored base
+    if (b >= 0 && b + 32 <= n) {
+      const uint64_t mask = (Lt >= 32) ? ~0ull : ((1ull << (2 * Lt)) - 1ull);
+      const uint64_t y = mismatch_slots(F.load64(b), REV ? G.tag_pk_rc[k] : G.tag_pk_fwd[k]) & mask;
+      return dcrx_popc64(y) <= 1;
+    }
+  }
   const uint8_t *t = G.tag_ascii + k * 32;
   int m = min(Lt, hi - lo);
   int d = max(Lt, hi - lo) - m;
@@ -284,59 +298,93 @@ DCRX_DEV uint32_t trans_at(const uint32_t *lds_trans, const DevTables &T, uint32
 // rescue different classes side by side.  Returns true with `out` filled on success;
 // otherwise the caller bumps the "found half not other half" counter.
 // ------------------------------------------------------------------------------
-template <bool REV, bool TABLE_LDS>
-DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, const int GENE,
-                       const int HALF, int end_of_v, XDat &out, const Counters &C) {
+// Candidates of one half-tag hit: every keyword of class (GENE, HALF) that ends at
+// state `st` reached after frame position `i`, each with its tags in ascending index.
+template <bool REV>
+DCRX_DEVNI bool rescue_at(const DevTables &T, const Frame<REV> &F, const int GENE, const int HALF, const uint32_t st,
+                          const int i, const int end_of_v, XDat &out, const Counters &C) {
   const int CLS = (GENE == 0) ? (HALF == 1 ? K_VH1 : K_VH2) : (HALF == 1 ? K_JH1 : K_JH2);
-  const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
   const GeneDevPtrs &G = T.g[GENE];
   const int n = F.n();
   const int split = G.split;
+  for (uint32_t o = T.st_out[st];; o++) {
+    const uint32_t ent = T.outs[o];
+    if ((int)(ent & 7u) == CLS) {
+      const int hlen = (int)((ent >> 3) & 63u);
+      const uint32_t gk = T.kw_base[CLS] + ((ent >> 9) & 0xFFFFu);
+      const int p = i + 1 - hlen;                          // hold_x[i][1]
+      const int k0 = (int)T.kw_first[gk];                  // half_seqs.index(...)
+      const int L0 = (int)G.tag_len[k0];
+      for (uint32_t x = T.kw_begin[gk]; x < T.kw_begin[gk + 1]; x++) {
+        const int k = (int)T.kw_tags[x];                   // indices, ascending
+        const int Lk = (int)G.tag_len[k];
+        const int q = (HALF == 1) ? p : p - split;         // window start
+        int lo, hi;
+        pyslice(n, q, q + L0, lo, hi);                     // :302-307 / :348-357 / :429-434 / :482-491
+        if (Lk != hi - lo) continue;
+        pyslice(n, q, (HALF == 1) ? p + Lk : p + Lk - split, lo, hi);  // :311-314 / :361-366
+        if (!hamming_le1<REV>(G, k, F, lo, hi)) continue;
+        if (GENE == 0) {
+          C.add(HALF == 1 ? DCRX_C_VERR2 : DCRX_C_VERR1);  // :318 / :370
+          const int te = (HALF == 1) ? p + G.jump[k] - 1 : p + G.jump[k] - split - 1;  // :320-322 / :372-377
+          int end_v, dels;
+          if (get_v_deletions<REV>(G, F, k, te, end_v, dels, C)) {
+            out.match = k; out.pos = end_v; out.dels = dels; out.tagpos = q;  // :327-333 / :382-388
+            return true;
+          }
+        } else {
+          C.add(HALF == 1 ? DCRX_C_JERR2 : DCRX_C_JERR1);  // :445 / :504
+          const int ts = (HALF == 1) ? p - G.jump[k] : p - G.jump[k] - split;  // :447-449 / :506-510
+          const int jend = (HALF == 1) ? p + hlen + split : p + hlen;          // :450-454 / :511
+          int start_j, dels;
+          if (get_j_deletions<REV>(G, F, k, ts, end_of_v, start_j, dels, C)) {
+            out.match = k; out.pos = start_j; out.dels = dels; out.tagpos = jend;  // :463-468 / :520-525
+            return true;
+          }
+        }
+      }
+    }
+    if (ent >> 31) break;
+  }
+  return false;
+}
+
+// Rescue by re-scanning the frame (any read: exception bytes reset the machine).
+template <bool REV, bool TABLE_LDS>
+DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, const int GENE,
+                       const int HALF, int end_of_v, XDat &out, const Counters &C) {
+  const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
+  const int n = F.n();
   uint32_t e = 0;
   for (int i = 0; i < n; i++) {
     if (F.has_exc() && F.exc_index(i) >= 0) { e = 0; continue; }  // unknown byte: machine back to the root
     e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + 4u * (uint32_t)F.code(i));
     if (!((e >> BIT) & 1u)) continue;
-    const uint32_t st = (e & TE_ROW_MASK) >> 4;
-    for (uint32_t o = T.st_out[st];; o++) {
-      const uint32_t ent = T.outs[o];
-      if ((int)(ent & 7u) == CLS) {
-        const int hlen = (int)((ent >> 3) & 63u);
-        const uint32_t gk = T.kw_base[CLS] + ((ent >> 9) & 0xFFFFu);
-        const int p = i + 1 - hlen;                          // hold_x[i][1]
-        const int k0 = (int)T.kw_first[gk];                  // half_seqs.index(...)
-        const int L0 = (int)G.tag_len[k0];
-        for (uint32_t x = T.kw_begin[gk]; x < T.kw_begin[gk + 1]; x++) {
-          const int k = (int)T.kw_tags[x];                   // indices, ascending
-          const int Lk = (int)G.tag_len[k];
-          const int q = (HALF == 1) ? p : p - split;         // window start
-          int lo, hi;
-          pyslice(n, q, q + L0, lo, hi);                     // :302-307 / :348-357 / :429-434 / :482-491
-          if (Lk != hi - lo) continue;
-          pyslice(n, q, (HALF == 1) ? p + Lk : p + Lk - split, lo, hi);  // :311-314 / :361-366
-          if (!hamming_le1<REV>(G, k, F, lo, hi)) continue;
-          if (GENE == 0) {
-            C.add(HALF == 1 ? DCRX_C_VERR2 : DCRX_C_VERR1);  // :318 / :370
-            const int te = (HALF == 1) ? p + G.jump[k] - 1 : p + G.jump[k] - split - 1;  // :320-322 / :372-377
-            int end_v, dels;
-            if (get_v_deletions<REV>(G, F, k, te, end_v, dels, C)) {
-              out.match = k; out.pos = end_v; out.dels = dels; out.tagpos = q;  // :327-333 / :382-388
-              return true;
-            }
-          } else {
-            C.add(HALF == 1 ? DCRX_C_JERR2 : DCRX_C_JERR1);  // :445 / :504
-            const int ts = (HALF == 1) ? p - G.jump[k] : p - G.jump[k] - split;  // :447-449 / :506-510
-            const int jend = (HALF == 1) ? p + hlen + split : p + hlen;          // :450-454 / :511
-            int start_j, dels;
-            if (get_j_deletions<REV>(G, F, k, ts, end_of_v, start_j, dels, C)) {
-              out.match = k; out.pos = start_j; out.dels = dels; out.tagpos = jend;  // :463-468 / :520-525
-              return true;
-            }
-          }
-        }
-      }
-      if (ent >> 31) break;
-    }
+    if (rescue_at<REV>(T, F, GENE, HALF, (e & TE_ROW_MASK) >> 4, i, end_of_v, out, C)) return true;
+  }
+  return false;
+}
+
+// Half-tag hits of one read, kept in LDS by the collecting scan of the queue kernel:
+// per class (V half1, V half2, J half1, J half2) up to HH_K entries `state<<9 | end_pos<<23 | 1`
+// in scan order, and the four hit counts (8 bits each, saturating at 255).
+constexpr int HH_K = 6;
+constexpr int HH_STRIDE = 4 * HH_K + 1;  // dwords per lane (odd: conflict-free)
+struct HalfHits {
+  uint32_t *slot;
+  uint32_t cnts;
+  DCRX_DEV int count(int cls4) const { return (int)((cnts >> (8 * cls4)) & 0xFFu); }
+};
+
+// Rescue from the collected hit list (same order as the re-scan would meet them).
+template <bool REV>
+DCRX_DEVNI bool rescue_list(const DevTables &T, const Frame<REV> &F, const HalfHits &hh, const int GENE,
+                            const int HALF, int end_of_v, XDat &out, const Counters &C) {
+  const int cls4 = GENE * 2 + (HALF - 1);
+  const int cnt = hh.count(cls4);
+  for (int h = 0; h < cnt; h++) {
+    const uint32_t t = hh.slot[cls4 * HH_K + h];
+    if (rescue_at<REV>(T, F, GENE, HALF, (t >> 9) & 0x3FFFu, (int)(t >> 23), end_of_v, out, C)) return true;
   }
   return false;
 }
@@ -393,6 +441,59 @@ DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
   return ScanOut{acc, vacc, jacc};
 }
 
+// Collecting scan (queue kernel): scan_fast that also appends every half-tag hit to the
+// read's LDS lists.
+DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
+  while (hb) {
+    const int c = dcrx_ctz32(hb);
+    hb &= hb - 1u;
+    const uint32_t idx = (hh.cnts >> (8 * c)) & 0xFFu;
+    if (idx < (uint32_t)HH_K) hh.slot[c * HH_K + (int)idx] = t;
+    if (idx < 255u) hh.cnts += 1u << (8 * c);
+  }
+}
+
+#define DCRX_STEP_C(CODE)                                                                       \
+  do {                                                                                          \
+    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));         \
+    acc |= e;                                                                                   \
+    const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
+    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
+    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
+    const uint32_t hb_ = (e >> TE_VH1_BIT) & 0xFu;                                              \
+    if (hb_) collect_hits(hh, hb_, t_);                                                         \
+    it += (1u << ACC_POS_SHIFT);                                                                \
+  } while (0)
+
+template <bool REV, bool TABLE_LDS>
+DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const uint32_t *words, int n,
+                              HalfHits &hh) {
+  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  hh.cnts = 0;
+  if (n > 0) {
+    const int top = (n - 1) >> 4;
+    const int cnt = ((n - 1) & 15) + 1;
+    if (REV) {
+      uint32_t wp = ~words[top] << (2 * (16 - cnt));
+      for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp >> 30); wp <<= 2; }
+      for (int kk = top - 1; kk >= 0; kk--) {
+        const uint32_t wv = ~words[kk];
+#pragma unroll
+        for (int j = 15; j >= 0; j--) DCRX_STEP_C(dcrx_ubfe(wv, 2 * j, 2));
+      }
+    } else {
+      for (int kk = 0; kk < top; kk++) {
+        const uint32_t wv = words[kk];
+#pragma unroll
+        for (int j = 0; j < 16; j++) DCRX_STEP_C(dcrx_ubfe(wv, 2 * j, 2));
+      }
+      uint32_t wp = words[top];
+      for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp & 3u); wp >>= 2; }
+    }
+  }
+  return ScanOut{acc, vacc, jacc};
+}
+
 // Slow scan: any read (exception bytes reset the machine, like acora on a
 // character outside its keywords).
 template <bool REV, bool TABLE_LDS>
@@ -417,7 +518,8 @@ constexpr int DCRX_S_DEFER = 255;
 
 template <bool REV, bool TABLE_LDS, bool DEFER>
 DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, const ScanOut &so,
-                         const dcrx::CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
+                         const dcrx::CfgDev &cfg, const Counters &C, dcrx_record_t &rec,
+                         const HalfHits *hh = nullptr) {
   const Frame<REV> F(rv);
   const int n = rv.n;
   const GeneDevPtrs &GV = T.g[0];
@@ -442,7 +544,8 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_VH1_BIT) & 3u) {                // a V half1 (:294-335) or half2 (:339-390) keyword occurs
       if (DEFER) return DCRX_S_DEFER;
       const int half = ((so.acc >> TE_VH1_BIT) & 1u) ? 1 : 2;  // half2 is tried only when no half1 hit exists
-      if (!rescue<REV, TABLE_LDS>(T, lds_trans, F, 0, half, 0, vdat, C)) {
+      if (!(hh ? rescue_list<REV>(T, F, *hh, 0, half, 0, vdat, C)
+               : rescue<REV, TABLE_LDS>(T, lds_trans, F, 0, half, 0, vdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDV1NOTV2 : DCRX_C_FOUNDV2NOTV1);       // :334 / :389
         return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : DCRX_S_V_HALF2_EXHAUSTED;
       }
@@ -471,7 +574,8 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_JH1_BIT) & 3u) {                // a J half1 (:422-470) or half2 (:473-527) keyword occurs
       if (DEFER) return DCRX_S_DEFER;                        // nothing has been counted for this read yet
       const int half = ((so.acc >> TE_JH1_BIT) & 1u) ? 1 : 2;
-      if (!rescue<REV, TABLE_LDS>(T, lds_trans, F, 1, half, end_of_v, jdat, C)) {
+      if (!(hh ? rescue_list<REV>(T, F, *hh, 1, half, end_of_v, jdat, C)
+               : rescue<REV, TABLE_LDS>(T, lds_trans, F, 1, half, end_of_v, jdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDJ1NOTJ2 : DCRX_C_FOUNDV2NOTV1);       // :469 / :526 (the reference bumps the V key)
         jstatus = half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : DCRX_S_J_HALF2_EXHAUSTED;
       }
@@ -617,12 +721,62 @@ DCRX_DEV bool decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, 
     status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1;
   } else {                                                            // :999-1001
     const ScanOut so = scan_fast<true, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+    if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {  // profiling aid: price the scan alone
+      rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.acc >> 16); rec.v_start = (uint16_t)so.vacc; rec.j_end = (uint16_t)so.jacc;
+      rec.status = 254; rec.frame = 0;
+      dcrx_store_record(records + r, rec);
+      return true;
+    }
     status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0;
   }
   if (status == DCRX_S_DEFER) return false;
   C.add(DCRX_C_READ_COUNT);                                           // :991
   if (status == DCRX_S_OK) {
     C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+  return true;
+}
+
+// ------------------------------------------------------------------------------
+// Queue-kernel form for clean reads that only needed a half-tag rescue: one
+// collecting scan, then dcr_frame with the rescue fed from the LDS hit lists.
+// Returns false (nothing counted, nothing written) when the read must take
+// decombine_one instead: exception bytes, orientation `both`, forced slow
+// reader, or more than HH_K hits in a list it needs.
+// ------------------------------------------------------------------------------
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+DCRX_DEV bool decombine_rescue_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
+                                   const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
+                                   uint32_t *hh_slot) {
+  if (cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER)) return false;
+  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) return false;
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  HalfHits hh;
+  hh.slot = hh_slot;
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {
+    const ScanOut so = scan_collect<false, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
+    if (hh.count(0) > HH_K || hh.count(1) > HH_K || hh.count(2) > HH_K || hh.count(3) > HH_K) return false;
+    status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
+  } else {
+    const ScanOut so = scan_collect<true, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
+    if (hh.count(0) > HH_K || hh.count(1) > HH_K || hh.count(2) > HH_K || hh.count(3) > HH_K) return false;
+    status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
+  }
+  C.add(DCRX_C_READ_COUNT);
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);
     if (frame) C.add(DCRX_C_FRAME_FORWARD);
   }
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;

@@ -34,6 +34,8 @@ struct GeneDevPtrs {
   const uint8_t *tag_len;      // len(v_seqs[k])
   const int32_t *jump;         // jump_to_end_v[k] / jump_to_start_j[k]
   const uint8_t *tag_ascii;    // [k*32], the tag's characters
+  const uint64_t *tag_pk_fwd;  // tag 2-bit packed: slot s = tag[s]
+  const uint64_t *tag_pk_rc;   // slot y = complement of tag[len-1-y] (the tag as the packed FORWARD read shows it in the reverse frame)
   const uint32_t *reg_off;     // byte offset of region k inside reg_bytes
   const uint32_t *reg_len;     // len(v_regions[k])
   const uint8_t *reg_bytes;    // upper-cased germline characters

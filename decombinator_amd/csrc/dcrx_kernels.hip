@@ -33,6 +33,13 @@
 
 namespace dcrx {
 
+// LDS beyond the counters + DFA (LaunchPlan::lds_bytes): the fast kernel's per-wave deferral
+// buffers, the queue kernel's half-tag hit lists
+constexpr int DCRX_WQ_CAP = 128;
+constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
+constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
+constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
+
 // ------------------------------------------------------------------------------
 // Fast kernel: persistent blocks, each stages the DFA into LDS once and then
 // strides over tiles of DCRX_BLOCK reads.  Reads that need the general path
@@ -48,7 +55,8 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
                                                                uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
-  uint32_t *lds_trans = smem + DCRX_N_COUNTERS;       // [n_states*4] when TABLE_LDS
+  uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
+  uint32_t *lds_trans = lds_wq + (DCRX_BLOCK / 64) * DCRX_WQ_CAP;  // [n_states*4] when TABLE_LDS
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   if (TABLE_LDS) {
@@ -60,6 +68,10 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
+  // per-wave staging of deferred read indices: flushed to the global queue 64+ at a time, so
+  // that the queue tail sees one atomic per ~100 deferred reads instead of one per wave and tile
+  uint32_t *wq = lds_wq + (tid >> 6) * DCRX_WQ_CAP;
+  uint32_t wq_n = 0;
 
   for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
     const uint64_t r = tile * DCRX_BLOCK + tid;
@@ -67,12 +79,22 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
     if (r < B.n_reads) defer = !decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
     const unsigned long long m = __ballot(defer);
     if (m) {
-      const int leader = __ffsll(m) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(queue_count, (uint32_t)__popcll(m));
-      base = __shfl(base, leader);
-      if (defer) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      wq_n += (uint32_t)__popcll(m);
+      if (wq_n >= 64) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue_count, wq_n);
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
+        wq_n = 0;
+      }
     }
+  }
+  if (wq_n) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(queue_count, wq_n);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
@@ -87,7 +109,9 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables 
                                                                       const uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
-  uint32_t *lds_trans = smem + DCRX_N_COUNTERS;
+  uint32_t *lds_hh = smem + DCRX_N_COUNTERS;           // [DCRX_QBLOCK][HH_STRIDE] half-tag hit lists
+  uint32_t *lds_trans = lds_hh + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD;
+  static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
   const uint32_t n_queued = *queue_count;
   if ((uint64_t)blockIdx.x * DCRX_QBLOCK >= n_queued) {  // nothing for this block: its tallies are zero
@@ -103,20 +127,30 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables 
   __syncthreads();
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
-  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK)
-    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], nw, C, records);
+  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK) {
+    const uint64_t r = (uint64_t)queue[i];
+    if (!decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, C, records, lds_hh + tid * HH_STRIDE))
+      decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+  }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
 
-// Sums the per-block tallies into the caller's uint64[DCRX_N_COUNTERS].
-__global__ void reduce_counts_kernel(const uint32_t *__restrict__ block_counts, int n_blocks,
-                                     uint64_t *__restrict__ out) {
-  const int c = threadIdx.x;
-  if (c >= DCRX_N_COUNTERS) return;
+// Sums the per-block tallies into the caller's uint64[DCRX_N_COUNTERS]:
+// one block of 1024 threads, 32 threads per counter.
+__global__ __launch_bounds__(1024) void reduce_counts_kernel(const uint32_t *__restrict__ block_counts, int n_blocks,
+                                                             uint64_t *__restrict__ out) {
+  __shared__ uint64_t part[1024];
+  const int c = threadIdx.x & (DCRX_N_COUNTERS - 1), part_id = threadIdx.x / DCRX_N_COUNTERS;
   uint64_t s = 0;
-  for (int b = 0; b < n_blocks; b++) s += block_counts[(size_t)b * DCRX_N_COUNTERS + c];
-  out[c] = s;
+  for (int b = part_id; b < n_blocks; b += 1024 / DCRX_N_COUNTERS) s += block_counts[(size_t)b * DCRX_N_COUNTERS + c];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < DCRX_N_COUNTERS) {
+    uint64_t tot = 0;
+    for (int p = 0; p < 1024 / DCRX_N_COUNTERS; p++) tot += part[p * DCRX_N_COUNTERS + threadIdx.x];
+    out[threadIdx.x] = tot;
+  }
 }
 
 // Marks reads that own at least one exception.
@@ -214,12 +248,13 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
                               hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
   auto kqueue = decombine_queue_kernel<TABLE_LDS, UNIFORM>;
-  if (P.lds_bytes > 48 * 1024) {
+  if (P.lds_bytes + DCRX_QUEUE_LDS_EXTRA > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(P.lds_bytes + DCRX_FAST_LDS_EXTRA));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kqueue), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)P.lds_bytes);
+                            (int)(P.lds_bytes + DCRX_QUEUE_LDS_EXTRA));
     if (e != hipSuccess) return e;
   }
   hipError_t e;
@@ -227,9 +262,9 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
   // two rounds and leave the tiles of the late blocks for the end)
   static int occ_fast = 0, occ_queue = 0;
   if (!occ_fast) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, DCRX_BLOCK, P.lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, DCRX_BLOCK, P.lds_bytes + DCRX_FAST_LDS_EXTRA);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_queue, kqueue, DCRX_QBLOCK, P.lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_queue, kqueue, DCRX_QBLOCK, P.lds_bytes + DCRX_QUEUE_LDS_EXTRA);
     if (e != hipSuccess) return e;
     if (occ_fast < 1) occ_fast = 1;
     if (occ_queue < 1) occ_queue = 1;
@@ -237,12 +272,12 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
   const uint32_t grid = std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_queue);
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), P.lds_bytes, s, T, B, cfg, rec, block_counts, queue,
-                     queue_count);
+  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), P.lds_bytes + DCRX_FAST_LDS_EXTRA, s, T, B, cfg, rec,
+                     block_counts, queue, queue_count);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(kqueue, dim3(qgrid), dim3(DCRX_QBLOCK), P.lds_bytes, s, T, B, cfg, rec,
+  hipLaunchKernelGGL(kqueue, dim3(qgrid), dim3(DCRX_QBLOCK), P.lds_bytes + DCRX_QUEUE_LDS_EXTRA, s, T, B, cfg, rec,
                      block_counts + (size_t)P.grid * DCRX_N_COUNTERS, queue, queue_count);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -279,7 +314,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
                 : launch_pair<false, false>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop);
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(64), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
   return hipGetLastError();
 }
 

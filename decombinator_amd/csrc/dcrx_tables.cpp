@@ -80,7 +80,7 @@ DevTables HostTables::resolve(const uint8_t *base) const {
   fix(d.trans); fix(d.st_full); fix(d.st_out); fix(d.outs);
   fix(d.kw_base); fix(d.kw_first); fix(d.kw_begin); fix(d.kw_tags); fix(d.comp);
   for (int g = 0; g < 2; g++) {
-    fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].reg_off);
+    fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].tag_pk_fwd); fix(d.g[g].tag_pk_rc); fix(d.g[g].reg_off);
     fix(d.g[g].reg_len); fix(d.g[g].reg_bytes); fix(d.g[g].reg_pk_off); fix(d.g[g].reg_pk);
     fix(d.g[g].reg_pk_rc); fix(d.g[g].reg_clean); fix(d.g[g].w64_fwd); fix(d.g[g].w64_rc); fix(d.g[g].w64_ok);
   }
@@ -286,12 +286,17 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     std::vector<uint8_t> tag_len(G.n), tag_ascii(G.n * 32, 0), reg_bytes, reg_clean(G.n);
     std::vector<int32_t> jump(G.n);
     std::vector<uint32_t> reg_off(G.n), reg_len(G.n), reg_pk_off(G.n), reg_pk, reg_pk_rc;
-    std::vector<uint64_t> w64_fwd(G.n, 0), w64_rc(G.n, 0);
+    std::vector<uint64_t> w64_fwd(G.n, 0), w64_rc(G.n, 0), tag_pk_fwd(G.n, 0), tag_pk_rc(G.n, 0);
     std::vector<uint8_t> w64_ok(G.n, 0);
     for (uint32_t k = 0; k < G.n; k++) {
       tag_len[k] = (uint8_t)G.tags[k].size();
       std::memcpy(&tag_ascii[k * 32], G.tags[k].data(), G.tags[k].size());
       jump[k] = G.jumps[k];
+      for (size_t s = 0; s < G.tags[k].size(); s++) {
+        const uint64_t c = (uint64_t)base_code(G.tags[k][s]);
+        tag_pk_fwd[k] |= c << (2 * s);
+        tag_pk_rc[k] |= (c ^ 3) << (2 * (G.tags[k].size() - 1 - s));
+      }
       reg_off[k] = (uint32_t)reg_bytes.size();
       reg_len[k] = (uint32_t)G.regions[k].size();
       reg_bytes.insert(reg_bytes.end(), G.regions[k].begin(), G.regions[k].end());
@@ -322,6 +327,8 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     P.tag_len = as_off<uint8_t>(B.put(tag_len));
     P.jump = as_off<int32_t>(B.put(jump));
     P.tag_ascii = as_off<uint8_t>(B.put(tag_ascii));
+    P.tag_pk_fwd = as_off<uint64_t>(B.put(tag_pk_fwd));
+    P.tag_pk_rc = as_off<uint64_t>(B.put(tag_pk_rc));
     P.reg_off = as_off<uint32_t>(B.put(reg_off));
     P.reg_len = as_off<uint32_t>(B.put(reg_len));
     P.reg_bytes = as_off<uint8_t>(B.put(reg_bytes));

@@ -1,0 +1,49 @@
+"""Ad-hoc wider CPU check of the device code through tests/host_emul (run by hand
+or from test_emul_parity.py): synthetic mixtures, orientations, ragged lengths."""
+import numpy as np
+
+from decombinator_amd import _native as nat, synth
+from oracle import oracle as orc
+from tests import parity_util as pu
+
+
+def run(n=200000):
+    for cfgno, sub in ((2, 0.005), (5, 0.02)):
+        ts = synth.config_tagset(cfgno)
+        d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+                 j_regions=ts.j_regions, v_half_split=ts.half_splits[0], j_half_split=ts.half_splits[1])
+        t = pu.native_tables(d)
+        ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                              [r.upper() for r in ts.j_regions], *ts.half_splits)
+        be = pu.Backend("emul", d)
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=cfgno, sub_rate=sub, n_rate=0.002), 0, n)
+        reads = nat.unpack_reads(hb)
+        rec, cnt = be.run(hb)
+        orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(rec, orec, reads, "synth")
+        pu.assert_counters_equal(cnt, ocnt)
+        reads2 = [orc.revcomp(r) if i % 2 else r for i, r in enumerate(reads[:n // 3])]
+        b = nat.pack_reads(reads2)
+        for o in ("forward", "both"):
+            rec, cnt = be.run(b, o)
+            orec, ocnt = pu.oracle_records(ot, reads2, o, False, 130)
+            pu.assert_records_equal(rec, orec, reads2, o)
+            pu.assert_counters_equal(cnt, ocnt)
+        rng = np.random.default_rng(11)
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=9, read_len=320, n_rate=0.01), 0, n // 4, stride=80)
+        reads = nat.unpack_reads(hb)
+        cut = rng.integers(0, 321, size=len(reads))
+        start = rng.integers(0, 120, size=len(reads))
+        reads = [r[s:s + c] if i % 3 else r[:c] for i, (r, s, c) in enumerate(zip(reads, start, cut))]
+        b = nat.pack_reads(reads, stride=80)
+        for allow in (False, True):
+            rec, cnt = be.run(b, allow_ns=allow)
+            orec, ocnt = pu.oracle_records(ot, reads, "reverse", allow, 130)
+            pu.assert_records_equal(rec, orec, reads, "ragged")
+            pu.assert_counters_equal(cnt, ocnt)
+    return True
+
+
+if __name__ == "__main__":
+    run(300000)
+    print("emul extended ok")

@@ -36,13 +36,17 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
   Counters CC{counts};
   for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
   for (uint64_t r = 0; r < b->n_reads; r++) {
-    // fast kernel first; what it defers goes through the general path (queue kernel)
+    // fast kernel first; what it defers goes to the queue kernel: the list-fed rescue, or the
+    // general path (decombine_one)
+    uint32_t hh_slot[HH_STRIDE];
     if (b->lens) {
       if (!decombine_fast_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records))
-        decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+        if (!decombine_rescue_one<false, false>(T, nullptr, B, C, r, CC, records, hh_slot))
+          decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
     } else {
       if (!decombine_fast_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records))
-        decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+        if (!decombine_rescue_one<false, true>(T, nullptr, B, C, r, CC, records, hh_slot))
+          decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
     }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
   }

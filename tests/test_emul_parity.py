@@ -12,3 +12,8 @@ from tests import parity_util as pu
 @pytest.mark.parametrize("flags", [0, nat.F_FORCE_SLOW_READER], ids=["fast", "slowreader"])
 def test_emul_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("emul", path, flags) > 500
+
+
+def test_emul_synthetic_orientations_and_ragged_lengths():
+    from tests import emul_extended
+    assert emul_extended.run(60000)
