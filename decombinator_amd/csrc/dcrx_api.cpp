@@ -107,7 +107,7 @@ int dcrx_tables_info(const dcrx_tables_t *t, dcrx_tables_info_t *info) {
   info->n_states = t->host.n_states; info->dfa_bytes = t->host.dfa_bytes;
   for (int c = 0; c < 6; c++) info->n_keywords[c] = t->host.n_keywords[c];
   info->max_tag_len = t->host.max_tag_len;
-  info->tables_in_lds = t->host.dfa_bytes + 128 <= 144 * 1024;
+  info->tables_in_lds = t->host.rel.lds_image_bytes + 128 <= 120 * 1024;
   info->equal_len_per_automaton = t->host.equal_len_per_automaton ? 1 : 0;
   return DCRX_OK;
 }
@@ -166,10 +166,10 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     t->dev = t->host.resolve(t->d_blob);
     // launch plan: persistent blocks of DCRX_BLOCK threads, the DFA resident in LDS
     const uint32_t lds_cap = 160 * 1024;
-    const uint32_t want = t->host.dfa_bytes + DCRX_N_COUNTERS * 4;
+    const uint32_t want = t->host.rel.lds_image_bytes + DCRX_N_COUNTERS * 4;
     LaunchPlan P;
     P.n_cu = (uint32_t)prop.multiProcessorCount;
-    P.table_in_lds = want <= 144 * 1024;
+    P.table_in_lds = want <= 120 * 1024;
     P.lds_bytes = P.table_in_lds ? want : DCRX_N_COUNTERS * 4;
     uint32_t per_cu = std::min<uint32_t>(2048 / DCRX_BLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.grid = (uint32_t)prop.multiProcessorCount * per_cu;

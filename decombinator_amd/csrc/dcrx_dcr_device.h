@@ -52,6 +52,20 @@ using std::max;
 
 namespace dcrx {
 
+// The table pointers of `T` that lie inside the LDS image, re-pointed at the copy of the image
+// that starts at `lds_image` (a kernel's shared memory).
+DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_image) {
+  DevTables L = T;
+#define DCRX_MV(p) L.p = reinterpret_cast<decltype(L.p)>(lds_image + (reinterpret_cast<const uint8_t *>(T.p) - T.image))
+  DCRX_MV(st_full); DCRX_MV(st_out); DCRX_MV(outs); DCRX_MV(kw_base); DCRX_MV(kw_first); DCRX_MV(kw_begin); DCRX_MV(kw_tags);
+  for (int g = 0; g < 2; g++) {
+    DCRX_MV(g[g].tag_len); DCRX_MV(g[g].jump); DCRX_MV(g[g].tag_pk_fwd); DCRX_MV(g[g].tag_pk_rc);
+    DCRX_MV(g[g].w64_fwd); DCRX_MV(g[g].w64_rc); DCRX_MV(g[g].w64_ok); DCRX_MV(g[g].reg_len);
+  }
+#undef DCRX_MV
+  return L;
+}
+
 // ------------------------------------------------------------------------------
 // accumulator layout for a full-tag class: count | state<<9 | end_pos<<23.
 // Summed over hits; when count == 1 the upper fields are that hit's state and
@@ -307,7 +321,7 @@ DCRX_DEVNI bool rescue_at(const DevTables &T, const Frame<REV> &F, const int GEN
   const GeneDevPtrs &G = T.g[GENE];
   const int n = F.n();
   const int split = G.split;
-  for (uint32_t o = T.st_out[st];; o++) {
+  for (uint32_t o = T.st_out[st - T.first_out];; o++) {
     const uint32_t ent = T.outs[o];
     if ((int)(ent & 7u) == CLS) {
       const int hlen = (int)((ent >> 3) & 63u);
@@ -534,7 +548,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     if (vcount == 1) {
       const uint32_t st = (so.vacc >> ACC_STATE_SHIFT) & 0x3FFFu;
       const int iend = (int)(so.vacc >> ACC_POS_SHIFT);
-      const int v = (int)(T.st_full[st] & 0xFFFFu);          // v_seqs.index(tag) :282
+      const int v = (int)(T.st_full[st - T.first_out] & 0xFFFFu);          // v_seqs.index(tag) :282
       const int p = iend + 1 - (int)GV.tag_len[v];           // hold_v[0][1]
       const int te = p + GV.jump[v] - 1;                     // :283-285
       int end_v, dels;
@@ -564,7 +578,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     else if (jcount == 1) {
       const uint32_t st = (so.jacc >> ACC_STATE_SHIFT) & 0x3FFFu;
       const int iend = (int)(so.jacc >> ACC_POS_SHIFT);
-      const int j = (int)(T.st_full[st] >> 16);              // j_seqs.index(tag) :406
+      const int j = (int)(T.st_full[st - T.first_out] >> 16);              // j_seqs.index(tag) :406
       const int Lj = (int)GJ.tag_len[j];
       const int p = iend + 1 - Lj;
       const int ts = p - GJ.jump[j];                         // :407-409

@@ -54,10 +54,13 @@ struct GeneDevPtrs {
 
 struct DevTables {
   uint32_t n_states;
+  uint32_t first_out;         // states >= first_out are the ones where some keyword ends
   uint32_t dfa_bytes;
-  const uint32_t *trans;      // [n_states*4] transition entries (dcrx_tables.h)
-  const uint32_t *st_full;    // [n_states] V tag | J tag << 16 ending at the state (0xFFFF none)
-  const uint32_t *st_out;     // [n_states+1] CSR into outs
+  uint32_t lds_image_bytes;   // image[0 .. lds_image_bytes) = DFA + side tables: what the kernels stage in LDS
+  const uint8_t *image;       // start of the table blob (== trans)
+  const uint32_t *trans;      // [n_states*4] transition entries
+  const uint32_t *st_full;    // [state - first_out] V tag | J tag << 16 ending at the state (0xFFFF none)
+  const uint32_t *st_out;     // [state - first_out (+1)] CSR into outs
   const uint32_t *outs;       // per-state output list, longest keyword first
   const uint32_t *kw_base;    // [K_NCLASS] first global keyword id of each class
   const uint32_t *kw_first;   // [n_kw_total] first tag index holding the keyword (list.index)

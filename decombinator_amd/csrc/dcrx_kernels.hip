@@ -48,7 +48,7 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD
 // rare, long, divergent work runs in dense waves instead of stalling this one.
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN>
-__global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, BatchDev B, CfgDev cfg,
+__global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                dcrx_record_t *__restrict__ records,
                                                                uint32_t *__restrict__ block_counts,
                                                                uint32_t *__restrict__ queue,
@@ -60,11 +60,12 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   if (TABLE_LDS) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(T.trans);
+    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
     uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
-    for (uint32_t i = tid; i < T.n_states; i += DCRX_BLOCK) dst[i] = src[i];
+    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_BLOCK) dst[i] = src[i];
   }
   __syncthreads();
+  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T, Batc
 
 // Queue kernel: the general per-read path (decombine_one) over the compacted queue.
 template <bool TABLE_LDS, bool UNIFORM_LEN>
-__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables T, BatchDev B, CfgDev cfg,
+__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                       dcrx_record_t *__restrict__ records,
                                                                       uint32_t *__restrict__ block_counts,
                                                                       const uint32_t *__restrict__ queue,
@@ -120,11 +121,12 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables 
   }
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   if (TABLE_LDS) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(T.trans);
+    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
     uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
-    for (uint32_t i = tid; i < T.n_states; i += DCRX_QBLOCK) dst[i] = src[i];
+    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_QBLOCK) dst[i] = src[i];
   }
   __syncthreads();
+  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
   for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK) {

@@ -77,7 +77,7 @@ DevTables HostTables::resolve(const uint8_t *base) const {
     using P = std::remove_reference_t<decltype(p)>;
     p = reinterpret_cast<P>(base + reinterpret_cast<uintptr_t>(p));
   };
-  fix(d.trans); fix(d.st_full); fix(d.st_out); fix(d.outs);
+  fix(d.image); fix(d.trans); fix(d.st_full); fix(d.st_out); fix(d.outs);
   fix(d.kw_base); fix(d.kw_first); fix(d.kw_begin); fix(d.kw_tags); fix(d.comp);
   for (int g = 0; g < 2; g++) {
     fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].tag_pk_fwd); fix(d.g[g].tag_pk_rc); fix(d.g[g].reg_off);
@@ -239,11 +239,31 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     if (((o >> 9) & 0x3FFFFF) > 0xFFFF) return fail(DCRX_E_UNSUPPORTED, "keyword id overflow");
   }
 
+  // Renumber: states without any output first (the root stays 0), output states last, so that
+  // the per-output-state side tables are small and indexed by state - first_out.
+  std::vector<uint32_t> new_id(S), old_of(S);
+  uint32_t first_out = 0;
+  {
+    uint32_t nx = 0;
+    for (uint32_t s = 0; s < S; s++) if (!st_flags[s]) { new_id[s] = nx; old_of[nx++] = s; }
+    first_out = nx;
+    for (uint32_t s = 0; s < S; s++) if (st_flags[s]) { new_id[s] = nx; old_of[nx++] = s; }
+  }
+  const uint32_t NO = S - first_out;
+  std::vector<uint32_t> st_full_c(NO ? NO : 1, 0xFFFFFFFFu), st_out_c(NO + 1, 0), outs_c;
+  for (uint32_t o = 0; o < NO; o++) {
+    const uint32_t s = old_of[first_out + o];
+    st_full_c[o] = st_full[s];
+    st_out_c[o] = (uint32_t)outs_c.size();
+    for (uint32_t x = st_out[s]; x < st_out[s + 1]; x++) outs_c.push_back(outs[x]);
+  }
+  st_out_c[NO] = (uint32_t)outs_c.size();
+
   std::vector<uint32_t> trans(S * 4);
   for (uint32_t s = 0; s < S; s++)
     for (int c = 0; c < 4; c++) {
-      uint32_t t = (uint32_t)delta[s * 4 + c];
-      trans[s * 4 + c] = (t * 16u) | st_flags[t];
+      const uint32_t t = (uint32_t)delta[s * 4 + c];
+      trans[new_id[s] * 4 + c] = (new_id[t] * 16u) | st_flags[t];
     }
   H.dfa_bytes = S * 16u;
 
@@ -257,55 +277,52 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     }
   kw_begin.push_back((uint32_t)kw_tags.size());
 
-  // ---- blob ---------------------------------------------------------------------
+  // ---- blob: the LDS image first (DFA + every side table the per-read code touches on its
+  // common paths), then what only the general/slow paths read from global memory ----------------
   Blob B;
   DevTables &R = H.rel;
   R.n_states = S;
+  R.first_out = first_out;
   R.dfa_bytes = H.dfa_bytes;
+  R.image = as_off<uint8_t>(0);
   R.trans = as_off<uint32_t>(B.put(trans));
-  R.st_full = as_off<uint32_t>(B.put(st_full));
-  R.st_out = as_off<uint32_t>(B.put(st_out));
-  R.outs = as_off<uint32_t>(B.put(outs));
+  R.st_full = as_off<uint32_t>(B.put(st_full_c));
+  R.st_out = as_off<uint32_t>(B.put(st_out_c));
+  R.outs = as_off<uint32_t>(B.put(outs_c));
   R.kw_base = as_off<uint32_t>(B.put(kw_base));
   R.kw_first = as_off<uint32_t>(B.put(kw_first));
   R.kw_begin = as_off<uint32_t>(B.put(kw_begin));
   R.kw_tags = as_off<uint32_t>(B.put(kw_tags));
-  {
-    // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged
-    std::vector<uint8_t> comp(256);
-    for (int c = 0; c < 256; c++) comp[c] = (uint8_t)c;
-    const char *ck = "ACGTMRWSYKVHDBXNU", *cv = "TGCAKYWSRMBDHVXNA";
-    for (int i = 0; ck[i]; i++) {
-      comp[(uint8_t)ck[i]] = (uint8_t)cv[i];
-      comp[(uint8_t)(ck[i] + 32)] = (uint8_t)(cv[i] + 32);
-    }
-    R.comp = as_off<uint8_t>(B.put(comp));
-  }
+  struct GeneArrays {
+    std::vector<uint8_t> tag_len, tag_ascii, reg_bytes, reg_clean, w64_ok;
+    std::vector<int32_t> jump;
+    std::vector<uint32_t> reg_off, reg_len, reg_pk_off, reg_pk, reg_pk_rc;
+    std::vector<uint64_t> w64_fwd, w64_rc, tag_pk_fwd, tag_pk_rc;
+  } GA[2];
   for (int g = 0; g < 2; g++) {
     const GeneHost &G = H.g[g];
-    std::vector<uint8_t> tag_len(G.n), tag_ascii(G.n * 32, 0), reg_bytes, reg_clean(G.n);
-    std::vector<int32_t> jump(G.n);
-    std::vector<uint32_t> reg_off(G.n), reg_len(G.n), reg_pk_off(G.n), reg_pk, reg_pk_rc;
-    std::vector<uint64_t> w64_fwd(G.n, 0), w64_rc(G.n, 0), tag_pk_fwd(G.n, 0), tag_pk_rc(G.n, 0);
-    std::vector<uint8_t> w64_ok(G.n, 0);
+    GeneArrays &A = GA[g];
+    A.tag_len.resize(G.n); A.tag_ascii.assign(G.n * 32, 0); A.reg_clean.resize(G.n); A.w64_ok.assign(G.n, 0);
+    A.jump.resize(G.n); A.reg_off.resize(G.n); A.reg_len.resize(G.n); A.reg_pk_off.resize(G.n);
+    A.w64_fwd.assign(G.n, 0); A.w64_rc.assign(G.n, 0); A.tag_pk_fwd.assign(G.n, 0); A.tag_pk_rc.assign(G.n, 0);
     for (uint32_t k = 0; k < G.n; k++) {
-      tag_len[k] = (uint8_t)G.tags[k].size();
-      std::memcpy(&tag_ascii[k * 32], G.tags[k].data(), G.tags[k].size());
-      jump[k] = G.jumps[k];
+      A.tag_len[k] = (uint8_t)G.tags[k].size();
+      std::memcpy(&A.tag_ascii[k * 32], G.tags[k].data(), G.tags[k].size());
+      A.jump[k] = G.jumps[k];
       for (size_t s = 0; s < G.tags[k].size(); s++) {
         const uint64_t c = (uint64_t)base_code(G.tags[k][s]);
-        tag_pk_fwd[k] |= c << (2 * s);
-        tag_pk_rc[k] |= (c ^ 3) << (2 * (G.tags[k].size() - 1 - s));
+        A.tag_pk_fwd[k] |= c << (2 * s);
+        A.tag_pk_rc[k] |= (c ^ 3) << (2 * (G.tags[k].size() - 1 - s));
       }
-      reg_off[k] = (uint32_t)reg_bytes.size();
-      reg_len[k] = (uint32_t)G.regions[k].size();
-      reg_bytes.insert(reg_bytes.end(), G.regions[k].begin(), G.regions[k].end());
+      A.reg_off[k] = (uint32_t)A.reg_bytes.size();
+      A.reg_len[k] = (uint32_t)G.regions[k].size();
+      A.reg_bytes.insert(A.reg_bytes.end(), G.regions[k].begin(), G.regions[k].end());
       bool clean = true;
       for (char c : G.regions[k]) if (base_code(c) < 0) clean = false;
-      reg_clean[k] = clean ? 1 : 0;
-      reg_pk_off[k] = (uint32_t)reg_pk.size();
-      pack_region(G.regions[k], false, &reg_pk);
-      pack_region(G.regions[k], true, &reg_pk_rc);
+      A.reg_clean[k] = clean ? 1 : 0;
+      A.reg_pk_off[k] = (uint32_t)A.reg_pk.size();
+      pack_region(G.regions[k], false, &A.reg_pk);
+      pack_region(G.regions[k], true, &A.reg_pk_rc);
       // walk window: V = last 32 nt (get_v_deletions starts at the 3' end, :754), J = first 32 nt (:793)
       const std::string &r = G.regions[k];
       if (r.size() >= 32) {
@@ -318,27 +335,44 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
           f |= (uint64_t)c << (2 * s);
           rcw |= (uint64_t)(c ^ 3) << (2 * (31 - s));
         }
-        if (ok) { w64_fwd[k] = f; w64_rc[k] = rcw; w64_ok[k] = 1; }
+        if (ok) { A.w64_fwd[k] = f; A.w64_rc[k] = rcw; A.w64_ok[k] = 1; }
       }
     }
     GeneDevPtrs &P = R.g[g];
     P.n = G.n;
     P.split = G.split;
-    P.tag_len = as_off<uint8_t>(B.put(tag_len));
-    P.jump = as_off<int32_t>(B.put(jump));
-    P.tag_ascii = as_off<uint8_t>(B.put(tag_ascii));
-    P.tag_pk_fwd = as_off<uint64_t>(B.put(tag_pk_fwd));
-    P.tag_pk_rc = as_off<uint64_t>(B.put(tag_pk_rc));
-    P.reg_off = as_off<uint32_t>(B.put(reg_off));
-    P.reg_len = as_off<uint32_t>(B.put(reg_len));
-    P.reg_bytes = as_off<uint8_t>(B.put(reg_bytes));
-    P.reg_pk_off = as_off<uint32_t>(B.put(reg_pk_off));
-    P.reg_pk = as_off<uint32_t>(B.put(reg_pk));
-    P.reg_pk_rc = as_off<uint32_t>(B.put(reg_pk_rc));
-    P.reg_clean = as_off<uint8_t>(B.put(reg_clean));
-    P.w64_fwd = as_off<uint64_t>(B.put(w64_fwd));
-    P.w64_rc = as_off<uint64_t>(B.put(w64_rc));
-    P.w64_ok = as_off<uint8_t>(B.put(w64_ok));
+    // LDS-image part
+    P.tag_len = as_off<uint8_t>(B.put(A.tag_len));
+    P.jump = as_off<int32_t>(B.put(A.jump));
+    P.tag_pk_fwd = as_off<uint64_t>(B.put(A.tag_pk_fwd));
+    P.tag_pk_rc = as_off<uint64_t>(B.put(A.tag_pk_rc));
+    P.w64_fwd = as_off<uint64_t>(B.put(A.w64_fwd));
+    P.w64_rc = as_off<uint64_t>(B.put(A.w64_rc));
+    P.w64_ok = as_off<uint8_t>(B.put(A.w64_ok));
+    P.reg_len = as_off<uint32_t>(B.put(A.reg_len));
+  }
+  R.lds_image_bytes = (uint32_t)((B.bytes.size() + 15) & ~(size_t)15);
+  for (int g = 0; g < 2; g++) {
+    GeneArrays &A = GA[g];
+    GeneDevPtrs &P = R.g[g];
+    P.tag_ascii = as_off<uint8_t>(B.put(A.tag_ascii));
+    P.reg_off = as_off<uint32_t>(B.put(A.reg_off));
+    P.reg_bytes = as_off<uint8_t>(B.put(A.reg_bytes));
+    P.reg_pk_off = as_off<uint32_t>(B.put(A.reg_pk_off));
+    P.reg_pk = as_off<uint32_t>(B.put(A.reg_pk));
+    P.reg_pk_rc = as_off<uint32_t>(B.put(A.reg_pk_rc));
+    P.reg_clean = as_off<uint8_t>(B.put(A.reg_clean));
+  }
+  {
+    // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged
+    std::vector<uint8_t> comp(256);
+    for (int c = 0; c < 256; c++) comp[c] = (uint8_t)c;
+    const char *ck = "ACGTMRWSYKVHDBXNU", *cv = "TGCAKYWSRMBDHVXNA";
+    for (int i = 0; ck[i]; i++) {
+      comp[(uint8_t)ck[i]] = (uint8_t)cv[i];
+      comp[(uint8_t)(ck[i] + 32)] = (uint8_t)(cv[i] + 32);
+    }
+    R.comp = as_off<uint8_t>(B.put(comp));
   }
   B.reserve(64);
   H.blob.swap(B.bytes);
