@@ -49,7 +49,7 @@ struct dcrx_tables {
   uint32_t *d_block_counts = nullptr;
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
-  uint32_t *d_queue = nullptr;  // [exc_flag_reads + 1]: slot 0 = count, then read indices
+  uint32_t *d_queue = nullptr;  // [4 counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
   uint64_t compact_reads = 0;
@@ -175,8 +175,9 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     P.grid = (uint32_t)prop.multiProcessorCount * per_cu;
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
+    P.ggrid = (uint32_t)prop.multiProcessorCount * std::min<uint32_t>(2048 / DCRX_GBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     t->plan = P;
-    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid) * DCRX_N_COUNTERS * 4));
+    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid + P.ggrid) * DCRX_N_COUNTERS * 4));
     t->device = dev;
   }
   if (max_reads < 4096) max_reads = 4096;  // workspace exists even for empty batches
@@ -184,7 +185,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
     (void)hipFree(t->d_queue); t->d_queue = nullptr;
     HIP_TRY(hipMalloc(&t->d_exc_flag, ((max_reads + 31) / 32) * 4 + 16));
-    HIP_TRY(hipMalloc(&t->d_queue, (max_reads + 4) * 4));
+    HIP_TRY(hipMalloc(&t->d_queue, (2 * max_reads + 8) * 4));  // [count, gcount, -, -][rescue queue][general queue]
     t->exc_flag_reads = max_reads;
   }
   if (max_reads > t->compact_reads) {
@@ -236,8 +237,8 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
-  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, t->d_queue + 4, t->d_queue, d_counters,
-                           (hipStream_t)stream,
+  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, t->d_queue + 4, t->d_queue + 4 + t->exc_flag_reads,
+                           t->d_queue, d_counters, (hipStream_t)stream,
                            t->ev_start, t->ev_stop));
   return DCRX_OK;
 }

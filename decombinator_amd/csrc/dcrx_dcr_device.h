@@ -174,6 +174,29 @@ DCRX_DEV int first_clean_down(uint64_t z, int k0) {
   return cand ? 31 - ((63 - dcrx_clz64(cand)) >> 1) : -1;
 }
 
+// Walks a read's exception list in frame order while a scan advances: hit(i) is true
+// exactly when frame position i holds an exception byte.  One list load per exception,
+// none per symbol.
+template <bool REV>
+struct ExcCursor {
+  const ReadView &r;
+  int x, nextpos;
+  DCRX_DEV explicit ExcCursor(const ReadView &rv) : r(rv) {
+    x = REV ? rv.e1 - 1 : rv.e0;
+    load();
+  }
+  DCRX_DEV void load() {
+    const bool any = REV ? (x >= r.e0) : (x < r.e1);
+    nextpos = any ? (REV ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x]) : 0x7FFFFFFF;
+  }
+  DCRX_DEV bool hit(int i) {
+    if (i != nextpos) return false;
+    x += REV ? -1 : 1;
+    load();
+    return true;
+  }
+};
+
 // Python s[a:b] bounds on a sequence of length n
 DCRX_DEV void pyslice(int n, int a, int b, int &lo, int &hi) {
   if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
@@ -370,8 +393,9 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
   const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
   const int n = F.n();
   uint32_t e = 0;
+  ExcCursor<REV> xc(F.r);
   for (int i = 0; i < n; i++) {
-    if (F.has_exc() && F.exc_index(i) >= 0) { e = 0; continue; }  // unknown byte: machine back to the root
+    if (xc.hit(i)) { e = 0; continue; }  // unknown byte: machine back to the root
     e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + 4u * (uint32_t)F.code(i));
     if (!((e >> BIT) & 1u)) continue;
     if (rescue_at<REV>(T, F, GENE, HALF, (e & TE_ROW_MASK) >> 4, i, end_of_v, out, C)) return true;
@@ -382,7 +406,7 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
 // Half-tag hits of one read, kept in LDS by the collecting scan of the queue kernel:
 // per class (V half1, V half2, J half1, J half2) up to HH_K entries `state<<9 | end_pos<<23 | 1`
 // in scan order, and the four hit counts (8 bits each, saturating at 255).
-constexpr int HH_K = 6;
+constexpr int HH_K = 4;
 constexpr int HH_STRIDE = 4 * HH_K + 1;  // dwords per lane (odd: conflict-free)
 struct HalfHits {
   uint32_t *slot;
@@ -514,8 +538,9 @@ template <bool REV, bool TABLE_LDS>
 DCRX_DEVNI ScanOut scan_slow(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F) {
   uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
   const int n = F.n();
+  ExcCursor<REV> xc(F.r);
   for (int i = 0; i < n; i++) {
-    if (F.has_exc() && F.exc_index(i) >= 0) { e = 0; it += (1u << ACC_POS_SHIFT); continue; }
+    if (xc.hit(i)) { e = 0; it += (1u << ACC_POS_SHIFT); continue; }
     DCRX_STEP(F.code(i));
   }
   return ScanOut{acc, vacc, jacc};
@@ -647,10 +672,16 @@ DCRX_DEV int attempt(const DevTables &T, const uint32_t *lds_trans, const ReadVi
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg,
-                            uint64_t r, uint32_t nw, const Counters &C, dcrx_record_t *records) {
+                            uint64_t r, uint32_t nw, const Counters &C, dcrx_record_t *records,
+                            uint32_t *word_slot = nullptr) {
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  if (word_slot) {  // general kernel: the per-symbol accessors then read LDS, not global memory
+    for (uint32_t k = 0; k < nw; k++) word_slot[k] = rv.words[k];
+    word_slot[nw] = 0; word_slot[nw + 1] = 0;
+    rv.words = word_slot;
+  }
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
@@ -700,16 +731,18 @@ DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const
 
 // ------------------------------------------------------------------------------
 // Fast-kernel form of decombine_one: clean reads (no exception bytes), one frame,
-// no half-tag rescue.  Returns false — having touched neither counters nor the
-// record — when the read needs the general path (decombine_one, run by the queue
-// kernel): exception bytes, orientation `both`, or a half-tag rescue.
+// no half-tag rescue.  Returns FAST_DONE, or — having touched neither counters nor
+// the record — FAST_TO_RESCUE (a half-tag rescue is needed: rescue kernel) or
+// FAST_TO_GENERAL (exception bytes, orientation `both`: general kernel).
 // ------------------------------------------------------------------------------
+enum { FAST_DONE = 0, FAST_TO_RESCUE = 1, FAST_TO_GENERAL = 2 };
+
 template <bool TABLE_LDS, bool UNIFORM_LEN>
-DCRX_DEV bool decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
+DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, uint32_t nw, const Counters &C,
                                  dcrx_record_t *records) {
-  if (cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER)) return false;
-  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) return false;
+  if (cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER)) return FAST_TO_GENERAL;
+  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) return FAST_TO_GENERAL;
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
@@ -739,11 +772,11 @@ DCRX_DEV bool decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, 
       rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.acc >> 16); rec.v_start = (uint16_t)so.vacc; rec.j_end = (uint16_t)so.jacc;
       rec.status = 254; rec.frame = 0;
       dcrx_store_record(records + r, rec);
-      return true;
+      return FAST_DONE;
     }
     status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0;
   }
-  if (status == DCRX_S_DEFER) return false;
+  if (status == DCRX_S_DEFER) return FAST_TO_RESCUE;
   C.add(DCRX_C_READ_COUNT);                                           // :991
   if (status == DCRX_S_OK) {
     C.add(DCRX_C_VJ_COUNT);                                           // :1013
@@ -751,11 +784,11 @@ DCRX_DEV bool decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, 
   }
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
   dcrx_store_record(records + r, rec);
-  return true;
+  return FAST_DONE;
 }
 
 // ------------------------------------------------------------------------------
-// Queue-kernel form for clean reads that only needed a half-tag rescue: one
+// Rescue-kernel form for clean reads that only needed a half-tag rescue: one
 // collecting scan, then dcr_frame with the rescue fed from the LDS hit lists.
 // Returns false (nothing counted, nothing written) when the read must take
 // decombine_one instead: exception bytes, orientation `both`, forced slow

@@ -39,6 +39,9 @@ constexpr int DCRX_WQ_CAP = 128;
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
+constexpr int DCRX_GW_STRIDE = DCRX_NWMAX + 3;  // words + 2 spare, odd
+constexpr int DCRX_GW_PAD = (4 - (DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE) % 4) % 4;
+constexpr uint32_t DCRX_GENERAL_LDS_EXTRA = (DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) * 4;
 
 // ------------------------------------------------------------------------------
 // Fast kernel: persistent blocks, each stages the DFA into LDS once and then
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
                                                                dcrx_record_t *__restrict__ records,
                                                                uint32_t *__restrict__ block_counts,
                                                                uint32_t *__restrict__ queue,
-                                                               uint32_t *__restrict__ queue_count) {
+                                                               uint32_t *__restrict__ queue_count,
+                                                               uint32_t *__restrict__ gqueue) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
@@ -76,8 +80,9 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
 
   for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
     const uint64_t r = tile * DCRX_BLOCK + tid;
-    bool defer = false;
-    if (r < B.n_reads) defer = !decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    int what = FAST_DONE;
+    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    const bool defer = what == FAST_TO_RESCUE;
     const unsigned long long m = __ballot(defer);
     if (m) {
       if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
@@ -90,6 +95,16 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
         wq_n = 0;
       }
     }
+    // reads for the general kernel are rare (exception bytes) unless the whole batch runs in
+    // orientation `both`: one atomic per wave that has any
+    const unsigned long long mg = __ballot(what == FAST_TO_GENERAL);
+    if (mg) {
+      const int leader = __ffsll(mg) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(queue_count + 1, (uint32_t)__popcll(mg));
+      base = __shfl(base, leader);
+      if (what == FAST_TO_GENERAL) gqueue[base + (uint32_t)__popcll(mg & ((1ull << lane) - 1ull))] = (uint32_t)r;
+    }
   }
   if (wq_n) {
     uint32_t base = 0;
@@ -101,20 +116,24 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
 
-// Queue kernel: the general per-read path (decombine_one) over the compacted queue.
+// Rescue kernel: clean reads whose V or J tag needs the half-tag rescue, in dense waves.
+// One collecting scan per read (half-tag hits into per-lane LDS lists), then the rescue
+// feeds from the lists.  A read with more hits than a list holds goes on to the general
+// kernel.
 template <bool TABLE_LDS, bool UNIFORM_LEN>
-__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables T0, BatchDev B, CfgDev cfg,
-                                                                      dcrx_record_t *__restrict__ records,
-                                                                      uint32_t *__restrict__ block_counts,
-                                                                      const uint32_t *__restrict__ queue,
-                                                                      const uint32_t *__restrict__ queue_count) {
+__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables T0, BatchDev B, CfgDev cfg,
+                                                                       dcrx_record_t *__restrict__ records,
+                                                                       uint32_t *__restrict__ block_counts,
+                                                                       const uint32_t *__restrict__ queue,
+                                                                       uint32_t *__restrict__ queue_count,
+                                                                       uint32_t *__restrict__ gqueue) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_hh = smem + DCRX_N_COUNTERS;           // [DCRX_QBLOCK][HH_STRIDE] half-tag hit lists
   uint32_t *lds_trans = lds_hh + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD;
   static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
-  const uint32_t n_queued = *queue_count;
+  const uint32_t n_queued = queue_count[0];
   if ((uint64_t)blockIdx.x * DCRX_QBLOCK >= n_queued) {  // nothing for this block: its tallies are zero
     if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
     return;
@@ -128,12 +147,47 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_queue_kernel(DevTables 
   __syncthreads();
   const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
-  const uint32_t nw = B.stride >> 2;
   for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK) {
     const uint64_t r = (uint64_t)queue[i];
     if (!decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, C, records, lds_hh + tid * HH_STRIDE))
-      decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+      gqueue[atomicAdd(queue_count + 1, 1u)] = (uint32_t)r;
   }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
+}
+
+// General kernel: decombine_one (any read: exception bytes, orientation `both`, list overflow)
+// over its own queue, each read's words copied to a per-lane LDS slot first.
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+__global__ __launch_bounds__(DCRX_GBLOCK) void decombine_general_kernel(DevTables T0, BatchDev B, CfgDev cfg,
+                                                                        dcrx_record_t *__restrict__ records,
+                                                                        uint32_t *__restrict__ block_counts,
+                                                                        const uint32_t *__restrict__ gqueue,
+                                                                        const uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_words = smem + DCRX_N_COUNTERS;        // [DCRX_GBLOCK][DCRX_GW_STRIDE]
+  uint32_t *lds_trans = lds_words + DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD;
+  static_assert(((DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
+  const int tid = threadIdx.x;
+  const uint32_t n_queued = queue_count[1];
+  if ((uint64_t)blockIdx.x * DCRX_GBLOCK >= n_queued) {
+    if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
+    return;
+  }
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  if (TABLE_LDS) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
+    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_GBLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
+  const Counters C{lds_counts};
+  const uint32_t nw = B.stride >> 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_GBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_GBLOCK)
+    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], nw, C, records,
+                                          lds_words + tid * DCRX_GW_STRIDE);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
@@ -246,41 +300,52 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM>
 static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *queue_count,
-                              hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
+                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
-  auto kqueue = decombine_queue_kernel<TABLE_LDS, UNIFORM>;
-  if (P.lds_bytes + DCRX_QUEUE_LDS_EXTRA > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(P.lds_bytes + DCRX_FAST_LDS_EXTRA));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kqueue), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(P.lds_bytes + DCRX_QUEUE_LDS_EXTRA));
-    if (e != hipSuccess) return e;
-  }
+  auto krescue = decombine_rescue_kernel<TABLE_LDS, UNIFORM>;
+  auto kgeneral = decombine_general_kernel<TABLE_LDS, UNIFORM>;
+  const uint32_t lds_fast = P.lds_bytes + DCRX_FAST_LDS_EXTRA, lds_rescue = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA,
+                 lds_general = P.lds_bytes + DCRX_GENERAL_LDS_EXTRA;
   hipError_t e;
   // persistent grids: exactly as many blocks as are resident at once (a larger grid would run in
   // two rounds and leave the tiles of the late blocks for the end)
-  static int occ_fast = 0, occ_queue = 0;
+  static int occ_fast = 0, occ_rescue = 0, occ_general = 0;
   if (!occ_fast) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, DCRX_BLOCK, P.lds_bytes + DCRX_FAST_LDS_EXTRA);
+    if (std::max(lds_rescue, std::max(lds_fast, lds_general)) > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(krescue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rescue);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kgeneral), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_general);
+      if (e != hipSuccess) return e;
+    }
+    int o1 = 0, o2 = 0, o3 = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kfast, DCRX_BLOCK, lds_fast);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_queue, kqueue, DCRX_QBLOCK, P.lds_bytes + DCRX_QUEUE_LDS_EXTRA);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, krescue, DCRX_QBLOCK, lds_rescue);
     if (e != hipSuccess) return e;
-    if (occ_fast < 1) occ_fast = 1;
-    if (occ_queue < 1) occ_queue = 1;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, kgeneral, DCRX_GBLOCK, lds_general);
+    if (e != hipSuccess) return e;
+    occ_rescue = std::max(o2, 1); occ_general = std::max(o3, 1); occ_fast = std::max(o1, 1);
   }
   const uint32_t grid = std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
-  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_queue);
+  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_rescue);
+  const uint32_t ggrid = std::min<uint32_t>(P.ggrid, P.n_cu * (uint32_t)occ_general);
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), P.lds_bytes + DCRX_FAST_LDS_EXTRA, s, T, B, cfg, rec,
-                     block_counts, queue, queue_count);
+  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count,
+                     gqueue);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(kqueue, dim3(qgrid), dim3(DCRX_QBLOCK), P.lds_bytes + DCRX_QUEUE_LDS_EXTRA, s, T, B, cfg, rec,
-                     block_counts + (size_t)P.grid * DCRX_N_COUNTERS, queue, queue_count);
+  uint32_t *bc_rescue = block_counts + (size_t)P.grid * DCRX_N_COUNTERS;
+  uint32_t *bc_general = bc_rescue + (size_t)P.qgrid * DCRX_N_COUNTERS;
+  hipLaunchKernelGGL(krescue, dim3(qgrid), dim3(DCRX_QBLOCK), lds_rescue, s, T, B, cfg, rec, bc_rescue, queue,
+                     queue_count, gqueue);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kgeneral, dim3(ggrid), dim3(DCRX_GBLOCK), lds_general, s, T, B, cfg, rec, bc_general, gqueue,
+                     queue_count);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   // blocks that were not launched contribute zero tallies
@@ -288,15 +353,19 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
     e = hipMemsetAsync(block_counts + (size_t)grid * DCRX_N_COUNTERS, 0, (size_t)(P.grid - grid) * DCRX_N_COUNTERS * 4, s);
     if (e != hipSuccess) return e;
   }
-  if (qgrid < P.qgrid)
-    e = hipMemsetAsync(block_counts + (size_t)(P.grid + qgrid) * DCRX_N_COUNTERS, 0,
-                       (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
+  if (qgrid < P.qgrid) {
+    e = hipMemsetAsync(bc_rescue + (size_t)qgrid * DCRX_N_COUNTERS, 0, (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  if (ggrid < P.ggrid)
+    e = hipMemsetAsync(bc_general + (size_t)ggrid * DCRX_N_COUNTERS, 0, (size_t)(P.ggrid - ggrid) * DCRX_N_COUNTERS * 4, s);
   return e;
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                            dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *queue_count,
-                            uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
+                            uint32_t *queue_count, uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
   hipError_t e;
   if (B.n_exc) {
     e = hipMemsetAsync(const_cast<uint32_t *>(B.exc_flag), 0, ((B.n_reads + 31) / 32) * 4, s);
@@ -305,18 +374,18 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
     hipLaunchKernelGGL(mark_exceptions_kernel, dim3(g), dim3(256), 0, s, B.exc_read, B.n_exc,
                        const_cast<uint32_t *>(B.exc_flag));
   }
-  e = hipMemsetAsync(queue_count, 0, 4, s);
+  e = hipMemsetAsync(queue_count, 0, 8, s);
   if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
   if (P.table_in_lds) {
-    e = uniform ? launch_pair<true, true>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop)
-                : launch_pair<true, false>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop);
+    e = uniform ? launch_pair<true, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+                : launch_pair<true, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
   } else {
-    e = uniform ? launch_pair<false, true>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop)
-                : launch_pair<false, false>(P, T, B, cfg, rec, block_counts, queue, queue_count, s, ev_start, ev_stop);
+    e = uniform ? launch_pair<false, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+                : launch_pair<false, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid + P.ggrid), d_counters);
   return hipGetLastError();
 }
 

@@ -8,7 +8,8 @@
 #define DCRX_NWMAX 20
 #define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
 #define DCRX_BLOCK 512   /* fast kernel */
-#define DCRX_QBLOCK 256  /* queue kernel */
+#define DCRX_QBLOCK 512  /* rescue kernel */
+#define DCRX_GBLOCK 256  /* general kernel */
 
 namespace dcrx {
 

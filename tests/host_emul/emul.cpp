@@ -36,17 +36,21 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
   Counters CC{counts};
   for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
   for (uint64_t r = 0; r < b->n_reads; r++) {
-    // fast kernel first; what it defers goes to the queue kernel: the list-fed rescue, or the
-    // general path (decombine_one)
+    // fast kernel first; what it defers goes to the rescue kernel (list-fed rescue) or to the
+    // general kernel (decombine_one on an LDS copy of the words)
     uint32_t hh_slot[HH_STRIDE];
+    uint32_t word_slot[DCRX_NWMAX + 3];
+    const uint32_t nw = b->stride / 4;
     if (b->lens) {
-      if (!decombine_fast_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records))
-        if (!decombine_rescue_one<false, false>(T, nullptr, B, C, r, CC, records, hh_slot))
-          decombine_one<false, false>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+      int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
+      if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, false>(T, nullptr, B, C, r, CC, records, hh_slot))
+        what = FAST_TO_GENERAL;
+      if (what == FAST_TO_GENERAL) decombine_one<false, false>(T, nullptr, B, C, r, nw, CC, records, word_slot);
     } else {
-      if (!decombine_fast_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records))
-        if (!decombine_rescue_one<false, true>(T, nullptr, B, C, r, CC, records, hh_slot))
-          decombine_one<false, true>(T, nullptr, B, C, r, b->stride / 4, CC, records);
+      int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
+      if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, true>(T, nullptr, B, C, r, CC, records, hh_slot))
+        what = FAST_TO_GENERAL;
+      if (what == FAST_TO_GENERAL) decombine_one<false, true>(T, nullptr, B, C, r, nw, CC, records, word_slot);
     }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
   }
