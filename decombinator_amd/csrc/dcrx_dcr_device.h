@@ -25,6 +25,9 @@ DCRX_DEV int dcrx_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
 }
+// pointer into LDS with its address space spelled out (ds_read/ds_write instead of flat_*)
+typedef __attribute__((address_space(3))) uint32_t dcrx_lds_u32;
+#define DCRX_TO_LDS(p) ((dcrx_lds_u32 *)(p))
 using ::min;
 using ::max;
 #else
@@ -43,6 +46,8 @@ inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
 inline int dcrx_popc64(uint64_t v) { return __builtin_popcountll(v); }
 inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
+typedef uint32_t dcrx_lds_u32;
+#define DCRX_TO_LDS(p) (p)
 struct uint2 { uint32_t x, y; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 #define __align__(n) alignas(n)
@@ -112,6 +117,14 @@ struct Frame {
     return -1;
   }
   DCRX_DEV bool has_exc() const { return r.e1 > r.e0; }
+  // no exception byte at frame positions [a, b)
+  DCRX_DEV bool clean(int a, int b) const {
+    for (int x = r.e0; x < r.e1; x++) {
+      const int i = REV ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
+      if (i >= a && i < b) return false;
+    }
+    return true;
+  }
   // the character str(read)[i] the reference would see
   DCRX_DEVNI uint8_t chr(int i) const {
     if (has_exc()) {
@@ -221,7 +234,7 @@ DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const Fram
   const int n = F.n();
   // fast path: both slices are whole 10-mers inside their sequences, nothing but ACGT involved
   if (ga >= 0 && gb <= Lg && gb - ga == rb - ra && ra >= 0 && rb <= n && gb - ga <= 16 && gb > ga &&
-      !F.has_exc() && G.reg_clean[g]) {
+      G.reg_clean[g] && F.clean(ra, rb)) {
     int len = gb - ga;
     uint32_t rw = F.window(ra, len);
     uint32_t gw = REV ? packed_window(G.reg_pk_rc + G.reg_pk_off[g], Lg - ga - len, len)
@@ -250,7 +263,7 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v
   f += 1;                                                   // :764
   // Bit-parallel form of the loop below for the common geometry: the first 23 iterations
   // only touch read[f-32:f] and the last 32 germline bases, all whole 10-mers of pure ACGT.
-  if (f >= 32 && f < n && !F.has_exc() && G.w64_ok[v_match]) {
+  if (f >= 32 && f < n && G.w64_ok[v_match] && F.clean(f - 32, f)) {
     const uint64_t rw = REV ? F.load64(n - f) : F.load64(f - 32);
     const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[v_match] : G.w64_fwd[v_match]);
     const int k = REV ? first_clean_up(or10_up(y), 0) : first_clean_down(or10_down(y), 0);
@@ -278,7 +291,7 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j
   int pos = 0;                                              // :793
   // Bit-parallel form of the loop below while it stays inside read[ts:ts+32] and the first
   // 32 germline bases: skipped steps (f < end_of_v, :798-800) only raise the first position tried.
-  if (f >= 0 && f + 32 <= n && !F.has_exc() && G.w64_ok[j_match]) {
+  if (f >= 0 && f + 32 <= n && G.w64_ok[j_match] && F.clean(f, f + 32)) {
     const int k0 = end_of_v > f ? end_of_v - f : 0;
     const uint64_t rw = REV ? F.load64(n - f - 32) : F.load64(f);
     const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[j_match] : G.w64_fwd[j_match]);
@@ -303,9 +316,9 @@ DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const Frame<REV> &F, in
   const int Lt = (int)G.tag_len[k];
   const int n = F.n();
   // packed form: the slice is the whole tag-long window, pure ACGT, and a 32-base load covers it
-  if (hi - lo == Lt && !F.has_exc()) {
+  if (hi - lo == Lt) {
     const int b = REV ? n - lo - Lt : lo;           // forward position of the window's first stored base
-    if (b >= 0 && b + 32 <= n) {
+    if (b >= 0 && b + 32 <= n && F.clean(lo, hi)) {
       const uint64_t mask = (Lt >= 32) ? ~0ull : ((1ull << (2 * Lt)) - 1ull);
       const uint64_t y = mismatch_slots(F.load64(b), REV ? G.tag_pk_rc[k] : G.tag_pk_fwd[k]) & mask;
       return dcrx_popc64(y) <= 1;
@@ -409,7 +422,7 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
 constexpr int HH_K = 4;
 constexpr int HH_STRIDE = 4 * HH_K + 1;  // dwords per lane (odd: conflict-free)
 struct HalfHits {
-  uint32_t *slot;
+  dcrx_lds_u32 *slot;
   uint32_t cnts;
   DCRX_DEV int count(int cls4) const { return (int)((cnts >> (8 * cls4)) & 0xFFu); }
 };
@@ -695,6 +708,12 @@ DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const
       while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
       rv.e1 = (int)lo;
       slow = true;
+      if (word_slot && rv.e1 - rv.e0 <= DCRX_EXC_LDS) {  // and its few exception entries
+        uint16_t *xp = reinterpret_cast<uint16_t *>(word_slot + DCRX_NWMAX + 2);
+        uint8_t *xb = reinterpret_cast<uint8_t *>(word_slot + DCRX_NWMAX + 2 + DCRX_EXC_LDS / 2);
+        for (int x = rv.e0; x < rv.e1; x++) { xp[x - rv.e0] = B.exc_pos[x]; xb[x - rv.e0] = B.exc_chr[x]; }
+        rv.exc_pos = xp - rv.e0; rv.exc_chr = xb - rv.e0;
+      }
     }
   }
   // the read's words, for the register-resident fast scan
@@ -807,7 +826,7 @@ DCRX_DEV bool decombine_rescue_one(const DevTables &T, const uint32_t *lds_trans
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   HalfHits hh;
-  hh.slot = hh_slot;
+  hh.slot = DCRX_TO_LDS(hh_slot);
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;

@@ -39,7 +39,7 @@ constexpr int DCRX_WQ_CAP = 128;
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
-constexpr int DCRX_GW_STRIDE = DCRX_NWMAX + 3;  // words + 2 spare, odd
+constexpr int DCRX_GW_STRIDE = DCRX_GSLOT_DWORDS | 1;  // odd: conflict-free
 constexpr int DCRX_GW_PAD = (4 - (DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_GENERAL_LDS_EXTRA = (DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) * 4;
 

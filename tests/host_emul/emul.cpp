@@ -39,7 +39,7 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     // fast kernel first; what it defers goes to the rescue kernel (list-fed rescue) or to the
     // general kernel (decombine_one on an LDS copy of the words)
     uint32_t hh_slot[HH_STRIDE];
-    uint32_t word_slot[DCRX_NWMAX + 3];
+    uint32_t word_slot[DCRX_GSLOT_DWORDS + 1];
     const uint32_t nw = b->stride / 4;
     if (b->lens) {
       int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
