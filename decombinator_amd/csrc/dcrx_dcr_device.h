@@ -711,8 +711,9 @@ DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const
       if (word_slot && rv.e1 - rv.e0 <= DCRX_EXC_LDS) {  // and its few exception entries
         uint16_t *xp = reinterpret_cast<uint16_t *>(word_slot + DCRX_NWMAX + 2);
         uint8_t *xb = reinterpret_cast<uint8_t *>(word_slot + DCRX_NWMAX + 2 + DCRX_EXC_LDS / 2);
-        for (int x = rv.e0; x < rv.e1; x++) { xp[x - rv.e0] = B.exc_pos[x]; xb[x - rv.e0] = B.exc_chr[x]; }
-        rv.exc_pos = xp - rv.e0; rv.exc_chr = xb - rv.e0;
+        const int cnt = rv.e1 - rv.e0;
+        for (int x = 0; x < cnt; x++) { xp[x] = B.exc_pos[rv.e0 + x]; xb[x] = B.exc_chr[rv.e0 + x]; }
+        rv.exc_pos = xp; rv.exc_chr = xb; rv.e0 = 0; rv.e1 = cnt;  // indices re-based onto the LDS copy
       }
     }
   }
