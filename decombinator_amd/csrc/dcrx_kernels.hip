@@ -55,8 +55,7 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
                                                                dcrx_record_t *__restrict__ records,
                                                                uint32_t *__restrict__ block_counts,
                                                                uint32_t *__restrict__ queue,
-                                                               uint32_t *__restrict__ queue_count,
-                                                               uint32_t *__restrict__ gqueue) {
+                                                               uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
@@ -95,16 +94,8 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
         wq_n = 0;
       }
     }
-    // reads for the general kernel are rare (exception bytes) unless the whole batch runs in
-    // orientation `both`: one atomic per wave that has any
-    const unsigned long long mg = __ballot(what == FAST_TO_GENERAL);
-    if (mg) {
-      const int leader = __ffsll(mg) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(queue_count + 1, (uint32_t)__popcll(mg));
-      base = __shfl(base, leader);
-      if (what == FAST_TO_GENERAL) gqueue[base + (uint32_t)__popcll(mg & ((1ull << lane) - 1ull))] = (uint32_t)r;
-    }
+    // FAST_TO_GENERAL reads (exception bytes) are already on the general kernel's list, which is
+    // built from the exception list before this kernel starts
   }
   if (wq_n) {
     uint32_t base = 0;
@@ -125,8 +116,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
                                                                        dcrx_record_t *__restrict__ records,
                                                                        uint32_t *__restrict__ block_counts,
                                                                        const uint32_t *__restrict__ queue,
-                                                                       uint32_t *__restrict__ queue_count,
-                                                                       uint32_t *__restrict__ gqueue) {
+                                                                       const uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_hh = smem + DCRX_N_COUNTERS;           // [DCRX_QBLOCK][HH_STRIDE] half-tag hit lists
@@ -150,7 +140,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
   for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK) {
     const uint64_t r = (uint64_t)queue[i];
     if (!decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, C, records, lds_hh + tid * HH_STRIDE))
-      gqueue[atomicAdd(queue_count + 1, 1u)] = (uint32_t)r;
+      decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, B.stride >> 2, C, records);  // a hit list overflowed
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
@@ -206,6 +196,21 @@ __global__ __launch_bounds__(1024) void reduce_counts_kernel(const uint32_t *__r
     uint64_t tot = 0;
     for (int p = 0; p < 1024 / DCRX_N_COUNTERS; p++) tot += part[p * DCRX_N_COUNTERS + threadIdx.x];
     out[threadIdx.x] = tot;
+  }
+}
+
+// The general kernel's work list: every read when `all` (orientation `both`, forced slow
+// reader), else each read that owns an exception byte, once.
+__global__ void build_general_queue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all,
+                                           uint64_t n_reads, uint32_t *__restrict__ gqueue,
+                                           uint32_t *__restrict__ gcount) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (all) {
+    if (i < n_reads) gqueue[i] = (uint32_t)i;
+    if (i == 0) *gcount = (uint32_t)n_reads;
+  } else if (i < n_exc) {
+    const uint32_t r = exc_read[i];
+    if (i == 0 || exc_read[i - 1] != r) gqueue[atomicAdd(gcount, 1u)] = r;
   }
 }
 
@@ -299,9 +304,9 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM>
-static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
-                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
+                             dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
+                             uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
   auto krescue = decombine_rescue_kernel<TABLE_LDS, UNIFORM>;
   auto kgeneral = decombine_general_kernel<TABLE_LDS, UNIFORM>;
@@ -329,25 +334,43 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
     if (e != hipSuccess) return e;
     occ_rescue = std::max(o2, 1); occ_general = std::max(o3, 1); occ_fast = std::max(o1, 1);
   }
-  const uint32_t grid = std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
-  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_rescue);
-  const uint32_t ggrid = std::min<uint32_t>(P.ggrid, P.n_cu * (uint32_t)occ_general);
-  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count,
-                     gqueue);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
+  const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
+  const uint32_t qgrid = all_general ? 0 : std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_rescue);
+  const bool any_general = all_general || B.n_exc > 0;
+  const uint32_t ggrid = any_general ? std::min<uint32_t>(P.ggrid, P.n_cu * (uint32_t)occ_general) : 0;
   uint32_t *bc_rescue = block_counts + (size_t)P.grid * DCRX_N_COUNTERS;
   uint32_t *bc_general = bc_rescue + (size_t)P.qgrid * DCRX_N_COUNTERS;
-  hipLaunchKernelGGL(krescue, dim3(qgrid), dim3(DCRX_QBLOCK), lds_rescue, s, T, B, cfg, rec, bc_rescue, queue,
-                     queue_count, gqueue);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kgeneral, dim3(ggrid), dim3(DCRX_GBLOCK), lds_general, s, T, B, cfg, rec, bc_general, gqueue,
-                     queue_count);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+
+  // The general kernel (few, long, divergent reads) runs beside the fast and rescue kernels on
+  // the plan's auxiliary stream: fork after its work list exists, join before the counter sum.
+  if (any_general) {
+    const uint64_t items = all_general ? B.n_reads : B.n_exc;
+    hipLaunchKernelGGL(build_general_queue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read,
+                       B.n_exc, all_general ? 1 : 0, B.n_reads, gqueue, queue_count + 1);
+    e = hipEventRecord(P.ev_fork, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamWaitEvent(P.aux, P.ev_fork, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kgeneral, dim3(ggrid), dim3(DCRX_GBLOCK), lds_general, P.aux, T, B, cfg, rec, bc_general, gqueue,
+                       queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(P.ev_join, P.aux);
+    if (e != hipSuccess) return e;
+  }
+  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
+  if (grid) {
+    hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  if (qgrid) {
+    hipLaunchKernelGGL(krescue, dim3(qgrid), dim3(DCRX_QBLOCK), lds_rescue, s, T, B, cfg, rec, bc_rescue, queue, queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   // blocks that were not launched contribute zero tallies
   if (grid < P.grid) {
     e = hipMemsetAsync(block_counts + (size_t)grid * DCRX_N_COUNTERS, 0, (size_t)(P.grid - grid) * DCRX_N_COUNTERS * 4, s);
@@ -357,8 +380,11 @@ static hipError_t launch_pair(const LaunchPlan &P, const DevTables &T, const Bat
     e = hipMemsetAsync(bc_rescue + (size_t)qgrid * DCRX_N_COUNTERS, 0, (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
     if (e != hipSuccess) return e;
   }
-  if (ggrid < P.ggrid)
+  if (ggrid < P.ggrid) {
     e = hipMemsetAsync(bc_general + (size_t)ggrid * DCRX_N_COUNTERS, 0, (size_t)(P.ggrid - ggrid) * DCRX_N_COUNTERS * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  if (any_general) e = hipStreamWaitEvent(s, P.ev_join, 0);
   return e;
 }
 
@@ -378,11 +404,11 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
   if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
   if (P.table_in_lds) {
-    e = uniform ? launch_pair<true, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
-                : launch_pair<true, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
+    e = uniform ? launch_all<true, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+                : launch_all<true, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
   } else {
-    e = uniform ? launch_pair<false, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
-                : launch_pair<false, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
+    e = uniform ? launch_all<false, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+                : launch_all<false, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid + P.ggrid), d_counters);

@@ -44,12 +44,12 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     if (b->lens) {
       int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
       if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, false>(T, nullptr, B, C, r, CC, records, hh_slot))
-        what = FAST_TO_GENERAL;
+        decombine_one<false, false>(T, nullptr, B, C, r, nw, CC, records);  // list overflow: inline in the rescue kernel
       if (what == FAST_TO_GENERAL) decombine_one<false, false>(T, nullptr, B, C, r, nw, CC, records, word_slot);
     } else {
       int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
       if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, true>(T, nullptr, B, C, r, CC, records, hh_slot))
-        what = FAST_TO_GENERAL;
+        decombine_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
       if (what == FAST_TO_GENERAL) decombine_one<false, true>(T, nullptr, B, C, r, nw, CC, records, word_slot);
     }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
