@@ -596,7 +596,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_VH1_BIT) & 3u) {                // a V half1 (:294-335) or half2 (:339-390) keyword occurs
       if (DEFER) return DCRX_S_DEFER;
       const int half = ((so.acc >> TE_VH1_BIT) & 1u) ? 1 : 2;  // half2 is tried only when no half1 hit exists
-      if (!(hh ? rescue_list<REV>(T, F, *hh, 0, half, 0, vdat, C)
+      if (!((hh && hh->count(half - 1) <= HH_K) ? rescue_list<REV>(T, F, *hh, 0, half, 0, vdat, C)
                : rescue<REV, TABLE_LDS>(T, lds_trans, F, 0, half, 0, vdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDV1NOTV2 : DCRX_C_FOUNDV2NOTV1);       // :334 / :389
         return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : DCRX_S_V_HALF2_EXHAUSTED;
@@ -626,7 +626,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_JH1_BIT) & 3u) {                // a J half1 (:422-470) or half2 (:473-527) keyword occurs
       if (DEFER) return DCRX_S_DEFER;                        // nothing has been counted for this read yet
       const int half = ((so.acc >> TE_JH1_BIT) & 1u) ? 1 : 2;
-      if (!(hh ? rescue_list<REV>(T, F, *hh, 1, half, end_of_v, jdat, C)
+      if (!((hh && hh->count(2 + half - 1) <= HH_K) ? rescue_list<REV>(T, F, *hh, 1, half, end_of_v, jdat, C)
                : rescue<REV, TABLE_LDS>(T, lds_trans, F, 1, half, end_of_v, jdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDJ1NOTJ2 : DCRX_C_FOUNDV2NOTV1);       // :469 / :526 (the reference bumps the V key)
         jstatus = half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : DCRX_S_J_HALF2_EXHAUSTED;
@@ -810,9 +810,9 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
 // ------------------------------------------------------------------------------
 // Rescue-kernel form for clean reads that only needed a half-tag rescue: one
 // collecting scan, then dcr_frame with the rescue fed from the LDS hit lists.
-// Returns false (nothing counted, nothing written) when the read must take
-// decombine_one instead: exception bytes, orientation `both`, forced slow
-// reader, or more than HH_K hits in a list it needs.
+// A class with more than HH_K hits falls back to the re-scanning rescue inside
+// dcr_frame.  Returns false (nothing counted, nothing written) only for reads that
+// never belong here: exception bytes, orientation `both`, forced slow reader.
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 DCRX_DEV bool decombine_rescue_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
@@ -834,11 +834,9 @@ DCRX_DEV bool decombine_rescue_one(const DevTables &T, const uint32_t *lds_trans
   int status, frame;
   if (cfg.orientation == DCRX_ORIENT_FORWARD) {
     const ScanOut so = scan_collect<false, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
-    if (hh.count(0) > HH_K || hh.count(1) > HH_K || hh.count(2) > HH_K || hh.count(3) > HH_K) return false;
     status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
   } else {
     const ScanOut so = scan_collect<true, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
-    if (hh.count(0) > HH_K || hh.count(1) > HH_K || hh.count(2) > HH_K || hh.count(3) > HH_K) return false;
     status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
   }
   C.add(DCRX_C_READ_COUNT);

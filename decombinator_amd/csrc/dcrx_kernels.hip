@@ -36,6 +36,7 @@ namespace dcrx {
 // LDS beyond the counters + DFA (LaunchPlan::lds_bytes): the fast kernel's per-wave deferral
 // buffers, the queue kernel's half-tag hit lists
 constexpr int DCRX_WQ_CAP = 128;
+constexpr int DCRX_CHUNK = 4;  // 64-read tiles a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
                                                                uint32_t *__restrict__ block_counts,
                                                                uint32_t *__restrict__ queue,
                                                                uint32_t *__restrict__ queue_count) {
+  uint32_t *tile_ticket = queue_count + 2;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
@@ -77,25 +79,35 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   uint32_t *wq = lds_wq + (tid >> 6) * DCRX_WQ_CAP;
   uint32_t wq_n = 0;
 
-  for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
-    const uint64_t r = tile * DCRX_BLOCK + tid;
-    int what = FAST_DONE;
-    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
-    const bool defer = what == FAST_TO_RESCUE;
-    const unsigned long long m = __ballot(defer);
-    if (m) {
-      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
-      wq_n += (uint32_t)__popcll(m);
-      if (wq_n >= 64) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue_count, wq_n);
-        base = __shfl(base, 0);
-        for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
-        wq_n = 0;
+  // Work distribution: every wave claims DCRX_CHUNK consecutive 64-read tiles at a time from a
+  // global ticket, so blocks that become resident late (another kernel holds their CU) simply
+  // claim less instead of holding the launch's tail.
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
+    ticket = __shfl(ticket, 0);
+    const uint64_t first = (uint64_t)ticket * (64 * DCRX_CHUNK);
+    if (first >= B.n_reads) break;
+    for (int c = 0; c < DCRX_CHUNK; c++) {
+      const uint64_t r = first + (uint64_t)c * 64 + lane;
+      int what = FAST_DONE;
+      if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+      // FAST_TO_GENERAL reads (exception bytes) are already on the general kernel's list, which is
+      // built from the exception list before this kernel starts
+      const bool defer = what == FAST_TO_RESCUE;
+      const unsigned long long m = __ballot(defer);
+      if (m) {
+        if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        wq_n += (uint32_t)__popcll(m);
+        if (wq_n >= 64) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(queue_count, wq_n);
+          base = __shfl(base, 0);
+          for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
+          wq_n = 0;
+        }
       }
     }
-    // FAST_TO_GENERAL reads (exception bytes) are already on the general kernel's list, which is
-    // built from the exception list before this kernel starts
   }
   if (wq_n) {
     uint32_t base = 0;
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
                                                                        dcrx_record_t *__restrict__ records,
                                                                        uint32_t *__restrict__ block_counts,
                                                                        const uint32_t *__restrict__ queue,
-                                                                       const uint32_t *__restrict__ queue_count) {
+                                                                       uint32_t *__restrict__ queue_count) {
+  uint32_t *tile_ticket = queue_count + 3;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_hh = smem + DCRX_N_COUNTERS;           // [DCRX_QBLOCK][HH_STRIDE] half-tag hit lists
@@ -137,10 +150,16 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
   __syncthreads();
   const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
-  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_QBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_QBLOCK) {
-    const uint64_t r = (uint64_t)queue[i];
-    if (!decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, C, records, lds_hh + tid * HH_STRIDE))
-      decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, B.stride >> 2, C, records);  // a hit list overflowed
+  const int lane = tid & 63;
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
+    ticket = __shfl(ticket, 0);
+    const uint64_t i = (uint64_t)ticket * 64 + lane;
+    if ((uint64_t)ticket * 64 >= n_queued) break;
+    if (i < n_queued)
+      decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
+                                                   lds_hh + tid * HH_STRIDE);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
@@ -400,7 +419,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
     hipLaunchKernelGGL(mark_exceptions_kernel, dim3(g), dim3(256), 0, s, B.exc_read, B.n_exc,
                        const_cast<uint32_t *>(B.exc_flag));
   }
-  e = hipMemsetAsync(queue_count, 0, 8, s);
+  e = hipMemsetAsync(queue_count, 0, 16, s);  // rescue count, general count, fast ticket, rescue ticket
   if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
   if (P.table_in_lds) {
