@@ -202,10 +202,10 @@ struct ExcCursor {
     const bool any = REV ? (x >= r.e0) : (x < r.e1);
     nextpos = any ? (REV ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x]) : 0x7FFFFFFF;
   }
+  DCRX_DEV void advance() { x += REV ? -1 : 1; load(); }
   DCRX_DEV bool hit(int i) {
     if (i != nextpos) return false;
-    x += REV ? -1 : 1;
-    load();
+    advance();
     return true;
   }
 };
@@ -506,20 +506,27 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
 
 #define DCRX_STEP_C(CODE)                                                                       \
   do {                                                                                          \
-    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));         \
-    acc |= e;                                                                                   \
-    const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
-    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
-    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
-    const uint32_t hb_ = (e >> TE_VH1_BIT) & 0xFu;                                              \
-    if (hb_) collect_hits(hh, hb_, t_);                                                         \
+    if (EXC && (int)(it >> ACC_POS_SHIFT) == xc.nextpos) {                                      \
+      e = 0; xc.advance();   /* a byte outside ACGT: the machine goes back to the root */      \
+    } else {                                                                                    \
+      e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));       \
+      acc |= e;                                                                                 \
+      const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                        \
+      vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                \
+      jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                \
+      const uint32_t hb_ = (e >> TE_VH1_BIT) & 0xFu;                                            \
+      if (hb_) collect_hits(hh, hb_, t_);                                                       \
+    }                                                                                           \
     it += (1u << ACC_POS_SHIFT);                                                                \
   } while (0)
 
-template <bool REV, bool TABLE_LDS>
-DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const uint32_t *words, int n,
-                              HalfHits &hh) {
+// EXC: the read may hold exception bytes (walked with an ExcCursor while scanning).
+template <bool REV, bool TABLE_LDS, bool EXC>
+DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh) {
+  const uint32_t *words = rv.words;
+  const int n = rv.n;
   uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  ExcCursor<REV> xc(rv);
   hh.cnts = 0;
   if (n > 0) {
     const int top = (n - 1) >> 4;
@@ -541,20 +548,6 @@ DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, con
       uint32_t wp = words[top];
       for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp & 3u); wp >>= 2; }
     }
-  }
-  return ScanOut{acc, vacc, jacc};
-}
-
-// Slow scan: any read (exception bytes reset the machine, like acora on a
-// character outside its keywords).
-template <bool REV, bool TABLE_LDS>
-DCRX_DEVNI ScanOut scan_slow(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F) {
-  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
-  const int n = F.n();
-  ExcCursor<REV> xc(F.r);
-  for (int i = 0; i < n; i++) {
-    if (xc.hit(i)) { e = 0; it += (1u << ACC_POS_SHIFT); continue; }
-    DCRX_STEP(F.code(i));
   }
   return ScanOut{acc, vacc, jacc};
 }
@@ -667,91 +660,11 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
   return DCRX_S_OK;
 }
 
-// One frame of one read: scan (fast or slow reader) then dcr_frame.
-template <bool REV, bool TABLE_LDS>
-DCRX_DEV int attempt(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv,
-                                       const uint32_t (&w)[DCRX_NWMAX], bool slow, const CfgDev &cfg,
-                                       const Counters &C, dcrx_record_t &rec) {
-  ScanOut so;
-  if (!slow) so = scan_fast<REV, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
-  else so = scan_slow<REV, TABLE_LDS>(T, lds_trans, Frame<REV>(rv));
-  return dcr_frame<REV, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec);
-}
-
-
 // ------------------------------------------------------------------------------
 // One read through the orientation dispatch of the reference's read loop
-// (decombine.py:991, :998-1013) and out as a 16-byte record.
-// ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN>
-DCRX_DEV void decombine_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg,
-                            uint64_t r, uint32_t nw, const Counters &C, dcrx_record_t *records,
-                            uint32_t *word_slot = nullptr) {
-  ReadView rv;
-  rv.comp = T.comp;
-  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
-  if (word_slot) {  // general kernel: the per-symbol accessors then read LDS, not global memory
-    for (uint32_t k = 0; k < nw; k++) word_slot[k] = rv.words[k];
-    word_slot[nw] = 0; word_slot[nw + 1] = 0;
-    rv.words = word_slot;
-  }
-  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
-  rv.e0 = rv.e1 = 0;
-  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
-  bool slow = (cfg.flags & DCRX_F_FORCE_SLOW_READER) != 0;
-  if (B.n_exc) {
-    if ((B.exc_flag[r >> 5] >> (r & 31)) & 1u) {
-      // binary search of this read's slice in the sorted exception list
-      uint64_t lo = 0, hi = B.n_exc;
-      while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
-      rv.e0 = (int)lo;
-      while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
-      rv.e1 = (int)lo;
-      slow = true;
-      if (word_slot && rv.e1 - rv.e0 <= DCRX_EXC_LDS) {  // and its few exception entries
-        uint16_t *xp = reinterpret_cast<uint16_t *>(word_slot + DCRX_NWMAX + 2);
-        uint8_t *xb = reinterpret_cast<uint8_t *>(word_slot + DCRX_NWMAX + 2 + DCRX_EXC_LDS / 2);
-        const int cnt = rv.e1 - rv.e0;
-        for (int x = 0; x < cnt; x++) { xp[x] = B.exc_pos[rv.e0 + x]; xb[x] = B.exc_chr[rv.e0 + x]; }
-        rv.exc_pos = xp; rv.exc_chr = xb; rv.e0 = 0; rv.e1 = cnt;  // indices re-based onto the LDS copy
-      }
-    }
-  }
-  // the read's words, for the register-resident fast scan
-  uint32_t w[DCRX_NWMAX];
-  {
-    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
-#pragma unroll
-    for (int k = 0; k < DCRX_NWMAX / 2; k++) {
-      uint2 t = make_uint2(0u, 0u);
-      if ((uint32_t)(2 * k) < nw) t = wp2[k];
-      w[2 * k] = t.x; w[2 * k + 1] = t.y;
-    }
-  }
-  __align__(16) dcrx_record_t rec;
-  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
-  rec.vdel = rec.jdel = 0;
-  int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
-    status = attempt<false, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 1;
-  } else {                                                            // :999-1001, :1005-1007
-    status = attempt<true, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 0;
-    if (cfg.orientation == DCRX_ORIENT_BOTH && status != DCRX_S_OK) {  // :1008-1010
-      status = attempt<false, TABLE_LDS>(T, lds_trans, rv, w, slow, cfg, C, rec); frame = 1;
-    }
-  }
-  C.add(DCRX_C_READ_COUNT);                                           // :991
-  if (status == DCRX_S_OK) {
-    C.add(DCRX_C_VJ_COUNT);                                           // :1013
-    if (frame) C.add(DCRX_C_FRAME_FORWARD);
-  }
-  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
-  dcrx_store_record(records + r, rec);
-}
-
-// ------------------------------------------------------------------------------
-// Fast-kernel form of decombine_one: clean reads (no exception bytes), one frame,
-// no half-tag rescue.  Returns FAST_DONE, or — having touched neither counters nor
+// (decombine.py:991, :998-1013) and out as a 16-byte record, in two forms.
+//
+// Fast-kernel form: clean reads (no exception bytes), one frame, no half-tag rescue.  Returns FAST_DONE, or — having touched neither counters nor
 // the record — FAST_TO_RESCUE (a half-tag rescue is needed: rescue kernel) or
 // FAST_TO_GENERAL (exception bytes, orientation `both`: general kernel).
 // ------------------------------------------------------------------------------
@@ -808,45 +721,64 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
 }
 
 // ------------------------------------------------------------------------------
-// Rescue-kernel form for clean reads that only needed a half-tag rescue: one
-// collecting scan, then dcr_frame with the rescue fed from the LDS hit lists.
-// A class with more than HH_K hits falls back to the re-scanning rescue inside
-// dcr_frame.  Returns false (nothing counted, nothing written) only for reads that
-// never belong here: exception bytes, orientation `both`, forced slow reader.
+// List form (rescue and general kernels): one collecting scan per frame, then
+// dcr_frame with the rescue fed from the LDS hit lists (a class with more than HH_K
+// hits falls back to the re-scanning rescue inside dcr_frame).
+// EXC = false: clean reads that only needed a half-tag rescue (rescue kernel).
+// EXC = true : any read — exception bytes, orientation `both` with its second,
+//              forward attempt (decombine.py:1005-1010) — the general kernel;
+//              `slot` then also holds an LDS copy of the read's first
+//              DCRX_EXC_LDS exception entries.
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN>
-DCRX_DEV bool decombine_rescue_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
-                                   const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
-                                   uint32_t *hh_slot) {
-  if (cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER)) return false;
-  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) return false;
+template <bool TABLE_LDS, bool UNIFORM_LEN, bool EXC>
+DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
+                                 const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
+                                 uint32_t *slot) {
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  if (EXC && B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
+    // binary search of this read's slice in the sorted exception list
+    uint64_t lo = 0, hi = B.n_exc;
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
+    rv.e0 = (int)lo;
+    while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
+    rv.e1 = (int)lo;
+    if (rv.e1 - rv.e0 <= DCRX_EXC_LDS) {
+      uint16_t *xp = reinterpret_cast<uint16_t *>(slot + HH_STRIDE);
+      uint8_t *xb = reinterpret_cast<uint8_t *>(slot + HH_STRIDE + DCRX_EXC_LDS / 2);
+      const int cnt = rv.e1 - rv.e0;
+      for (int x = 0; x < cnt; x++) { xp[x] = B.exc_pos[rv.e0 + x]; xb[x] = B.exc_chr[rv.e0 + x]; }
+      rv.exc_pos = xp; rv.exc_chr = xb; rv.e0 = 0; rv.e1 = cnt;  // indices re-based onto the LDS copy
+    }
+  }
   HalfHits hh;
-  hh.slot = DCRX_TO_LDS(hh_slot);
+  hh.slot = DCRX_TO_LDS(slot);
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
   int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) {
-    const ScanOut so = scan_collect<false, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
+    const ScanOut so = scan_collect<false, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
     status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
-  } else {
-    const ScanOut so = scan_collect<true, TABLE_LDS>(T, lds_trans, rv.words, rv.n, hh);
+  } else {                                                            // :999-1001, :1005-1007
+    const ScanOut so = scan_collect<true, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
     status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
+    if (EXC && cfg.orientation == DCRX_ORIENT_BOTH && status != DCRX_S_OK) {  // :1008-1010
+      const ScanOut so2 = scan_collect<false, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
+      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so2, cfg, C, rec, &hh); frame = 1;
+    }
   }
-  C.add(DCRX_C_READ_COUNT);
+  C.add(DCRX_C_READ_COUNT);                                           // :991
   if (status == DCRX_S_OK) {
-    C.add(DCRX_C_VJ_COUNT);
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
     if (frame) C.add(DCRX_C_FRAME_FORWARD);
   }
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
   dcrx_store_record(records + r, rec);
-  return true;
 }
 
 }  // namespace dcrx

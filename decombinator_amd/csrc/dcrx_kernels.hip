@@ -40,7 +40,7 @@ constexpr int DCRX_CHUNK = 4;  // 64-read tiles a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
-constexpr int DCRX_GW_STRIDE = DCRX_GSLOT_DWORDS | 1;  // odd: conflict-free
+constexpr int DCRX_GW_STRIDE = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // hit lists + exception copy; odd: conflict-free
 constexpr int DCRX_GW_PAD = (4 - (DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE) % 4) % 4;
 constexpr uint32_t DCRX_GENERAL_LDS_EXTRA = (DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) * 4;
 
@@ -158,15 +158,15 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
     const uint64_t i = (uint64_t)ticket * 64 + lane;
     if ((uint64_t)ticket * 64 >= n_queued) break;
     if (i < n_queued)
-      decombine_rescue_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
-                                                   lds_hh + tid * HH_STRIDE);
+      decombine_list_one<TABLE_LDS, UNIFORM_LEN, false>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
+                                                        lds_hh + tid * HH_STRIDE);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
 
-// General kernel: decombine_one (any read: exception bytes, orientation `both`, list overflow)
-// over its own queue, each read's words copied to a per-lane LDS slot first.
+// General kernel: the list form with exception bytes and orientation `both` enabled, over the
+// reads named by the exception list (or every read for `both` / the forced slow reader).
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 __global__ __launch_bounds__(DCRX_GBLOCK) void decombine_general_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                         dcrx_record_t *__restrict__ records,
@@ -193,10 +193,9 @@ __global__ __launch_bounds__(DCRX_GBLOCK) void decombine_general_kernel(DevTable
   __syncthreads();
   const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
-  const uint32_t nw = B.stride >> 2;
   for (uint64_t i = (uint64_t)blockIdx.x * DCRX_GBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_GBLOCK)
-    decombine_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], nw, C, records,
-                                          lds_words + tid * DCRX_GW_STRIDE);
+    decombine_list_one<TABLE_LDS, UNIFORM_LEN, true>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
+                                                     lds_words + tid * DCRX_GW_STRIDE);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }

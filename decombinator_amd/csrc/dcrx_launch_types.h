@@ -11,8 +11,8 @@
 #define DCRX_QBLOCK 512  /* rescue kernel */
 #define DCRX_GBLOCK 256  /* general kernel */
 #define DCRX_EXC_LDS 8    /* exception entries of a read the general kernel keeps in LDS */
-/* dwords of a general-kernel lane slot: words + 2 spare + exception positions (u16) + bytes (u8) */
-#define DCRX_GSLOT_DWORDS (DCRX_NWMAX + 2 + DCRX_EXC_LDS / 2 + DCRX_EXC_LDS / 4)
+/* extra dwords of a general-kernel lane slot after the hit lists: exception positions (u16) + bytes (u8) */
+#define DCRX_GSLOT_EXTRA (DCRX_EXC_LDS / 2 + DCRX_EXC_LDS / 4)
 
 namespace dcrx {
 

@@ -36,21 +36,27 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
   Counters CC{counts};
   for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
   for (uint64_t r = 0; r < b->n_reads; r++) {
-    // fast kernel first; what it defers goes to the rescue kernel (list-fed rescue) or to the
-    // general kernel (decombine_one on an LDS copy of the words)
-    uint32_t hh_slot[HH_STRIDE];
-    uint32_t word_slot[DCRX_GSLOT_DWORDS + 1];
+    // what the launch does: reads of the general list (exception bytes; every read for `both` /
+    // forced slow reader) take the general kernel's form; the rest go through the fast kernel and,
+    // when deferred, the rescue kernel's form.
+    uint32_t slot[HH_STRIDE + DCRX_GSLOT_EXTRA + 2];
     const uint32_t nw = b->stride / 4;
+    const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
+    const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
-      int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
-      if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, false>(T, nullptr, B, C, r, CC, records, hh_slot))
-        decombine_one<false, false>(T, nullptr, B, C, r, nw, CC, records);  // list overflow: inline in the rescue kernel
-      if (what == FAST_TO_GENERAL) decombine_one<false, false>(T, nullptr, B, C, r, nw, CC, records, word_slot);
+      if (general) decombine_list_one<false, false, true>(T, nullptr, B, C, r, CC, records, slot);
+      else {
+        const int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, false, false>(T, nullptr, B, C, r, CC, records, slot);
+        else if (what != FAST_DONE) return -100;
+      }
     } else {
-      int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
-      if (what == FAST_TO_RESCUE && !decombine_rescue_one<false, true>(T, nullptr, B, C, r, CC, records, hh_slot))
-        decombine_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
-      if (what == FAST_TO_GENERAL) decombine_one<false, true>(T, nullptr, B, C, r, nw, CC, records, word_slot);
+      if (general) decombine_list_one<false, true, true>(T, nullptr, B, C, r, CC, records, slot);
+      else {
+        const int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, true, false>(T, nullptr, B, C, r, CC, records, slot);
+        else if (what != FAST_DONE) return -100;
+      }
     }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
   }
