@@ -64,10 +64,6 @@ static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_block_counts); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue);
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
-  if (t->plan.aux) (void)hipStreamDestroy(t->plan.aux);
-  if (t->plan.ev_fork) (void)hipEventDestroy(t->plan.ev_fork);
-  if (t->plan.ev_join) (void)hipEventDestroy(t->plan.ev_join);
-  t->plan.aux = nullptr; t->plan.ev_fork = nullptr; t->plan.ev_join = nullptr;
   t->d_blob = nullptr; t->d_block_counts = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
   t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
@@ -179,13 +175,8 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     P.grid = (uint32_t)prop.multiProcessorCount * per_cu;
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
-    P.ggrid = (uint32_t)prop.multiProcessorCount * std::min<uint32_t>(2048 / DCRX_GBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
-    P.aux = nullptr; P.ev_fork = nullptr; P.ev_join = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&P.aux, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&P.ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&P.ev_join, hipEventDisableTiming));
     t->plan = P;
-    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid + P.ggrid) * DCRX_N_COUNTERS * 4));
+    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid) * DCRX_N_COUNTERS * 4));
     t->device = dev;
   }
   if (max_reads < 4096) max_reads = 4096;  // workspace exists even for empty batches

@@ -13,7 +13,7 @@
 
 #ifndef DCRX_HOST_EMUL
 #define DCRX_DEV __device__ __forceinline__
-#define DCRX_DEVNI __device__
+#define DCRX_DEVNI __device__ __forceinline__
 DCRX_DEV uint32_t dcrx_funnel_r(uint32_t lo, uint32_t hi, uint32_t sh) { return __funnelshift_r(lo, hi, sh); }
 DCRX_DEV int dcrx_sbfe(int v, uint32_t off, uint32_t w) { return __builtin_amdgcn_sbfe(v, off, w); }
 DCRX_DEV uint32_t dcrx_ubfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
@@ -399,19 +399,32 @@ DCRX_DEVNI bool rescue_at(const DevTables &T, const Frame<REV> &F, const int GEN
   return false;
 }
 
-// Rescue by re-scanning the frame (any read: exception bytes reset the machine).
+// Rescue by re-scanning the frame (any read: exception bytes reset the machine).  Only taken
+// when a hit list overflowed; walks the packed words like the scans do (one load per 16 bases).
 template <bool REV, bool TABLE_LDS>
 DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Frame<REV> &F, const int GENE,
                        const int HALF, int end_of_v, XDat &out, const Counters &C) {
   const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
   const int n = F.n();
+  if (n <= 0) return false;
   uint32_t e = 0;
   ExcCursor<REV> xc(F.r);
-  for (int i = 0; i < n; i++) {
-    if (xc.hit(i)) { e = 0; continue; }  // unknown byte: machine back to the root
-    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + 4u * (uint32_t)F.code(i));
-    if (!((e >> BIT) & 1u)) continue;
-    if (rescue_at<REV>(T, F, GENE, HALF, (e & TE_ROW_MASK) >> 4, i, end_of_v, out, C)) return true;
+  const int top = (n - 1) >> 4;
+  int i = 0;
+  for (int wi = 0; wi <= top; wi++) {
+    const int kk = REV ? top - wi : wi;                       // word index in scan order
+    const int cnt = (kk == top) ? ((n - 1) & 15) + 1 : 16;    // bases it holds
+    uint32_t wv = F.r.words[kk];
+    if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
+#pragma unroll 1
+    for (int k = 0; k < cnt; k++, i++) {
+      const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
+      wv = REV ? (wv << 2) : (wv >> 2);
+      if (xc.hit(i)) { e = 0; continue; }                     // unknown byte: machine back to the root
+      e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
+      if (!((e >> BIT) & 1u)) continue;
+      if (rescue_at<REV>(T, F, GENE, HALF, (e & TE_ROW_MASK) >> 4, i, end_of_v, out, C)) return true;
+    }
   }
   return false;
 }
@@ -420,7 +433,7 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
 // per class (V half1, V half2, J half1, J half2) up to HH_K entries `state<<9 | end_pos<<23 | 1`
 // in scan order, and the four hit counts (8 bits each, saturating at 255).
 constexpr int HH_K = 4;
-constexpr int HH_STRIDE = 4 * HH_K + 1;  // dwords per lane (odd: conflict-free)
+constexpr int HH_STRIDE = 4 * HH_K;  // dwords per lane
 struct HalfHits {
   dcrx_lds_u32 *slot;
   uint32_t cnts;
@@ -506,7 +519,7 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
 
 #define DCRX_STEP_C(CODE)                                                                       \
   do {                                                                                          \
-    if (EXC && (int)(it >> ACC_POS_SHIFT) == xc.nextpos) {                                      \
+    if ((int)(it >> ACC_POS_SHIFT) == xc.nextpos) {                                      \
       e = 0; xc.advance();   /* a byte outside ACGT: the machine goes back to the root */      \
     } else {                                                                                    \
       e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));       \
@@ -520,8 +533,8 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
     it += (1u << ACC_POS_SHIFT);                                                                \
   } while (0)
 
-// EXC: the read may hold exception bytes (walked with an ExcCursor while scanning).
-template <bool REV, bool TABLE_LDS, bool EXC>
+// Exception bytes are walked with an ExcCursor while scanning (a clean read never matches it).
+template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh) {
   const uint32_t *words = rv.words;
   const int n = rv.n;
@@ -721,16 +734,14 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
 }
 
 // ------------------------------------------------------------------------------
-// List form (rescue and general kernels): one collecting scan per frame, then
-// dcr_frame with the rescue fed from the LDS hit lists (a class with more than HH_K
-// hits falls back to the re-scanning rescue inside dcr_frame).
-// EXC = false: clean reads that only needed a half-tag rescue (rescue kernel).
-// EXC = true : any read — exception bytes, orientation `both` with its second,
-//              forward attempt (decombine.py:1005-1010) — the general kernel;
-//              `slot` then also holds an LDS copy of the read's first
-//              DCRX_EXC_LDS exception entries.
+// List form (list kernel): any read — exception bytes, orientation `both` with its
+// second, forward attempt (decombine.py:1005-1010), half-tag rescue.  One collecting
+// scan per frame, then dcr_frame with the rescue fed from the LDS hit lists (a class
+// with more than HH_K hits falls back to the re-scanning rescue inside dcr_frame).
+// `slot`: this lane's LDS area (hit lists, then a copy of the read's first
+// DCRX_EXC_LDS exception entries).
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN, bool EXC>
+template <bool TABLE_LDS, bool UNIFORM_LEN>
 DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
                                  uint32_t *slot) {
@@ -740,7 +751,7 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
-  if (EXC && B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
+  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
     // binary search of this read's slice in the sorted exception list
     uint64_t lo = 0, hi = B.n_exc;
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
@@ -760,16 +771,17 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
-  int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
-    const ScanOut so = scan_collect<false, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
-    status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
-  } else {                                                            // :999-1001, :1005-1007
-    const ScanOut so = scan_collect<true, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
-    status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
-    if (EXC && cfg.orientation == DCRX_ORIENT_BOTH && status != DCRX_S_OK) {  // :1008-1010
-      const ScanOut so2 = scan_collect<false, TABLE_LDS, EXC>(T, lds_trans, rv, hh);
-      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so2, cfg, C, rec, &hh); frame = 1;
+  // Orientation dispatch of decombine.py:999-1010 as a loop, so that each frame's code exists
+  // once: reverse (unless `forward`), then forward for `forward`, or for `both` after a miss.
+  int status = DCRX_S_V_NONE, frame = 0;
+  for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
+    if (attempt == 0) {
+      const ScanOut so = scan_collect<true, TABLE_LDS>(T, lds_trans, rv, hh);
+      status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
+      if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
+    } else {
+      const ScanOut so = scan_collect<false, TABLE_LDS>(T, lds_trans, rv, hh);
+      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
     }
   }
   C.add(DCRX_C_READ_COUNT);                                           // :991

@@ -38,11 +38,9 @@ namespace dcrx {
 constexpr int DCRX_WQ_CAP = 128;
 constexpr int DCRX_CHUNK = 4;  // 64-read tiles a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
-constexpr int DCRX_HH_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE) % 4) % 4;
-constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) * 4;
-constexpr int DCRX_GW_STRIDE = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // hit lists + exception copy; odd: conflict-free
-constexpr int DCRX_GW_PAD = (4 - (DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE) % 4) % 4;
-constexpr uint32_t DCRX_GENERAL_LDS_EXTRA = (DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) * 4;
+constexpr int DCRX_LSLOT = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // per-lane dwords: hit lists + exception copy; odd: conflict-free
+constexpr int DCRX_LSLOT_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT) % 4) % 4;
+constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) * 4;
 
 // ------------------------------------------------------------------------------
 // Fast kernel: persistent blocks, each stages the DFA into LDS once and then
@@ -119,25 +117,30 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
 
-// Rescue kernel: clean reads whose V or J tag needs the half-tag rescue, in dense waves.
-// One collecting scan per read (half-tag hits into per-lane LDS lists), then the rescue
-// feeds from the lists.  A read with more hits than a list holds goes on to the general
-// kernel.
+// List kernel: everything the fast kernel does not finish, in dense waves.  Two work lists,
+// claimed 64 reads at a time through one ticket: first the general list (reads with exception
+// bytes, or every read for orientation `both` / the forced slow reader — built from the
+// exception list before the fast kernel starts; they are the longest poles, so they go first),
+// then the rescue queue the fast kernel filled (clean reads whose V or J tag needs the
+// half-tag rescue).  One collecting scan per frame (half-tag hits into per-lane LDS lists),
+// then the rescue feeds from the lists.
 template <bool TABLE_LDS, bool UNIFORM_LEN>
-__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables T0, BatchDev B, CfgDev cfg,
-                                                                       dcrx_record_t *__restrict__ records,
-                                                                       uint32_t *__restrict__ block_counts,
-                                                                       const uint32_t *__restrict__ queue,
-                                                                       uint32_t *__restrict__ queue_count) {
+__global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T0, BatchDev B, CfgDev cfg,
+                                                                     dcrx_record_t *__restrict__ records,
+                                                                     uint32_t *__restrict__ block_counts,
+                                                                     const uint32_t *__restrict__ queue,
+                                                                     const uint32_t *__restrict__ gqueue,
+                                                                     uint32_t *__restrict__ queue_count) {
   uint32_t *tile_ticket = queue_count + 3;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
-  uint32_t *lds_hh = smem + DCRX_N_COUNTERS;           // [DCRX_QBLOCK][HH_STRIDE] half-tag hit lists
-  uint32_t *lds_trans = lds_hh + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD;
-  static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * HH_STRIDE + DCRX_HH_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
+  uint32_t *lds_slots = smem + DCRX_N_COUNTERS;        // [DCRX_QBLOCK][DCRX_LSLOT]: hit lists + exception copy
+  uint32_t *lds_trans = lds_slots + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD;
+  static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
-  const uint32_t n_queued = queue_count[0];
-  if ((uint64_t)blockIdx.x * DCRX_QBLOCK >= n_queued) {  // nothing for this block: its tallies are zero
+  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
+  const uint32_t t_general = (n_general + 63) / 64, t_rescue = (n_rescue + 63) / 64;
+  if ((uint64_t)blockIdx.x * (DCRX_QBLOCK / 64) >= (uint64_t)t_general + t_rescue) {  // nothing left for this block
     if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
     return;
   }
@@ -155,47 +158,13 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_rescue_kernel(DevTables
     uint32_t ticket = 0;
     if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
     ticket = __shfl(ticket, 0);
-    const uint64_t i = (uint64_t)ticket * 64 + lane;
-    if ((uint64_t)ticket * 64 >= n_queued) break;
-    if (i < n_queued)
-      decombine_list_one<TABLE_LDS, UNIFORM_LEN, false>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
-                                                        lds_hh + tid * HH_STRIDE);
+    if (ticket >= t_general + t_rescue) break;
+    const bool general = ticket < t_general;
+    const uint32_t i = (general ? ticket : ticket - t_general) * 64 + lane;
+    if (i < (general ? n_general : n_rescue))
+      decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)(general ? gqueue[i] : queue[i]), C,
+                                                 records, lds_slots + tid * DCRX_LSLOT);
   }
-  __syncthreads();
-  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
-}
-
-// General kernel: the list form with exception bytes and orientation `both` enabled, over the
-// reads named by the exception list (or every read for `both` / the forced slow reader).
-template <bool TABLE_LDS, bool UNIFORM_LEN>
-__global__ __launch_bounds__(DCRX_GBLOCK) void decombine_general_kernel(DevTables T0, BatchDev B, CfgDev cfg,
-                                                                        dcrx_record_t *__restrict__ records,
-                                                                        uint32_t *__restrict__ block_counts,
-                                                                        const uint32_t *__restrict__ gqueue,
-                                                                        const uint32_t *__restrict__ queue_count) {
-  extern __shared__ __align__(16) uint32_t smem[];
-  uint32_t *lds_counts = smem;
-  uint32_t *lds_words = smem + DCRX_N_COUNTERS;        // [DCRX_GBLOCK][DCRX_GW_STRIDE]
-  uint32_t *lds_trans = lds_words + DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD;
-  static_assert(((DCRX_N_COUNTERS + DCRX_GBLOCK * DCRX_GW_STRIDE + DCRX_GW_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
-  const int tid = threadIdx.x;
-  const uint32_t n_queued = queue_count[1];
-  if ((uint64_t)blockIdx.x * DCRX_GBLOCK >= n_queued) {
-    if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
-    return;
-  }
-  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  if (TABLE_LDS) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
-    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_GBLOCK) dst[i] = src[i];
-  }
-  __syncthreads();
-  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
-  const Counters C{lds_counts};
-  for (uint64_t i = (uint64_t)blockIdx.x * DCRX_GBLOCK + tid; i < n_queued; i += (uint64_t)gridDim.x * DCRX_GBLOCK)
-    decombine_list_one<TABLE_LDS, UNIFORM_LEN, true>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
-                                                     lds_words + tid * DCRX_GW_STRIDE);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
 }
@@ -326,56 +295,33 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
-  auto krescue = decombine_rescue_kernel<TABLE_LDS, UNIFORM>;
-  auto kgeneral = decombine_general_kernel<TABLE_LDS, UNIFORM>;
-  const uint32_t lds_fast = P.lds_bytes + DCRX_FAST_LDS_EXTRA, lds_rescue = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA,
-                 lds_general = P.lds_bytes + DCRX_GENERAL_LDS_EXTRA;
+  auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM>;
+  const uint32_t lds_fast = P.lds_bytes + DCRX_FAST_LDS_EXTRA, lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
   hipError_t e;
-  // persistent grids: exactly as many blocks as are resident at once (a larger grid would run in
-  // two rounds and leave the tiles of the late blocks for the end)
-  static int occ_fast = 0, occ_rescue = 0, occ_general = 0;
+  // persistent grids: as many blocks as are resident at once
+  static int occ_fast = 0, occ_list = 0;
   if (!occ_fast) {
-    if (std::max(lds_rescue, std::max(lds_fast, lds_general)) > 48 * 1024) {
+    if (std::max(lds_fast, lds_list) > 48 * 1024) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
       if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(krescue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rescue);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kgeneral), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_general);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(klist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list);
       if (e != hipSuccess) return e;
     }
-    int o1 = 0, o2 = 0, o3 = 0;
+    int o1 = 0, o2 = 0;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kfast, DCRX_BLOCK, lds_fast);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, krescue, DCRX_QBLOCK, lds_rescue);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, klist, DCRX_QBLOCK, lds_list);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, kgeneral, DCRX_GBLOCK, lds_general);
-    if (e != hipSuccess) return e;
-    occ_rescue = std::max(o2, 1); occ_general = std::max(o3, 1); occ_fast = std::max(o1, 1);
+    occ_list = std::max(o2, 1); occ_fast = std::max(o1, 1);
   }
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
-  const uint32_t qgrid = all_general ? 0 : std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_rescue);
-  const bool any_general = all_general || B.n_exc > 0;
-  const uint32_t ggrid = any_general ? std::min<uint32_t>(P.ggrid, P.n_cu * (uint32_t)occ_general) : 0;
-  uint32_t *bc_rescue = block_counts + (size_t)P.grid * DCRX_N_COUNTERS;
-  uint32_t *bc_general = bc_rescue + (size_t)P.qgrid * DCRX_N_COUNTERS;
-
-  // The general kernel (few, long, divergent reads) runs beside the fast and rescue kernels on
-  // the plan's auxiliary stream: fork after its work list exists, join before the counter sum.
-  if (any_general) {
+  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_list);
+  uint32_t *bc_list = block_counts + (size_t)P.grid * DCRX_N_COUNTERS;
+  if (all_general || B.n_exc > 0) {
     const uint64_t items = all_general ? B.n_reads : B.n_exc;
     hipLaunchKernelGGL(build_general_queue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read,
                        B.n_exc, all_general ? 1 : 0, B.n_reads, gqueue, queue_count + 1);
-    e = hipEventRecord(P.ev_fork, s);
-    if (e != hipSuccess) return e;
-    e = hipStreamWaitEvent(P.aux, P.ev_fork, 0);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kgeneral, dim3(ggrid), dim3(DCRX_GBLOCK), lds_general, P.aux, T, B, cfg, rec, bc_general, gqueue,
-                       queue_count);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = hipEventRecord(P.ev_join, P.aux);
-    if (e != hipSuccess) return e;
   }
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (grid) {
@@ -384,25 +330,16 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     if (e != hipSuccess) return e;
   }
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  if (qgrid) {
-    hipLaunchKernelGGL(krescue, dim3(qgrid), dim3(DCRX_QBLOCK), lds_rescue, s, T, B, cfg, rec, bc_rescue, queue, queue_count);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-  }
+  hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, bc_list, queue, gqueue, queue_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
   // blocks that were not launched contribute zero tallies
   if (grid < P.grid) {
     e = hipMemsetAsync(block_counts + (size_t)grid * DCRX_N_COUNTERS, 0, (size_t)(P.grid - grid) * DCRX_N_COUNTERS * 4, s);
     if (e != hipSuccess) return e;
   }
-  if (qgrid < P.qgrid) {
-    e = hipMemsetAsync(bc_rescue + (size_t)qgrid * DCRX_N_COUNTERS, 0, (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
-    if (e != hipSuccess) return e;
-  }
-  if (ggrid < P.ggrid) {
-    e = hipMemsetAsync(bc_general + (size_t)ggrid * DCRX_N_COUNTERS, 0, (size_t)(P.ggrid - ggrid) * DCRX_N_COUNTERS * 4, s);
-    if (e != hipSuccess) return e;
-  }
-  if (any_general) e = hipStreamWaitEvent(s, P.ev_join, 0);
+  if (qgrid < P.qgrid)
+    e = hipMemsetAsync(bc_list + (size_t)qgrid * DCRX_N_COUNTERS, 0, (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
   return e;
 }
 
@@ -429,7 +366,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
                 : launch_all<false, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid + P.ggrid), d_counters);
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
   return hipGetLastError();
 }
 

@@ -15,12 +15,9 @@ namespace dcrx {
 struct LaunchPlan {
   uint32_t n_cu;
   uint32_t grid;   // fast kernel (upper bound; capped by measured occupancy at launch)
-  uint32_t qgrid;  // rescue kernel
-  uint32_t ggrid;  // general kernel
+  uint32_t qgrid;  // list kernel
   uint32_t lds_bytes;
   bool table_in_lds;
-  hipStream_t aux;           // general kernel runs here, beside the fast and rescue kernels
-  hipEvent_t ev_fork, ev_join;
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,

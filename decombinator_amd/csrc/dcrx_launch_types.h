@@ -8,9 +8,8 @@
 #define DCRX_NWMAX 20
 #define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
 #define DCRX_BLOCK 512   /* fast kernel */
-#define DCRX_QBLOCK 512  /* rescue kernel */
-#define DCRX_GBLOCK 256  /* general kernel */
-#define DCRX_EXC_LDS 8    /* exception entries of a read the general kernel keeps in LDS */
+#define DCRX_QBLOCK 512  /* list kernel */
+#define DCRX_EXC_LDS 4    /* exception entries of a read the list kernel keeps in LDS */
 /* extra dwords of a general-kernel lane slot after the hit lists: exception positions (u16) + bytes (u8) */
 #define DCRX_GSLOT_EXTRA (DCRX_EXC_LDS / 2 + DCRX_EXC_LDS / 4)
 

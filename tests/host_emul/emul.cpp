@@ -44,17 +44,17 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
-      if (general) decombine_list_one<false, false, true>(T, nullptr, B, C, r, CC, records, slot);
+      if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) decombine_list_one<false, false, false>(T, nullptr, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
-      if (general) decombine_list_one<false, true, true>(T, nullptr, B, C, r, CC, records, slot);
+      if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) decombine_list_one<false, true, false>(T, nullptr, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     }
