@@ -36,7 +36,7 @@ namespace dcrx {
 // LDS beyond the counters + DFA (LaunchPlan::lds_bytes): the fast kernel's per-wave deferral
 // buffers, the queue kernel's half-tag hit lists
 constexpr int DCRX_WQ_CAP = 128;
-constexpr int DCRX_CHUNK = 4;  // 64-read tiles a wave claims per ticket
+constexpr int DCRX_CHUNK = 2;  // 64-read tiles of the rescue queue a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_LSLOT = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // per-lane dwords: hit lists + exception copy; odd: conflict-free
 constexpr int DCRX_LSLOT_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT) % 4) % 4;
@@ -55,7 +55,6 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
                                                                uint32_t *__restrict__ block_counts,
                                                                uint32_t *__restrict__ queue,
                                                                uint32_t *__restrict__ queue_count) {
-  uint32_t *tile_ticket = queue_count + 2;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
@@ -77,33 +76,26 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   uint32_t *wq = lds_wq + (tid >> 6) * DCRX_WQ_CAP;
   uint32_t wq_n = 0;
 
-  // Work distribution: every wave claims DCRX_CHUNK consecutive 64-read tiles at a time from a
-  // global ticket, so blocks that become resident late (another kernel holds their CU) simply
-  // claim less instead of holding the launch's tail.
-  for (;;) {
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
-    ticket = __shfl(ticket, 0);
-    const uint64_t first = (uint64_t)ticket * (64 * DCRX_CHUNK);
-    if (first >= B.n_reads) break;
-    for (int c = 0; c < DCRX_CHUNK; c++) {
-      const uint64_t r = first + (uint64_t)c * 64 + lane;
-      int what = FAST_DONE;
-      if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
-      // FAST_TO_GENERAL reads (exception bytes) are already on the general kernel's list, which is
-      // built from the exception list before this kernel starts
-      const bool defer = what == FAST_TO_RESCUE;
-      const unsigned long long m = __ballot(defer);
-      if (m) {
-        if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
-        wq_n += (uint32_t)__popcll(m);
-        if (wq_n >= 64) {
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(queue_count, wq_n);
-          base = __shfl(base, 0);
-          for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
-          wq_n = 0;
-        }
+  // Static work distribution: block b takes tiles b, b + grid, ... (the grid is exactly the
+  // resident capacity, so every block runs from the start; a global ticket per wave-tile was
+  // measured slower: one atomic address sustains only ~90 tickets/us).
+  for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
+    const uint64_t r = tile * DCRX_BLOCK + tid;
+    int what = FAST_DONE;
+    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
+    // from the exception list before this kernel starts
+    const bool defer = what == FAST_TO_RESCUE;
+    const unsigned long long m = __ballot(defer);
+    if (m) {
+      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      wq_n += (uint32_t)__popcll(m);
+      if (wq_n >= 64) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue_count, wq_n);
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
+        wq_n = 0;
       }
     }
   }
@@ -139,7 +131,8 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
   const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
-  const uint32_t t_general = (n_general + 63) / 64, t_rescue = (n_rescue + 63) / 64;
+  // tickets: one per 64 general reads, one per DCRX_CHUNK*64 rescue reads
+  const uint32_t t_general = (n_general + 63) / 64, t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   if ((uint64_t)blockIdx.x * (DCRX_QBLOCK / 64) >= (uint64_t)t_general + t_rescue) {  // nothing left for this block
     if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
     return;
@@ -159,11 +152,20 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
     ticket = __shfl(ticket, 0);
     if (ticket >= t_general + t_rescue) break;
-    const bool general = ticket < t_general;
-    const uint32_t i = (general ? ticket : ticket - t_general) * 64 + lane;
-    if (i < (general ? n_general : n_rescue))
-      decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)(general ? gqueue[i] : queue[i]), C,
-                                                 records, lds_slots + tid * DCRX_LSLOT);
+    if (ticket < t_general) {
+      const uint32_t i = ticket * 64 + lane;
+      if (i < n_general)
+        decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
+                                                   lds_slots + tid * DCRX_LSLOT);
+    } else {
+      const uint32_t first = (ticket - t_general) * (64 * DCRX_CHUNK);
+      for (int c = 0; c < DCRX_CHUNK; c++) {
+        const uint32_t i = first + (uint32_t)c * 64 + lane;
+        if (i < n_rescue)
+          decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
+                                                     lds_slots + tid * DCRX_LSLOT);
+      }
+    }
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
