@@ -28,6 +28,9 @@ DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
 // pointer into LDS with its address space spelled out (ds_read/ds_write instead of flat_*)
 typedef __attribute__((address_space(3))) uint32_t dcrx_lds_u32;
 #define DCRX_TO_LDS(p) ((dcrx_lds_u32 *)(p))
+DCRX_DEV uint32_t dcrx_lds_address(const uint8_t *p) {
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const uint8_t *)(p));
+}
 using ::min;
 using ::max;
 #else
@@ -48,6 +51,8 @@ inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
 typedef uint32_t dcrx_lds_u32;
 #define DCRX_TO_LDS(p) (p)
+inline uint32_t dcrx_lds_address(const uint8_t *) { return 0; }
+struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 #define __align__(n) alignas(n)
@@ -68,7 +73,23 @@ DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_image) {
     DCRX_MV(g[g].w64_fwd); DCRX_MV(g[g].w64_rc); DCRX_MV(g[g].w64_ok); DCRX_MV(g[g].reg_len);
   }
 #undef DCRX_MV
+  L.row0 = dcrx_lds_address(lds_image);
   return L;
+}
+
+// Copies the LDS image (DFA + side tables) from global memory; the DFA part gets the image's
+// own LDS address added to every row field, making the rows absolute LDS addresses.
+template <int BLOCK>
+DCRX_DEV void stage_lds_image(const DevTables &T0, uint32_t *lds_image, int tid) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
+  uint4 *dst = reinterpret_cast<uint4 *>(lds_image);
+  const uint32_t row0 = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_image));
+  const uint32_t n_dfa = T0.dfa_bytes / 16, n_all = T0.lds_image_bytes / 16;
+  for (uint32_t i = tid; i < n_all; i += BLOCK) {
+    uint4 v = src[i];
+    if (i < n_dfa) { v.x += row0; v.y += row0; v.z += row0; v.w += row0; }
+    dst[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -333,9 +354,14 @@ DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const Frame<REV> &F, in
 
 struct XDat { int match, pos, dels, tagpos; };  // (v_match,end_v,v_dels,v_seq_start) / (j_match,start_j,j_dels,j_seq_end)
 
+// One transition.  TABLE_LDS: `byte_addr` is the absolute LDS address of the entry (the staged
+// table's rows carry their own LDS address, so the look-up needs no base add); otherwise a byte
+// offset into the table in global memory.
 template <bool TABLE_LDS>
 DCRX_DEV uint32_t trans_at(const uint32_t *lds_trans, const DevTables &T, uint32_t byte_addr) {
-  if (TABLE_LDS) return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_trans) + byte_addr);
+#ifndef DCRX_HOST_EMUL
+  if (TABLE_LDS) return *reinterpret_cast<const dcrx_lds_u32 *>(static_cast<uintptr_t>(byte_addr));
+#endif
   return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.trans) + byte_addr);
 }
 
@@ -407,7 +433,7 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
   const int BIT = (GENE == 0) ? (HALF == 1 ? TE_VH1_BIT : TE_VH2_BIT) : (HALF == 1 ? TE_JH1_BIT : TE_JH2_BIT);
   const int n = F.n();
   if (n <= 0) return false;
-  uint32_t e = 0;
+  uint32_t e = T.row0;
   ExcCursor<REV> xc(F.r);
   const int top = (n - 1) >> 4;
   int i = 0;
@@ -420,10 +446,10 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
     for (int k = 0; k < cnt; k++, i++) {
       const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
       wv = REV ? (wv << 2) : (wv >> 2);
-      if (xc.hit(i)) { e = 0; continue; }                     // unknown byte: machine back to the root
+      if (xc.hit(i)) { e = T.row0; continue; }                // unknown byte: machine back to the root
       e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
       if (!((e >> BIT) & 1u)) continue;
-      if (rescue_at<REV>(T, F, GENE, HALF, (e & TE_ROW_MASK) >> 4, i, end_of_v, out, C)) return true;
+      if (rescue_at<REV>(T, F, GENE, HALF, ((e & TE_ROW_MASK) - T.row0) >> 4, i, end_of_v, out, C)) return true;
     }
   }
   return false;
@@ -448,7 +474,7 @@ DCRX_DEVNI bool rescue_list(const DevTables &T, const Frame<REV> &F, const HalfH
   const int cnt = hh.count(cls4);
   for (int h = 0; h < cnt; h++) {
     const uint32_t t = hh.slot[cls4 * HH_K + h];
-    if (rescue_at<REV>(T, F, GENE, HALF, (t >> 9) & 0x3FFFu, (int)(t >> 23), end_of_v, out, C)) return true;
+    if (rescue_at<REV>(T, F, GENE, HALF, ((t >> 9) & 0x3FFFu) - (T.row0 >> 4), (int)(t >> 23), end_of_v, out, C)) return true;
   }
   return false;
 }
@@ -461,7 +487,7 @@ struct ScanOut { uint32_t acc, vacc, jacc; };
 
 #define DCRX_STEP(CODE)                                                                         \
   do {                                                                                          \
-    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));         \
+    e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) | ((uint32_t)(CODE) << 2));         \
     acc |= e;                                                                                   \
     const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
     vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                      \
@@ -469,11 +495,12 @@ struct ScanOut { uint32_t acc, vacc, jacc; };
     it += (1u << ACC_POS_SHIFT);                                                                \
   } while (0)
 
-// Fast scan: no exceptions in this read.  w[] holds the read's first nw words.
-template <bool REV, bool TABLE_LDS>
+// Fast scan: no exceptions in this read.  w[] holds the read's first NW words (NW = 10 for
+// strides up to 40 bytes, i.e. 150-nt reads; DCRX_NWMAX otherwise).
+template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
-                                             const uint32_t (&w)[DCRX_NWMAX], const uint32_t *words, int n) {
-  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+                                             const uint32_t (&w)[NW], const uint32_t *words, int n) {
+  uint32_t e = T.row0, acc = 0, vacc = 0, jacc = 0, it = 1u;
   if (n > 0) {
     const int top = (n - 1) >> 4;           // index of the last (possibly partial) word
     const int cnt = ((n - 1) & 15) + 1;     // bases in it
@@ -482,7 +509,7 @@ DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
       uint32_t wp = ~words[top] << (2 * (16 - cnt));
       for (int k = 0; k < cnt; k++) { DCRX_STEP(wp >> 30); wp <<= 2; }
 #pragma unroll
-      for (int kk = DCRX_NWMAX - 1; kk >= 0; kk--) {
+      for (int kk = NW - 1; kk >= 0; kk--) {
         if (kk < top) {
           const uint32_t wv = ~w[kk];
 #pragma unroll
@@ -491,7 +518,7 @@ DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < DCRX_NWMAX; kk++) {
+      for (int kk = 0; kk < NW; kk++) {
         if (kk < top) {
           const uint32_t wv = w[kk];
 #pragma unroll
@@ -520,7 +547,7 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
 #define DCRX_STEP_C(CODE)                                                                       \
   do {                                                                                          \
     if ((int)(it >> ACC_POS_SHIFT) == xc.nextpos) {                                      \
-      e = 0; xc.advance();   /* a byte outside ACGT: the machine goes back to the root */      \
+      e = T.row0; xc.advance();   /* a byte outside ACGT: the machine goes back to the root */ \
     } else {                                                                                    \
       e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + ((uint32_t)(CODE) << 2));       \
       acc |= e;                                                                                 \
@@ -538,7 +565,7 @@ template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh) {
   const uint32_t *words = rv.words;
   const int n = rv.n;
-  uint32_t e = 0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  uint32_t e = T.row0, acc = 0, vacc = 0, jacc = 0, it = 1u;
   ExcCursor<REV> xc(rv);
   hh.cnts = 0;
   if (n > 0) {
@@ -590,7 +617,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     if ((so.acc >> TE_VMULTI_BIT) & 1u) vcount = 2;          // two tags ended at one position
     if (vcount > 1) { C.add(DCRX_C_MULTIPLE_V_MATCHES); return DCRX_S_V_MULTI; }  // :278-280
     if (vcount == 1) {
-      const uint32_t st = (so.vacc >> ACC_STATE_SHIFT) & 0x3FFFu;
+      const uint32_t st = ((so.vacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
       const int iend = (int)(so.vacc >> ACC_POS_SHIFT);
       const int v = (int)(T.st_full[st - T.first_out] & 0xFFFFu);          // v_seqs.index(tag) :282
       const int p = iend + 1 - (int)GV.tag_len[v];           // hold_v[0][1]
@@ -620,7 +647,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     if ((so.acc >> TE_JMULTI_BIT) & 1u) jcount = 2;
     if (jcount > 1) { C.add(DCRX_C_MULTIPLE_J_MATCHES); jstatus = DCRX_S_J_MULTI; }  // :402-404
     else if (jcount == 1) {
-      const uint32_t st = (so.jacc >> ACC_STATE_SHIFT) & 0x3FFFu;
+      const uint32_t st = ((so.jacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
       const int iend = (int)(so.jacc >> ACC_POS_SHIFT);
       const int j = (int)(T.st_full[st - T.first_out] >> 16);              // j_seqs.index(tag) :406
       const int Lj = (int)GJ.tag_len[j];
@@ -683,7 +710,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
 // ------------------------------------------------------------------------------
 enum { FAST_DONE = 0, FAST_TO_RESCUE = 1, FAST_TO_GENERAL = 2 };
 
-template <bool TABLE_LDS, bool UNIFORM_LEN>
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
 DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, uint32_t nw, const Counters &C,
                                  dcrx_record_t *records) {
@@ -695,11 +722,11 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
-  uint32_t w[DCRX_NWMAX];
+  uint32_t w[NW];
   {
     const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
 #pragma unroll
-    for (int k = 0; k < DCRX_NWMAX / 2; k++) {
+    for (int k = 0; k < NW / 2; k++) {
       uint2 t = make_uint2(0u, 0u);
       if ((uint32_t)(2 * k) < nw) t = wp2[k];
       w[2 * k] = t.x; w[2 * k + 1] = t.y;
@@ -710,10 +737,10 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
   rec.vdel = rec.jdel = 0;
   int status, frame;
   if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
-    const ScanOut so = scan_fast<false, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+    const ScanOut so = scan_fast<false, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n);
     status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1;
   } else {                                                            // :999-1001
-    const ScanOut so = scan_fast<true, TABLE_LDS>(T, lds_trans, w, rv.words, rv.n);
+    const ScanOut so = scan_fast<true, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n);
     if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {  // profiling aid: price the scan alone
       rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.acc >> 16); rec.v_start = (uint16_t)so.vacc; rec.j_end = (uint16_t)so.jacc;
       rec.status = 254; rec.frame = 0;

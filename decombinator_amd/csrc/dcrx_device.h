@@ -55,6 +55,8 @@ struct GeneDevPtrs {
 struct DevTables {
   uint32_t n_states;
   uint32_t first_out;         // states >= first_out are the ones where some keyword ends
+  uint32_t row0;              // what a transition entry's row field is relative to: 0 in global memory,
+                              // the staged table's LDS address inside a kernel
   uint32_t dfa_bytes;
   uint32_t lds_image_bytes;   // image[0 .. lds_image_bytes) = DFA + side tables: what the kernels stage in LDS
   const uint8_t *image;       // start of the table blob (== trans)

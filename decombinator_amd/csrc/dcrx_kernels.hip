@@ -49,7 +49,7 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 // wavefront ballot into a queue of read indices for the queue kernel, so that the
 // rare, long, divergent work runs in dense waves instead of stalling this one.
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN>
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
 __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                dcrx_record_t *__restrict__ records,
                                                                uint32_t *__restrict__ block_counts,
@@ -61,11 +61,7 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   uint32_t *lds_trans = lds_wq + (DCRX_BLOCK / 64) * DCRX_WQ_CAP;  // [n_states*4] when TABLE_LDS
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  if (TABLE_LDS) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
-    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_BLOCK) dst[i] = src[i];
-  }
+  if (TABLE_LDS) stage_lds_image<DCRX_BLOCK>(T0, lds_trans, tid);
   __syncthreads();
   const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
@@ -82,7 +78,7 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
     const uint64_t r = tile * DCRX_BLOCK + tid;
     int what = FAST_DONE;
-    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, nw, C, records);
+    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW>(T, lds_trans, B, cfg, r, nw, C, records);
     // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
     // from the exception list before this kernel starts
     const bool defer = what == FAST_TO_RESCUE;
@@ -138,11 +134,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     return;
   }
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  if (TABLE_LDS) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
-    for (uint32_t i = tid; i < T0.lds_image_bytes / 16; i += DCRX_QBLOCK) dst[i] = src[i];
-  }
+  if (TABLE_LDS) stage_lds_image<DCRX_QBLOCK>(T0, lds_trans, tid);
   __syncthreads();
   const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
@@ -292,11 +284,11 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // ------------------------------------------------------------------------------
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM>
+template <bool TABLE_LDS, bool UNIFORM, int NW>
 static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  auto kfast = decombine_kernel<TABLE_LDS, UNIFORM>;
+  auto kfast = decombine_kernel<TABLE_LDS, UNIFORM, NW>;
   auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM>;
   const uint32_t lds_fast = P.lds_bytes + DCRX_FAST_LDS_EXTRA, lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
   hipError_t e;
@@ -360,13 +352,16 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
   e = hipMemsetAsync(queue_count, 0, 16, s);  // rescue count, general count, fast ticket, rescue ticket
   if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
+  const bool nw10 = B.stride <= 40;  // 150-nt reads: ten words in registers instead of DCRX_NWMAX
+#define DCRX_LAUNCH(TL, UN, NW_) launch_all<TL, UN, NW_>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
   if (P.table_in_lds) {
-    e = uniform ? launch_all<true, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
-                : launch_all<true, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
+    if (nw10) e = uniform ? DCRX_LAUNCH(true, true, 10) : DCRX_LAUNCH(true, false, 10);
+    else e = uniform ? DCRX_LAUNCH(true, true, DCRX_NWMAX) : DCRX_LAUNCH(true, false, DCRX_NWMAX);
   } else {
-    e = uniform ? launch_all<false, true>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
-                : launch_all<false, false>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop);
+    if (nw10) e = uniform ? DCRX_LAUNCH(false, true, 10) : DCRX_LAUNCH(false, false, 10);
+    else e = uniform ? DCRX_LAUNCH(false, true, DCRX_NWMAX) : DCRX_LAUNCH(false, false, DCRX_NWMAX);
   }
+#undef DCRX_LAUNCH
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
   return hipGetLastError();

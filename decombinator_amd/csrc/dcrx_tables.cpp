@@ -283,6 +283,7 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
   DevTables &R = H.rel;
   R.n_states = S;
   R.first_out = first_out;
+  R.row0 = 0;
   R.dfa_bytes = H.dfa_bytes;
   R.image = as_off<uint8_t>(0);
   R.trans = as_off<uint32_t>(B.put(trans));

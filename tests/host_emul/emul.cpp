@@ -46,14 +46,14 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     if (b->lens) {
       if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
       else {
-        const int what = decombine_fast_one<false, false>(T, nullptr, B, C, r, nw, CC, records);
+        const int what = (b->stride <= 40 ? decombine_fast_one<false, false, 10>(T, nullptr, B, C, r, nw, CC, records) : decombine_fast_one<false, false, DCRX_NWMAX>(T, nullptr, B, C, r, nw, CC, records));
         if (what == FAST_TO_RESCUE) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
       if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
       else {
-        const int what = decombine_fast_one<false, true>(T, nullptr, B, C, r, nw, CC, records);
+        const int what = (b->stride <= 40 ? decombine_fast_one<false, true, 10>(T, nullptr, B, C, r, nw, CC, records) : decombine_fast_one<false, true, DCRX_NWMAX>(T, nullptr, B, C, r, nw, CC, records));
         if (what == FAST_TO_RESCUE) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
