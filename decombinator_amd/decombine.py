@@ -1,0 +1,455 @@
+"""Host side of the `decombine` stage: same entry points and argument meaning as
+the reference's src/decombinator/decombine.py, with the per-read body of its
+read loop (reference decombine.py:998-1013: revcomp -> dcr -> vanalysis /
+janalysis -> get_*_deletions) replaced by batched calls into libdcrx.so, the
+HIP implementation (decombinator_amd/csrc, through decombinator_amd/_native.py).
+
+What stays on the host, as BASELINE.json's north_star asks: FASTQ reading
+(`readfq`), barcode slicing, row assembly for the `.n12` output, the summary
+log.  There is no CPU implementation of the hot path here: without the built
+library or without a GPU, `decombinator()` raises.
+
+Mirrored reference functions (file:line in /root/reference/src/decombinator/decombine.py):
+  opener_check :118   fastq_check :126   revcomp :182   read_tcr_file :187
+  readfq :228         import_tcr_info :593   get_v_tags :820   get_j_tags :847
+  sort_permissions :869   decombinator :881
+"""
+from __future__ import annotations
+
+import collections as coll
+import gzip
+import itertools
+import os
+import sys
+from time import strftime, time
+
+import numpy as np
+
+from . import _native as nat
+
+__version__ = "0.1.0"
+
+chainnams = {"a": "alpha", "b": "beta", "g": "gamma", "d": "delta"}
+
+# Bio.Seq's ambiguous-DNA complement (both cases, U like T), as reference revcomp() applies it
+_COMP = str.maketrans("ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna")
+
+# reads sent to the GPU per dcrx_decombine call
+BATCH_READS = 1 << 20
+
+# module-level state kept for callers that used the reference's globals
+counts: coll.Counter = coll.Counter()
+_current = None  # the ChainTables of the last import_tcr_info()
+
+
+def opener_check(inputargs):
+    """gzip.open for *.gz inputs, open otherwise (reference :118-123)."""
+    return gzip.open if inputargs["infile"].endswith(".gz") else open
+
+
+def revcomp(read: str) -> str:
+    """Reverse complement as Bio.Seq does it (reference :182-184)."""
+    return read.translate(_COMP)[::-1]
+
+
+def sort_permissions(fl):
+    """Output files are made world read/writable like the reference does (:869-873)."""
+    if oct(os.stat(fl).st_mode)[4:] != "666":
+        os.chmod(fl, 0o666)
+
+
+def readfq(fp):
+    """FASTA/FASTQ record generator with the behaviour of the reference's readfq
+    (:228-265, Heng Li's reader): yields (name, seq, qual-or-None); name is the
+    header without its first character up to the first space; sequence and quality
+    may span lines; a FASTQ record whose quality is cut short by EOF comes out as a
+    FASTA record."""
+    pending = None  # a header line already consumed
+    while True:
+        if pending is None:
+            for line in fp:
+                if line[0] in ">@":
+                    pending = line[:-1]
+                    break
+            if pending is None:
+                return
+        name = pending[1:].partition(" ")[0]
+        pending = None
+        chunks = []
+        for line in fp:
+            if line[0] in "@+>":
+                pending = line[:-1]
+                break
+            chunks.append(line[:-1])
+        seq = "".join(chunks)
+        if pending is None or pending[0] != "+":
+            yield name, seq, None
+            if pending is None:
+                return
+            continue
+        pending = None
+        qchunks, got = [], 0
+        complete = False
+        for line in fp:
+            qchunks.append(line[:-1])
+            got += len(line) - 1
+            if got >= len(seq):
+                complete = True
+                break
+        if not complete:
+            yield name, seq, None
+            return
+        yield name, seq, "".join(qchunks)
+
+
+def _new_summary_file(summaryname, logpath, date, chain_given, chain, samplenam):
+    """Opens `summaryname`, or the first free `..._Summary<N>.csv` (reference :141-155, :1082-1095)."""
+    if not os.path.exists(summaryname):
+        return summaryname, open(summaryname, "wt")
+    for i in range(2, 10000):
+        name = logpath + date + "_"
+        if chain_given:
+            name += chainnams[chain] + "_"
+        name += samplenam + "_Decombinator_Summary" + str(i) + ".csv"
+        if not os.path.exists(name):
+            return name, open(name, "wt")
+    raise RuntimeError("no free summary file name")
+
+
+def fastq_check(inputargs, opener, samplenam, summaryname, logpath, chain=None) -> None:
+    """Rudimentary FASTQ sanity check (reference :126-179): fewer than four lines is a
+    ValueError (after writing the two-line empty-input log); then a '@' header, a '+'
+    separator and equal sequence/quality lengths are required."""
+    chain = chain if chain is not None else (_current.chain if _current else None)
+    with opener(inputargs["infile"], "rt") as possfq:
+        head = list(itertools.islice(possfq, 4))
+        if len(head) < 4:
+            if inputargs["suppresssummary"] == False:  # noqa: E712
+                inout_name = "_".join(f"{samplenam}".split("_")[:-1]) + f"_{chainnams[chain]}"
+                summstr = "OutputFile," + inout_name + "\nNumberReadsInput," + "0"
+                name, fh = _new_summary_file(summaryname, logpath, strftime("%Y_%m_%d"), inputargs["chain"], chain, samplenam)
+                print(summstr, file=fh)
+                fh.close()
+                sort_permissions(name)
+            raise ValueError(
+                "There are fewer than four lines in this file, and thus it is not a valid FASTQ file. "
+                "Please check input and try again.")
+        # the reference validates the NEXT four lines (its islice continues on the same handle);
+        # a one-record file therefore has nothing to validate (do not crash)
+        read = list(itertools.islice(possfq, 0, 4))
+    if len(read) < 4:
+        read = head
+    if read[0][0] != "@":
+        raise ValueError(f"Expected @ symbol at beginning of file for valid FASTQ. Found {read[0][0]}.")
+    if read[2][0] != "+":
+        raise ValueError(f"Expected + symbol at beginning of third line for valid FASTQ. Found {read[2][0]}.")
+    if len(read[1]) != len(read[3]):
+        raise ValueError(
+            f"Length of read to match length of read quality. Found read length = {len(read[1])} "
+            f"and read quality length = {len(read[3])}")
+
+
+def read_tcr_file(species, tagset, gene, filetype, expected_dir_name, chain):
+    """Path of `<species>_<tagset>_TR<CHAIN><GENE>.<filetype>`: working directory first,
+    then the tag/FASTA directory (reference :187-225).  The reference would now try GitHub;
+    this build is offline-only and exits with the reference's message instead."""
+    expected_file = f"{species}_{tagset}_TR{chain.upper()}{gene.upper()}.{filetype}"
+    if os.path.isfile(expected_file):
+        return expected_file
+    cand = expected_dir_name + os.sep + expected_file
+    if os.path.isfile(cand):
+        return cand
+    print("Cannot find following file locally or online:", expected_file)
+    print("Please either run Decombinator with internet access, or point Decombinator to local copies "
+          "of the tag and FASTA files with the '-tf' flag.")
+    sys.exit()
+
+
+def _parse_tags(handle, half_split):
+    seqs, jumps = [], []
+    for line in handle:
+        fields = line.rstrip("\n").split()
+        seqs.append(fields[0])
+        jumps.append(int(fields[1]))
+    half1 = [s[0:half_split] for s in seqs]
+    half2 = [s[half_split:] for s in seqs]
+    return [seqs, half1, half2, jumps]
+
+
+def get_v_tags(file_v, half_split):
+    """[v_seqs, half1_v_seqs, half2_v_seqs, jump_to_end_v] from a .tags file (reference :820-844)."""
+    return _parse_tags(file_v, half_split)
+
+
+def get_j_tags(file_j, half_split):
+    """[j_seqs, half1_j_seqs, half2_j_seqs, jump_to_start_j] (reference :847-866)."""
+    return _parse_tags(file_j, half_split)
+
+
+def _read_fasta(path):
+    """(id, sequence) per record in file order; what SeqIO.parse(path, 'fasta') gives the
+    reference at :690 (sequence lines joined, header up to the first whitespace as id)."""
+    out, header, chunks = [], None, []
+    with open(path, "rt") as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if header is not None:
+                    out.append((header.split()[0] if header.split() else "", "".join(chunks)))
+                header, chunks = line[1:], []
+            elif header is not None:
+                chunks.append(line.strip())
+    if header is not None:
+        out.append((header.split()[0] if header.split() else "", "".join(chunks)))
+    return out
+
+
+class ChainTables:
+    """What import_tcr_info() leaves in module globals in the reference (:593-746), for one
+    chain, plus the compiled device tables."""
+
+    def __init__(self, chain, tags, species, v, j, v_genes, j_genes, v_half_split, j_half_split):
+        self.chain, self.tags, self.species = chain, tags, species
+        self.v_seqs, self.half1_v_seqs, self.half2_v_seqs, self.jump_to_end_v = v
+        self.j_seqs, self.half1_j_seqs, self.half2_j_seqs, self.jump_to_start_j = j
+        self.v_genes, self.j_genes = v_genes, j_genes
+        self.v_regions = [s.upper() for _, s in v_genes]
+        self.j_regions = [s.upper() for _, s in j_genes]
+        self.v_half_split, self.j_half_split = v_half_split, j_half_split
+        if len(self.v_regions) < len(self.v_seqs) or len(self.j_regions) < len(self.j_seqs):
+            raise ValueError("fewer FASTA records than tags: tag index i needs FASTA record i")
+        self.tables = nat.Tables(self.v_seqs, self.jump_to_end_v, self.v_regions[:len(self.v_seqs)],
+                                 self.j_seqs, self.jump_to_start_j, self.j_regions[:len(self.j_seqs)],
+                                 v_half_split, j_half_split)
+
+
+def import_tcr_info(inputargs) -> ChainTables:
+    """Chain resolution, tag-set/species validation, tag + FASTA loading (reference :593-746).
+    Returns the tables (also kept as the module's current tables) and resets `counts`."""
+    global counts, _current
+    counts = coll.Counter()
+    nochain_error = ("TCR chain not recognised. \n Please either include (one) chain name in the file name "
+                     "(i.e. alpha/beta/gamma/delta),\n or use the '-c' flag with an explicit chain option "
+                     "(a/b/g/d, case-insensitive).")
+    inner = [x for x in chainnams.values() if x in inputargs["infile"].lower()]
+    if len(inner) == 1:
+        counts["chain_detected"] = 1
+    if inputargs["chain"]:
+        c = inputargs["chain"].upper()
+        chain = {"A": "a", "ALPHA": "a", "TRA": "a", "TCRA": "a", "B": "b", "BETA": "b", "TRB": "b", "TCRB": "b",
+                 "G": "g", "GAMMA": "g", "TRG": "g", "TCRG": "g", "D": "d", "DELTA": "d", "TRD": "d",
+                 "TCRD": "d"}.get(c)
+        if chain is None:
+            print(nochain_error)
+            sys.exit()
+    elif counts["chain_detected"] == 1:
+        chain = inner[0][0]
+    else:
+        print(nochain_error)
+        sys.exit()
+
+    print("Importing TCR", chainnams[chain], "gene sequences...")
+    # the reference rewrites inputargs["tags"] in place for mouse and for gamma/delta (:640-654)
+    if inputargs["tags"] == "extended" and inputargs["species"] == "mouse":
+        print("Please note that there is currently no extended tag set for mouse TCR genes.\n"
+              " Decombinator will now switch the tag set in use from 'extended' to 'original'.")
+        inputargs["tags"] = "original"
+    if inputargs["tags"] == "extended" and chain in ("g", "d"):
+        print("Please note that there is currently no extended tag set for gamma/delta TCR genes.\n"
+              " Decombinator will now switch the tag set in use from 'extended' to 'original'.")
+        inputargs["tags"] = "original"
+    if inputargs["tags"] == "extended":
+        v_half_split, j_half_split = 10, 10
+    elif inputargs["tags"] == "original":
+        v_half_split, j_half_split = 10, 6
+    else:
+        print("Tag set unrecognised; should be either 'extended' or 'original' for human, or just 'original' "
+              "for mouse. \n Please check tag set and species flag.")
+        sys.exit()
+    if inputargs["species"] not in ["human", "mouse"]:
+        print("Species not recognised. Please select either 'human' (default) or 'mouse'.")
+        sys.exit()
+
+    parsed, genes = {}, {}
+    for gene, split in (("v", v_half_split), ("j", j_half_split)):
+        fasta = read_tcr_file(inputargs["species"], inputargs["tags"], gene, "fasta", inputargs["tagfastadir"], chain)
+        genes[gene] = _read_fasta(fasta)
+        tagf = read_tcr_file(inputargs["species"], inputargs["tags"], gene, "tags", inputargs["tagfastadir"], chain)
+        with open(tagf, "r") as fh:
+            parsed[gene] = (get_v_tags if gene == "v" else get_j_tags)(fh, split)
+    _current = ChainTables(chain, inputargs["tags"], inputargs["species"], parsed["v"], parsed["j"],
+                           genes["v"], genes["j"], v_half_split, j_half_split)
+    return _current
+
+
+def dcr(read, inputargs, tcr: ChainTables | None = None):
+    """dcr(read) for ONE read in the frame as given (reference :534-585), through the GPU
+    path.  Returns the reference's 7-list or None and adds to `counts`.  Convenience for
+    interactive use and tests; the pipeline calls the library on batches."""
+    tcr = tcr or _current
+    if tcr is None:
+        raise RuntimeError("import_tcr_info() has not been called")
+    rec, cnt = nat.decombine(tcr.tables, nat.pack_reads([read]), "forward", inputargs["allowNs"],
+                             inputargs["lenthreshold"])
+    _add_counts(cnt, skip=("read_count", "vj_count", "frame_forward"))
+    r = rec[0]
+    if int(r["status"]) != 0:
+        return None
+    s, l = int(r["ins_start"]), int(r["ins_len"])
+    return [int(r["v"]), int(r["j"]), int(r["vdel"]), int(r["jdel"]), read[s:s + l], int(r["v_start"]), int(r["j_end"])]
+
+
+def _add_counts(cnt, skip=()):
+    for i, name in enumerate(nat.COUNTER_NAMES):
+        if name in skip or name == "frame_forward":
+            continue
+        v = int(cnt[i])
+        if v:
+            counts[name] += v
+
+
+def assemble_rows(records, reads, quals, ids, bcs, bcqs, sampling_tails=None):
+    """`.n12` rows from device records (reference :1012-1039): for each decombined read
+    [v, j, vdel, jdel, insert, id, inter-tag seq, inter-tag qual, barcode, barcode qual]
+    (+ v_tail with sampling_analysis)."""
+    rows = []
+    for k in np.nonzero(records["status"] == 0)[0]:
+        r = records[k]
+        vdj, q = reads[k], quals[k]
+        if int(r["frame"]) == 0:              # reverse: dcr() saw revcomp(vdj) (:1015-1017)
+            frame_read, frame_q = revcomp(vdj), q[::-1]
+        else:                                 # forward (:1018-1020)
+            frame_read, frame_q = vdj, q
+        s, l = int(r["ins_start"]), int(r["ins_len"])
+        a, b = int(r["v_start"]), int(r["j_end"])
+        row = [str(int(r["v"])), str(int(r["j"])), str(int(r["vdel"])), str(int(r["jdel"])),
+               frame_read[s:s + l], ids[k], frame_read[a:b], frame_q[a:b], bcs[k], bcqs[k]]
+        if sampling_tails is not None:
+            row.append(sampling_tails[k])
+        rows.append(row)
+    return rows
+
+
+def _summary_text(inputargs, chain, samplenam, date, timetaken):
+    """The Decombinator summary CSV body (reference :1097-1195), line for line."""
+    inout_name = "_".join(f"{samplenam}".split("_")[:-1]) + f"_{chainnams[chain]}"
+    lines = ["Property,Value", "Directory," + os.getcwd(), "InputFile," + inout_name, "OutputFile," + inout_name,
+             "DateFinished," + date, "TimeFinished," + strftime("%H:%M:%S"),
+             "TimeTaken(Seconds)," + str(round(timetaken, 2)), "", "InputArguments:,"]
+    for s in ["species", "chain", "extension", "tags", "dontgzip", "allowNs", "orientation", "lenthreshold",
+              "bc_read", "bclength"]:
+        lines.append(s + "," + str(inputargs[s]))
+    counts["pc_decombined"] = counts["vj_count"] / counts["read_count"]
+    lines += ["", "NumberReadsInput," + str(counts["read_count"]),
+              "NumberReadsDecombined," + str(counts["vj_count"]),
+              "PercentReadsDecombined," + str(round(counts["pc_decombined"], 3)),
+              "", "ReadsAssignedUsingHalfTags:,",
+              "V1error," + str(counts["verr1"]), "V2error," + str(counts["verr2"]),
+              "J1error," + str(counts["jerr1"]), "J2error," + str(counts["jerr2"]),
+              "", "ReadsFilteredOut:,",
+              "AmbiguousBaseCall(DCR)," + str(counts["dcrfilter_intertagN"]),
+              "AmbiguousBaseCall(Barcode)," + str(counts["dcrfilter_barcodeN"]),
+              "OverlongInterTagSeq," + str(counts["dcrfilter_toolong_intertag"]),
+              "ImpossibleDeletions," + str(counts["dcrfilter_imposs_deletion"]),
+              "OverlappingTagBoundaries," + str(counts["dcrfilter_tag_overlap"]),
+              "", "ReadsFailedAssignment:,",
+              "MultipleVtagMatches," + str(counts["multiple_v_matches"]),
+              "VTagAtEndRead," + str(counts["v_del_failed_tag_at_end"]),
+              "VDeletionsUndetermined," + str(counts["v_del_failed"]),
+              "FoundV1HalfTagNotV2," + str(counts["foundv1notv2"]),
+              "FoundV2HalfTagNotV1," + str(counts["foundv2notv1"]),
+              "NoVDetected," + str(counts["no_vtags_found"]),
+              "MultipleJTagMatches," + str(counts["multiple_j_matches"]),
+              "JDeletionsUndermined," + str(counts["j_del_failed"]),
+              "FoundJ1HalfTagNotJ2," + str(counts["foundj1notj2"]),
+              "FoundJ2HalfTagNotJ1," + str(counts["foundj2notj1"]),
+              "NoJDetected," + str(counts["no_j_assigned"])]
+    return "\n".join(lines)
+
+
+def decombinator(inputargs: dict) -> list:
+    """The decombine stage (reference decombinator(), :881-1202): returns the list of
+    10-field rows that write_out_intermediate() turns into the `.n12` file."""
+    print("Running Decombinator (MI355X / HIP build) version", __version__)
+    opener = opener_check(inputargs)
+    tcr = import_tcr_info(inputargs)
+    chain = tcr.chain
+    samplenam = str(inputargs["infile"].split(".")[0])
+    if os.sep in samplenam:
+        samplenam = samplenam.split(os.sep)[-1]
+
+    summaryname = logpath = None
+    date = strftime("%Y_%m_%d")
+    if inputargs["suppresssummary"] == False:  # noqa: E712
+        logpath = inputargs["outpath"] + f"Logs{os.sep}"
+        if not os.path.exists(logpath):
+            os.makedirs(logpath)
+        summaryname = logpath + date + "_"
+        if inputargs["chain"]:
+            summaryname += chainnams[chain] + "_"
+        summaryname += samplenam + "_Decombinator_Summary.csv"
+    if inputargs["dontcheck"] == False:  # noqa: E712
+        # (the reference crashes here with suppresssummary=True; this build checks anyway)
+        fastq_check(inputargs, opener, samplenam, summaryname, logpath, chain)
+
+    bclength = inputargs["bclength"]
+    counts["start_time"] = time()
+    print("Decombining FASTQ data...")
+    outdata = []
+    orientation = inputargs["orientation"]
+    if orientation not in nat.ORIENTATIONS:
+        raise ValueError("orientation must be forward, reverse or both")
+
+    if inputargs["nobarcoding"] == False:  # noqa: E712
+        fq1 = readfq(opener(inputargs["infile"], "rt"))
+        if inputargs["bc_read"] == "R2":
+            fq2 = readfq(opener(inputargs["infile"].replace("1.f", "2.f"), "rt"))
+        elif inputargs["bc_read"] == "R1":
+            fq2 = fq1   # like the reference: zip() then consumes TWO records of the file per iteration (:956-961)
+        else:
+            raise ValueError("bc_read must be R1 or R2")
+        pairs = zip(fq1, fq2)
+        sampling = bool(inputargs.get("sampling_analysis"))
+        while True:
+            ids, reads, quals, bcs, bcqs, tails = [], [], [], [], [], ([] if sampling else None)
+            for record1, record2 in itertools.islice(pairs, BATCH_READS):
+                if inputargs["bc_read"] == "R2":
+                    vdj, vdjqual = record1[1], record1[2]
+                    bc, bcq = record2[1][:bclength], record2[2][:bclength]
+                else:
+                    vdj, vdjqual = record1[1][bclength:], record1[2][bclength:]
+                    bc, bcq = record1[1][0:bclength], record1[2][0:bclength]
+                if sampling:
+                    tails.append(record2[1][bclength:bclength + 31])
+                if "N" in bc and inputargs["allowNs"] == False:  # noqa: E712
+                    counts["dcrfilter_barcodeN"] += 1            # counted, never dropped (:985-989)
+                ids.append(record1[0]); reads.append(vdj); quals.append(vdjqual); bcs.append(bc); bcqs.append(bcq)
+            if not reads:
+                break
+            before = counts["read_count"]
+            counts["read_count"] += len(reads)
+            if inputargs["dontcount"] == False and counts["read_count"] // 100000 > before // 100000:  # noqa: E712
+                print("\t read", (counts["read_count"] // 100000) * 100000)
+            rec, cnt = nat.decombine(tcr.tables, nat.pack_reads(reads), orientation, inputargs["allowNs"],
+                                     inputargs["lenthreshold"])
+            _add_counts(cnt, skip=("read_count",))
+            outdata.extend(assemble_rows(rec, reads, quals, ids, bcs, bcqs, tails))
+    else:
+        # reference behaviour: with nobarcoding the read loop never runs
+        if inputargs["extension"] == "n12":
+            print("Non-barcoding option selected, but default output file extension (n12) detected. "
+                  "Automatically changing to 'nbc'.")
+
+    counts["end_time"] = time()
+    timetaken = counts["end_time"] - counts["start_time"]
+    print("Analysed", "{:,}".format(counts["read_count"]), "reads, finding", "{:,}".format(counts["vj_count"]),
+          chainnams[chain], "VJ rearrangements")
+    print("Reading from", inputargs["infile"] + ", writing to variable")
+    print("Took", str(round(timetaken, 2)), "seconds")
+
+    if inputargs["suppresssummary"] == False:  # noqa: E712
+        name, fh = _new_summary_file(summaryname, logpath, date, inputargs["chain"], chain, samplenam)
+        print(_summary_text(inputargs, chain, samplenam, date, timetaken), file=fh)
+        fh.close()
+        sort_permissions(name)
+    return outdata

@@ -165,6 +165,60 @@ def make_edge_tagset(seed: int = 14) -> synth.TagSet:
     return ts
 
 
+def gen_stage_fixture(out_path: str, seed: int = 77, n_pairs: int = 700):
+    """Whole-stage known answer: the reference's own decombinator() (decombine.py:881-1202) on a
+    synthetic paired FASTQ, for bc_read R2 and R1, orientation reverse and both.  Stores the
+    FASTQ text, the returned rows and the summary-file body."""
+    import glob
+    import io as _io
+    import contextlib
+    ts = synth.make_tagset("human", "extended", "b", n_v=20, n_j=8, seed=21, n_shared_groups=3)
+    rng = np.random.default_rng(seed)
+    r1, r2 = [], []
+    for i in range(n_pairs):
+        sense = casegen.mixture_read(ts, rng, 150, sub_rate=0.01, n_rate=0.03)
+        read = casegen.revcomp(sense) if i % 7 else sense            # a few sense-strand reads for `both`
+        if i % 50 == 3:
+            read = read[:int(rng.integers(30, 149))]                  # ragged lengths
+        q1 = "".join(chr(int(c)) for c in rng.integers(35, 74, size=len(read)))
+        bc = casegen.rand_seq(rng, 42)
+        if i % 40 == 5:
+            bc = bc[:10] + "N" + bc[11:]
+        tail = casegen.rand_seq(rng, 108)
+        q2 = "".join(chr(int(c)) for c in rng.integers(35, 74, size=150))
+        name = f"SYN:{i}:{int(rng.integers(1000, 9999))}"
+        r1.append(f"@{name} 1:N:0:AAAA\n{read}\n+\n{q1}\n")
+        r2.append(f"@{name} 2:N:0:AAAA\n{bc + tail}\n+\n{q2}\n")
+    fq1, fq2 = "".join(r1), "".join(r2)
+    runs = []
+    m = ref_driver.module()
+    with tempfile.TemporaryDirectory() as td:
+        tagdir = os.path.join(td, "tags"); ts.write(tagdir)
+        open(os.path.join(td, "SYNTH_1.fq"), "w").write(fq1)
+        open(os.path.join(td, "SYNTH_2.fq"), "w").write(fq2)
+        for bc_read, orientation, allow in (("R2", "reverse", False), ("R2", "both", True), ("R1", "reverse", False)):
+            outdir = os.path.join(td, f"out_{bc_read}_{orientation}") + os.sep
+            os.makedirs(outdir)
+            args = dict(infile=os.path.join(td, "SYNTH_1.fq"), chain="b", bc_read=bc_read, suppresssummary=False,
+                        dontgzip=True, dontcheck=False, dontcount=True, extension="n12", prefix="dcr_",
+                        orientation=orientation, tags="extended", species="human", allowNs=allow, lenthreshold=130,
+                        tagfastadir=tagdir, nobarcoding=False, bclength=42, outpath=outdir, dontsave=False,
+                        command="decombine", sampling_analysis=False)
+            with contextlib.redirect_stdout(_io.StringIO()):
+                rows = m.decombinator(dict(args))
+            logs = glob.glob(outdir + "Logs/*.csv")
+            assert len(logs) == 1
+            body = open(logs[0]).read().split("\n")
+            keep = [ln for ln in body if not ln.startswith(("Directory,", "DateFinished,", "TimeFinished,", "TimeTaken"))]
+            runs.append({"bc_read": bc_read, "orientation": orientation, "allowNs": allow, "rows": rows,
+                         "summary_lines": keep, "log_name_tail": os.path.basename(logs[0]).split("_", 3)[3]})
+            print(f"stage fixture {bc_read}/{orientation}: {len(rows)} rows")
+    with open(out_path, "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py gen_stage_fixture",
+                   "source": "reference decombinator() (decombine.py:881-1202), unmodified, + oracle/refshim stand-ins",
+                   "tagset": tagset_dict(ts), "fastq_r1": fq1, "fastq_r2": fq2, "runs": runs}, f, separators=(",", ":"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bulk", type=int, default=0)
@@ -194,6 +248,7 @@ def main():
                            "tagset": tagset_dict(ts), "cases": res}, f, separators=(",", ":"))
             if args.bulk:
                 bad += bulk_crosscheck(ts, td, args.bulk, seed + 1000)
+    gen_stage_fixture(os.path.join(GOLDEN, "stage_human_extended_b.json"))
     if args.bulk:
         print("bulk cross-check mismatches:", bad)
         sys.exit(1 if bad else 0)

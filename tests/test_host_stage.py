@@ -1,0 +1,145 @@
+"""Host side of the decombine stage (decombinator_amd/decombine.py, io.py) against the
+whole-stage known answer captured from the reference's own decombinator()
+(tests/golden/stage_human_extended_b.json): rows of the `.n12` and the summary body.
+
+Without a GPU the device call is replaced IN THE TEST by the oracle (a stand-in for the
+device, so that FASTQ reading, barcode slicing, R1-mode pairing, row assembly, counters and
+the log are checked on CPU); `-m gpu` runs the same comparison through the real HIP path."""
+import io as _io
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from decombinator_amd import _native as nat
+from decombinator_amd import decombine as dec
+from decombinator_amd import io as dio
+from decombinator_amd import synth
+from tests import parity_util as pu
+
+FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "stage_human_extended_b.json")
+
+
+@pytest.fixture(scope="module")
+def stage():
+    return json.load(open(FIXTURE))
+
+
+@pytest.fixture()
+def workdir(tmp_path, stage):
+    ts = stage["tagset"]
+    t = synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"],
+                     v_jumps=ts["v_jumps"], v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"],
+                     j_jumps=ts["j_jumps"], j_names=ts["j_names"], j_regions=ts["j_regions"])
+    t.write(str(tmp_path / "tags"))
+    (tmp_path / "SYNTH_1.fq").write_text(stage["fastq_r1"])
+    (tmp_path / "SYNTH_2.fq").write_text(stage["fastq_r2"])
+    return tmp_path
+
+
+def _oracle_device(stage):
+    """nat.decombine stand-in backed by the oracle (CPU tests only)."""
+    from tests import golden_util as gu
+    ot = gu.oracle_tables(stage["tagset"])
+
+    def fake(tables, batch, orientation="reverse", allow_ns=False, lenthreshold=130, flags=0):
+        reads = nat.unpack_reads(batch)
+        return pu.oracle_records(ot, reads, orientation, allow_ns, lenthreshold)
+    return fake
+
+
+def _run_and_compare(stage, workdir, run):
+    outdir = workdir / f"out_{run['bc_read']}_{run['orientation']}"
+    outdir.mkdir()
+    args = dio.create_args_dict(infile=str(workdir / "SYNTH_1.fq"), chain="b", bc_read=run["bc_read"], dontgzip=True,
+                                dontcount=True, orientation=run["orientation"], allowNs=run["allowNs"],
+                                tagfastadir=str(workdir / "tags"), outpath=str(outdir) + os.sep, command="decombine")
+    rows = dec.decombinator(args)
+    assert rows == run["rows"]
+    logs = list((outdir / "Logs").glob("*.csv"))
+    assert len(logs) == 1 and logs[0].name.split("_", 3)[3] == run["log_name_tail"]
+    body = logs[0].read_text().split("\n")
+    keep = [ln for ln in body if not ln.startswith(("Directory,", "DateFinished,", "TimeFinished,", "TimeTaken"))]
+    assert keep == run["summary_lines"]
+    out = dio.write_out_intermediate(rows, args, ".n12")
+    text = open(out).read()
+    assert text == "".join(", ".join(r) + "\n" for r in run["rows"])
+    assert os.path.basename(out) == "dcr_SYNTH_1_beta.n12" and oct(os.stat(out).st_mode)[-3:] == "666"
+
+
+@pytest.mark.parametrize("k", [0, 1, 2], ids=["R2-reverse", "R2-both-allowNs", "R1-reverse"])
+def test_stage_host_logic_with_oracle_as_device(stage, workdir, monkeypatch, k):
+    monkeypatch.setattr(nat, "decombine", _oracle_device(stage))
+    _run_and_compare(stage, workdir, stage["runs"][k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 2], ids=["R2-reverse", "R2-both-allowNs", "R1-reverse"])
+def test_stage_through_hip_path(stage, workdir, k):
+    _run_and_compare(stage, workdir, stage["runs"][k])
+
+
+def test_readfq_behaviour(stage):
+    recs = list(dec.readfq(_io.StringIO(stage["fastq_r1"])))
+    assert len(recs) == 700 and recs[0][0].startswith("SYN:0:") and all(len(r[1]) == len(r[2]) for r in recs)
+    # multi-line FASTQ, FASTA records, header without space, quality cut short by EOF
+    txt = "@a x y\nAC\nGT\n+\nII\nII\n>b\nAAAA\nCC\n@c\nACGT\n+anything\nIIII\n@d\nACGT\n+\nII\n"
+    got = list(dec.readfq(_io.StringIO(txt)))
+    assert got == [("a", "ACGT", "IIII"), ("b", "AAAACC", None), ("c", "ACGT", "IIII"), ("d", "ACGT", None)]
+    assert list(dec.readfq(_io.StringIO(""))) == []
+
+
+def test_revcomp_matches_biopython_table():
+    assert dec.revcomp("ACGTNacgtnRYKMBVDHSWXU-") == "-AXWSDHBVKMRYnacgtNACGT"
+
+
+def test_import_tcr_info_rules(workdir, capsys):
+    base = dict(infile="sample_beta_1.fq", chain=None, tags="extended", species="human",
+                tagfastadir=str(workdir / "tags"))
+    t = dec.import_tcr_info(dict(base))
+    assert t.chain == "b" and dec.counts["chain_detected"] == 1 and (t.v_half_split, t.j_half_split) == (10, 10)
+    assert t.half1_v_seqs[0] == t.v_seqs[0][:10] and t.half2_j_seqs[0] == t.j_seqs[0][10:]
+    assert t.tables.info()["n_v"] == 20
+    for bad in (dict(base, infile="x_1.fq"), dict(base, chain="q"), dict(base, tags="weird", chain="b"),
+                dict(base, species="dog", chain="b"), dict(base, chain="a")):   # alpha files are not there
+        with pytest.raises(SystemExit):
+            dec.import_tcr_info(bad)
+    args = dict(base, chain="g")
+    with pytest.raises(SystemExit):        # gamma switches to `original`, whose files are missing here
+        dec.import_tcr_info(args)
+    assert args["tags"] == "original"      # rewritten in place like the reference (decombine.py:648-654)
+
+
+def test_fastq_check_and_empty_input_log(workdir, monkeypatch, stage):
+    monkeypatch.setattr(nat, "decombine", _oracle_device(stage))
+    out = workdir / "o"
+    out.mkdir()
+    empty = workdir / "empty_merge.fq"
+    empty.write_text("")
+    args = dio.create_args_dict(infile=str(empty), chain="b", bc_read="R2", tagfastadir=str(workdir / "tags"),
+                                outpath=str(out) + os.sep)
+    date = time.strftime("%Y_%m_%d")
+    for n in ("", "2"):   # the second run must open ..._Summary2.csv (reference tests/test_decombine.py:75-94)
+        with pytest.raises(ValueError, match="fewer than four lines"):
+            dec.decombinator(dict(args))
+        log = out / "Logs" / f"{date}_beta_empty_merge_Decombinator_Summary{n}.csv"
+        assert log.read_text() == "OutputFile,empty_beta\nNumberReadsInput,0\n"
+    bad = workdir / "bad_1.fq"
+    bad.write_text("@r\nACGT\n+\nIIII\n>r2\nACGT\n+\nIIII\n")
+    with pytest.raises(ValueError, match="Expected @ symbol"):
+        dec.decombinator(dict(args, infile=str(bad)))
+    bad.write_text("@r\nACGT\n+\nIIII\n@r2\nACGT\n+\nIII\n")
+    with pytest.raises(ValueError, match="read quality"):
+        dec.decombinator(dict(args, infile=str(bad)))
+
+
+def test_cli_parser_flags():
+    a = dio.cli_args(["decombine", "-in", "x_1.fq", "-br", "R2", "-c", "b", "-bl", "30", "-or", "both", "-N",
+                      "-tg", "original", "-sp", "mouse", "-ln", "100", "-tfdir", "T", "-dz", "-op", "o/"])
+    assert (a["command"], a["bclength"], a["orientation"], a["allowNs"], a["tags"], a["species"], a["lenthreshold"],
+            a["tagfastadir"], a["dontgzip"], a["outpath"]) == ("decombine", 30, "both", True, "original", "mouse",
+                                                                100, "T", True, "o/")
+    p = dio.cli_args(["pipeline", "-in", "x_1.fq", "-c", "b", "-br", "R2", "-bl", "42", "-ol", "M13"])
+    assert p["command"] == "pipeline" and p["oligo"] == "M13"
