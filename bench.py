@@ -112,7 +112,9 @@ def main():
         sys.exit("bench.py needs a GPU: the decombine hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     nat.check(nat.lib().dcrx_set_device(local_rank))
-    if world > 1:
+    # DCRX_BENCH_FORCE_GATHER=1 under torchrun with one rank exercises the RCCL path on one GPU
+    use_dist = world > 1 or (os.environ.get("DCRX_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -145,7 +147,7 @@ def main():
     batch.exc_read, batch.exc_pos, batch.exc_chr = (d_er.data_ptr(), d_ep.data_ptr(), d_ec.data_ptr()) if len(er) else (None, None, None)
     cfg = nat.make_cfg("reverse", False, 130, args.cfg_flags)
     nat.check(nat.lib().dcrx_reserve_device(tables.handle, n))
-    gather = sharded.TupleGather(n, world, rank, dev) if world > 1 else None
+    gather = sharded.TupleGather(n, world, rank, dev) if use_dist else None
 
     def step(ev_pair=None):
         if ev_pair is not None:
@@ -158,7 +160,7 @@ def main():
             gather.step(d_rec, n, first, sptr)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +175,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -225,7 +227,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -143,3 +143,49 @@ def test_cli_parser_flags():
                                                                 100, "T", True, "o/")
     p = dio.cli_args(["pipeline", "-in", "x_1.fq", "-c", "b", "-br", "R2", "-bl", "42", "-ol", "M13"])
     assert p["command"] == "pipeline" and p["oligo"] == "M13"
+
+
+# ---- the reference's own golden .n12 (tests/resources/dcr_TINY_1_{alpha,beta}.n12) -----------
+# The real tag files are not available offline; oracle/rebuild_tiny_tagset.py reconstructs the
+# part of the human extended set that the fixtures pin.  With it, every row of the reference's
+# fixture must come out, in order (reference tests/test_pipeline.py:63-84, test_subparsers.py:104-125).
+
+def _tiny(chain_name, tmp_path):
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"tiny_{chain_name}.json")))
+    ts = fx["tagset"]
+    t = synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"],
+                     v_jumps=ts["v_jumps"], v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"],
+                     j_jumps=ts["j_jumps"], j_names=ts["j_names"], j_regions=ts["j_regions"])
+    t.write(str(tmp_path / "tags"))
+    (tmp_path / "TINY_1.fq").write_text(fx["fastq_r1"])
+    (tmp_path / "TINY_2.fq").write_text(fx["fastq_r2"])
+    args = dio.create_args_dict(infile=str(tmp_path / "TINY_1.fq"), chain=ts["chain"], bc_read="R2", dontgzip=True,
+                                dontcount=True, tagfastadir=str(tmp_path / "tags"), outpath=str(tmp_path) + os.sep,
+                                command="decombine")
+    return fx, args
+
+
+def _check_tiny(fx, args):
+    rows = dec.decombinator(args)
+    assert len(fx["reproduced_fixture_rows"]) == len(fx["reference_fixture_rows"])   # 35/35 alpha, 48/48 beta
+    assert rows == fx["reference_fixture_rows"]
+    assert rows == fx["rows_with_reconstructed_tagset"]
+    for k, v in fx["counts_with_reconstructed_tagset"].items():
+        if k not in ("chain_detected",):
+            assert dec.counts[k] == v, k
+    out = dio.write_out_intermediate(rows, args, ".n12")
+    assert os.path.basename(out) == f"dcr_TINY_1_{dec.chainnams[args['chain']]}.n12"
+
+
+@pytest.mark.parametrize("chain_name", ["alpha", "beta"])
+def test_reference_n12_fixture_with_oracle_as_device(chain_name, tmp_path, monkeypatch):
+    fx, args = _tiny(chain_name, tmp_path)
+    monkeypatch.setattr(nat, "decombine", _oracle_device(fx))
+    _check_tiny(fx, args)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain_name", ["alpha", "beta"])
+def test_reference_n12_fixture_through_hip_path(chain_name, tmp_path):
+    fx, args = _tiny(chain_name, tmp_path)
+    _check_tiny(fx, args)
