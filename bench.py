@@ -49,11 +49,9 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
                           [r.upper() for r in ts.j_regions], vs, js)
     hb = nat.synth_reads_host(tables, cfg_synth, 0, sample_reads)
-    reads = nat.unpack_reads(hb)
-    buf = np.frombuffer("".join(reads).encode("latin-1") + b"\0", dtype=np.uint8)
-    offsets = np.arange(sample_reads + 1, dtype=np.uint64) * READ_LEN
+    buf, offsets = nat.unpack_reads_raw(hb)
     t0 = time.perf_counter()
-    n1 = sample_reads // 4
+    n1 = min(sample_reads, 4_000_000)
     ot.decombine_batch(buf, offsets[:n1 + 1])
     t1 = time.perf_counter() - t0
     cores = os.cpu_count() or 1
@@ -85,7 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cfg-flags", type=int, default=0, help="profiling only: DCRX_F_* bits (results are then not checked)")
     args = ap.parse_args()

@@ -283,6 +283,18 @@ def pack_reads(reads, stride: int | None = None) -> PackedBatch:
                        er[:got].copy(), ep[:got].copy(), ec[:got].copy())
 
 
+def unpack_reads_raw(batch: PackedBatch):
+    """Inverse of pack_reads into one ASCII buffer: (uint8 buffer with a trailing NUL, uint64 offsets[n+1])."""
+    n = batch.n_reads
+    lens = batch.lens.astype(np.uint64) if batch.lens is not None else np.full(n, batch.read_len, dtype=np.uint64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    out = np.zeros(int(offsets[-1]) + 1, dtype=np.uint8)
+    b = batch.as_c()
+    check(lib().dcrx_unpack_reads(C.byref(b), offsets.ctypes.data, out.ctypes.data))
+    return out, offsets
+
+
 def unpack_reads(batch: PackedBatch):
     """Inverse of pack_reads: list of str."""
     n = batch.n_reads

@@ -268,15 +268,18 @@ static int list_index(char **list, int n, const char *s) {
   return -1;
 }
 
-/* findall() wrapper with a growing buffer */
-typedef struct { ac_hit_t *h; int n; } hits_t;
-static hits_t findall(const ac_t *a, const char *read, int n) {
-  hits_t r; int cap = 64;
-  r.h = (ac_hit_t *)malloc(sizeof(ac_hit_t) * (size_t)cap);
-  r.n = ac_findall(a, read, n, r.h, cap);
-  if (r.n > cap) { cap = r.n; r.h = (ac_hit_t *)realloc(r.h, sizeof(ac_hit_t) * (size_t)cap); r.n = ac_findall(a, read, n, r.h, cap); }
-  return r;
+/* findall() wrapper: hits go to a small inline buffer, a heap buffer only when a read has more
+ * than 32 of them (keeps the timed CPU baseline free of allocator traffic) */
+typedef struct { ac_hit_t *h; int n; ac_hit_t inl[32]; } hits_t;
+static void findall_into(hits_t *r, const ac_t *a, const char *read, int n) {
+  r->h = r->inl;
+  r->n = ac_findall(a, read, n, r->h, 32);
+  if (r->n > 32) {
+    r->h = (ac_hit_t *)malloc(sizeof(ac_hit_t) * (size_t)r->n);
+    r->n = ac_findall(a, read, n, r->h, r->n);
+  }
 }
+static void hits_free(hits_t *r) { if (r->h != r->inl) free(r->h); }
 
 /* ------------------------------------------------------------------------ */
 /* get_v_deletions — decombine.py:749-785                                    */
@@ -329,15 +332,15 @@ typedef struct { long match, pos, dels, tagpos; } xdat_t; /* (v_match,end_v,v_de
 /* ------------------------------------------------------------------------ */
 static int vanalysis(const gene_t *g, const char *read, long n, xdat_t *out, int *status,
                      uint64_t *counts) {
-  hits_t hold_v = findall(g->key, read, (int)n);               /* :275 */
+  hits_t hold_v; findall_into(&hold_v, g->key, read, (int)n);               /* :275 */
   if (hold_v.n) {                                              /* :277 */
     if (hold_v.n > 1) {                                        /* :278-280 */
-      counts[DCRX_C_MULTIPLE_V_MATCHES]++; *status = DCRX_S_V_MULTI; free(hold_v.h); return 0;
+      counts[DCRX_C_MULTIPLE_V_MATCHES]++; *status = DCRX_S_V_MULTI; hits_free(&hold_v); return 0;
     }
     int v_match = list_index(g->seqs, g->n, g->key->kw[hold_v.h[0].kw]); /* :282 */
     long p = hold_v.h[0].start;
     long temp_end_v = p + g->jump[v_match] - 1;                /* :283-285 */
-    free(hold_v.h);
+    hits_free(&hold_v);
     long end_v, dels;
     uint64_t before = counts[DCRX_C_V_DEL_FAILED_TAG_AT_END];
     if (get_v_deletions(g, read, n, v_match, temp_end_v, &end_v, &dels, counts)) { /* :288-290 */
@@ -346,8 +349,8 @@ static int vanalysis(const gene_t *g, const char *read, long n, xdat_t *out, int
     *status = (counts[DCRX_C_V_DEL_FAILED_TAG_AT_END] != before) ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;
     return 0;                                                  /* falls off the if: None */
   }
-  free(hold_v.h);
-  hits_t hold_v1 = findall(g->half1_key, read, (int)n);        /* :294 */
+  hits_free(&hold_v);
+  hits_t hold_v1; findall_into(&hold_v1, g->half1_key, read, (int)n);        /* :294 */
   if (hold_v1.n) {                                             /* :296 */
     for (int i = 0; i < hold_v1.n; i++) {                      /* :297 */
       const char *h = g->half1_key->kw[hold_v1.h[i].kw]; long p = hold_v1.h[i].start;
@@ -364,16 +367,16 @@ static int vanalysis(const gene_t *g, const char *read, long n, xdat_t *out, int
           long end_v, dels;
           if (get_v_deletions(g, read, n, k, temp_end_v, &end_v, &dels, counts)) { /* :323-326 */
             out->match = k; out->pos = end_v; out->dels = dels; out->tagpos = p; /* :327-333 */
-            free(hold_v1.h); return 1;
+            hits_free(&hold_v1); return 1;
           }
         }
       }
     }
     counts[DCRX_C_FOUNDV1NOTV2]++; *status = DCRX_S_V_HALF1_EXHAUSTED; /* :334-335 */
-    free(hold_v1.h); return 0;
+    hits_free(&hold_v1); return 0;
   }
-  free(hold_v1.h);
-  hits_t hold_v2 = findall(g->half2_key, read, (int)n);        /* :339 */
+  hits_free(&hold_v1);
+  hits_t hold_v2; findall_into(&hold_v2, g->half2_key, read, (int)n);        /* :339 */
   if (hold_v2.n) {                                             /* :340 */
     for (int i = 0; i < hold_v2.n; i++) {                      /* :341 */
       const char *h = g->half2_key->kw[hold_v2.h[i].kw]; long p = hold_v2.h[i].start;
@@ -391,15 +394,15 @@ static int vanalysis(const gene_t *g, const char *read, long n, xdat_t *out, int
           long end_v, dels;
           if (get_v_deletions(g, read, n, k, temp_end_v, &end_v, &dels, counts)) { /* :378-381 */
             out->match = k; out->pos = end_v; out->dels = dels; out->tagpos = q; /* :382-388 */
-            free(hold_v2.h); return 1;
+            hits_free(&hold_v2); return 1;
           }
         }
       }
     }
     counts[DCRX_C_FOUNDV2NOTV1]++; *status = DCRX_S_V_HALF2_EXHAUSTED; /* :389-390 */
-    free(hold_v2.h); return 0;
+    hits_free(&hold_v2); return 0;
   }
-  free(hold_v2.h);
+  hits_free(&hold_v2);
   counts[DCRX_C_NO_VTAGS_FOUND]++; *status = DCRX_S_V_NONE;    /* :393-394 */
   return 0;
 }
@@ -409,25 +412,25 @@ static int vanalysis(const gene_t *g, const char *read, long n, xdat_t *out, int
 /* ------------------------------------------------------------------------ */
 static int janalysis(const gene_t *g, const char *read, long n, long end_of_v, xdat_t *out,
                      int *status, uint64_t *counts) {
-  hits_t hold_j = findall(g->key, read, (int)n);               /* :399 */
+  hits_t hold_j; findall_into(&hold_j, g->key, read, (int)n);               /* :399 */
   if (hold_j.n) {                                              /* :401 */
     if (hold_j.n > 1) {                                        /* :402-404 */
-      counts[DCRX_C_MULTIPLE_J_MATCHES]++; *status = DCRX_S_J_MULTI; free(hold_j.h); return 0;
+      counts[DCRX_C_MULTIPLE_J_MATCHES]++; *status = DCRX_S_J_MULTI; hits_free(&hold_j); return 0;
     }
     const char *kw = g->key->kw[hold_j.h[0].kw];
     int j_match = list_index(g->seqs, g->n, kw);               /* :406 */
     long p = hold_j.h[0].start;
     long temp_start_j = p - g->jump[j_match];                  /* :407-409 */
     long j_seq_end = p + (long)strlen(kw);                     /* :411 */
-    free(hold_j.h);
+    hits_free(&hold_j);
     long start_j, dels;
     if (get_j_deletions(g, read, n, j_match, temp_start_j, end_of_v, &start_j, &dels, counts)) { /* :413-418 */
       out->match = j_match; out->pos = start_j; out->dels = dels; out->tagpos = j_seq_end; return 1;
     }
     *status = DCRX_S_J_WALK_FAIL; return 0;
   }
-  free(hold_j.h);
-  hits_t hold_j1 = findall(g->half1_key, read, (int)n);        /* :422 */
+  hits_free(&hold_j);
+  hits_t hold_j1; findall_into(&hold_j1, g->half1_key, read, (int)n);        /* :422 */
   if (hold_j1.n) {                                             /* :423 */
     for (int i = 0; i < hold_j1.n; i++) {                      /* :424 */
       const char *h = g->half1_key->kw[hold_j1.h[i].kw]; long p = hold_j1.h[i].start;
@@ -445,16 +448,16 @@ static int janalysis(const gene_t *g, const char *read, long n, long end_of_v, x
           long start_j, dels;
           if (get_j_deletions(g, read, n, k, temp_start_j, end_of_v, &start_j, &dels, counts)) { /* :455-462 */
             out->match = k; out->pos = start_j; out->dels = dels; out->tagpos = j_seq_end; /* :463-468 */
-            free(hold_j1.h); return 1;
+            hits_free(&hold_j1); return 1;
           }
         }
       }
     }
     counts[DCRX_C_FOUNDJ1NOTJ2]++; *status = DCRX_S_J_HALF1_EXHAUSTED; /* :469-470 */
-    free(hold_j1.h); return 0;
+    hits_free(&hold_j1); return 0;
   }
-  free(hold_j1.h);
-  hits_t hold_j2 = findall(g->half2_key, read, (int)n);        /* :473 */
+  hits_free(&hold_j1);
+  hits_t hold_j2; findall_into(&hold_j2, g->half2_key, read, (int)n);        /* :473 */
   if (hold_j2.n) {                                             /* :474 */
     for (int i = 0; i < hold_j2.n; i++) {                      /* :475 */
       const char *h = g->half2_key->kw[hold_j2.h[i].kw]; long p = hold_j2.h[i].start;
@@ -473,15 +476,15 @@ static int janalysis(const gene_t *g, const char *read, long n, long end_of_v, x
           long start_j, dels;
           if (get_j_deletions(g, read, n, k, temp_start_j, end_of_v, &start_j, &dels, counts)) { /* :512-519 */
             out->match = k; out->pos = start_j; out->dels = dels; out->tagpos = j_seq_end; /* :520-525 */
-            free(hold_j2.h); return 1;
+            hits_free(&hold_j2); return 1;
           }
         }
       }
     }
     counts[DCRX_C_FOUNDV2NOTV1]++; *status = DCRX_S_J_HALF2_EXHAUSTED; /* :526-527 (the reference bumps the V key) */
-    free(hold_j2.h); return 0;
+    hits_free(&hold_j2); return 0;
   }
-  free(hold_j2.h);
+  hits_free(&hold_j2);
   counts[DCRX_C_NO_J_ASSIGNED]++; *status = DCRX_S_J_NONE;      /* :530-531 */
   return 0;
 }
@@ -569,7 +572,7 @@ int dcro_findall(const dcro_tables *t, int gene, int which, const char *text, in
   const gene_t *g = gene ? &t->j : &t->v;
   const ac_t *a = which == 0 ? g->key : which == 1 ? g->half1_key : g->half2_key;
   char **list = which == 0 ? g->seqs : which == 1 ? g->half1 : g->half2;
-  hits_t h = findall(a, text, n);
+  hits_t h; findall_into(&h, a, text, n);
   for (int i = 0; i < h.n && i < cap; i++) { first_idx[i] = list_index(list, g->n, a->kw[h.h[i].kw]); start[i] = h.h[i].start; }
-  int cnt = h.n; free(h.h); return cnt;
+  int cnt = h.n; hits_free(&h); return cnt;
 }
