@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdcrx.so")
+# DCRX_LIB_PATH: developer override for A/B builds of the same library (never a different backend)
+LIB_PATH = os.environ.get("DCRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libdcrx.so")
 
 N_COUNTERS = 32
 ABI_VERSION = 1
@@ -38,6 +39,8 @@ STATUS_NAMES = [
 
 ORIENTATIONS = {"reverse": 0, "forward": 1, "both": 2}
 F_FORCE_SLOW_READER = 1
+F_PROFILE_SCAN_ONLY = 2
+F_ONE_BASE_SCAN = 4
 
 RECORD_DTYPE = np.dtype([
     ("v", "<u2"), ("j", "<u2"), ("v_start", "<u2"), ("j_end", "<u2"),

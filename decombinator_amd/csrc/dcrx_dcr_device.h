@@ -62,32 +62,31 @@ using std::max;
 
 namespace dcrx {
 
-// The table pointers of `T` that lie inside the LDS image, re-pointed at the copy of the image
-// that starts at `lds_image` (a kernel's shared memory).
-DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_image) {
+// The side-table pointers of `T`, re-pointed at an LDS copy: `lds_side` holds the bytes
+// image[side_off .. lds_image_bytes) (side_off = 0: the whole image, DFA first; side_off =
+// dfa_bytes: only the side tables, as the two-bases-per-step kernel stages them).
+DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_side, uint32_t side_off) {
   DevTables L = T;
-#define DCRX_MV(p) L.p = reinterpret_cast<decltype(L.p)>(lds_image + (reinterpret_cast<const uint8_t *>(T.p) - T.image))
+#define DCRX_MV(p) L.p = reinterpret_cast<decltype(L.p)>(lds_side + ((reinterpret_cast<const uint8_t *>(T.p) - T.image) - side_off))
   DCRX_MV(st_full); DCRX_MV(st_out); DCRX_MV(outs); DCRX_MV(kw_base); DCRX_MV(kw_first); DCRX_MV(kw_begin); DCRX_MV(kw_tags);
   for (int g = 0; g < 2; g++) {
     DCRX_MV(g[g].tag_len); DCRX_MV(g[g].jump); DCRX_MV(g[g].tag_pk_fwd); DCRX_MV(g[g].tag_pk_rc);
     DCRX_MV(g[g].w64_fwd); DCRX_MV(g[g].w64_rc); DCRX_MV(g[g].w64_ok); DCRX_MV(g[g].reg_len);
   }
 #undef DCRX_MV
-  L.row0 = dcrx_lds_address(lds_image);
   return L;
 }
 
-// Copies the LDS image (DFA + side tables) from global memory; the DFA part gets the image's
-// own LDS address added to every row field, making the rows absolute LDS addresses.
+// Copies `n16` 16-byte units from global memory into LDS; the first `n_rows16` of them are
+// transition rows whose row fields get `row_base` added (rows become absolute LDS addresses).
 template <int BLOCK>
-DCRX_DEV void stage_lds_image(const DevTables &T0, uint32_t *lds_image, int tid) {
-  const uint4 *src = reinterpret_cast<const uint4 *>(T0.image);
-  uint4 *dst = reinterpret_cast<uint4 *>(lds_image);
-  const uint32_t row0 = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_image));
-  const uint32_t n_dfa = T0.dfa_bytes / 16, n_all = T0.lds_image_bytes / 16;
-  for (uint32_t i = tid; i < n_all; i += BLOCK) {
+DCRX_DEV void stage_lds(const uint8_t *src_bytes, uint32_t *dst_words, uint32_t n16, uint32_t n_rows16,
+                        uint32_t row_base, int tid) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(src_bytes);
+  uint4 *dst = reinterpret_cast<uint4 *>(dst_words);
+  for (uint32_t i = tid; i < n16; i += BLOCK) {
     uint4 v = src[i];
-    if (i < n_dfa) { v.x += row0; v.y += row0; v.z += row0; v.w += row0; }
+    if (i < n_rows16) { v.x += row_base; v.y += row_base; v.z += row_base; v.w += row_base; }
     dst[i] = v;
   }
 }
@@ -483,22 +482,53 @@ DCRX_DEVNI bool rescue_list(const DevTables &T, const Frame<REV> &F, const HalfH
 // The scan.  STEP consumes one symbol: one LDS look-up, flags OR-ed into `acc`,
 // full-tag hits added into vacc / jacc.
 // ------------------------------------------------------------------------------
-struct ScanOut { uint32_t acc, vacc, jacc; };
+struct ScanAcc { uint32_t acc, vacc, jacc; };   // raw accumulators of a scan
+
+// What dcr_frame needs from a scan: the OR of all entry flags, and per full-tag class the hit
+// count (0, 1, or >= 2) and, for a single hit, the state it ends in and its end position.
+struct ScanOut {
+  uint32_t acc;
+  uint32_t vcount, jcount;
+  uint32_t vstate, jstate;
+  int vend, jend;
+};
+
+// One-base-per-step scans: the accumulators already hold state and position of a single hit.
+DCRX_DEV ScanOut finish4(const DevTables &T, const ScanAcc &a) {
+  ScanOut so;
+  so.acc = a.acc;
+  so.vcount = a.vacc & ACC_CNT_MASK;
+  if ((a.acc >> TE_VMULTI_BIT) & 1u) so.vcount = 2;          // two tags ended at one position
+  so.jcount = a.jacc & ACC_CNT_MASK;
+  if ((a.acc >> TE_JMULTI_BIT) & 1u) so.jcount = 2;
+  so.vstate = ((a.vacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
+  so.jstate = ((a.jacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
+  so.vend = (int)(a.vacc >> ACC_POS_SHIFT);
+  so.jend = (int)(a.jacc >> ACC_POS_SHIFT);
+  return so;
+}
+
+// developer experiment switches (timing only; results are wrong when set)
+#ifdef DCRX_EXPERIMENT_NO_J
+#define DCRX_EXP_JACC(x)
+#else
+#define DCRX_EXP_JACC(x) x
+#endif
 
 #define DCRX_STEP(CODE)                                                                         \
   do {                                                                                          \
     e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) | ((uint32_t)(CODE) << 2));         \
     acc |= e;                                                                                   \
     const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
-    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                      \
-    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                      \
+    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
+    DCRX_EXP_JACC(jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;)                   \
     it += (1u << ACC_POS_SHIFT);                                                                \
   } while (0)
 
 // Fast scan: no exceptions in this read.  w[] holds the read's first NW words (NW = 10 for
 // strides up to 40 bytes, i.e. 150-nt reads; DCRX_NWMAX otherwise).
 template <bool REV, bool TABLE_LDS, int NW>
-DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
+DCRX_DEV ScanAcc scan_fast(const DevTables &T, const uint32_t *lds_trans,
                                              const uint32_t (&w)[NW], const uint32_t *words, int n) {
   uint32_t e = T.row0, acc = 0, vacc = 0, jacc = 0, it = 1u;
   if (n > 0) {
@@ -529,7 +559,141 @@ DCRX_DEV ScanOut scan_fast(const DevTables &T, const uint32_t *lds_trans,
       for (int k = 0; k < cnt; k++) { DCRX_STEP(wp & 3u); wp >>= 2; }
     }
   }
-  return ScanOut{acc, vacc, jacc};
+  return ScanAcc{acc, vacc, jacc};
+}
+
+// ------------------------------------------------------------------------------
+// Two bases per step (fast kernel): one LDS look-up consumes a pair of bases.  The
+// accumulators sum, per full-tag class, `1 | state BEFORE the pair << 9 | pair index << 23`
+// over the pairs inside which a tag ends; finish16 turns a single hit into its exact end
+// position and end state.
+// ------------------------------------------------------------------------------
+constexpr uint32_t TE16_ROW_MASK = 0x3FFFFu;
+
+template <bool TABLE_LDS>
+DCRX_DEV uint32_t trans16_at(const DevTables &T, uint32_t byte_addr) {
+#ifndef DCRX_HOST_EMUL
+  if (TABLE_LDS) return *reinterpret_cast<const dcrx_lds_u32 *>(static_cast<uintptr_t>(byte_addr));
+#endif
+  return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.trans16) + byte_addr);
+}
+
+#define DCRX_STEP16(PAIR4) /* PAIR4 = (first base * 4 + second base) << 2 */                   \
+  do {                                                                                          \
+    const uint32_t rowp_ = e & TE16_ROW_MASK;                                                   \
+    e = trans16_at<TABLE_LDS>(T, rowp_ | (uint32_t)(PAIR4));                                    \
+    acc |= e;                                                                                   \
+    const uint32_t t_ = (rowp_ << 3) | it;                                                      \
+    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
+    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
+    it += (1u << ACC_POS_SHIFT);                                                                \
+  } while (0)
+
+struct ScanAcc16 { uint32_t acc, vacc, jacc, e_last; };
+
+// Pairs are (frame position 2k, 2k+1); an odd read length leaves one last base, which the
+// caller finishes with a one-base step (finish16).
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], const uint32_t *words, int n) {
+  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  const int npairs = n >> 1;
+  if (npairs > 0) {
+    // The frame's bases in scan order form a bit stream; it is consumed pair by pair.  REV: the
+    // stream starts at the top base of the last word.  Whole words hold 8 pairs only when the
+    // stream is word-aligned, i.e. when the partial top word holds an even number of bases.
+    const int top = (n - 1) >> 4;
+    const int cnt = ((n - 1) & 15) + 1;       // bases in the top word
+    if (REV) {
+      // top (partial) word first: cnt bases, from its top base down; complemented
+      uint32_t wp = ~words[top] << (2 * (16 - cnt));
+      const int pairs_top = cnt >> 1;
+      for (int k = 0; k < pairs_top; k++) { DCRX_STEP16((wp >> 28) << 2); wp <<= 4; }
+      if (cnt & 1) {
+        // odd: the pair straddles words; generic path (one base from wp, one from the next word), keeps
+        // straddling for every following word
+        uint32_t carry = wp >> 30;            // last base of the top word (already complemented)
+        for (int kk = top - 1; kk >= 0; kk--) {
+          const uint32_t wv = ~words[kk];
+          DCRX_STEP16(((carry << 2) | (wv >> 30)) << 2);
+#pragma unroll
+          for (int j = 14; j >= 2; j -= 2) DCRX_STEP16(dcrx_ubfe(wv, 2 * j - 2, 4) << 2);
+          carry = wv & 3u;
+        }
+      } else {
+#pragma unroll
+        for (int kk = NW - 1; kk >= 0; kk--) {
+          if (kk < top) {
+            const uint32_t wv = ~w[kk];
+#pragma unroll
+            for (int j = 7; j >= 0; j--) DCRX_STEP16(dcrx_ubfe(wv, 4 * j, 4) << 2);
+          }
+        }
+      }
+    } else {
+      // forward: pairs never straddle words (a word holds 16 bases from an even frame position)
+#pragma unroll
+      for (int kk = 0; kk < NW; kk++) {
+        if (kk < top) {
+          const uint32_t wv = w[kk];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t nib = dcrx_ubfe(wv, 4 * j, 4);           // second base in the high 2 bits
+            DCRX_STEP16((((nib & 3u) << 2) | (nib >> 2)) << 2);
+          }
+        }
+      }
+      uint32_t wp = words[top];
+      for (int k = 0; k < (cnt >> 1); k++) { DCRX_STEP16((((wp & 3u) << 2) | ((wp >> 2) & 3u)) << 2); wp >>= 4; }
+    }
+  }
+  return ScanAcc16{acc, vacc, jacc, e};
+}
+
+// Resolves the accumulators of a two-bases-per-step scan.  A single hit is located by redoing
+// its pair: the state before the pair and the pair index are in the accumulator; the pair's
+// bases come from the read; the entry says whether the tag ends at the first or the second
+// base.  An odd read length leaves a last base, stepped here with the one-base table.
+template <bool REV, bool TABLE_LDS>
+DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a) {
+  ScanOut so;
+  so.acc = a.acc & ~((1u << TE16_V2_BIT) | (1u << TE16_J2_BIT));
+  so.vcount = a.vacc & ACC_CNT_MASK;
+  if ((a.acc >> TE_VMULTI_BIT) & 1u) so.vcount = 2;
+  so.jcount = a.jacc & ACC_CNT_MASK;
+  if ((a.acc >> TE_JMULTI_BIT) & 1u) so.jcount = 2;
+  so.vstate = so.jstate = 0; so.vend = so.jend = 0;
+  const int n = F.n();
+  // one-base step from state index st (new numbering) with base c, in the global 4-ary table
+  auto step4 = [&](uint32_t st, int c) { return T.trans[st * 4 + (uint32_t)c]; };
+  auto locate = [&](uint32_t accv, int full_bit, int second_bit, uint32_t &state, int &end) {
+    const uint32_t sprev = ((accv >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row16_0 >> 6);
+    const int k = (int)(accv >> ACC_POS_SHIFT);
+    const int c1 = F.code(2 * k), c2 = F.code(2 * k + 1);
+    const uint32_t e1 = step4(sprev, c1);                  // global table: rows relative, state * 16
+    if ((e1 >> full_bit) & 1u) { state = (e1 & TE_ROW_MASK) >> 4; end = 2 * k; }
+    else { const uint32_t e2 = step4((e1 & TE_ROW_MASK) >> 4, c2); state = (e2 & TE_ROW_MASK) >> 4; end = 2 * k + 1; }
+    (void)second_bit;
+  };
+  if (n & 1) {
+    // the last base: one-base step from the state after the last pair
+    const uint32_t slast = ((a.e_last & TE16_ROW_MASK) - T.row16_0) >> 6;
+    const uint32_t e = step4(slast, F.code(n - 1));
+    so.acc |= e & ~TE_ROW_MASK;
+    if ((e >> TE_VMULTI_BIT) & 1u) so.vcount = 2;
+    if ((e >> TE_JMULTI_BIT) & 1u) so.jcount = 2;
+    if ((e >> TE_VFULL_BIT) & 1u) {
+      if (so.vcount == 0) { so.vcount = 1; so.vstate = (e & TE_ROW_MASK) >> 4; so.vend = n - 1; }
+      else if (so.vcount == 1) so.vcount = 2;
+    } else if (so.vcount == 1) locate(a.vacc, TE_VFULL_BIT, TE16_V2_BIT, so.vstate, so.vend);
+    if ((e >> TE_JFULL_BIT) & 1u) {
+      if (so.jcount == 0) { so.jcount = 1; so.jstate = (e & TE_ROW_MASK) >> 4; so.jend = n - 1; }
+      else if (so.jcount == 1) so.jcount = 2;
+    } else if (so.jcount == 1) locate(a.jacc, TE_JFULL_BIT, TE16_J2_BIT, so.jstate, so.jend);
+    return so;
+  }
+  if (so.vcount == 1) locate(a.vacc, TE_VFULL_BIT, TE16_V2_BIT, so.vstate, so.vend);
+  if (so.jcount == 1) locate(a.jacc, TE_JFULL_BIT, TE16_J2_BIT, so.jstate, so.jend);
+  return so;
 }
 
 // Collecting scan (queue kernel): scan_fast that also appends every half-tag hit to the
@@ -589,7 +753,7 @@ DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, con
       for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp & 3u); wp >>= 2; }
     }
   }
-  return ScanOut{acc, vacc, jacc};
+  return finish4(T, ScanAcc{acc, vacc, jacc});
 }
 
 // ------------------------------------------------------------------------------
@@ -613,12 +777,11 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
 
   // ---- vanalysis ---------------------------------------------------------------
   {
-    uint32_t vcount = so.vacc & ACC_CNT_MASK;
-    if ((so.acc >> TE_VMULTI_BIT) & 1u) vcount = 2;          // two tags ended at one position
+    const uint32_t vcount = so.vcount;
     if (vcount > 1) { C.add(DCRX_C_MULTIPLE_V_MATCHES); return DCRX_S_V_MULTI; }  // :278-280
     if (vcount == 1) {
-      const uint32_t st = ((so.vacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
-      const int iend = (int)(so.vacc >> ACC_POS_SHIFT);
+      const uint32_t st = so.vstate;
+      const int iend = so.vend;
       const int v = (int)(T.st_full[st - T.first_out] & 0xFFFFu);          // v_seqs.index(tag) :282
       const int p = iend + 1 - (int)GV.tag_len[v];           // hold_v[0][1]
       const int te = p + GV.jump[v] - 1;                     // :283-285
@@ -643,12 +806,11 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
   // ---- janalysis ---------------------------------------------------------------
   int jstatus = DCRX_S_OK;
   {
-    uint32_t jcount = so.jacc & ACC_CNT_MASK;
-    if ((so.acc >> TE_JMULTI_BIT) & 1u) jcount = 2;
+    const uint32_t jcount = so.jcount;
     if (jcount > 1) { C.add(DCRX_C_MULTIPLE_J_MATCHES); jstatus = DCRX_S_J_MULTI; }  // :402-404
     else if (jcount == 1) {
-      const uint32_t st = ((so.jacc >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row0 >> 4);
-      const int iend = (int)(so.jacc >> ACC_POS_SHIFT);
+      const uint32_t st = so.jstate;
+      const int iend = so.jend;
       const int j = (int)(T.st_full[st - T.first_out] >> 16);              // j_seqs.index(tag) :406
       const int Lj = (int)GJ.tag_len[j];
       const int p = iend + 1 - Lj;
@@ -710,7 +872,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
 // ------------------------------------------------------------------------------
 enum { FAST_DONE = 0, FAST_TO_RESCUE = 1, FAST_TO_GENERAL = 2 };
 
-template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
 DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, uint32_t nw, const Counters &C,
                                  dcrx_record_t *records) {
@@ -736,19 +898,31 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
   int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
-    const ScanOut so = scan_fast<false, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n);
-    status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1;
-  } else {                                                            // :999-1001
-    const ScanOut so = scan_fast<true, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n);
+  ScanOut so;
+  const bool fwd = cfg.orientation == DCRX_ORIENT_FORWARD;           // decombine.py:1002-1004, else :999-1001
+  if (ARITY == 16) {
+    const ScanAcc16 a = fwd ? scan_fast16<false, TABLE_LDS, NW>(T, w, rv.words, rv.n)
+                            : scan_fast16<true, TABLE_LDS, NW>(T, w, rv.words, rv.n);
     if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {  // profiling aid: price the scan alone
-      rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.acc >> 16); rec.v_start = (uint16_t)so.vacc; rec.j_end = (uint16_t)so.jacc;
+      rec.v = (uint16_t)a.acc; rec.j = (uint16_t)(a.acc >> 16); rec.v_start = (uint16_t)a.vacc; rec.j_end = (uint16_t)a.jacc;
       rec.status = 254; rec.frame = 0;
       dcrx_store_record(records + r, rec);
       return FAST_DONE;
     }
-    status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0;
+    so = fwd ? finish16<false, TABLE_LDS>(T, Frame<false>(rv), a) : finish16<true, TABLE_LDS>(T, Frame<true>(rv), a);
+  } else {
+    const ScanAcc a = fwd ? scan_fast<false, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n)
+                          : scan_fast<true, TABLE_LDS, NW>(T, lds_trans, w, rv.words, rv.n);
+    if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {
+      rec.v = (uint16_t)a.acc; rec.j = (uint16_t)(a.acc >> 16); rec.v_start = (uint16_t)a.vacc; rec.j_end = (uint16_t)a.jacc;
+      rec.status = 254; rec.frame = 0;
+      dcrx_store_record(records + r, rec);
+      return FAST_DONE;
+    }
+    so = finish4(T, a);
   }
+  if (fwd) { status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1; }
+  else { status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0; }
   if (status == DCRX_S_DEFER) return FAST_TO_RESCUE;
   C.add(DCRX_C_READ_COUNT);                                           // :991
   if (status == DCRX_S_OK) {

@@ -21,6 +21,15 @@ constexpr int TE_VFULL_BIT = 18, TE_JFULL_BIT = 19;
 constexpr int TE_VH1_BIT = 20, TE_VH2_BIT = 21, TE_JH1_BIT = 22, TE_JH2_BIT = 23;
 constexpr int TE_VMULTI_BIT = 24, TE_JMULTI_BIT = 25;
 constexpr uint32_t MAX_STATES = 16383;
+
+// ---- two-bases-per-step table (fast kernel): entry for (state, first base * 4 + second base) ------
+// bits 0..17  byte offset of the row of the state after both bases (state * 64)
+// bit  18/19  a V / J tag ends at the first or the second base of the pair
+// bit  20..23 half-tag classes ending at either base (OR)
+// bit  24/25  two or more V / J tags end inside the pair
+// bit  26/27  the V / J tag of bit 18/19 ends at the SECOND base
+constexpr int TE16_V2_BIT = 26, TE16_J2_BIT = 27;
+constexpr uint32_t MAX_STATES16 = 4095;
 constexpr uint32_t MAX_TAG_LEN = 32;
 
 // entry of the per-state output list: class | len<<3 | kw<<9 | last<<31
@@ -61,6 +70,9 @@ struct DevTables {
   uint32_t lds_image_bytes;   // image[0 .. lds_image_bytes) = DFA + side tables: what the kernels stage in LDS
   const uint8_t *image;       // start of the table blob (== trans)
   const uint32_t *trans;      // [n_states*4] transition entries
+  const uint32_t *trans16;    // [n_states*16] two-bases-per-step entries (null when the automaton has > 4095 states)
+  uint32_t dfa16_bytes;
+  uint32_t row16_0;           // like row0, for trans16
   const uint32_t *st_full;    // [state - first_out] V tag | J tag << 16 ending at the state (0xFFFF none)
   const uint32_t *st_out;     // [state - first_out (+1)] CSR into outs
   const uint32_t *outs;       // per-state output list, longest keyword first

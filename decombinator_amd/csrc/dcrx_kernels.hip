@@ -38,6 +38,7 @@ namespace dcrx {
 constexpr int DCRX_WQ_CAP = 128;
 constexpr int DCRX_CHUNK = 2;  // 64-read tiles of the rescue queue a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
+constexpr uint32_t DCRX_FAST16_LDS_EXTRA = (DCRX_BLOCK16 / 64) * DCRX_WQ_CAP * 4;   // keeps the 64-byte rows aligned: 128 + 8192
 constexpr int DCRX_LSLOT = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // per-lane dwords: hit lists + exception copy; odd: conflict-free
 constexpr int DCRX_LSLOT_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) * 4;
@@ -49,21 +50,34 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 // wavefront ballot into a queue of read indices for the queue kernel, so that the
 // rare, long, divergent work runs in dense waves instead of stalling this one.
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
-__global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, BatchDev B, CfgDev cfg,
-                                                               dcrx_record_t *__restrict__ records,
-                                                               uint32_t *__restrict__ block_counts,
-                                                               uint32_t *__restrict__ queue,
-                                                               uint32_t *__restrict__ queue_count) {
-  extern __shared__ __align__(16) uint32_t smem[];
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
+__global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decombine_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, uint32_t *__restrict__ block_counts,
+    uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count) {
+  constexpr int BLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
+  extern __shared__ __align__(64) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
-  uint32_t *lds_trans = lds_wq + (DCRX_BLOCK / 64) * DCRX_WQ_CAP;  // [n_states*4] when TABLE_LDS
+  uint32_t *lds_trans = lds_wq + (BLOCK / 64) * DCRX_WQ_CAP;  // the DFA (rows of 16 or 64 bytes), then the side tables
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  if (TABLE_LDS) stage_lds_image<DCRX_BLOCK>(T0, lds_trans, tid);
+  DevTables T = T0;
+  if (TABLE_LDS) {
+    const uint32_t lds_addr = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans));
+    if (ARITY == 16) {
+      uint32_t *lds_side = lds_trans + T0.dfa16_bytes / 4;
+      stage_lds<BLOCK>(reinterpret_cast<const uint8_t *>(T0.trans16), lds_trans, T0.dfa16_bytes / 16, T0.dfa16_bytes / 16,
+                       lds_addr, tid);
+      stage_lds<BLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+      T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes);
+      T.row16_0 = lds_addr;
+    } else {
+      stage_lds<BLOCK>(T0.image, lds_trans, T0.lds_image_bytes / 16, T0.dfa_bytes / 16, lds_addr, tid);
+      T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans), 0);
+      T.row0 = lds_addr;
+    }
+  }
   __syncthreads();
-  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
@@ -75,10 +89,10 @@ __global__ __launch_bounds__(DCRX_BLOCK) void decombine_kernel(DevTables T0, Bat
   // Static work distribution: block b takes tiles b, b + grid, ... (the grid is exactly the
   // resident capacity, so every block runs from the start; a global ticket per wave-tile was
   // measured slower: one atomic address sustains only ~90 tickets/us).
-  for (uint64_t tile = blockIdx.x; tile * DCRX_BLOCK < B.n_reads; tile += gridDim.x) {
-    const uint64_t r = tile * DCRX_BLOCK + tid;
+  for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
+    const uint64_t r = tile * BLOCK + tid;
     int what = FAST_DONE;
-    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW>(T, lds_trans, B, cfg, r, nw, C, records);
+    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW, ARITY>(T, lds_trans, B, cfg, r, nw, C, records);
     // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
     // from the exception list before this kernel starts
     const bool defer = what == FAST_TO_RESCUE;
@@ -134,9 +148,14 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     return;
   }
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  if (TABLE_LDS) stage_lds_image<DCRX_QBLOCK>(T0, lds_trans, tid);
+  DevTables T = T0;
+  if (TABLE_LDS) {
+    const uint32_t lds_addr = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans));
+    stage_lds<DCRX_QBLOCK>(T0.image, lds_trans, T0.lds_image_bytes / 16, T0.dfa_bytes / 16, lds_addr, tid);
+    T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans), 0);
+    T.row0 = lds_addr;
+  }
   __syncthreads();
-  const DevTables T = TABLE_LDS ? tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans)) : T0;
   const Counters C{lds_counts};
   const int lane = tid & 63;
   for (;;) {
@@ -284,13 +303,15 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // ------------------------------------------------------------------------------
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM, int NW>
+template <bool TABLE_LDS, bool UNIFORM, int NW, int ARITY>
 static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
                              dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  auto kfast = decombine_kernel<TABLE_LDS, UNIFORM, NW>;
+  auto kfast = decombine_kernel<TABLE_LDS, UNIFORM, NW, ARITY>;
+  constexpr uint32_t FBLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
   auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM>;
-  const uint32_t lds_fast = P.lds_bytes + DCRX_FAST_LDS_EXTRA, lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
+  const uint32_t lds_fast = ARITY == 16 ? P.lds16_bytes + DCRX_FAST16_LDS_EXTRA : P.lds_bytes + DCRX_FAST_LDS_EXTRA;
+  const uint32_t lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
   hipError_t e;
   // persistent grids: as many blocks as are resident at once
   static int occ_fast = 0, occ_list = 0;
@@ -302,7 +323,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
       if (e != hipSuccess) return e;
     }
     int o1 = 0, o2 = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kfast, DCRX_BLOCK, lds_fast);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kfast, FBLOCK, lds_fast);
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, klist, DCRX_QBLOCK, lds_list);
     if (e != hipSuccess) return e;
@@ -319,7 +340,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   }
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (grid) {
-    hipLaunchKernelGGL(kfast, dim3(grid), dim3(DCRX_BLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count);
+    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -353,13 +374,17 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
   if (e != hipSuccess) return e;
   const bool uniform = B.lens == nullptr;
   const bool nw10 = B.stride <= 40;  // 150-nt reads: ten words in registers instead of DCRX_NWMAX
-#define DCRX_LAUNCH(TL, UN, NW_) launch_all<TL, UN, NW_>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
-  if (P.table_in_lds) {
-    if (nw10) e = uniform ? DCRX_LAUNCH(true, true, 10) : DCRX_LAUNCH(true, false, 10);
-    else e = uniform ? DCRX_LAUNCH(true, true, DCRX_NWMAX) : DCRX_LAUNCH(true, false, DCRX_NWMAX);
+#define DCRX_LAUNCH(TL, UN, NW_, AR_) launch_all<TL, UN, NW_, AR_>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+  const bool pair_scan = P.table16_in_lds && !(cfg.flags & DCRX_F_ONE_BASE_SCAN);
+  if (P.table_in_lds && pair_scan) {
+    if (nw10) e = uniform ? DCRX_LAUNCH(true, true, 10, 16) : DCRX_LAUNCH(true, false, 10, 16);
+    else e = uniform ? DCRX_LAUNCH(true, true, DCRX_NWMAX, 16) : DCRX_LAUNCH(true, false, DCRX_NWMAX, 16);
+  } else if (P.table_in_lds) {
+    if (nw10) e = uniform ? DCRX_LAUNCH(true, true, 10, 4) : DCRX_LAUNCH(true, false, 10, 4);
+    else e = uniform ? DCRX_LAUNCH(true, true, DCRX_NWMAX, 4) : DCRX_LAUNCH(true, false, DCRX_NWMAX, 4);
   } else {
-    if (nw10) e = uniform ? DCRX_LAUNCH(false, true, 10) : DCRX_LAUNCH(false, false, 10);
-    else e = uniform ? DCRX_LAUNCH(false, true, DCRX_NWMAX) : DCRX_LAUNCH(false, false, DCRX_NWMAX);
+    if (nw10) e = uniform ? DCRX_LAUNCH(false, true, 10, 4) : DCRX_LAUNCH(false, false, 10, 4);
+    else e = uniform ? DCRX_LAUNCH(false, true, DCRX_NWMAX, 4) : DCRX_LAUNCH(false, false, DCRX_NWMAX, 4);
   }
 #undef DCRX_LAUNCH
   if (e != hipSuccess) return e;

@@ -18,6 +18,8 @@ struct LaunchPlan {
   uint32_t qgrid;  // list kernel
   uint32_t lds_bytes;
   bool table_in_lds;
+  bool table16_in_lds;       // the two-bases-per-step table + side tables fit beside the fast kernel's buffers
+  uint32_t lds16_bytes;      // counters + that table + side tables
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,

@@ -7,7 +7,8 @@
 // words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
 #define DCRX_NWMAX 20
 #define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
-#define DCRX_BLOCK 512   /* fast kernel */
+#define DCRX_BLOCK 512   /* fast kernel, one base per step */
+#define DCRX_BLOCK16 1024 /* fast kernel, two bases per step (one block per CU: the table takes most of the LDS) */
 #define DCRX_QBLOCK 512  /* list kernel */
 #define DCRX_EXC_LDS 4    /* exception entries of a read the list kernel keeps in LDS */
 /* extra dwords of a general-kernel lane slot after the hit lists: exception positions (u16) + bytes (u8) */

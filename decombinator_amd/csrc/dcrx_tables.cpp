@@ -77,7 +77,7 @@ DevTables HostTables::resolve(const uint8_t *base) const {
     using P = std::remove_reference_t<decltype(p)>;
     p = reinterpret_cast<P>(base + reinterpret_cast<uintptr_t>(p));
   };
-  fix(d.image); fix(d.trans); fix(d.st_full); fix(d.st_out); fix(d.outs);
+  fix(d.image); fix(d.trans); if (d.dfa16_bytes) fix(d.trans16); fix(d.st_full); fix(d.st_out); fix(d.outs);
   fix(d.kw_base); fix(d.kw_first); fix(d.kw_begin); fix(d.kw_tags); fix(d.comp);
   for (int g = 0; g < 2; g++) {
     fix(d.g[g].tag_len); fix(d.g[g].jump); fix(d.g[g].tag_ascii); fix(d.g[g].tag_pk_fwd); fix(d.g[g].tag_pk_rc); fix(d.g[g].reg_off);
@@ -363,6 +363,31 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     P.reg_pk = as_off<uint32_t>(B.put(A.reg_pk));
     P.reg_pk_rc = as_off<uint32_t>(B.put(A.reg_pk_rc));
     P.reg_clean = as_off<uint8_t>(B.put(A.reg_clean));
+  }
+  // two-bases-per-step table for the fast kernel (new numbering throughout)
+  R.trans16 = nullptr; R.dfa16_bytes = 0; R.row16_0 = 0;
+  if (S <= MAX_STATES16) {
+    std::vector<uint32_t> trans16((size_t)S * 16);
+    auto cnt_bits = [&](uint32_t fl, int full_bit, int multi_bit) { return ((fl >> full_bit) & 1u) + ((fl >> multi_bit) & 1u); };
+    for (uint32_t s = 0; s < S; s++)        // s: OLD numbering
+      for (int c1 = 0; c1 < 4; c1++)
+        for (int c2 = 0; c2 < 4; c2++) {
+          const uint32_t s1 = (uint32_t)delta[s * 4 + c1], s2 = (uint32_t)delta[s1 * 4 + c2];
+          const uint32_t f1 = st_flags[s1], f2 = st_flags[s2];
+          uint32_t e = new_id[s2] * 64u;
+          e |= (f1 | f2) & (0xFu << TE_VH1_BIT);
+          const uint32_t nv = cnt_bits(f1, TE_VFULL_BIT, TE_VMULTI_BIT) + cnt_bits(f2, TE_VFULL_BIT, TE_VMULTI_BIT);
+          const uint32_t nj = cnt_bits(f1, TE_JFULL_BIT, TE_JMULTI_BIT) + cnt_bits(f2, TE_JFULL_BIT, TE_JMULTI_BIT);
+          if (nv >= 1) e |= 1u << TE_VFULL_BIT;
+          if (nj >= 1) e |= 1u << TE_JFULL_BIT;
+          if (nv >= 2) e |= 1u << TE_VMULTI_BIT;
+          if (nj >= 2) e |= 1u << TE_JMULTI_BIT;
+          if ((f2 >> TE_VFULL_BIT) & 1u) e |= 1u << TE16_V2_BIT;
+          if ((f2 >> TE_JFULL_BIT) & 1u) e |= 1u << TE16_J2_BIT;
+          trans16[(size_t)new_id[s] * 16 + c1 * 4 + c2] = e;
+        }
+    R.trans16 = as_off<uint32_t>(B.put(trans16));
+    R.dfa16_bytes = S * 64u;
   }
   {
     // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged

@@ -18,17 +18,19 @@ def run(n=200000):
         be = pu.Backend("emul", d)
         hb = nat.synth_reads_host(t, nat.synth_cfg(seed=cfgno, sub_rate=sub, n_rate=0.002), 0, n)
         reads = nat.unpack_reads(hb)
-        rec, cnt = be.run(hb)
         orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
-        pu.assert_records_equal(rec, orec, reads, "synth")
-        pu.assert_counters_equal(cnt, ocnt)
+        for fl in (0, nat.F_ONE_BASE_SCAN):
+            rec, cnt = be.run(hb, flags=fl)
+            pu.assert_records_equal(rec, orec, reads, "synth")
+            pu.assert_counters_equal(cnt, ocnt)
         reads2 = [orc.revcomp(r) if i % 2 else r for i, r in enumerate(reads[:n // 3])]
         b = nat.pack_reads(reads2)
         for o in ("forward", "both"):
-            rec, cnt = be.run(b, o)
             orec, ocnt = pu.oracle_records(ot, reads2, o, False, 130)
-            pu.assert_records_equal(rec, orec, reads2, o)
-            pu.assert_counters_equal(cnt, ocnt)
+            for fl in (0, nat.F_ONE_BASE_SCAN):
+                rec, cnt = be.run(b, o, flags=fl)
+                pu.assert_records_equal(rec, orec, reads2, o)
+                pu.assert_counters_equal(cnt, ocnt)
         rng = np.random.default_rng(11)
         hb = nat.synth_reads_host(t, nat.synth_cfg(seed=9, read_len=320, n_rate=0.01), 0, n // 4, stride=80)
         reads = nat.unpack_reads(hb)

@@ -15,6 +15,16 @@
 
 using namespace dcrx;
 
+template <bool UNIFORM>
+static int fast_one(bool pair_scan, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
+                    const Counters &CC, dcrx_record_t *records) {
+  if (pair_scan)
+    return B.stride <= 40 ? decombine_fast_one<false, UNIFORM, 10, 16>(T, nullptr, B, C, r, nw, CC, records)
+                          : decombine_fast_one<false, UNIFORM, DCRX_NWMAX, 16>(T, nullptr, B, C, r, nw, CC, records);
+  return B.stride <= 40 ? decombine_fast_one<false, UNIFORM, 10, 4>(T, nullptr, B, C, r, nw, CC, records)
+                        : decombine_fast_one<false, UNIFORM, DCRX_NWMAX, 4>(T, nullptr, B, C, r, nw, CC, records);
+}
+
 extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
                               dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
   HostTables H;
@@ -41,19 +51,20 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     // when deferred, the rescue kernel's form.
     uint32_t slot[HH_STRIDE + DCRX_GSLOT_EXTRA + 2];
     const uint32_t nw = b->stride / 4;
+    const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
       if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
       else {
-        const int what = (b->stride <= 40 ? decombine_fast_one<false, false, 10>(T, nullptr, B, C, r, nw, CC, records) : decombine_fast_one<false, false, DCRX_NWMAX>(T, nullptr, B, C, r, nw, CC, records));
+        const int what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
         if (what == FAST_TO_RESCUE) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
       if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
       else {
-        const int what = (b->stride <= 40 ? decombine_fast_one<false, true, 10>(T, nullptr, B, C, r, nw, CC, records) : decombine_fast_one<false, true, DCRX_NWMAX>(T, nullptr, B, C, r, nw, CC, records));
+        const int what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
         if (what == FAST_TO_RESCUE) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }

@@ -29,7 +29,7 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_FORCE_SLOW_READER], ids=["fast", "slowreader"])
+@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER], ids=["pairscan", "onebase", "slowreader"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
