@@ -70,7 +70,7 @@ class TablesInfoC(C.Structure):
     _fields_ = [
         ("n_v", C.c_uint32), ("n_j", C.c_uint32), ("n_states", C.c_uint32), ("dfa_bytes", C.c_uint32),
         ("n_keywords", C.c_uint32 * 6), ("max_tag_len", C.c_uint32), ("tables_in_lds", C.c_uint32),
-        ("equal_len_per_automaton", C.c_uint32),
+        ("equal_len_per_automaton", C.c_uint32), ("pair_scan_bytes", C.c_uint32),
     ]
 
 
@@ -203,7 +203,7 @@ class Tables:
         return {"n_v": inf.n_v, "n_j": inf.n_j, "n_states": inf.n_states, "dfa_bytes": inf.dfa_bytes,
                 "n_keywords": list(inf.n_keywords), "max_tag_len": inf.max_tag_len,
                 "tables_in_lds": bool(inf.tables_in_lds),
-                "equal_len_per_automaton": bool(inf.equal_len_per_automaton)}
+                "equal_len_per_automaton": bool(inf.equal_len_per_automaton), "pair_scan_bytes": inf.pair_scan_bytes}
 
     def close(self):
         if self._h is not None:

@@ -109,6 +109,7 @@ int dcrx_tables_info(const dcrx_tables_t *t, dcrx_tables_info_t *info) {
   info->max_tag_len = t->host.max_tag_len;
   info->tables_in_lds = t->host.rel.lds_image_bytes + 128 <= 120 * 1024;
   info->equal_len_per_automaton = t->host.equal_len_per_automaton ? 1 : 0;
+  info->pair_scan_bytes = t->host.rel.dfa16_bytes;
   return DCRX_OK;
 }
 

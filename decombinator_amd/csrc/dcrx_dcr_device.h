@@ -578,15 +578,21 @@ DCRX_DEV uint32_t trans16_at(const DevTables &T, uint32_t byte_addr) {
   return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.trans16) + byte_addr);
 }
 
+// accumulator term of a pair: count in bits 0..5 (the row's low six bits are zero), the row of
+// the state BEFORE the pair in bits 6..17, the pair index in bits 18..25.  A count that wraps
+// (>= 64 hits) is caught by the OR-ed VFULL/JFULL flag: flag seen but count 0 means "many".
+constexpr int ACC16_PAIR_SHIFT = 18;
+constexpr uint32_t ACC16_CNT_MASK = 0x3Fu;
+
 #define DCRX_STEP16(PAIR4) /* PAIR4 = (first base * 4 + second base) << 2 */                   \
   do {                                                                                          \
     const uint32_t rowp_ = e & TE16_ROW_MASK;                                                   \
     e = trans16_at<TABLE_LDS>(T, rowp_ | (uint32_t)(PAIR4));                                    \
     acc |= e;                                                                                   \
-    const uint32_t t_ = (rowp_ << 3) | it;                                                      \
+    const uint32_t t_ = rowp_ | it;                                                             \
     vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
     jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
-    it += (1u << ACC_POS_SHIFT);                                                                \
+    it += (1u << ACC16_PAIR_SHIFT);                                                             \
   } while (0)
 
 struct ScanAcc16 { uint32_t acc, vacc, jacc, e_last; };
@@ -650,30 +656,37 @@ DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], cons
 }
 
 // Resolves the accumulators of a two-bases-per-step scan.  A single hit is located by redoing
-// its pair: the state before the pair and the pair index are in the accumulator; the pair's
-// bases come from the read; the entry says whether the tag ends at the first or the second
-// base.  An odd read length leaves a last base, stepped here with the one-base table.
+// its pair: the row of the state before the pair and the pair index are in the accumulator,
+// the pair's bases come from the read, and the LDS entry says whether the tag ends at the
+// second base (then its row is the end state) or at the first (one step in the one-base table
+// in global memory gives the end state).  An odd read length leaves a last base, stepped here
+// with the one-base table.
 template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a) {
   ScanOut so;
   so.acc = a.acc & ~((1u << TE16_V2_BIT) | (1u << TE16_J2_BIT));
-  so.vcount = a.vacc & ACC_CNT_MASK;
-  if ((a.acc >> TE_VMULTI_BIT) & 1u) so.vcount = 2;
-  so.jcount = a.jacc & ACC_CNT_MASK;
-  if ((a.acc >> TE_JMULTI_BIT) & 1u) so.jcount = 2;
+  so.vcount = a.vacc & ACC16_CNT_MASK;
+  if (((a.acc >> TE_VMULTI_BIT) & 1u) || (so.vcount == 0 && ((a.acc >> TE_VFULL_BIT) & 1u))) so.vcount = 2;
+  so.jcount = a.jacc & ACC16_CNT_MASK;
+  if (((a.acc >> TE_JMULTI_BIT) & 1u) || (so.jcount == 0 && ((a.acc >> TE_JFULL_BIT) & 1u))) so.jcount = 2;
   so.vstate = so.jstate = 0; so.vend = so.jend = 0;
   const int n = F.n();
-  // one-base step from state index st (new numbering) with base c, in the global 4-ary table
+  // one-base step from state index st (new numbering) with base c, in the global one-base table
   auto step4 = [&](uint32_t st, int c) { return T.trans[st * 4 + (uint32_t)c]; };
   auto locate = [&](uint32_t accv, int full_bit, int second_bit, uint32_t &state, int &end) {
-    const uint32_t sprev = ((accv >> ACC_STATE_SHIFT) & 0x3FFFu) - (T.row16_0 >> 6);
-    const int k = (int)(accv >> ACC_POS_SHIFT);
+    const uint32_t rowp = accv & TE16_ROW_MASK & ~ACC16_CNT_MASK;    // row (address) of the state before the pair
+    const int k = (int)((accv >> ACC16_PAIR_SHIFT) & 0xFFu);
     const int c1 = F.code(2 * k), c2 = F.code(2 * k + 1);
-    const uint32_t e1 = step4(sprev, c1);                  // global table: rows relative, state * 16
-    if ((e1 >> full_bit) & 1u) { state = (e1 & TE_ROW_MASK) >> 4; end = 2 * k; }
-    else { const uint32_t e2 = step4((e1 & TE_ROW_MASK) >> 4, c2); state = (e2 & TE_ROW_MASK) >> 4; end = 2 * k + 1; }
-    (void)second_bit;
+    const uint32_t e16 = trans16_at<TABLE_LDS>(T, rowp | (uint32_t)((c1 * 4 + c2) << 2));
+    if ((e16 >> second_bit) & 1u) {
+      state = ((e16 & TE16_ROW_MASK) - T.row16_0) >> 6; end = 2 * k + 1;
+    } else {
+      const uint32_t e1 = step4((rowp - T.row16_0) >> 6, c1);
+      state = (e1 & TE_ROW_MASK) >> 4; end = 2 * k;
+    }
+    (void)full_bit;
   };
+  bool vnew = false, jnew = false;
   if (n & 1) {
     // the last base: one-base step from the state after the last pair
     const uint32_t slast = ((a.e_last & TE16_ROW_MASK) - T.row16_0) >> 6;
@@ -682,17 +695,16 @@ DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc
     if ((e >> TE_VMULTI_BIT) & 1u) so.vcount = 2;
     if ((e >> TE_JMULTI_BIT) & 1u) so.jcount = 2;
     if ((e >> TE_VFULL_BIT) & 1u) {
-      if (so.vcount == 0) { so.vcount = 1; so.vstate = (e & TE_ROW_MASK) >> 4; so.vend = n - 1; }
+      if (so.vcount == 0) { so.vcount = 1; so.vstate = (e & TE_ROW_MASK) >> 4; so.vend = n - 1; vnew = true; }
       else if (so.vcount == 1) so.vcount = 2;
-    } else if (so.vcount == 1) locate(a.vacc, TE_VFULL_BIT, TE16_V2_BIT, so.vstate, so.vend);
+    }
     if ((e >> TE_JFULL_BIT) & 1u) {
-      if (so.jcount == 0) { so.jcount = 1; so.jstate = (e & TE_ROW_MASK) >> 4; so.jend = n - 1; }
+      if (so.jcount == 0) { so.jcount = 1; so.jstate = (e & TE_ROW_MASK) >> 4; so.jend = n - 1; jnew = true; }
       else if (so.jcount == 1) so.jcount = 2;
-    } else if (so.jcount == 1) locate(a.jacc, TE_JFULL_BIT, TE16_J2_BIT, so.jstate, so.jend);
-    return so;
+    }
   }
-  if (so.vcount == 1) locate(a.vacc, TE_VFULL_BIT, TE16_V2_BIT, so.vstate, so.vend);
-  if (so.jcount == 1) locate(a.jacc, TE_JFULL_BIT, TE16_J2_BIT, so.jstate, so.jend);
+  if (so.vcount == 1 && !vnew) locate(a.vacc, TE_VFULL_BIT, TE16_V2_BIT, so.vstate, so.vend);
+  if (so.jcount == 1 && !jnew) locate(a.jacc, TE_JFULL_BIT, TE16_J2_BIT, so.jstate, so.jend);
   return so;
 }
 

@@ -366,7 +366,22 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
   }
   // two-bases-per-step table for the fast kernel (new numbering throughout)
   R.trans16 = nullptr; R.dfa16_bytes = 0; R.row16_0 = 0;
-  if (S <= MAX_STATES16) {
+  // The pair scan counts full-tag hits in a 6-bit field.  64 or more hits of one class in a
+  // read of <= 320 nt need occurrences 4 or fewer bases apart, i.e. two tags of the class (or
+  // one tag with itself) that overlap consistently at a shift of 1..4: such sets keep the
+  // one-base scan, whose 9-bit count cannot wrap.
+  bool dense_overlaps = false;
+  for (int g = 0; g < 2 && !dense_overlaps; g++) {
+    const auto &tags = H.g[g].tags;
+    for (size_t x = 0; x < tags.size() && !dense_overlaps; x++)
+      for (size_t y = 0; y < tags.size() && !dense_overlaps; y++)
+        for (size_t dsh = 1; dsh <= 4; dsh++) {
+          if (dsh >= tags[x].size()) break;
+          const size_t ov = std::min(tags[x].size() - dsh, tags[y].size());
+          if (tags[x].compare(dsh, ov, tags[y], 0, ov) == 0) { dense_overlaps = true; break; }
+        }
+  }
+  if (S <= MAX_STATES16 && !dense_overlaps) {
     std::vector<uint32_t> trans16((size_t)S * 16);
     auto cnt_bits = [&](uint32_t fl, int full_bit, int multi_bit) { return ((fl >> full_bit) & 1u) + ((fl >> multi_bit) & 1u); };
     for (uint32_t s = 0; s < S; s++)        // s: OLD numbering

@@ -72,6 +72,8 @@ typedef struct dcrx_tables_info {
   uint32_t max_tag_len;
   uint32_t tables_in_lds;   /* 1 when the transition table fits the LDS budget */
   uint32_t equal_len_per_automaton; /* 1 when every automaton's keywords share one length (acora tie order then irrelevant) */
+  uint32_t pair_scan_bytes;  /* bytes of the two-bases-per-step table of the fast kernel; 0 = not built (> 4095 states,
+                                or tags that overlap themselves at shifts 1..4) */
 } dcrx_tables_info_t;
 
 /* Compiles the six Aho-Corasick automata of decombine.py:722-746 into one merged

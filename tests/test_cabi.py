@@ -139,3 +139,17 @@ def test_bad_arguments():
     with pytest.raises(nat.DcrxError) as e:
         nat.decombine(t, b)
     assert e.value.code == -1
+
+
+def test_pair_scan_table_is_built_only_when_safe():
+    ts = synth.config_tagset(2)
+    vs, js = ts.half_splits
+    t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, vs, js)
+    inf = t.info()
+    assert inf["pair_scan_bytes"] == inf["n_states"] * 64
+    # a tag that overlaps itself at shift 2 could occur 64+ times in a read: the 6-bit hit count of
+    # the pair scan could wrap, so the set must keep the one-base scan
+    vt = list(ts.v_tags)
+    vt[0] = "ACACACACACACACACACAC"
+    t2 = nat.Tables(vt, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, vs, js)
+    assert t2.info()["pair_scan_bytes"] == 0
