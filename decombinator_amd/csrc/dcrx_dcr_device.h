@@ -112,8 +112,6 @@ struct Counters {
 struct ReadView {
   const uint8_t *comp;    // 256-entry complement table (Biopython's, decombine.py:184)
   const uint32_t *words;  // this read's packed words (global memory)
-  const uint32_t *regs;   // the same words held in registers by the fast kernel (nregs of them), or null
-  int nregs;
   int n;
   int e0, e1;             // this read's slice of the exception list (e0 == e1: none)
   const uint16_t *exc_pos;
@@ -126,21 +124,9 @@ struct Frame {
   DCRX_DEVNI explicit Frame(const ReadView &rv) : r(rv) {}
   DCRX_DEV int n() const { return r.n; }
   DCRX_DEV int fpos(int i) const { return REV ? r.n - 1 - i : i; }
-  // packed word i of the read: from the register copy when there is one (a select chain: no
-  // memory round trip in the fast kernel's tail), else from global memory
-  DCRX_DEV uint32_t word(int i) const {
-    if (r.nregs) {
-      uint32_t v = 0;
-#pragma unroll
-      for (int k = 0; k < DCRX_NWMAX; k++)
-        if (k < r.nregs) v = (i == k) ? r.regs[k] : v;
-      return v;
-    }
-    return r.words[i];
-  }
   DCRX_DEV int code(int i) const {
     int m = fpos(i);
-    uint32_t w = word(m >> 4);
+    uint32_t w = r.words[m >> 4];
     int c = (int)((w >> ((m & 15) * 2)) & 3u);
     return REV ? (c ^ 3) : c;
   }
@@ -172,9 +158,9 @@ struct Frame {
   DCRX_DEV uint32_t window(int a, int len) const {
     int lo = REV ? r.n - a - len : a;
     int bit = lo * 2;
-    uint32_t w0 = word(bit >> 5);
+    uint32_t w0 = r.words[bit >> 5];
     int sh = bit & 31;
-    uint32_t w1 = (sh + 2 * len > 32) ? word((bit >> 5) + 1) : 0u;
+    uint32_t w1 = (sh + 2 * len > 32) ? r.words[(bit >> 5) + 1] : 0u;
     uint32_t v = dcrx_funnel_r(w0, w1, sh);
     return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
   }
@@ -182,8 +168,8 @@ struct Frame {
   // caller guarantees 0 <= b and b+32 <= n.
   DCRX_DEV uint64_t load64(int b) const {
     const int bit = b * 2, i = bit >> 5, sh = bit & 31;
-    const uint32_t w0 = word(i), w1 = word(i + 1);
-    const uint32_t w2 = sh ? word(i + 2) : 0u;
+    const uint32_t w0 = r.words[i], w1 = r.words[i + 1];
+    const uint32_t w2 = sh ? r.words[i + 2] : 0u;
     return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
   }
 };
@@ -909,7 +895,6 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
-  rv.regs = nullptr; rv.nregs = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   uint32_t w[NW];
   {
@@ -921,7 +906,6 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
       w[2 * k] = t.x; w[2 * k + 1] = t.y;
     }
   }
-  rv.regs = w; rv.nregs = NW;
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
@@ -979,7 +963,6 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
-  rv.regs = nullptr; rv.nregs = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
     // binary search of this read's slice in the sorted exception list
