@@ -174,7 +174,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     P.lds_bytes = P.table_in_lds ? want : DCRX_N_COUNTERS * 4;
     const uint32_t side_bytes = t->host.rel.lds_image_bytes - t->host.rel.dfa_bytes;
     P.lds16_bytes = DCRX_N_COUNTERS * 4 + t->host.rel.dfa16_bytes + side_bytes;
-    P.table16_in_lds = P.table_in_lds && t->host.rel.dfa16_bytes != 0 && P.lds16_bytes + 8192 + 1024 <= lds_cap;
+    P.table16_in_lds = P.table_in_lds && t->host.rel.dfa16_bytes != 0 && P.lds16_bytes + 32768 <= lds_cap;  // + wq and tail buffers of the 1024-thread block
     uint32_t per_cu = std::min<uint32_t>(2048 / DCRX_BLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.grid = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(per_cu, 1);  // upper bound for either fast kernel
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));

@@ -947,6 +947,87 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
 }
 
 // ------------------------------------------------------------------------------
+// Pair-scan fast kernel, split in two so that the tail can run on full waves:
+//   fast16_scan_one  loads the read into registers and scans it (every lane of a tile)
+//   fast16_tail_one  locates the hits, walks, filters, writes the record — for the reads
+//                    that have exactly one V tag (the others exit dcr_frame at once)
+// Between the two the kernel ballot-compacts the V-hit reads of successive tiles into a
+// per-wave LDS buffer of packed accumulators (TailEntry) and runs the tail 64 at a time.
+// ------------------------------------------------------------------------------
+struct TailEntry { uint32_t r, a, b; };   // read index | vacc(26)+flags(6) | jacc(26)+flags(4)
+
+DCRX_DEV TailEntry tail_pack(uint32_t r, const ScanAcc16 &s) {
+  TailEntry t;
+  t.r = r;
+  t.a = (s.vacc & 0x3FFFFFFu) | (((s.acc >> TE_VFULL_BIT) & 0x3Fu) << 26);   // VFULL JFULL VH1 VH2 JH1 JH2
+  t.b = (s.jacc & 0x3FFFFFFu) | (((s.acc >> TE_VMULTI_BIT) & 0xFu) << 26);   // VMULTI JMULTI V2 J2
+  return t;
+}
+DCRX_DEV ScanAcc16 tail_unpack(const TailEntry &t, uint32_t row16_0) {
+  ScanAcc16 s;
+  s.vacc = t.a & 0x3FFFFFFu;
+  s.jacc = t.b & 0x3FFFFFFu;
+  s.acc = ((t.a >> 26) << TE_VFULL_BIT) | ((t.b >> 26) << TE_VMULTI_BIT);
+  s.e_last = row16_0;   // only even read lengths are batched: no last single base
+  return s;
+}
+
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+DCRX_DEV ScanAcc16 fast16_scan_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t nw) {
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  uint32_t w[NW];
+  {
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(words);
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw) t = wp2[k];
+      w[2 * k] = t.x; w[2 * k + 1] = t.y;
+    }
+  }
+  return (cfg.orientation == DCRX_ORIENT_FORWARD) ? scan_fast16<false, TABLE_LDS, NW>(T, w, words, n)
+                                                  : scan_fast16<true, TABLE_LDS, NW>(T, w, words, n);
+}
+
+template <bool TABLE_LDS, bool UNIFORM_LEN>
+DCRX_DEV int fast16_tail_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg,
+                             uint64_t r, const ScanAcc16 &a, const Counters &C, dcrx_record_t *records) {
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {  // profiling aid: price the scan alone
+    rec.v = (uint16_t)a.acc; rec.j = (uint16_t)(a.acc >> 16); rec.v_start = (uint16_t)a.vacc; rec.j_end = (uint16_t)a.jacc;
+    rec.status = 254; rec.frame = 0;
+    dcrx_store_record(records + r, rec);
+    return FAST_DONE;
+  }
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {                       // decombine.py:1002-1004
+    const ScanOut so = finish16<false, TABLE_LDS>(T, Frame<false>(rv), a);
+    status = dcr_frame<false, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 1;
+  } else {                                                            // :999-1001
+    const ScanOut so = finish16<true, TABLE_LDS>(T, Frame<true>(rv), a);
+    status = dcr_frame<true, TABLE_LDS, true>(T, lds_trans, rv, so, cfg, C, rec); frame = 0;
+  }
+  if (status == DCRX_S_DEFER) return FAST_TO_RESCUE;
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+  return FAST_DONE;
+}
+
+// ------------------------------------------------------------------------------
 // List form (list kernel): any read — exception bytes, orientation `both` with its
 // second, forward attempt (decombine.py:1005-1010), half-tag rescue.  One collecting
 // scan per frame, then dcr_frame with the rescue fed from the LDS hit lists (a class

@@ -38,7 +38,9 @@ namespace dcrx {
 constexpr int DCRX_WQ_CAP = 128;
 constexpr int DCRX_CHUNK = 2;  // 64-read tiles of the rescue queue a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
-constexpr uint32_t DCRX_FAST16_LDS_EXTRA = (DCRX_BLOCK16 / 64) * DCRX_WQ_CAP * 4;   // keeps the 64-byte rows aligned: 128 + 8192
+constexpr int DCRX_TQ_CAP = 128;  // tail entries per wave (flushed at 64; 3 dwords each)
+constexpr uint32_t DCRX_FAST16_LDS_EXTRA = (DCRX_BLOCK16 / 64) * (DCRX_WQ_CAP + 3 * DCRX_TQ_CAP) * 4;  // 32 KB; keeps 64-byte rows aligned after the 128-byte counters
+static_assert((DCRX_N_COUNTERS * 4 + DCRX_FAST16_LDS_EXTRA) % 64 == 0, "pair-scan rows must be 64-byte aligned");
 constexpr int DCRX_LSLOT = (HH_STRIDE + DCRX_GSLOT_EXTRA) | 1;  // per-lane dwords: hit lists + exception copy; odd: conflict-free
 constexpr int DCRX_LSLOT_PAD = (4 - (DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT) % 4) % 4;
 constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) * 4;
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
   extern __shared__ __align__(64) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
   uint32_t *lds_wq = smem + DCRX_N_COUNTERS;          // [waves][DCRX_WQ_CAP]
-  uint32_t *lds_trans = lds_wq + (BLOCK / 64) * DCRX_WQ_CAP;  // the DFA (rows of 16 or 64 bytes), then the side tables
+  uint32_t *lds_tq = lds_wq + (BLOCK / 64) * DCRX_WQ_CAP;     // [waves][3 * DCRX_TQ_CAP] tail entries (pair scan only)
+  uint32_t *lds_trans = lds_tq + (ARITY == 16 ? (BLOCK / 64) * 3 * DCRX_TQ_CAP : 0);  // the DFA (rows of 16 or 64 bytes), then the side tables
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   DevTables T = T0;
@@ -89,16 +92,10 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
   // Static work distribution: block b takes tiles b, b + grid, ... (the grid is exactly the
   // resident capacity, so every block runs from the start; a global ticket per wave-tile was
   // measured slower: one atomic address sustains only ~90 tickets/us).
-  for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
-    const uint64_t r = tile * BLOCK + tid;
-    int what = FAST_DONE;
-    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW, ARITY>(T, lds_trans, B, cfg, r, nw, C, records);
-    // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
-    // from the exception list before this kernel starts
-    const bool defer = what == FAST_TO_RESCUE;
+  auto to_rescue = [&](bool defer, uint32_t r32) {
     const unsigned long long m = __ballot(defer);
     if (m) {
-      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r32;
       wq_n += (uint32_t)__popcll(m);
       if (wq_n >= 64) {
         uint32_t base = 0;
@@ -108,6 +105,60 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
         wq_n = 0;
       }
     }
+  };
+  // Pair scan, uniform even read length: the tail (hit location, walks, filters) is batched.
+  // Reads with exactly one V tag are ballot-compacted, tile after tile, into this wave's LDS
+  // buffer of packed accumulators; whenever 64 are waiting the tail runs on a full wave.
+  const bool batched = ARITY == 16 && UNIFORM_LEN && !(B.read_len & 1u);
+  if (ARITY == 16 && batched) {
+    uint32_t *tq = lds_tq + (tid >> 6) * (3 * DCRX_TQ_CAP);
+    uint32_t tq_n = 0;
+    auto run_tail = [&](uint32_t first, uint32_t count) {   // entries [first, first+count) of this wave's buffer
+      bool defer = false;
+      uint32_t r32 = 0;
+      if ((uint32_t)lane < count) {
+        const uint32_t *en = tq + 3 * (first + lane);
+        const TailEntry te{en[0], en[1], en[2]};
+        r32 = te.r;
+        defer = fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)te.r, tail_unpack(te, T.row16_0), C,
+                                                        records) == FAST_TO_RESCUE;
+      }
+      to_rescue(defer, r32);
+    };
+    for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
+      const uint64_t r = tile * BLOCK + tid;
+      bool live = r < B.n_reads;
+      if (live && B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) live = false;   // on the general list already
+      ScanAcc16 a{0, 0, 0, 0};
+      if (live) a = fast16_scan_one<TABLE_LDS, UNIFORM_LEN, NW>(T, B, cfg, r, nw);
+      const bool one_v = live && !(cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) && (a.vacc & ACC16_CNT_MASK) == 1 &&
+                         !((a.acc >> TE_VMULTI_BIT) & 1u);
+      // no single V tag: dcr_frame leaves at once (no V / several V) or the read is deferred (V half tags)
+      bool defer = false;
+      if (live && !one_v)
+        defer = fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, a, C, records) == FAST_TO_RESCUE;
+      to_rescue(defer, (uint32_t)r);
+      const unsigned long long m = __ballot(one_v);
+      if (m) {
+        if (one_v) {
+          const TailEntry te = tail_pack((uint32_t)r, a);
+          uint32_t *en = tq + 3 * (tq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+          en[0] = te.r; en[1] = te.a; en[2] = te.b;
+        }
+        tq_n += (uint32_t)__popcll(m);
+        if (tq_n >= 64) { tq_n -= 64; run_tail(tq_n, 64); }
+      }
+    }
+    if (tq_n) run_tail(0, tq_n);
+  } else {
+  for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
+    const uint64_t r = tile * BLOCK + tid;
+    int what = FAST_DONE;
+    if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW, ARITY>(T, lds_trans, B, cfg, r, nw, C, records);
+    // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
+    // from the exception list before this kernel starts
+    to_rescue(what == FAST_TO_RESCUE, (uint32_t)r);
+  }
   }
   if (wq_n) {
     uint32_t base = 0;
