@@ -112,8 +112,6 @@ struct Counters {
 struct ReadView {
   const uint8_t *comp;    // 256-entry complement table (Biopython's, decombine.py:184)
   const uint32_t *words;  // this read's packed words (global memory)
-  const uint32_t *regs;   // the same words held in registers (nregs of them; list kernel), or null
-  int nregs;
   int n;
   int e0, e1;             // this read's slice of the exception list (e0 == e1: none)
   const uint16_t *exc_pos;
@@ -126,21 +124,9 @@ struct Frame {
   DCRX_DEVNI explicit Frame(const ReadView &rv) : r(rv) {}
   DCRX_DEV int n() const { return r.n; }
   DCRX_DEV int fpos(int i) const { return REV ? r.n - 1 - i : i; }
-  // packed word i of the read: from the register copy when there is one (a select chain instead
-  // of a memory round trip), else from global memory
-  DCRX_DEV uint32_t word(int i) const {
-    if (r.nregs) {
-      uint32_t v = 0;
-#pragma unroll
-      for (int k = 0; k < DCRX_NWMAX; k++)
-        if (k < r.nregs) v = (i == k) ? r.regs[k] : v;
-      return v;
-    }
-    return r.words[i];
-  }
   DCRX_DEV int code(int i) const {
     int m = fpos(i);
-    uint32_t w = word(m >> 4);
+    uint32_t w = r.words[m >> 4];
     int c = (int)((w >> ((m & 15) * 2)) & 3u);
     return REV ? (c ^ 3) : c;
   }
@@ -172,9 +158,9 @@ struct Frame {
   DCRX_DEV uint32_t window(int a, int len) const {
     int lo = REV ? r.n - a - len : a;
     int bit = lo * 2;
-    uint32_t w0 = word(bit >> 5);
+    uint32_t w0 = r.words[bit >> 5];
     int sh = bit & 31;
-    uint32_t w1 = (sh + 2 * len > 32) ? word((bit >> 5) + 1) : 0u;
+    uint32_t w1 = (sh + 2 * len > 32) ? r.words[(bit >> 5) + 1] : 0u;
     uint32_t v = dcrx_funnel_r(w0, w1, sh);
     return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
   }
@@ -182,8 +168,8 @@ struct Frame {
   // caller guarantees 0 <= b and b+32 <= n.
   DCRX_DEV uint64_t load64(int b) const {
     const int bit = b * 2, i = bit >> 5, sh = bit & 31;
-    const uint32_t w0 = word(i), w1 = word(i + 1);
-    const uint32_t w2 = sh ? word(i + 2) : 0u;
+    const uint32_t w0 = r.words[i], w1 = r.words[i + 1];
+    const uint32_t w2 = sh ? r.words[i + 2] : 0u;
     return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
   }
 };
@@ -453,7 +439,7 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
   for (int wi = 0; wi <= top; wi++) {
     const int kk = REV ? top - wi : wi;                       // word index in scan order
     const int cnt = (kk == top) ? ((n - 1) & 15) + 1 : 16;    // bases it holds
-    uint32_t wv = F.word(kk);
+    uint32_t wv = F.r.words[kk];
     if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
 #pragma unroll 1
     for (int k = 0; k < cnt; k++, i++) {
@@ -751,8 +737,6 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
   } while (0)
 
 // Exception bytes are walked with an ExcCursor while scanning (a clean read never matches it).
-// The read's words are fetched one ahead of the word being scanned, so that each memory
-// latency hides behind sixteen steps.
 template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh) {
   const uint32_t *words = rv.words;
@@ -765,25 +749,19 @@ DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, con
     const int cnt = ((n - 1) & 15) + 1;
     if (REV) {
       uint32_t wp = ~words[top] << (2 * (16 - cnt));
-      uint32_t next = top > 0 ? words[top - 1] : 0u;
       for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp >> 30); wp <<= 2; }
-#pragma unroll 1
       for (int kk = top - 1; kk >= 0; kk--) {
-        const uint32_t wv = ~next;
-        next = kk > 0 ? words[kk - 1] : 0u;
+        const uint32_t wv = ~words[kk];
 #pragma unroll
         for (int j = 15; j >= 0; j--) DCRX_STEP_C(dcrx_ubfe(wv, 2 * j, 2));
       }
     } else {
-      uint32_t next = words[0];
-#pragma unroll 1
       for (int kk = 0; kk < top; kk++) {
-        const uint32_t wv = next;
-        next = words[kk + 1];
+        const uint32_t wv = words[kk];
 #pragma unroll
         for (int j = 0; j < 16; j++) DCRX_STEP_C(dcrx_ubfe(wv, 2 * j, 2));
       }
-      uint32_t wp = next;
+      uint32_t wp = words[top];
       for (int k = 0; k < cnt; k++) { DCRX_STEP_C(wp & 3u); wp >>= 2; }
     }
   }
@@ -917,7 +895,6 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
-  rv.regs = nullptr; rv.nregs = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   uint32_t w[NW];
   {
@@ -1021,7 +998,6 @@ DCRX_DEV int fast16_tail_one(const DevTables &T, const uint32_t *lds_trans, cons
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
-  rv.regs = nullptr; rv.nregs = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
@@ -1059,7 +1035,7 @@ DCRX_DEV int fast16_tail_one(const DevTables &T, const uint32_t *lds_trans, cons
 // `slot`: this lane's LDS area (hit lists, then a copy of the read's first
 // DCRX_EXC_LDS exception entries).
 // ------------------------------------------------------------------------------
-template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+template <bool TABLE_LDS, bool UNIFORM_LEN>
 DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
                                  uint32_t *slot) {
@@ -1068,7 +1044,6 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
-  rv.regs = nullptr; rv.nregs = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
   if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
     // binary search of this read's slice in the sorted exception list

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
 // then the rescue queue the fast kernel filled (clean reads whose V or J tag needs the
 // half-tag rescue).  One collecting scan per frame (half-tag hits into per-lane LDS lists),
 // then the rescue feeds from the lists.
-template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+template <bool TABLE_LDS, bool UNIFORM_LEN>
 __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                      dcrx_record_t *__restrict__ records,
                                                                      uint32_t *__restrict__ block_counts,
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     if (ticket < t_general) {
       const uint32_t i = ticket * 64 + lane;
       if (i < n_general)
-        decombine_list_one<TABLE_LDS, UNIFORM_LEN, NW>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
+        decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
                                                    lds_slots + tid * DCRX_LSLOT);
     } else {
       const uint32_t first = (ticket - t_general) * (64 * DCRX_CHUNK);
       for (int c = 0; c < DCRX_CHUNK; c++) {
         const uint32_t i = first + (uint32_t)c * 64 + lane;
         if (i < n_rescue)
-          decombine_list_one<TABLE_LDS, UNIFORM_LEN, NW>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
+          decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
                                                      lds_slots + tid * DCRX_LSLOT);
       }
     }
@@ -360,7 +360,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
                              uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM, NW, ARITY>;
   constexpr uint32_t FBLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
-  auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM, NW>;
+  auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM>;
   const uint32_t lds_fast = ARITY == 16 ? P.lds16_bytes + DCRX_FAST16_LDS_EXTRA : P.lds_bytes + DCRX_FAST_LDS_EXTRA;
   const uint32_t lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
   hipError_t e;

@@ -25,13 +25,6 @@ static int fast_one(bool pair_scan, const DevTables &T, const BatchDev &B, const
                         : decombine_fast_one<false, UNIFORM, DCRX_NWMAX, 4>(T, nullptr, B, C, r, nw, CC, records);
 }
 
-template <bool UNIFORM>
-static void list_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, const Counters &CC,
-                     dcrx_record_t *records, uint32_t *slot) {
-  if (B.stride <= 40) decombine_list_one<false, UNIFORM, 10>(T, nullptr, B, C, r, CC, records, slot);
-  else decombine_list_one<false, UNIFORM, DCRX_NWMAX>(T, nullptr, B, C, r, CC, records, slot);
-}
-
 extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
                               dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
   HostTables H;
@@ -62,17 +55,17 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
-      if (general) list_one<false>(T, B, C, r, CC, records, slot);
+      if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) list_one<false>(T, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
-      if (general) list_one<true>(T, B, C, r, CC, records, slot);
+      if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) list_one<true>(T, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     }
