@@ -158,6 +158,8 @@ def main():
             gather.step(d_rec, n, first, sptr)
 
     def fence():
+        if gather is not None:
+            gather.finish()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

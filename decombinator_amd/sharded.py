@@ -65,48 +65,70 @@ def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
 
 
 class TupleGather:
-    """Per-step fixed-capacity gather for the benchmark loop: no host sync inside
-    the timed region.  Every rank compacts its step's tuples on the device and
-    sends the first `cap` of them (cap = reads/2 covers the synthetic mixture's
-    ~42 % decombined reads; `check` verifies that after the run)."""
+    """Per-step fixed-capacity gather for the benchmark loop: no host sync inside the timed
+    region.  Every rank compacts its step's tuples on the device and sends the first `cap`
+    of them (cap = reads/2 covers the synthetic mixture's ~42 % decombined reads; `check`
+    verifies that after the run).  The gathers are issued asynchronously on RCCL's stream
+    with `depth` rotating buffer sets, so the gather of step k overlaps the scan of step
+    k+1; a buffer set is reused only after its previous gather has completed."""
 
-    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5):
+    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5,
+                 depth: int = 2):
         from . import _native as nat
         self.nat = nat
         self.world, self.rank = world, rank
         self.cap = int(n_reads * cap_fraction) + 1024
-        self.d_hits = torch.empty(n_reads * 16, dtype=torch.uint8, device=device)
-        self.d_idx = torch.empty(n_reads, dtype=torch.int64, device=device)
-        self.d_n = torch.zeros(1, dtype=torch.int64, device=device)
-        if rank == 0:
-            self.g_hits = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
-            self.g_idx = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(world)]
-            self.g_n = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        self.k = 0
+        self.slots = []
+        for _ in range(depth):
+            slot = {
+                "hits": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
+                "idx": torch.empty(n_reads, dtype=torch.int64, device=device),
+                "n": torch.zeros(1, dtype=torch.int64, device=device),
+                "work": [],
+            }
+            if rank == 0:
+                slot["g_hits"] = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
+                slot["g_idx"] = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(world)]
+                slot["g_n"] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+            self.slots.append(slot)
 
     def step(self, d_rec: torch.Tensor, n_reads: int, first_index: int, stream_ptr) -> None:
         nat = self.nat
-        nat.check(nat.lib().dcrx_compact_hits_device(d_rec.data_ptr(), n_reads, first_index,
-                                                     self.d_hits.data_ptr(), self.d_idx.data_ptr(),
-                                                     self.d_n.data_ptr(), stream_ptr))
-        h, i = self.d_hits[:self.cap * 16], self.d_idx[:self.cap]
+        s = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        for w in s["work"]:          # the compute stream waits for this set's previous gather
+            w.wait()
+        nat.check(nat.lib().dcrx_compact_hits_device(d_rec.data_ptr(), n_reads, first_index, s["hits"].data_ptr(),
+                                                     s["idx"].data_ptr(), s["n"].data_ptr(), stream_ptr))
+        h, i = s["hits"][:self.cap * 16], s["idx"][:self.cap]
         if self.rank == 0:
-            dist.gather(self.d_n, self.g_n, dst=0)
-            dist.gather(h, self.g_hits, dst=0)
-            dist.gather(i, self.g_idx, dst=0)
+            s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
+                         dist.gather(h, s["g_hits"], dst=0, async_op=True),
+                         dist.gather(i, s["g_idx"], dst=0, async_op=True)]
         else:
-            dist.gather(self.d_n, None, dst=0)
-            dist.gather(h, None, dst=0)
-            dist.gather(i, None, dst=0)
+            s["work"] = [dist.gather(s["n"], None, dst=0, async_op=True),
+                         dist.gather(h, None, dst=0, async_op=True),
+                         dist.gather(i, None, dst=0, async_op=True)]
+
+    def finish(self) -> None:
+        """Makes the current stream wait for every gather still in flight."""
+        for s in self.slots:
+            for w in s["work"]:
+                w.wait()
+            s["work"] = []
 
     def check(self, n_hits_local: int) -> None:
+        self.finish()
         if n_hits_local > self.cap:
             raise RuntimeError(f"rank {self.rank}: {n_hits_local} tuples exceed the gather capacity {self.cap}")
         if self.rank == 0:
-            got = [int(x.item()) for x in self.g_n]
+            last = self.slots[(self.k - 1) % len(self.slots)]
+            got = [int(x.item()) for x in last["g_n"]]
             if got[0] != n_hits_local or any(g <= 0 or g > self.cap for g in got):
                 raise RuntimeError(f"gathered tuple counts look wrong: {got}")
             # rank order = read order: every rank's indices lie in its own shard, ascending
             for r in range(self.world):
-                idx = self.g_idx[r][:got[r]]
+                idx = last["g_idx"][r][:got[r]]
                 if got[r] > 1 and not bool((idx[1:] > idx[:-1]).all()):
                     raise RuntimeError(f"tuples of rank {r} are not in read order")
