@@ -364,22 +364,22 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const uint32_t lds_fast = ARITY == 16 ? P.lds16_bytes + DCRX_FAST16_LDS_EXTRA : P.lds_bytes + DCRX_FAST_LDS_EXTRA;
   const uint32_t lds_list = P.lds_bytes + DCRX_QUEUE_LDS_EXTRA;
   hipError_t e;
-  // persistent grids: as many blocks as are resident at once
-  static int occ_fast = 0, occ_list = 0;
-  if (!occ_fast) {
-    if (std::max(lds_fast, lds_list) > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(klist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list);
-      if (e != hipSuccess) return e;
-    }
-    int o1 = 0, o2 = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kfast, FBLOCK, lds_fast);
+  // persistent grids: as many blocks as are resident at once for THIS table size (queried per
+  // launch: a host-side call, and tables of different sizes share the kernel instantiations)
+  static bool attr_set = false;
+  if (!attr_set) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, klist, DCRX_QBLOCK, lds_list);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(klist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    occ_list = std::max(o2, 1); occ_fast = std::max(o1, 1);
+    attr_set = true;
   }
+  int occ_fast = 0, occ_list = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, FBLOCK, lds_fast);
+  if (e != hipSuccess) return e;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_list, klist, DCRX_QBLOCK, lds_list);
+  if (e != hipSuccess) return e;
+  occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_list);
