@@ -161,6 +161,42 @@ def test_full_size_10M_properties_and_sampled_blocks():
         pu.assert_records_equal(rec[first:first + blk], orec, reads, f"block {b0}")
 
 
+@pytest.mark.parametrize("which", ["config3_alpha", "config3_beta", "config5_mouse_gd"])
+def test_100M_reads_sampled_blocks(which):
+    """BASELINE configs 3 and 5 at their full 100 M reads, device-resident: status histogram vs
+    counters, and 16 sampled 64k-read blocks bit-exact against the oracle (SURVEY.md §8(d)
+    "parity at scale").  Config 3 runs its two chains as two passes over the same reads."""
+    n = 100_000_000
+    if which == "config5_mouse_gd":
+        ts, seed, sub = synth.config_tagset(5), 5, 0.02
+    else:
+        a, b = synth.config3_tagsets()
+        ts, seed, sub = (a, 3, 0.005) if which.endswith("alpha") else (b, 3, 0.005)
+    t, ot = _tables(ts)
+    cfg = nat.synth_cfg(seed=seed, sub_rate=sub)
+    db = nat.synth_reads_device(t, cfg, 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    cnt = d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+    assert int(cnt[20]) == n
+    rng = np.random.default_rng(7)
+    blk = 65_536
+    hist_ok = 0
+    for b0 in rng.integers(0, n // blk, size=16):
+        first = int(b0) * blk
+        part = np.zeros(blk, dtype=nat.RECORD_DTYPE)
+        nat.check(nat.lib().dcrx_memcpy_d2h(part.ctypes.data, d_rec.ptr + first * 16, blk * 16))
+        hb = nat.synth_reads_host(t, cfg, first, blk)
+        reads = nat.unpack_reads(hb)
+        orec, _ = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(part, orec, reads, f"{which} block {b0}")
+        hist_ok += int((part["status"] == 0).sum())
+    # the sampled blocks' decombined fraction must match the whole run's within sampling noise
+    assert abs(hist_ok / (16 * blk) - int(cnt[19]) / n) < 0.01
+
+
 def test_compact_hits_matches_numpy():
     n = 1_000_003
     ts = synth.config_tagset(2)
