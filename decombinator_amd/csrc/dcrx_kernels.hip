@@ -133,10 +133,33 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
       if (live) a = fast16_scan_one<TABLE_LDS, UNIFORM_LEN, NW>(T, B, cfg, r, nw);
       const bool one_v = live && !(cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) && (a.vacc & ACC16_CNT_MASK) == 1 &&
                          !((a.acc >> TE_VMULTI_BIT) & 1u);
-      // no single V tag: dcr_frame leaves at once (no V / several V) or the read is deferred (V half tags)
+      // No single V tag: the outcome needs no walk.  No V tag and no V half tag -> NoVDetected
+      // (decombine.py:393); several V tags -> MultipleVtagMatches (:278-280); V half tags only ->
+      // rescue queue.  Tallies go through one ballot per outcome and wave.
       bool defer = false;
-      if (live && !one_v)
-        defer = fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, a, C, records) == FAST_TO_RESCUE;
+      if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {
+        if (live) fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, a, C, records);
+      } else {
+        const uint32_t vcnt = a.vacc & ACC16_CNT_MASK;
+        const bool vmulti = live && !one_v && (vcnt > 1 || ((a.acc >> TE_VMULTI_BIT) & 1u) || ((a.acc >> TE_VFULL_BIT) & 1u));
+        const bool vhalf = live && !one_v && !vmulti && ((a.acc >> TE_VH1_BIT) & 3u);
+        const bool vnone = live && !one_v && !vmulti && !vhalf;
+        defer = vhalf;
+        if (vnone || vmulti) {
+          __align__(16) dcrx_record_t rec;
+          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+          rec.vdel = rec.jdel = 0;
+          rec.status = (uint8_t)(vnone ? DCRX_S_V_NONE : DCRX_S_V_MULTI);
+          rec.frame = (uint8_t)(cfg.orientation == DCRX_ORIENT_FORWARD ? 1 : 0);
+          dcrx_store_record(records + r, rec);
+        }
+        const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
+        if (lane == 0) {
+          if (mn) atomicAdd(&lds_counts[DCRX_C_NO_VTAGS_FOUND], (uint32_t)__popcll(mn));
+          if (mm) atomicAdd(&lds_counts[DCRX_C_MULTIPLE_V_MATCHES], (uint32_t)__popcll(mm));
+          if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
+        }
+      }
       to_rescue(defer, (uint32_t)r);
       const unsigned long long m = __ballot(one_v);
       if (m) {
