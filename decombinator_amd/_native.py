@@ -87,6 +87,18 @@ class BatchC(C.Structure):
     ]
 
 
+class FastqBatchC(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_uint64), ("text", C.c_void_p), ("text_bytes", C.c_uint64),
+        ("name_off", C.c_void_p), ("name_len", C.c_void_p), ("seq_off", C.c_void_p), ("seq_len", C.c_void_p),
+        ("qual_off", C.c_void_p), ("qual_len", C.c_void_p),
+    ]
+
+
+class SpansC(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("start", C.c_void_p), ("len", C.c_void_p)]
+
+
 class SynthCfgC(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_rearranged", C.c_float),
                 ("sub_rate", C.c_float), ("n_rate", C.c_float)]
@@ -94,7 +106,8 @@ class SynthCfgC(C.Structure):
 
 # every symbol include/dcrx.h and include/dcrx_synth.h declare
 EXPORTS = [
-    "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_unpack_reads",
+    "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
+    "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
@@ -122,7 +135,15 @@ def lib():
         "dcrx_tables_destroy": (None, [vp]),
         "dcrx_tables_info": (i32, [vp, C.POINTER(TablesInfoC)]),
         "dcrx_pack_reads": (C.c_int64, [vp, vp, u64, u32, vp, vp, vp, vp, vp, u64]),
+        "dcrx_pack_reads_span": (C.c_int64, [vp, vp, vp, u64, u32, vp, vp, vp, vp, vp, u64]),
         "dcrx_unpack_reads": (i32, [C.POINTER(BatchC), vp, vp]),
+        "dcrx_fastq_open": (i32, [C.c_char_p, i32, C.POINTER(vp)]),
+        "dcrx_fastq_close": (None, [vp]),
+        "dcrx_fastq_next": (i32, [vp, u64, C.POINTER(FastqBatchC)]),
+        "dcrx_count_prefix_byte": (u64, [vp, vp, vp, u64, u32, i32]),
+        "dcrx_assemble_rows": (C.c_int64, [vp, u64, C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC),
+                                           C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC), C.c_char, vp, u64,
+                                           C.POINTER(u64)]),
         "dcrx_decombine": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp]),
         "dcrx_decombine_device": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp, vp]),
         "dcrx_set_timing_events": (i32, [vp, vp, vp]),
@@ -284,6 +305,148 @@ def pack_reads(reads, stride: int | None = None) -> PackedBatch:
     uniform = n > 0 and bool((lens64 == lens64[0]).all())
     return PackedBatch(packed, stride, int(lens64[0]) if uniform else 0, None if uniform else lens,
                        er[:got].copy(), ep[:got].copy(), ec[:got].copy())
+
+
+def pack_reads_span(text, start, length, stride: int | None = None) -> PackedBatch:
+    """Packs the reads text[start[r] : start[r]+length[r]] (bytes / uint8 buffer, uint64, uint32)."""
+    buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
+        np.ascontiguousarray(text, dtype=np.uint8)
+    start = np.ascontiguousarray(start, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.uint32)
+    n = len(start)
+    max_len = int(length.max()) if n else 0
+    if stride is None:
+        stride = stride_for(max_len)
+    packed = np.empty((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    cap = 1024 + n // 64
+    while True:
+        er = np.zeros(cap, dtype=np.uint32)
+        ep = np.zeros(cap, dtype=np.uint16)
+        ec = np.zeros(cap, dtype=np.uint8)
+        got = lib().dcrx_pack_reads_span(buf.ctypes.data if len(buf) else None, start.ctypes.data, length.ctypes.data, n,
+                                         stride, packed.ctypes.data if n else None, lens.ctypes.data, er.ctypes.data,
+                                         ep.ctypes.data, ec.ctypes.data, cap)
+        check(int(got))
+        if got <= cap:
+            break
+        cap = int(got)
+    uniform = n > 0 and bool((length == length[0]).all())
+    return PackedBatch(packed, stride, int(length[0]) if uniform else 0, None if uniform else lens,
+                       er[:got].copy(), ep[:got].copy(), ec[:got].copy())
+
+
+NO_QUAL = 0xFFFFFFFF
+
+
+class FastqBatch:
+    """One batch of records from FastqReader: `text` (bytes) plus offset / length arrays
+    (qual_len == NO_QUAL where the reference's readfq yields qual None)."""
+
+    __slots__ = ("n", "text", "name_off", "name_len", "seq_off", "seq_len", "qual_off", "qual_len")
+
+    def __init__(self, c: FastqBatchC):
+        n = self.n = int(c.n_records)
+        self.text = C.string_at(c.text, int(c.text_bytes)) if c.text_bytes else b""
+
+        def arr(ptr, ct, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).astype(dt, copy=True)
+        self.name_off, self.name_len = arr(c.name_off, C.c_uint64, np.uint64), arr(c.name_len, C.c_uint32, np.uint32)
+        self.seq_off, self.seq_len = arr(c.seq_off, C.c_uint64, np.uint64), arr(c.seq_len, C.c_uint32, np.uint32)
+        self.qual_off, self.qual_len = arr(c.qual_off, C.c_uint64, np.uint64), arr(c.qual_len, C.c_uint32, np.uint32)
+
+    def truncate(self, n: int) -> None:
+        self.n = n
+        for a in ("name_off", "name_len", "seq_off", "seq_len", "qual_off", "qual_len"):
+            setattr(self, a, getattr(self, a)[:n])
+
+    def name(self, k: int) -> str:
+        o = int(self.name_off[k])
+        return self.text[o:o + int(self.name_len[k])].decode("utf-8", "replace")
+
+    def seq(self, k: int) -> str:
+        o = int(self.seq_off[k])
+        return self.text[o:o + int(self.seq_len[k])].decode("latin-1")
+
+    def qual(self, k: int):
+        if int(self.qual_len[k]) == NO_QUAL:
+            return None
+        o = int(self.qual_off[k])
+        return self.text[o:o + int(self.qual_len[k])].decode("latin-1")
+
+    def records(self):
+        """(name, seq, qual) tuples, as readfq yields them."""
+        return [(self.name(k), self.seq(k), self.qual(k)) for k in range(self.n)]
+
+
+class FastqReader:
+    """Batch FASTQ / FASTA reader in libdcrx (dcrx_fastq_*): same records as readfq()."""
+
+    def __init__(self, path: str, gzipped: bool | None = None):
+        if gzipped is None:
+            gzipped = str(path).endswith(".gz")
+        self._h = C.c_void_p()
+        check(lib().dcrx_fastq_open(os.fsencode(path), int(bool(gzipped)), C.byref(self._h)))
+
+    def next(self, max_records: int) -> FastqBatch:
+        c = FastqBatchC()
+        check(lib().dcrx_fastq_next(self._h, int(max_records), C.byref(c)))
+        return FastqBatch(c)
+
+    def close(self) -> None:
+        if self._h:
+            lib().dcrx_fastq_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_prefix_byte(text: bytes, start, length, prefix: int, byte: str) -> int:
+    start = np.ascontiguousarray(start, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.uint32)
+    if len(start) == 0 or prefix <= 0:
+        return 0
+    buf = np.frombuffer(text, dtype=np.uint8)
+    return int(lib().dcrx_count_prefix_byte(buf.ctypes.data, start.ctypes.data, length.ctypes.data, len(start),
+                                            int(prefix), ord(byte)))
+
+
+def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep: str = "\x1f"):
+    """dcrx_assemble_rows: each argument after `records` is (text bytes, uint64 start[], uint32 len[]).
+    Returns (bytes blob of '\n'-terminated rows, number of rows)."""
+    keep = []
+
+    def spans(t):
+        if t is None:
+            return None
+        text, start, length = t
+        buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, dtype=np.uint8)
+        start = np.ascontiguousarray(start, dtype=np.uint64)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        keep.extend((buf, start, length))
+        return C.byref(SpansC(buf.ctypes.data, start.ctypes.data, length.ctypes.data))
+    records = np.ascontiguousarray(records)
+    args = [spans(t) for t in (vdj, qual, ident, bc, bcq, tail)]
+    nrows = C.c_uint64(0)
+    sep = field_sep.encode("latin-1")
+    need = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, None, 0, C.byref(nrows)))
+    check(need)
+    out = np.empty(max(need, 1), dtype=np.uint8)
+    got = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, out.ctypes.data, need, C.byref(nrows)))
+    check(got)
+    return out[:need].tobytes(), int(nrows.value)
 
 
 def unpack_reads_raw(batch: PackedBatch):

@@ -17,6 +17,9 @@
 #include "../../include/dcrx_synth.h"
 #include "dcrx_launch.h"
 #include "dcrx_synth_core.h"
+#include <cstdlib>
+#include <thread>
+
 #include "dcrx_tables.h"
 
 namespace dcrx {
@@ -29,6 +32,7 @@ using namespace dcrx;
 static thread_local std::string g_err;
 
 static int set_err(int code, const std::string &m) { g_err = m; return code; }
+namespace dcrx { int set_err(int code, const char *msg) { return ::set_err(code, std::string(msg)); } }
 static int hip_err(hipError_t e, const char *what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? DCRX_E_NOGPU : DCRX_E_HIP;
@@ -325,37 +329,108 @@ int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, u
 }
 
 // ---- host-side packing --------------------------------------------------------------
+extern "C++" {
+// Packs one read: 16 bases per step through a byte table whose top bit marks a byte that is
+// not one of "ACGT"; such a word is redone base by base to record the exception entries.
+namespace {
+struct PackCode {
+  uint8_t t[256];
+  PackCode() {
+    for (int c = 0; c < 256; c++) t[c] = 0x80;
+    t[(int)'A'] = 0; t[(int)'C'] = 1; t[(int)'G'] = 2; t[(int)'T'] = 3;
+  }
+};
+const PackCode g_pack_code;
+
+struct ExcEntry { uint32_t read; uint16_t pos; uint8_t chr; };
+
+inline void pack_one(const uint8_t *s, uint32_t len, uint8_t *out, uint32_t stride, uint32_t r, std::vector<ExcEntry> &exc) {
+  const uint8_t *t = g_pack_code.t;
+  uint32_t *ow = reinterpret_cast<uint32_t *>(out);
+  const uint32_t nwords = stride / 4, full = len / 16;
+  uint32_t k = 0;
+  for (; k < full; k++) {
+    const uint8_t *b = s + 16 * k;
+    uint32_t w = 0, bad = 0;
+    for (int i = 0; i < 16; i++) { const uint32_t c = t[b[i]]; bad |= c; w |= (c & 3u) << (2 * i); }
+    if (bad & 0x80u)
+      for (int i = 0; i < 16; i++)
+        if (t[b[i]] & 0x80u) exc.push_back(ExcEntry{r, (uint16_t)(16 * k + i), b[i]});
+    ow[k] = w;
+  }
+  if (len & 15u) {
+    const uint8_t *b = s + 16 * k;
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < (len & 15u); i++) {
+      const uint32_t c = t[b[i]];
+      if (c & 0x80u) exc.push_back(ExcEntry{r, (uint16_t)(16 * k + i), b[i]});
+      w |= (c & 3u) << (2 * i);
+    }
+    ow[k++] = w;
+  }
+  for (; k < nwords; k++) ow[k] = 0;
+}
+
+// start/len accessors differ between the two entry points; everything else is shared.  Reads are
+// split into contiguous ranges over a few threads; the ranges' exception lists are concatenated
+// in range order, which keeps the list sorted by read.
+template <class Span>
+int64_t pack_all(const char *ascii, const Span &span, uint64_t n_reads, uint32_t stride, uint8_t *packed, uint16_t *lens,
+                 uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr, uint64_t exc_cap) {
+  if ((n_reads && (!ascii || !packed)) || stride == 0 || (stride & 7u)) return set_err(DCRX_E_INVALID, "bad argument to the read packer");
+  if (n_reads > 0xFFFFFFFFull) return set_err(DCRX_E_INVALID, "more than 2^32-1 reads in one batch");
+  unsigned nt = 1;
+  if (n_reads >= (1u << 16)) {
+    nt = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("DCRX_HOST_THREADS")) nt = (unsigned)std::atoi(e);
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+  }
+  std::vector<std::vector<ExcEntry>> exc(nt);
+  std::vector<int> bad(nt, 0);
+  auto work = [&](unsigned k) {
+    const uint64_t lo = n_reads * k / nt, hi = n_reads * (k + 1) / nt;
+    for (uint64_t r = lo; r < hi; r++) {
+      const uint64_t len = span.len(r);
+      if (len > 4ull * stride || len > 65535) { bad[k] = 1; return; }
+      if (lens) lens[r] = (uint16_t)len;
+      pack_one(reinterpret_cast<const uint8_t *>(ascii) + span.start(r), (uint32_t)len, packed + r * (uint64_t)stride, stride,
+               (uint32_t)r, exc[k]);
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) th.emplace_back(work, k);
+    for (auto &x : th) x.join();
+  }
+  for (unsigned k = 0; k < nt; k++) if (bad[k]) return set_err(DCRX_E_INVALID, "read longer than 4*stride");
+  uint64_t n_exc = 0;
+  for (unsigned k = 0; k < nt; k++)
+    for (const ExcEntry &e : exc[k]) {
+      if (n_exc < exc_cap && exc_read) { exc_read[n_exc] = e.read; exc_pos[n_exc] = e.pos; exc_chr[n_exc] = e.chr; }
+      n_exc++;
+    }
+  return (int64_t)n_exc;
+}
+struct SpanOffsets { const uint64_t *o; uint64_t start(uint64_t r) const { return o[r]; } uint64_t len(uint64_t r) const { return o[r + 1] - o[r]; } };
+struct SpanStartLen { const uint64_t *s; const uint32_t *l; uint64_t start(uint64_t r) const { return s[r]; } uint64_t len(uint64_t r) const { return l[r]; } };
+}  // namespace
+
+}  // extern "C++"
+
 int64_t dcrx_pack_reads(const char *ascii, const uint64_t *offsets, uint64_t n_reads, uint32_t stride,
                         uint8_t *packed, uint16_t *lens, uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
                         uint64_t exc_cap) {
-  if ((n_reads && (!ascii || !offsets || !packed)) || stride == 0 || (stride & 7u))
-    return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads");
-  static int8_t code[256];
-  static bool code_ready = false;
-  if (!code_ready) {
-    for (int c = 0; c < 256; c++) code[c] = -1;
-    code[(int)'A'] = 0; code[(int)'C'] = 1; code[(int)'G'] = 2; code[(int)'T'] = 3;
-    code_ready = true;
-  }
-  uint64_t n_exc = 0;
-  for (uint64_t r = 0; r < n_reads; r++) {
-    const uint64_t len = offsets[r + 1] - offsets[r];
-    if (len > 4ull * stride || len > 65535) return set_err(DCRX_E_INVALID, "read longer than 4*stride");
-    if (lens) lens[r] = (uint16_t)len;
-    const uint8_t *s = reinterpret_cast<const uint8_t *>(ascii) + offsets[r];
-    uint8_t *out = packed + r * (uint64_t)stride;
-    std::memset(out, 0, stride);
-    for (uint64_t i = 0; i < len; i++) {
-      int c = code[s[i]];
-      if (c < 0) {
-        if (n_exc < exc_cap && exc_read) { exc_read[n_exc] = (uint32_t)r; exc_pos[n_exc] = (uint16_t)i; exc_chr[n_exc] = s[i]; }
-        n_exc++;
-        c = 0;
-      }
-      out[i >> 2] |= (uint8_t)(c << (2 * (i & 3)));
-    }
-  }
-  return (int64_t)n_exc;
+  if (n_reads && !offsets) return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads");
+  return pack_all(ascii, SpanOffsets{offsets}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
+}
+
+int64_t dcrx_pack_reads_span(const char *ascii, const uint64_t *start, const uint32_t *len, uint64_t n_reads, uint32_t stride,
+                             uint8_t *packed, uint16_t *lens, uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
+                             uint64_t exc_cap) {
+  if (n_reads && (!start || !len)) return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads_span");
+  return pack_all(ascii, SpanStartLen{start, len}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
 }
 
 int dcrx_unpack_reads(const dcrx_batch_t *b, const uint64_t *offsets, char *ascii) {

@@ -1,0 +1,83 @@
+// Bulk `.n12` row assembly (host only): what the reference's loop body builds for every
+// decombined read (src/decombinator/decombine.py:1012-1039) —
+//   [v, j, vdel, jdel, insert, read id, inter-tag sequence, inter-tag quality, barcode,
+//    barcode quality (, v_tail with sampling_analysis)]
+// from the 16-byte records and the byte spans of the FASTQ batch.  Strings are cut with
+// Python's slice clamping; the reverse frame is revcomp(vdj) / vdjqual[::-1] (:1015-1017)
+// with Bio.Seq's complement table (ambiguous codes, both cases, other bytes unchanged).
+// Output: one line per decombined read, in read order, fields separated by `field_sep`.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dcrx.h"
+#include "../../include/dcrx_codes.h"
+
+namespace dcrx { int set_err(int code, const char *msg); }
+using dcrx::set_err;
+
+namespace {
+struct Comp {
+  uint8_t t[256];
+  Comp() {
+    for (int c = 0; c < 256; c++) t[c] = (uint8_t)c;
+    const char *ck = "ACGTMRWSYKVHDBXNU", *cv = "TGCAKYWSRMBDHVXNA";
+    for (int i = 0; ck[i]; i++) {
+      t[(uint8_t)ck[i]] = (uint8_t)cv[i];
+      t[(uint8_t)(ck[i] + 32)] = (uint8_t)(cv[i] + 32);
+    }
+  }
+};
+const Comp g_comp;
+
+struct Out {
+  char *p; uint64_t cap, n;
+  void put(const char *s, uint64_t k) { if (n + k <= cap) std::memcpy(p + n, s, k); n += k; }
+  void ch(char c) { if (n < cap) p[n] = c; n++; }
+  void num(unsigned v) { char b[16]; const int k = std::snprintf(b, sizeof b, "%u", v); put(b, (uint64_t)k); }
+  // frame string [a, b) of a span of length len: forward = the bytes, reverse = reversed (and complemented)
+  void cut(const char *s, uint32_t len, bool rev, bool comp, uint32_t a, uint32_t b) {
+    if (b > len) b = len;
+    if (a >= b) return;
+    const uint64_t k = b - a;
+    if (n + k <= cap) {
+      char *o = p + n;
+      if (!rev) std::memcpy(o, s + a, k);
+      else if (comp) for (uint32_t i = a; i < b; i++) *o++ = (char)g_comp.t[(uint8_t)s[len - 1 - i]];
+      else for (uint32_t i = a; i < b; i++) *o++ = s[len - 1 - i];
+    }
+    n += k;
+  }
+};
+}  // namespace
+
+extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
+                                      const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
+                                      const dcrx_spans_t *bcq, const dcrx_spans_t *tail, char field_sep, char *out,
+                                      uint64_t out_cap, uint64_t *n_rows) {
+  if ((n_reads && !records) || !vdj || !qual || !id || !bc || !bcq)
+    return set_err(DCRX_E_INVALID, "null argument to dcrx_assemble_rows");
+  Out o{out, out ? out_cap : 0, 0};
+  uint64_t rows = 0;
+  for (uint64_t r = 0; r < n_reads; r++) {
+    const dcrx_record_t &c = records[r];
+    if (c.status != DCRX_S_OK) continue;
+    if (qual->len[r] == DCRX_FASTQ_NO_QUAL)
+      return set_err(DCRX_E_INVALID, "decombined read without a quality string");
+    const bool rev = c.frame == 0;
+    const char *s = vdj->text + vdj->start[r];
+    const char *q = qual->text + qual->start[r];
+    o.num(c.v); o.ch(field_sep); o.num(c.j); o.ch(field_sep); o.num(c.vdel); o.ch(field_sep); o.num(c.jdel); o.ch(field_sep);
+    o.cut(s, vdj->len[r], rev, true, c.ins_start, (uint32_t)c.ins_start + c.ins_len); o.ch(field_sep);
+    o.put(id->text + id->start[r], id->len[r]); o.ch(field_sep);
+    o.cut(s, vdj->len[r], rev, true, c.v_start, c.j_end); o.ch(field_sep);
+    o.cut(q, qual->len[r], rev, false, c.v_start, c.j_end); o.ch(field_sep);
+    o.put(bc->text + bc->start[r], bc->len[r]); o.ch(field_sep);
+    o.put(bcq->text + bcq->start[r], bcq->len[r]);
+    if (tail) { o.ch(field_sep); o.put(tail->text + tail->start[r], tail->len[r]); }
+    o.ch('\n');
+    rows++;
+  }
+  if (n_rows) *n_rows = rows;
+  return (int64_t)o.n;
+}

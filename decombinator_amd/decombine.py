@@ -36,6 +36,9 @@ _COMP = str.maketrans("ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", "TGCAKYWSRMBDHVXNAtg
 
 # reads sent to the GPU per dcrx_decombine call
 BATCH_READS = 1 << 20
+# wall seconds of the last decombinator() call by phase: FASTQ read, 2-bit pack, device call (H2D + kernels
+# + D2H), row assembly
+stage_seconds: dict = {}
 
 # module-level state kept for callers that used the reference's globals
 counts: coll.Counter = coll.Counter()
@@ -64,15 +67,15 @@ def readfq(fp):
     header without its first character up to the first space; sequence and quality
     may span lines; a FASTQ record whose quality is cut short by EOF comes out as a
     FASTA record."""
-    pending = None  # a header line already consumed
+    pending = None  # a header line already consumed; an EMPTY one counts as none (the reference tests truthiness)
     while True:
-        if pending is None:
+        if not pending:
             for line in fp:
                 if line[0] in ">@":
                     pending = line[:-1]
                     break
-            if pending is None:
-                return
+        if not pending:
+            return
         name = pending[1:].partition(" ")[0]
         pending = None
         chunks = []
@@ -82,9 +85,9 @@ def readfq(fp):
                 break
             chunks.append(line[:-1])
         seq = "".join(chunks)
-        if pending is None or pending[0] != "+":
+        if not pending or pending[0] != "+":
             yield name, seq, None
-            if pending is None:
+            if not pending:
                 return
             continue
         pending = None
@@ -330,6 +333,122 @@ def assemble_rows(records, reads, quals, ids, bcs, bcqs, sampling_tails=None):
     return rows
 
 
+class _Spans:
+    """One batch of read pairs as byte spans into the FASTQ batches' text buffers: what the
+    reference's loop body slices out of record1 / record2 (:963-984)."""
+    __slots__ = ("v_text", "v_start", "v_len", "q_start", "q_len", "id_text", "id_start", "id_len",
+                 "bc_text", "bc_start", "bc_len", "bcq_start", "bcq_len", "tail_start", "tail_len", "last")
+
+
+def _clip(off, length, lo, hi=None):
+    """Span of python's s[lo:hi] (0 <= lo <= hi) inside the span (off, length)."""
+    length = length.astype(np.int64)
+    a = np.minimum(lo, length)
+    b = length if hi is None else np.minimum(hi, length)
+    return (off + a.astype(np.uint64)), (b - a).astype(np.uint32)
+
+
+def _next_spans(rd1, rd2, bclength, sampling):
+    """The next BATCH_READS iterations of the reference's `for record1, record2 in zip(fq1, fq2)`
+    (:961): with bc_read R2 one record from each file, with R1 two consecutive records of the
+    one file (zip over the same generator).  None when the zip is exhausted."""
+    none_qual = "'NoneType' object is not subscriptable"      # what record[2][...] raises on a FASTA record
+    sp = _Spans()
+    if rd2 is not None:
+        b1 = rd1.next(BATCH_READS)
+        if b1.n == 0:
+            return None
+        b2 = rd2.next(b1.n)
+        sp.last = b2.n < b1.n          # zip() stops with the shorter file
+        if sp.last:
+            b1.truncate(b2.n)
+        if b1.n == 0:
+            return None
+        if (b2.qual_len == nat.NO_QUAL).any():
+            raise TypeError(none_qual)                           # record2[2][:bclength] (:972)
+        sp.v_text = sp.id_text = b1.text
+        sp.bc_text = b2.text
+        sp.v_start, sp.v_len = b1.seq_off, b1.seq_len                                   # vdj = record1[1] (:970)
+        sp.q_start, sp.q_len = b1.qual_off, b1.qual_len                                 # NO_QUAL: fails when sliced
+        sp.bc_start, sp.bc_len = _clip(b2.seq_off, b2.seq_len, 0, bclength)             # :971
+        sp.bcq_start, sp.bcq_len = _clip(b2.qual_off, b2.qual_len, 0, bclength)         # :972
+        sp.id_start, sp.id_len = b1.name_off, b1.name_len
+        r2_off, r2_len = b2.seq_off, b2.seq_len
+    else:
+        b = rd1.next(2 * BATCH_READS)
+        sp.last = b.n < 2 * BATCH_READS
+        n = b.n // 2                   # an unpaired last record is consumed and dropped by zip()
+        if n == 0:
+            return None
+        ev, od = slice(0, 2 * n, 2), slice(1, 2 * n, 2)
+        if (b.qual_len[ev] == nat.NO_QUAL).any():
+            raise TypeError(none_qual)                           # record1[2][bclength:] (:981)
+        sp.v_text = sp.id_text = sp.bc_text = b.text
+        sp.v_start, sp.v_len = _clip(b.seq_off[ev], b.seq_len[ev], bclength)            # :980
+        sp.q_start, sp.q_len = _clip(b.qual_off[ev], b.qual_len[ev], bclength)          # :981
+        sp.bc_start, sp.bc_len = _clip(b.seq_off[ev], b.seq_len[ev], 0, bclength)       # :982
+        sp.bcq_start, sp.bcq_len = _clip(b.qual_off[ev], b.qual_len[ev], 0, bclength)   # :983
+        sp.id_start, sp.id_len = b.name_off[ev], b.name_len[ev]
+        r2_off, r2_len = b.seq_off[od], b.seq_len[od]
+    sp.tail_start = sp.tail_len = None
+    if sampling:                                                 # v_tail = record2[1][bclength:bclength+31]
+        sp.tail_start, sp.tail_len = _clip(r2_off, r2_len, bclength, bclength + 31)
+    return sp
+
+
+_FIELD_SEP = "\x1f"
+
+
+def assemble_rows_spans(records, sp):
+    """assemble_rows for a batch held as spans, in bulk: libdcrx writes the rows as text
+    (dcrx_assemble_rows), which is split back into the reference's list-of-lists.  A batch whose
+    text holds the separator byte (never in a real FASTQ) takes the per-row path below."""
+    sep = _FIELD_SEP.encode()
+    if sep in sp.v_text or (sp.bc_text is not sp.v_text and sep in sp.bc_text):
+        return _assemble_rows_spans_py(records, sp)
+    hit = records["status"] == 0
+    if not hit.any():
+        return []
+    if (sp.q_len[hit] == nat.NO_QUAL).any():
+        raise TypeError("'NoneType' object is not subscriptable")   # tcrQ = vdjqual[...] on a FASTA record
+    tail = None if sp.tail_start is None else (sp.bc_text, sp.tail_start, sp.tail_len)
+    blob, n = nat.assemble_rows_blob(records, (sp.v_text, sp.v_start, sp.v_len), (sp.v_text, sp.q_start, sp.q_len),
+                                     (sp.id_text, sp.id_start, sp.id_len), (sp.bc_text, sp.bc_start, sp.bc_len),
+                                     (sp.bc_text, sp.bcq_start, sp.bcq_len), tail, _FIELD_SEP)
+    rows = [ln.split(_FIELD_SEP) for ln in blob.decode("utf-8", "replace").split("\n")]
+    rows.pop()                         # the text ends with a newline
+    assert len(rows) == n
+    return rows
+
+
+def _assemble_rows_spans_py(records, sp):
+    """Per-row form of assemble_rows_spans (also its cross-check in the tests)."""
+    rows = []
+
+    def cut(text, off, length, k):
+        o = int(off[k])
+        return text[o:o + int(length[k])].decode("latin-1")
+    for k in np.nonzero(records["status"] == 0)[0]:
+        r = records[k]
+        if int(sp.q_len[k]) == nat.NO_QUAL:
+            raise TypeError("'NoneType' object is not subscriptable")   # tcrQ = vdjqual[...] on a FASTA record
+        vdj, q = cut(sp.v_text, sp.v_start, sp.v_len, k), cut(sp.v_text, sp.q_start, sp.q_len, k)
+        if int(r["frame"]) == 0:
+            frame_read, frame_q = revcomp(vdj), q[::-1]
+        else:
+            frame_read, frame_q = vdj, q
+        s, l = int(r["ins_start"]), int(r["ins_len"])
+        a, b = int(r["v_start"]), int(r["j_end"])
+        o = int(sp.id_start[k])
+        row = [str(int(r["v"])), str(int(r["j"])), str(int(r["vdel"])), str(int(r["jdel"])),
+               frame_read[s:s + l], sp.id_text[o:o + int(sp.id_len[k])].decode("utf-8", "replace"), frame_read[a:b],
+               frame_q[a:b], cut(sp.bc_text, sp.bc_start, sp.bc_len, k), cut(sp.bc_text, sp.bcq_start, sp.bcq_len, k)]
+        if sp.tail_start is not None:
+            row.append(cut(sp.bc_text, sp.tail_start, sp.tail_len, k))
+        rows.append(row)
+    return rows
+
+
 def _summary_text(inputargs, chain, samplenam, date, timetaken):
     """The Decombinator summary CSV body (reference :1097-1195), line for line."""
     inout_name = "_".join(f"{samplenam}".split("_")[:-1]) + f"_{chainnams[chain]}"
@@ -394,6 +513,7 @@ def decombinator(inputargs: dict) -> list:
 
     bclength = inputargs["bclength"]
     counts["start_time"] = time()
+    stage_seconds.clear()
     print("Decombining FASTQ data...")
     outdata = []
     orientation = inputargs["orientation"]
@@ -401,39 +521,43 @@ def decombinator(inputargs: dict) -> list:
         raise ValueError("orientation must be forward, reverse or both")
 
     if inputargs["nobarcoding"] == False:  # noqa: E712
-        fq1 = readfq(opener(inputargs["infile"], "rt"))
-        if inputargs["bc_read"] == "R2":
-            fq2 = readfq(opener(inputargs["infile"].replace("1.f", "2.f"), "rt"))
-        elif inputargs["bc_read"] == "R1":
-            fq2 = fq1   # like the reference: zip() then consumes TWO records of the file per iteration (:956-961)
-        else:
+        if inputargs["bc_read"] not in ("R1", "R2"):
             raise ValueError("bc_read must be R1 or R2")
-        pairs = zip(fq1, fq2)
+        paired = inputargs["bc_read"] == "R2"
+        gz = inputargs["infile"].endswith(".gz")       # opener_check: one opener for both files (:118-123)
+        rd1 = nat.FastqReader(inputargs["infile"], gz)
+        rd2 = nat.FastqReader(inputargs["infile"].replace("1.f", "2.f"), gz) if paired else None
         sampling = bool(inputargs.get("sampling_analysis"))
-        while True:
-            ids, reads, quals, bcs, bcqs, tails = [], [], [], [], [], ([] if sampling else None)
-            for record1, record2 in itertools.islice(pairs, BATCH_READS):
-                if inputargs["bc_read"] == "R2":
-                    vdj, vdjqual = record1[1], record1[2]
-                    bc, bcq = record2[1][:bclength], record2[2][:bclength]
-                else:
-                    vdj, vdjqual = record1[1][bclength:], record1[2][bclength:]
-                    bc, bcq = record1[1][0:bclength], record1[2][0:bclength]
-                if sampling:
-                    tails.append(record2[1][bclength:bclength + 31])
-                if "N" in bc and inputargs["allowNs"] == False:  # noqa: E712
-                    counts["dcrfilter_barcodeN"] += 1            # counted, never dropped (:985-989)
-                ids.append(record1[0]); reads.append(vdj); quals.append(vdjqual); bcs.append(bc); bcqs.append(bcq)
-            if not reads:
-                break
-            before = counts["read_count"]
-            counts["read_count"] += len(reads)
-            if inputargs["dontcount"] == False and counts["read_count"] // 100000 > before // 100000:  # noqa: E712
-                print("\t read", (counts["read_count"] // 100000) * 100000)
-            rec, cnt = nat.decombine(tcr.tables, nat.pack_reads(reads), orientation, inputargs["allowNs"],
-                                     inputargs["lenthreshold"])
-            _add_counts(cnt, skip=("read_count",))
-            outdata.extend(assemble_rows(rec, reads, quals, ids, bcs, bcqs, tails))
+        try:
+            while True:
+                t0 = time()
+                spans = _next_spans(rd1, rd2, bclength, sampling)
+                if spans is None:
+                    break
+                n = len(spans.v_start)
+                if inputargs["allowNs"] == False:  # noqa: E712    counted, never dropped (:985-989)
+                    counts["dcrfilter_barcodeN"] += nat.count_prefix_byte(spans.bc_text, spans.bc_start, spans.bc_len,
+                                                                          1 << 30, "N")
+                before = counts["read_count"]
+                counts["read_count"] += n
+                if inputargs["dontcount"] == False and counts["read_count"] // 100000 > before // 100000:  # noqa: E712
+                    print("\t read", (counts["read_count"] // 100000) * 100000)
+                t1 = time()
+                batch = nat.pack_reads_span(spans.v_text, spans.v_start, spans.v_len)
+                t2 = time()
+                rec, cnt = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])
+                t3 = time()
+                _add_counts(cnt, skip=("read_count",))
+                outdata.extend(assemble_rows_spans(rec, spans))
+                t4 = time()
+                for key, dt in (("read", t1 - t0), ("pack", t2 - t1), ("device", t3 - t2), ("rows", t4 - t3)):
+                    stage_seconds[key] = stage_seconds.get(key, 0.0) + dt
+                if spans.last:
+                    break
+        finally:
+            rd1.close()
+            if rd2 is not None:
+                rd2.close()
     else:
         # reference behaviour: with nobarcoding the read loop never runs
         if inputargs["extension"] == "n12":

@@ -146,9 +146,68 @@ int64_t dcrx_pack_reads(const char *ascii, const uint64_t *offsets, uint64_t n_r
                         uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
                         uint64_t exc_cap);
 
+/* Same, for reads that are not contiguous: read r is ascii[start[r] .. start[r]+len[r]).
+ * This is the form the batch reader below hands out (and the R1 mode's vdj = seq[bclength:],
+ * decombine.py:980). */
+int64_t dcrx_pack_reads_span(const char *ascii, const uint64_t *start, const uint32_t *len,
+                             uint64_t n_reads, uint32_t stride, uint8_t *packed, uint16_t *lens,
+                             uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
+                             uint64_t exc_cap);
+
 /* Inverse of dcrx_pack_reads: writes lens[r] (or read_len) ASCII bytes of read r
  * to ascii + offsets[r], exception bytes restored. */
 int dcrx_unpack_reads(const dcrx_batch_t *host_batch, const uint64_t *offsets, char *ascii);
+
+/* ---- FASTQ / FASTA batch reader (host only) ----
+ * Replaces the generator readfq (decombine.py:228-265) over the reference's opener
+ * (opener_check, :118-123; text mode = universal newlines), record for record: header up to
+ * the first space, multi-line sequences and qualities, FASTA records (no quality), a
+ * truncated last record, and the l[:-1] quirk of an unterminated last line.  A batch is a
+ * set of offsets into one text buffer owned by the reader, valid until the next call on the
+ * same reader. */
+typedef struct dcrx_fastq dcrx_fastq_t;
+
+#define DCRX_FASTQ_NO_QUAL 0xFFFFFFFFu /* qual_len of a record the reference yields with qual None */
+
+typedef struct {
+  uint64_t n_records;
+  const char *text;
+  uint64_t text_bytes;
+  const uint64_t *name_off; const uint32_t *name_len;
+  const uint64_t *seq_off;  const uint32_t *seq_len;
+  const uint64_t *qual_off; const uint32_t *qual_len;
+} dcrx_fastq_batch_t;
+
+/* gzipped != 0: the file must be gzip (gzip.open); 0: read as it is (open). */
+int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out);
+void dcrx_fastq_close(dcrx_fastq_t *reader);
+/* Up to max_records further records; n_records == 0 means the file is exhausted. */
+int dcrx_fastq_next(dcrx_fastq_t *reader, uint64_t max_records, dcrx_fastq_batch_t *out);
+
+/* How many of the n spans hold `byte` within their first `prefix` bytes: the reference's
+ * `"N" in bc` tally over bc = seq[:bclength] (decombine.py:985-989). */
+uint64_t dcrx_count_prefix_byte(const char *text, const uint64_t *start, const uint32_t *len,
+                                uint64_t n, uint32_t prefix, int byte);
+
+/* ---- bulk `.n12` row assembly (host only) ----
+ * Replaces the row building of the read loop (decombine.py:1012-1039) for a whole batch:
+ * for every record with status DCRX_S_OK, in read order, one line
+ *   v j vdel jdel insert id inter-tag-seq inter-tag-qual barcode barcode-qual [v_tail]
+ * with `field_sep` between fields and '\n' after the row.  vdj / qual / id / bc / bcq / tail
+ * give read r's strings as spans (tail may be NULL: no sampling_analysis).  The reverse frame
+ * is revcomp(vdj) and qual[::-1] (:1015-1017); slices clamp like Python's.
+ * Returns the number of bytes the rows take; they are written only when that fits out_cap
+ * (call with out = NULL to size the buffer).  *n_rows = rows. */
+typedef struct {
+  const char *text;
+  const uint64_t *start;
+  const uint32_t *len;
+} dcrx_spans_t;
+
+int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
+                           const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
+                           const dcrx_spans_t *bcq, const dcrx_spans_t *tail, char field_sep,
+                           char *out, uint64_t out_cap, uint64_t *n_rows);
 
 /* ---- the hot path: replaces the body of the read loop, decombine.py:998-1013 ---- */
 

@@ -189,3 +189,66 @@ def test_reference_n12_fixture_with_oracle_as_device(chain_name, tmp_path, monke
 def test_reference_n12_fixture_through_hip_path(chain_name, tmp_path):
     fx, args = _tiny(chain_name, tmp_path)
     _check_tiny(fx, args)
+
+
+# ---- input variants (tests/golden/stage_variants.json, oracle/gen_stage_variants.py) --------------
+VARIANTS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "stage_variants.json")))
+VARIANT_IDS = [r["name"] for r in VARIANTS["runs"]]
+
+
+def _run_variant(run, tmp_path, batch_reads, monkeypatch):
+    import gzip
+    ts = VARIANTS["tagset"]
+    t = synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"],
+                     v_jumps=ts["v_jumps"], v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"],
+                     j_jumps=ts["j_jumps"], j_names=ts["j_names"], j_regions=ts["j_regions"])
+    t.write(str(tmp_path / "tags"))
+    ext = ".fq.gz" if run["gz"] else ".fq"
+    op = gzip.open if run["gz"] else open
+    for k, text in (("1", run["fastq_r1"]), ("2", run["fastq_r2"])):
+        if text is not None:
+            with op(tmp_path / f"VAR_{k}{ext}", "wb") as f:
+                f.write(text.encode())
+    monkeypatch.setattr(dec, "BATCH_READS", batch_reads)
+    dec.counts.clear()
+    args = dio.create_args_dict(infile=str(tmp_path / f"VAR_1{ext}"), chain="b", dontgzip=True, dontcount=True,
+                                dontcheck=True, suppresssummary=True, tagfastadir=str(tmp_path / "tags"),
+                                outpath=str(tmp_path) + os.sep, command="decombine", **run["args"])
+    rows = dec.decombinator(args)
+    assert rows == run["rows"]
+    got = {k: v for k, v in dec.counts.items() if isinstance(v, int) and v}
+    exp = {k: v for k, v in run["counts"].items() if v}
+    assert got == exp
+
+
+@pytest.mark.parametrize("batch_reads", [64, 1 << 20])
+@pytest.mark.parametrize("k", range(len(VARIANT_IDS)), ids=VARIANT_IDS)
+def test_stage_variants_with_oracle_as_device(k, batch_reads, tmp_path, monkeypatch):
+    monkeypatch.setattr(nat, "decombine", _oracle_device(VARIANTS))
+    _run_variant(VARIANTS["runs"][k], tmp_path, batch_reads, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(VARIANT_IDS)), ids=VARIANT_IDS)
+def test_stage_variants_through_hip_path(k, tmp_path, monkeypatch):
+    _run_variant(VARIANTS["runs"][k], tmp_path, 100, monkeypatch)
+
+
+def test_fasta_record_raises_like_the_reference(tmp_path, monkeypatch):
+    """A record without quality: the reference fails with TypeError on record[2][...]."""
+    ts = VARIANTS["tagset"]
+    t = synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"],
+                     v_jumps=ts["v_jumps"], v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"],
+                     j_jumps=ts["j_jumps"], j_names=ts["j_names"], j_regions=ts["j_regions"])
+    t.write(str(tmp_path / "tags"))
+    (tmp_path / "F_1.fq").write_text("@a\nACGT\n+\nIIII\n>b\nACGT\n")
+    (tmp_path / "F_2.fq").write_text("@a\nACGT\n+\nIIII\n>b\nACGT\n")
+    monkeypatch.setattr(nat, "decombine", _oracle_device(VARIANTS))
+    for bc_read in ("R1", "R2"):
+        args = dio.create_args_dict(infile=str(tmp_path / "F_1.fq"), chain="b", dontgzip=True, dontcount=True,
+                                    dontcheck=True, suppresssummary=True, tagfastadir=str(tmp_path / "tags"),
+                                    outpath=str(tmp_path) + os.sep, command="decombine", bc_read=bc_read, bclength=2)
+        if bc_read == "R1":
+            (tmp_path / "F_1.fq").write_text(">b\nACGT\n@a\nACGT\n+\nIIII\n")
+        with pytest.raises(TypeError):
+            dec.decombinator(args)
