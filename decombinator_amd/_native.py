@@ -309,8 +309,7 @@ def pack_reads(reads, stride: int | None = None) -> PackedBatch:
 
 def pack_reads_span(text, start, length, stride: int | None = None) -> PackedBatch:
     """Packs the reads text[start[r] : start[r]+length[r]] (bytes / uint8 buffer, uint64, uint32)."""
-    buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
-        np.ascontiguousarray(text, dtype=np.uint8)
+    buf = text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
     start = np.ascontiguousarray(start, dtype=np.uint64)
     length = np.ascontiguousarray(length, dtype=np.uint32)
     n = len(start)
@@ -347,7 +346,8 @@ class FastqBatch:
 
     def __init__(self, c: FastqBatchC):
         n = self.n = int(c.n_records)
-        self.text = C.string_at(c.text, int(c.text_bytes)) if c.text_bytes else b""
+        # zero-copy window on the reader's buffer: valid until the next call of next() on that reader
+        self.text = (C.c_char * int(c.text_bytes)).from_address(c.text) if c.text_bytes else b""
 
         def arr(ptr, ct, dt):
             if n == 0:
@@ -423,6 +423,10 @@ def count_prefix_byte(text: bytes, start, length, prefix: int, byte: str) -> int
                                             int(prefix), ord(byte)))
 
 
+class SeparatorClash(RuntimeError):
+    """A row field contains the field separator byte: the caller assembles that batch row by row."""
+
+
 def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep: str = "\x1f"):
     """dcrx_assemble_rows: each argument after `records` is (text bytes, uint64 start[], uint32 len[]).
     Returns (bytes blob of '\n'-terminated rows, number of rows)."""
@@ -442,6 +446,8 @@ def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep:
     nrows = C.c_uint64(0)
     sep = field_sep.encode("latin-1")
     need = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, None, 0, C.byref(nrows)))
+    if need == -2:                      # DCRX_E_UNSUPPORTED
+        raise SeparatorClash(lib().dcrx_last_error().decode("utf-8", "replace"))
     check(need)
     out = np.empty(max(need, 1), dtype=np.uint8)
     got = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, out.ctypes.data, need, C.byref(nrows)))

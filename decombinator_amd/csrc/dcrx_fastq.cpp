@@ -18,6 +18,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -36,10 +37,31 @@ struct dcrx_fastq {
   bool have_last = false;
   std::string last;
   bool finished = false;
-  // batch storage
-  std::vector<char> text;
-  std::vector<uint64_t> name_off, seq_off, qual_off;
-  std::vector<uint32_t> name_len, seq_len, qual_len;
+  // Batch storage, twice: while the caller works on one parsed chunk a worker thread parses the
+  // next one into the other (the file is only ever touched by one of them at a time).
+  struct Store {
+    std::vector<char> text;
+    std::vector<uint64_t> name_off, seq_off, qual_off;
+    std::vector<uint32_t> name_len, seq_len, qual_len;
+    void clear() {
+      text.clear(); name_off.clear(); seq_off.clear(); qual_off.clear();
+      name_len.clear(); seq_len.clear(); qual_len.clear();
+    }
+    void emit(uint64_t no, uint32_t nl, uint64_t so, uint32_t sl, uint64_t qo, uint32_t ql) {
+      name_off.push_back(no); name_len.push_back(nl);
+      seq_off.push_back(so); seq_len.push_back(sl);
+      qual_off.push_back(qo); qual_len.push_back(ql);
+    }
+  };
+  Store st[2];
+  int cur = 0;               // the store being handed out
+  size_t cursor = 0;         // records of st[cur] already handed out
+  bool cur_valid = false;
+  std::future<int> ahead;    // parse of st[cur ^ 1] in flight
+  bool ahead_valid = false;
+  const char *err_msg = nullptr;
+
+  int parse(Store &S, uint64_t max_records);
 
   long raw_read(char *dst, size_t cap) {
     if (gz) {
@@ -108,6 +130,66 @@ struct dcrx_fastq {
   }
 };
 
+int dcrx_fastq::parse(Store &S, uint64_t max_records) {
+  dcrx_fastq *f = this;
+  S.clear();
+  int err = 0;
+  const char *p; size_t len;
+  while (!f->finished && S.name_off.size() < max_records) {
+    if (!f->have_last || f->last.empty()) {                   // :231-235  look for the next header
+      f->have_last = false;
+      while (f->next_line(p, len, err)) {
+        if (p[0] == '>' || p[0] == '@') { f->last.assign(p, len - 1); f->have_last = true; break; }
+      }
+    }
+    if (err) { err_msg = "read error in FASTQ file"; return DCRX_E_INVALID; }
+    if (!f->have_last || f->last.empty()) { f->finished = true; break; }   // :236-237
+    // :238  name = last[1:].partition(" ")[0]
+    const uint64_t name_off = S.text.size();
+    {
+      const char *h = f->last.data() + 1;
+      const size_t hl = f->last.size() - 1;
+      const void *sp = std::memchr(h, ' ', hl);
+      const size_t nl = sp ? (size_t)((const char *)sp - h) : hl;
+      S.text.insert(S.text.end(), h, h + nl);
+    }
+    const uint32_t name_len = (uint32_t)(S.text.size() - name_off);
+    f->have_last = false; f->last.clear();
+    const uint64_t seq_off = S.text.size();
+    while (f->next_line(p, len, err)) {                       // :239-243
+      if (p[0] == '@' || p[0] == '+' || p[0] == '>') { f->last.assign(p, len - 1); f->have_last = true; break; }
+      S.text.insert(S.text.end(), p, p + len - 1);
+    }
+    if (err) { err_msg = "read error in FASTQ file"; return DCRX_E_INVALID; }
+    const uint64_t seq_len64 = S.text.size() - seq_off;
+    if (seq_len64 > 0xFFFFFFF0ull) { err_msg = "sequence too long"; return DCRX_E_INVALID; }
+    const uint32_t seq_len = (uint32_t)seq_len64;
+    const bool last_true = f->have_last && !f->last.empty();
+    if (!last_true || f->last[0] != '+') {                    // :244-247  FASTA record
+      S.emit(name_off, name_len, seq_off, seq_len, 0, DCRX_FASTQ_NO_QUAL);
+      if (!last_true) { f->finished = true; break; }
+      continue;
+    }
+    const uint64_t qual_off = S.text.size();                 // :248-260
+    uint64_t leng = 0;
+    bool complete = false;
+    while (f->next_line(p, len, err)) {
+      S.text.insert(S.text.end(), p, p + len - 1);
+      leng += len - 1;
+      if (leng >= seq_len) { complete = true; break; }
+    }
+    if (err) { err_msg = "read error in FASTQ file"; return DCRX_E_INVALID; }
+    if (complete) {
+      f->have_last = false; f->last.clear();
+      S.emit(name_off, name_len, seq_off, seq_len, qual_off, (uint32_t)leng);
+    } else {                                                  // :261-263  EOF inside the quality
+      S.emit(name_off, name_len, seq_off, seq_len, 0, DCRX_FASTQ_NO_QUAL);
+      f->finished = true;
+    }
+  }
+  return DCRX_OK;
+}
+
 extern "C" {
 
 int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out) {
@@ -137,6 +219,7 @@ int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out) {
 
 void dcrx_fastq_close(dcrx_fastq_t *f) {
   if (!f) return;
+  if (f->ahead_valid) { f->ahead.get(); f->ahead_valid = false; }
   if (f->gz) gzclose(f->gz);
   if (f->fp) std::fclose(f->fp);
   delete f;
@@ -144,74 +227,38 @@ void dcrx_fastq_close(dcrx_fastq_t *f) {
 
 int dcrx_fastq_next(dcrx_fastq_t *f, uint64_t max_records, dcrx_fastq_batch_t *out) {
   if (!f || !out) return set_err(DCRX_E_INVALID, "null argument to dcrx_fastq_next");
-  f->text.clear();
-  f->name_off.clear(); f->seq_off.clear(); f->qual_off.clear();
-  f->name_len.clear(); f->seq_len.clear(); f->qual_len.clear();
-  int err = 0;
-  const char *p; size_t len;
-  auto emit = [&](uint64_t no, uint32_t nl, uint64_t so, uint32_t sl, uint64_t qo, uint32_t ql) {
-    f->name_off.push_back(no); f->name_len.push_back(nl);
-    f->seq_off.push_back(so); f->seq_len.push_back(sl);
-    f->qual_off.push_back(qo); f->qual_len.push_back(ql);
-  };
-  while (!f->finished && f->name_off.size() < max_records) {
-    if (!f->have_last || f->last.empty()) {                   // :231-235  look for the next header
-      f->have_last = false;
-      while (f->next_line(p, len, err)) {
-        if (p[0] == '>' || p[0] == '@') { f->last.assign(p, len - 1); f->have_last = true; break; }
-      }
+  std::memset(out, 0, sizeof *out);
+  if (max_records == 0) return DCRX_OK;
+  if (!f->cur_valid || f->cursor >= f->st[f->cur].name_off.size()) {
+    // the current chunk is used up: take the one parsed ahead, or parse now
+    int rc;
+    if (f->ahead_valid) {
+      rc = f->ahead.get();
+      f->ahead_valid = false;
+      f->cur ^= 1;
+    } else {
+      rc = f->parse(f->st[f->cur], max_records);
     }
-    if (err) return set_err(DCRX_E_INVALID, "read error in FASTQ file");
-    if (!f->have_last || f->last.empty()) { f->finished = true; break; }   // :236-237
-    // :238  name = last[1:].partition(" ")[0]
-    const uint64_t name_off = f->text.size();
-    {
-      const char *h = f->last.data() + 1;
-      const size_t hl = f->last.size() - 1;
-      const void *sp = std::memchr(h, ' ', hl);
-      const size_t nl = sp ? (size_t)((const char *)sp - h) : hl;
-      f->text.insert(f->text.end(), h, h + nl);
-    }
-    const uint32_t name_len = (uint32_t)(f->text.size() - name_off);
-    f->have_last = false; f->last.clear();
-    const uint64_t seq_off = f->text.size();
-    while (f->next_line(p, len, err)) {                       // :239-243
-      if (p[0] == '@' || p[0] == '+' || p[0] == '>') { f->last.assign(p, len - 1); f->have_last = true; break; }
-      f->text.insert(f->text.end(), p, p + len - 1);
-    }
-    if (err) return set_err(DCRX_E_INVALID, "read error in FASTQ file");
-    const uint64_t seq_len64 = f->text.size() - seq_off;
-    if (seq_len64 > 0xFFFFFFF0ull) return set_err(DCRX_E_INVALID, "sequence too long");
-    const uint32_t seq_len = (uint32_t)seq_len64;
-    const bool last_true = f->have_last && !f->last.empty();
-    if (!last_true || f->last[0] != '+') {                    // :244-247  FASTA record
-      emit(name_off, name_len, seq_off, seq_len, 0, DCRX_FASTQ_NO_QUAL);
-      if (!last_true) { f->finished = true; break; }
-      continue;
-    }
-    const uint64_t qual_off = f->text.size();                 // :248-260
-    uint64_t leng = 0;
-    bool complete = false;
-    while (f->next_line(p, len, err)) {
-      f->text.insert(f->text.end(), p, p + len - 1);
-      leng += len - 1;
-      if (leng >= seq_len) { complete = true; break; }
-    }
-    if (err) return set_err(DCRX_E_INVALID, "read error in FASTQ file");
-    if (complete) {
-      f->have_last = false; f->last.clear();
-      emit(name_off, name_len, seq_off, seq_len, qual_off, (uint32_t)leng);
-    } else {                                                  // :261-263  EOF inside the quality
-      emit(name_off, name_len, seq_off, seq_len, 0, DCRX_FASTQ_NO_QUAL);
-      f->finished = true;
+    if (rc != DCRX_OK) return set_err(rc, f->err_msg ? f->err_msg : "FASTQ reader failed");
+    f->cur_valid = true;
+    f->cursor = 0;
+    if (!f->finished) {      // read ahead while the caller works on this chunk
+      dcrx_fastq::Store *other = &f->st[f->cur ^ 1];
+      f->ahead = std::async(std::launch::async, [f, other, max_records] { return f->parse(*other, max_records); });
+      f->ahead_valid = true;
     }
   }
-  out->n_records = f->name_off.size();
-  out->text = f->text.data();
-  out->text_bytes = f->text.size();
-  out->name_off = f->name_off.data(); out->name_len = f->name_len.data();
-  out->seq_off = f->seq_off.data(); out->seq_len = f->seq_len.data();
-  out->qual_off = f->qual_off.data(); out->qual_len = f->qual_len.data();
+  const dcrx_fastq::Store &S = f->st[f->cur];
+  const size_t have = S.name_off.size() - f->cursor;
+  const size_t k = have < max_records ? have : (size_t)max_records;
+  const size_t c = f->cursor;
+  out->n_records = k;
+  out->text = S.text.data();
+  out->text_bytes = S.text.size();
+  out->name_off = S.name_off.data() + c; out->name_len = S.name_len.data() + c;
+  out->seq_off = S.seq_off.data() + c; out->seq_len = S.seq_len.data() + c;
+  out->qual_off = S.qual_off.data() + c; out->qual_len = S.qual_len.data() + c;
+  f->cursor += k;
   return DCRX_OK;
 }
 

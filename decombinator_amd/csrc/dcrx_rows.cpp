@@ -32,7 +32,12 @@ const Comp g_comp;
 
 struct Out {
   char *p; uint64_t cap, n;
-  void put(const char *s, uint64_t k) { if (n + k <= cap) std::memcpy(p + n, s, k); n += k; }
+  char sep; bool clash;      // clash: a field holds the separator byte itself
+  void put(const char *s, uint64_t k) {
+    if (k && std::memchr(s, sep, k)) clash = true;
+    if (n + k <= cap) std::memcpy(p + n, s, k);
+    n += k;
+  }
   void ch(char c) { if (n < cap) p[n] = c; n++; }
   void num(unsigned v) { char b[16]; const int k = std::snprintf(b, sizeof b, "%u", v); put(b, (uint64_t)k); }
   // frame string [a, b) of a span of length len: forward = the bytes, reverse = reversed (and complemented)
@@ -40,6 +45,7 @@ struct Out {
     if (b > len) b = len;
     if (a >= b) return;
     const uint64_t k = b - a;
+    if (std::memchr(rev ? s + (len - b) : s + a, sep, k)) clash = true;
     if (n + k <= cap) {
       char *o = p + n;
       if (!rev) std::memcpy(o, s + a, k);
@@ -57,7 +63,7 @@ extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_r
                                       uint64_t out_cap, uint64_t *n_rows) {
   if ((n_reads && !records) || !vdj || !qual || !id || !bc || !bcq)
     return set_err(DCRX_E_INVALID, "null argument to dcrx_assemble_rows");
-  Out o{out, out ? out_cap : 0, 0};
+  Out o{out, out ? out_cap : 0, 0, field_sep, false};
   uint64_t rows = 0;
   for (uint64_t r = 0; r < n_reads; r++) {
     const dcrx_record_t &c = records[r];
@@ -79,5 +85,6 @@ extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_r
     rows++;
   }
   if (n_rows) *n_rows = rows;
+  if (o.clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the separator byte");
   return (int64_t)o.n;
 }

@@ -17,6 +17,7 @@ Mirrored reference functions (file:line in /root/reference/src/decombinator/deco
 from __future__ import annotations
 
 import collections as coll
+import collections.abc
 import gzip
 import itertools
 import os
@@ -399,24 +400,96 @@ def _next_spans(rd1, rd2, bclength, sampling):
 _FIELD_SEP = "\x1f"
 
 
-def assemble_rows_spans(records, sp):
+class N12Rows(coll.abc.Sequence):
+    """The rows decombinator() returns (reference: a list of 10/11-field lists, :1039), kept as
+    the text libdcrx assembled and turned into lists only when somebody asks: iteration, indexing,
+    len() and == with a list behave like the reference's list; write_out_intermediate() writes
+    the text without ever building the lists."""
+
+    def __init__(self):
+        self._chunks = []      # (bytes blob with _FIELD_SEP between fields and "\n" after each row | None, list | None)
+        self._len = 0
+        self._lists = None
+
+    def _add_blob(self, blob: bytes, n: int) -> None:
+        if n:
+            self._chunks.append([blob, None, n])
+            self._len += n
+            self._lists = None
+
+    def extend(self, rows) -> None:
+        rows = list(rows)
+        if rows:
+            self._chunks.append([None, rows, len(rows)])
+            self._len += len(rows)
+            self._lists = None
+
+    def append(self, row) -> None:
+        self.extend([row])
+
+    @staticmethod
+    def _split(blob: bytes):
+        rows = [ln.split(_FIELD_SEP) for ln in blob.decode("utf-8", "replace").split("\n")]
+        rows.pop()             # the text ends with a newline
+        return rows
+
+    def __len__(self):
+        return self._len
+
+    def __iter__(self):
+        for blob, rows, _ in self._chunks:
+            yield from (rows if rows is not None else self._split(blob))
+
+    def _all(self):
+        if self._lists is None:
+            self._lists = list(iter(self))
+        return self._lists
+
+    def __getitem__(self, k):
+        return self._all()[k]
+
+    def __eq__(self, other):
+        if isinstance(other, (list, N12Rows)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def __repr__(self):
+        return f"N12Rows({self._len} rows)"
+
+    def write_text(self, fh, joiner: str = ", ") -> None:
+        """One row per line, fields joined by `joiner` (reference io.py:507-509)."""
+        sep, j = _FIELD_SEP.encode(), joiner.encode()
+        for blob, rows, _ in self._chunks:
+            if rows is not None:
+                fh.write("".join(joiner.join(map(str, r)) + "\n" for r in rows))
+            else:
+                fh.write(blob.replace(sep, j).decode("utf-8", "replace"))
+
+
+def assemble_rows_spans(records, sp, into=None):
     """assemble_rows for a batch held as spans, in bulk: libdcrx writes the rows as text
     (dcrx_assemble_rows), which is split back into the reference's list-of-lists.  A batch whose
     text holds the separator byte (never in a real FASTQ) takes the per-row path below."""
-    sep = _FIELD_SEP.encode()
-    if sep in sp.v_text or (sp.bc_text is not sp.v_text and sep in sp.bc_text):
-        return _assemble_rows_spans_py(records, sp)
     hit = records["status"] == 0
     if not hit.any():
-        return []
+        return None if into is not None else []
     if (sp.q_len[hit] == nat.NO_QUAL).any():
         raise TypeError("'NoneType' object is not subscriptable")   # tcrQ = vdjqual[...] on a FASTA record
     tail = None if sp.tail_start is None else (sp.bc_text, sp.tail_start, sp.tail_len)
-    blob, n = nat.assemble_rows_blob(records, (sp.v_text, sp.v_start, sp.v_len), (sp.v_text, sp.q_start, sp.q_len),
-                                     (sp.id_text, sp.id_start, sp.id_len), (sp.bc_text, sp.bc_start, sp.bc_len),
-                                     (sp.bc_text, sp.bcq_start, sp.bcq_len), tail, _FIELD_SEP)
-    rows = [ln.split(_FIELD_SEP) for ln in blob.decode("utf-8", "replace").split("\n")]
-    rows.pop()                         # the text ends with a newline
+    try:
+        blob, n = nat.assemble_rows_blob(records, (sp.v_text, sp.v_start, sp.v_len), (sp.v_text, sp.q_start, sp.q_len),
+                                         (sp.id_text, sp.id_start, sp.id_len), (sp.bc_text, sp.bc_start, sp.bc_len),
+                                         (sp.bc_text, sp.bcq_start, sp.bcq_len), tail, _FIELD_SEP)
+    except nat.SeparatorClash:
+        rows = _assemble_rows_spans_py(records, sp)
+        if into is not None:
+            into.extend(rows)
+            return None
+        return rows
+    if into is not None:
+        into._add_blob(blob, n)
+        return None
+    rows = N12Rows._split(blob)
     assert len(rows) == n
     return rows
 
@@ -487,8 +560,9 @@ def _summary_text(inputargs, chain, samplenam, date, timetaken):
 
 
 def decombinator(inputargs: dict) -> list:
-    """The decombine stage (reference decombinator(), :881-1202): returns the list of
-    10-field rows that write_out_intermediate() turns into the `.n12` file."""
+    """The decombine stage (reference decombinator(), :881-1202): returns the 10-field rows
+    that write_out_intermediate() turns into the `.n12` file, as an N12Rows sequence (a lazy
+    list of lists)."""
     print("Running Decombinator (MI355X / HIP build) version", __version__)
     opener = opener_check(inputargs)
     tcr = import_tcr_info(inputargs)
@@ -515,7 +589,7 @@ def decombinator(inputargs: dict) -> list:
     counts["start_time"] = time()
     stage_seconds.clear()
     print("Decombining FASTQ data...")
-    outdata = []
+    outdata = N12Rows()
     orientation = inputargs["orientation"]
     if orientation not in nat.ORIENTATIONS:
         raise ValueError("orientation must be forward, reverse or both")
@@ -548,7 +622,7 @@ def decombinator(inputargs: dict) -> list:
                 rec, cnt = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])
                 t3 = time()
                 _add_counts(cnt, skip=("read_count",))
-                outdata.extend(assemble_rows_spans(rec, spans))
+                assemble_rows_spans(rec, spans, into=outdata)
                 t4 = time()
                 for key, dt in (("read", t1 - t0), ("pack", t2 - t1), ("device", t3 - t2), ("rows", t4 - t3)):
                     stage_seconds[key] = stage_seconds.get(key, 0.0) + dt

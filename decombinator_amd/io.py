@@ -113,8 +113,11 @@ def write_out_intermediate(data: list, inputargs: dict, suffix: str):
         outfilename = (inputargs["outpath"] + inputargs["prefix"] + f"{filename_id}"
                        + f"_{chainnams[inputargs['chain'].lower()]}" + suffix)
     with open(outfilename, "w") as outfile:
-        for line in data:
-            outfile.write(", ".join(map(str, line)) + "\n")
+        if hasattr(data, "write_text"):          # decombine.N12Rows: the rows are text already
+            data.write_text(outfile, ", ")
+        else:
+            for line in data:
+                outfile.write(", ".join(map(str, line)) + "\n")
     if not inputargs["dontgzip"]:
         print("Compressing intermediate output file to", outfilename + ".gz")
         with open(outfilename) as infile, gzip.open(outfilename + ".gz", "wt") as outfile:

@@ -197,7 +197,8 @@ uint64_t dcrx_count_prefix_byte(const char *text, const uint64_t *start, const u
  * give read r's strings as spans (tail may be NULL: no sampling_analysis).  The reverse frame
  * is revcomp(vdj) and qual[::-1] (:1015-1017); slices clamp like Python's.
  * Returns the number of bytes the rows take; they are written only when that fits out_cap
- * (call with out = NULL to size the buffer).  *n_rows = rows. */
+ * (call with out = NULL to size the buffer).  *n_rows = rows.  DCRX_E_UNSUPPORTED when a field
+ * itself contains field_sep (or '\n' cannot occur: lines are split there). */
 typedef struct {
   const char *text;
   const uint64_t *start;

@@ -160,3 +160,32 @@ def test_bulk_row_assembly_equals_per_row_assembly():
         # and the list form used by the reference-shaped API
         lst = host.assemble_rows(rec, seqs, quals, ids, bcs, bcqs, tails if with_tail else None)
         assert lst == bulk
+
+
+def test_separator_byte_in_a_field_falls_back_to_the_per_row_path():
+    rec = np.zeros(2, dtype=nat.RECORD_DTYPE)
+    rec["frame"] = 1
+    rec["j_end"] = 4
+    text = b"ACGT|IIII|id\x1fx|AC|II|ACGT|IIII|id2|AC|II|"
+    start = np.array([0, 5, 10, 15, 18, 21, 26, 31, 35, 38], dtype=np.uint64)
+    lens = np.array([4, 4, 4, 2, 2, 4, 4, 3, 2, 2], dtype=np.uint32)
+
+    class SP:
+        pass
+    sp = SP()
+    sp.v_text = sp.id_text = sp.bc_text = text
+    sp.v_start, sp.v_len = start[0::5], lens[0::5]
+    sp.q_start, sp.q_len = start[1::5], lens[1::5]
+    sp.id_start, sp.id_len = start[2::5], lens[2::5]
+    sp.bc_start, sp.bc_len = start[3::5], lens[3::5]
+    sp.bcq_start, sp.bcq_len = start[4::5], lens[4::5]
+    sp.tail_start = sp.tail_len = None
+    with pytest.raises(nat.SeparatorClash):
+        nat.assemble_rows_blob(rec, (text, sp.v_start, sp.v_len), (text, sp.q_start, sp.q_len), (text, sp.id_start, sp.id_len),
+                               (text, sp.bc_start, sp.bc_len), (text, sp.bcq_start, sp.bcq_len))
+    rows = host.assemble_rows_spans(rec, sp)
+    assert rows == [["0", "0", "0", "0", "", "id\x1fx", "ACGT", "IIII", "AC", "II"],
+                    ["0", "0", "0", "0", "", "id2", "ACGT", "IIII", "AC", "II"]]
+    out = host.N12Rows()
+    host.assemble_rows_spans(rec, sp, into=out)
+    assert out == rows and len(out) == 2 and out[1][5] == "id2"

@@ -37,7 +37,7 @@ with tempfile.TemporaryDirectory() as td:
     size = os.path.getsize(os.path.join(td, "S_1" + ext)) + os.path.getsize(os.path.join(td, "S_2" + ext))
     a = dio.create_args_dict(infile=os.path.join(td, "S_1" + ext), chain="b", bc_read="R2", dontgzip=True, dontcount=True,
                              dontcheck=True, suppresssummary=True, tagfastadir=os.path.join(td, "tags"),
-                             outpath=td + os.sep, command="decombine")
+                             outpath=td + os.sep, command="decombine", tags=ts.tags, species=ts.species)
     for rep in range(2):
         dec.counts.clear()
         t0 = time.perf_counter()
