@@ -142,7 +142,7 @@ def lib():
         "dcrx_fastq_next": (i32, [vp, u64, C.POINTER(FastqBatchC)]),
         "dcrx_count_prefix_byte": (u64, [vp, vp, vp, u64, u32, i32]),
         "dcrx_assemble_rows": (C.c_int64, [vp, u64, C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC),
-                                           C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC), C.c_char, vp, u64,
+                                           C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC), C.c_char_p, vp, u64,
                                            C.POINTER(u64)]),
         "dcrx_decombine": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp]),
         "dcrx_decombine_device": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp, vp]),
@@ -427,7 +427,7 @@ class SeparatorClash(RuntimeError):
     """A row field contains the field separator byte: the caller assembles that batch row by row."""
 
 
-def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep: str = "\x1f"):
+def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep: str = ", "):
     """dcrx_assemble_rows: each argument after `records` is (text bytes, uint64 start[], uint32 len[]).
     Returns (bytes blob of '\n'-terminated rows, number of rows)."""
     keep = []
@@ -446,13 +446,17 @@ def assemble_rows_blob(records, vdj, qual, ident, bc, bcq, tail=None, field_sep:
     nrows = C.c_uint64(0)
     sep = field_sep.encode("latin-1")
     need = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, None, 0, C.byref(nrows)))
-    if need == -2:                      # DCRX_E_UNSUPPORTED
-        raise SeparatorClash(lib().dcrx_last_error().decode("utf-8", "replace"))
     check(need)
-    out = np.empty(max(need, 1), dtype=np.uint8)
-    got = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, out.ctypes.data, need, C.byref(nrows)))
-    check(got)
-    return out[:need].tobytes(), int(nrows.value)
+    out = bytearray(need)
+    if need:
+        ptr = (C.c_char * need).from_buffer(out)
+        got = int(lib().dcrx_assemble_rows(records.ctypes.data, len(records), *args, sep, C.addressof(ptr), need,
+                                           C.byref(nrows)))
+        del ptr
+        if got == -2:                   # DCRX_E_UNSUPPORTED
+            raise SeparatorClash(lib().dcrx_last_error().decode("utf-8", "replace"))
+        check(got)
+    return out, int(nrows.value)
 
 
 def unpack_reads_raw(batch: PackedBatch):

@@ -6,7 +6,9 @@
 // Python's slice clamping; the reverse frame is revcomp(vdj) / vdjqual[::-1] (:1015-1017)
 // with Bio.Seq's complement table (ambiguous codes, both cases, other bytes unchanged).
 // Output: one line per decombined read, in read order, fields separated by `field_sep`.
-#include <cstdio>
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   // memmem
+#endif
 #include <cstring>
 #include <vector>
 
@@ -30,28 +32,35 @@ struct Comp {
 };
 const Comp g_comp;
 
+inline uint32_t ndigits(unsigned v) { return v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : 5; }
+inline uint32_t clamp_len(uint32_t len, uint32_t a, uint32_t b) { if (b > len) b = len; return a < b ? b - a : 0; }
+
 struct Out {
-  char *p; uint64_t cap, n;
-  char sep; bool clash;      // clash: a field holds the separator byte itself
+  char *p; uint64_t n;
+  const char *sep; size_t sep_len; bool clash;      // clash: a field holds the separator itself
+  bool holds_sep(const char *s, uint64_t k) const { return k >= sep_len && memmem(s, k, sep, sep_len) != nullptr; }
   void put(const char *s, uint64_t k) {
-    if (k && std::memchr(s, sep, k)) clash = true;
-    if (n + k <= cap) std::memcpy(p + n, s, k);
+    if (holds_sep(s, k)) clash = true;
+    std::memcpy(p + n, s, k);
     n += k;
   }
-  void ch(char c) { if (n < cap) p[n] = c; n++; }
-  void num(unsigned v) { char b[16]; const int k = std::snprintf(b, sizeof b, "%u", v); put(b, (uint64_t)k); }
+  void ch(char c) { p[n++] = c; }
+  void fs() { std::memcpy(p + n, sep, sep_len); n += sep_len; }
+  void num(unsigned v) {     // v < 65536
+    char b[8]; int k = 0;
+    do { b[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) p[n++] = b[--k];
+  }
   // frame string [a, b) of a span of length len: forward = the bytes, reverse = reversed (and complemented)
   void cut(const char *s, uint32_t len, bool rev, bool comp, uint32_t a, uint32_t b) {
     if (b > len) b = len;
     if (a >= b) return;
     const uint64_t k = b - a;
-    if (std::memchr(rev ? s + (len - b) : s + a, sep, k)) clash = true;
-    if (n + k <= cap) {
-      char *o = p + n;
-      if (!rev) std::memcpy(o, s + a, k);
-      else if (comp) for (uint32_t i = a; i < b; i++) *o++ = (char)g_comp.t[(uint8_t)s[len - 1 - i]];
-      else for (uint32_t i = a; i < b; i++) *o++ = s[len - 1 - i];
-    }
+    char *o = p + n;
+    if (!rev) std::memcpy(o, s + a, k);
+    else if (comp) for (uint32_t i = a; i < b; i++) *o++ = (char)g_comp.t[(uint8_t)s[len - 1 - i]];
+    else for (uint32_t i = a; i < b; i++) *o++ = s[len - 1 - i];
+    if (holds_sep(p + n, k)) clash = true;
     n += k;
   }
 };
@@ -59,32 +68,44 @@ struct Out {
 
 extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
                                       const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
-                                      const dcrx_spans_t *bcq, const dcrx_spans_t *tail, char field_sep, char *out,
+                                      const dcrx_spans_t *bcq, const dcrx_spans_t *tail, const char *field_sep, char *out,
                                       uint64_t out_cap, uint64_t *n_rows) {
-  if ((n_reads && !records) || !vdj || !qual || !id || !bc || !bcq)
+  if ((n_reads && !records) || !vdj || !qual || !id || !bc || !bcq || !field_sep || !field_sep[0])
     return set_err(DCRX_E_INVALID, "null argument to dcrx_assemble_rows");
-  Out o{out, out ? out_cap : 0, 0, field_sep, false};
-  uint64_t rows = 0;
+  const size_t sep_len = std::strlen(field_sep);
+  // sizing pass: arithmetic only
+  uint64_t rows = 0, need = 0;
   for (uint64_t r = 0; r < n_reads; r++) {
     const dcrx_record_t &c = records[r];
     if (c.status != DCRX_S_OK) continue;
     if (qual->len[r] == DCRX_FASTQ_NO_QUAL)
       return set_err(DCRX_E_INVALID, "decombined read without a quality string");
-    const bool rev = c.frame == 0;
-    const char *s = vdj->text + vdj->start[r];
-    const char *q = qual->text + qual->start[r];
-    o.num(c.v); o.ch(field_sep); o.num(c.j); o.ch(field_sep); o.num(c.vdel); o.ch(field_sep); o.num(c.jdel); o.ch(field_sep);
-    o.cut(s, vdj->len[r], rev, true, c.ins_start, (uint32_t)c.ins_start + c.ins_len); o.ch(field_sep);
-    o.put(id->text + id->start[r], id->len[r]); o.ch(field_sep);
-    o.cut(s, vdj->len[r], rev, true, c.v_start, c.j_end); o.ch(field_sep);
-    o.cut(q, qual->len[r], rev, false, c.v_start, c.j_end); o.ch(field_sep);
-    o.put(bc->text + bc->start[r], bc->len[r]); o.ch(field_sep);
-    o.put(bcq->text + bcq->start[r], bcq->len[r]);
-    if (tail) { o.ch(field_sep); o.put(tail->text + tail->start[r], tail->len[r]); }
-    o.ch('\n');
+    need += ndigits(c.v) + ndigits(c.j) + ndigits(c.vdel) + ndigits(c.jdel) + 9 * sep_len + 1
+          + clamp_len(vdj->len[r], c.ins_start, (uint32_t)c.ins_start + c.ins_len) + id->len[r]
+          + clamp_len(vdj->len[r], c.v_start, c.j_end) + clamp_len(qual->len[r], c.v_start, c.j_end)
+          + bc->len[r] + bcq->len[r] + (tail ? sep_len + tail->len[r] : 0);
     rows++;
   }
   if (n_rows) *n_rows = rows;
-  if (o.clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the separator byte");
-  return (int64_t)o.n;
+  if (!out || need > out_cap) return (int64_t)need;
+  Out o{out, 0, field_sep, sep_len, false};
+  for (uint64_t r = 0; r < n_reads; r++) {
+    const dcrx_record_t &c = records[r];
+    if (c.status != DCRX_S_OK) continue;
+    const bool rev = c.frame == 0;
+    const char *s = vdj->text + vdj->start[r];
+    const char *q = qual->text + qual->start[r];
+    o.num(c.v); o.fs(); o.num(c.j); o.fs(); o.num(c.vdel); o.fs(); o.num(c.jdel); o.fs();
+    o.cut(s, vdj->len[r], rev, true, c.ins_start, (uint32_t)c.ins_start + c.ins_len); o.fs();
+    o.put(id->text + id->start[r], id->len[r]); o.fs();
+    o.cut(s, vdj->len[r], rev, true, c.v_start, c.j_end); o.fs();
+    o.cut(q, qual->len[r], rev, false, c.v_start, c.j_end); o.fs();
+    o.put(bc->text + bc->start[r], bc->len[r]); o.fs();
+    o.put(bcq->text + bcq->start[r], bcq->len[r]);
+    if (tail) { o.fs(); o.put(tail->text + tail->start[r], tail->len[r]); }
+    o.ch('\n');
+  }
+  if (n_rows) *n_rows = rows;
+  if (o.clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the field separator");
+  return (int64_t)need;
 }

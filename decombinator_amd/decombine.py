@@ -397,7 +397,7 @@ def _next_spans(rd1, rd2, bclength, sampling):
     return sp
 
 
-_FIELD_SEP = "\x1f"
+_FIELD_SEP = ", "      # the `.n12` separator (io.py:507-509); no field of a well-formed FASTQ can hold it
 
 
 class N12Rows(coll.abc.Sequence):
@@ -463,7 +463,8 @@ class N12Rows(coll.abc.Sequence):
             if rows is not None:
                 fh.write("".join(joiner.join(map(str, r)) + "\n" for r in rows))
             else:
-                fh.write(blob.replace(sep, j).decode("utf-8", "replace"))
+                fh.flush()                     # the FASTQ's own bytes, as the reference's text mode writes them
+                fh.buffer.write(blob if sep == j else blob.replace(sep, j))
 
 
 def assemble_rows_spans(records, sp, into=None):

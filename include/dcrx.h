@@ -193,11 +193,12 @@ uint64_t dcrx_count_prefix_byte(const char *text, const uint64_t *start, const u
  * Replaces the row building of the read loop (decombine.py:1012-1039) for a whole batch:
  * for every record with status DCRX_S_OK, in read order, one line
  *   v j vdel jdel insert id inter-tag-seq inter-tag-qual barcode barcode-qual [v_tail]
- * with `field_sep` between fields and '\n' after the row.  vdj / qual / id / bc / bcq / tail
+ * with the string `field_sep` (", " gives the `.n12` text itself, io.py:507-509) between fields
+ * and '\n' after the row.  vdj / qual / id / bc / bcq / tail
  * give read r's strings as spans (tail may be NULL: no sampling_analysis).  The reverse frame
  * is revcomp(vdj) and qual[::-1] (:1015-1017); slices clamp like Python's.
- * Returns the number of bytes the rows take; they are written only when that fits out_cap
- * (call with out = NULL to size the buffer).  *n_rows = rows.  DCRX_E_UNSUPPORTED when a field
+ * Returns the number of bytes the rows take (computed without touching the text); they are
+ * written only when out != NULL and that fits out_cap (call with out = NULL to size the buffer).  *n_rows = rows.  DCRX_E_UNSUPPORTED when a field
  * itself contains field_sep (or '\n' cannot occur: lines are split there). */
 typedef struct {
   const char *text;
@@ -207,7 +208,7 @@ typedef struct {
 
 int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
                            const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
-                           const dcrx_spans_t *bcq, const dcrx_spans_t *tail, char field_sep,
+                           const dcrx_spans_t *bcq, const dcrx_spans_t *tail, const char *field_sep,
                            char *out, uint64_t out_cap, uint64_t *n_rows);
 
 /* ---- the hot path: replaces the body of the read loop, decombine.py:998-1013 ---- */

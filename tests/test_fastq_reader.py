@@ -162,13 +162,14 @@ def test_bulk_row_assembly_equals_per_row_assembly():
         assert lst == bulk
 
 
-def test_separator_byte_in_a_field_falls_back_to_the_per_row_path():
+def test_separator_inside_a_field_falls_back_to_the_per_row_path():
     rec = np.zeros(2, dtype=nat.RECORD_DTYPE)
     rec["frame"] = 1
     rec["j_end"] = 4
-    text = b"ACGT|IIII|id\x1fx|AC|II|ACGT|IIII|id2|AC|II|"
-    start = np.array([0, 5, 10, 15, 18, 21, 26, 31, 35, 38], dtype=np.uint64)
-    lens = np.array([4, 4, 4, 2, 2, 4, 4, 3, 2, 2], dtype=np.uint32)
+    text = b"ACGT|IIII|id, x|AC|II|ACGT|IIII|id2|AC|II|"
+    lens = np.array([4, 4, 5, 2, 2, 4, 4, 3, 2, 2], dtype=np.uint32)
+    start = np.zeros(10, dtype=np.uint64)
+    start[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 1)
 
     class SP:
         pass
@@ -184,7 +185,7 @@ def test_separator_byte_in_a_field_falls_back_to_the_per_row_path():
         nat.assemble_rows_blob(rec, (text, sp.v_start, sp.v_len), (text, sp.q_start, sp.q_len), (text, sp.id_start, sp.id_len),
                                (text, sp.bc_start, sp.bc_len), (text, sp.bcq_start, sp.bcq_len))
     rows = host.assemble_rows_spans(rec, sp)
-    assert rows == [["0", "0", "0", "0", "", "id\x1fx", "ACGT", "IIII", "AC", "II"],
+    assert rows == [["0", "0", "0", "0", "", "id, x", "ACGT", "IIII", "AC", "II"],
                     ["0", "0", "0", "0", "", "id2", "ACGT", "IIII", "AC", "II"]]
     out = host.N12Rows()
     host.assemble_rows_spans(rec, sp, into=out)
