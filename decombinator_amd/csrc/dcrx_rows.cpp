@@ -10,6 +10,8 @@
 #define _GNU_SOURCE   // memmem
 #endif
 #include <cstring>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../include/dcrx.h"
@@ -73,39 +75,73 @@ extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_r
   if ((n_reads && !records) || !vdj || !qual || !id || !bc || !bcq || !field_sep || !field_sep[0])
     return set_err(DCRX_E_INVALID, "null argument to dcrx_assemble_rows");
   const size_t sep_len = std::strlen(field_sep);
-  // sizing pass: arithmetic only
+  // Reads are split into contiguous ranges over a few threads: a sizing pass (arithmetic only)
+  // gives every range its place in the output, then the ranges are written independently.
+  unsigned nt = 1;
+  if (n_reads >= (1u << 16)) {
+    nt = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("DCRX_HOST_THREADS")) nt = (unsigned)std::atoi(e);
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+  }
+  std::vector<uint64_t> r_need(nt, 0), r_rows(nt, 0);
+  std::vector<int> r_bad(nt, 0), r_clash(nt, 0);
+  auto range = [&](unsigned k, uint64_t &lo, uint64_t &hi) { lo = n_reads * k / nt; hi = n_reads * (k + 1) / nt; };
+  auto size_pass = [&](unsigned k) {
+    uint64_t lo, hi; range(k, lo, hi);
+    uint64_t rows = 0, need = 0;
+    for (uint64_t r = lo; r < hi; r++) {
+      const dcrx_record_t &c = records[r];
+      if (c.status != DCRX_S_OK) continue;
+      if (qual->len[r] == DCRX_FASTQ_NO_QUAL) { r_bad[k] = 1; return; }
+      need += ndigits(c.v) + ndigits(c.j) + ndigits(c.vdel) + ndigits(c.jdel) + 9 * sep_len + 1
+            + clamp_len(vdj->len[r], c.ins_start, (uint32_t)c.ins_start + c.ins_len) + id->len[r]
+            + clamp_len(vdj->len[r], c.v_start, c.j_end) + clamp_len(qual->len[r], c.v_start, c.j_end)
+            + bc->len[r] + bcq->len[r] + (tail ? sep_len + tail->len[r] : 0);
+      rows++;
+    }
+    r_need[k] = need; r_rows[k] = rows;
+  };
+  auto run = [&](auto &&fn) {
+    if (nt == 1) { fn(0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) th.emplace_back(fn, k);
+    for (auto &x : th) x.join();
+  };
+  run(size_pass);
   uint64_t rows = 0, need = 0;
-  for (uint64_t r = 0; r < n_reads; r++) {
-    const dcrx_record_t &c = records[r];
-    if (c.status != DCRX_S_OK) continue;
-    if (qual->len[r] == DCRX_FASTQ_NO_QUAL)
-      return set_err(DCRX_E_INVALID, "decombined read without a quality string");
-    need += ndigits(c.v) + ndigits(c.j) + ndigits(c.vdel) + ndigits(c.jdel) + 9 * sep_len + 1
-          + clamp_len(vdj->len[r], c.ins_start, (uint32_t)c.ins_start + c.ins_len) + id->len[r]
-          + clamp_len(vdj->len[r], c.v_start, c.j_end) + clamp_len(qual->len[r], c.v_start, c.j_end)
-          + bc->len[r] + bcq->len[r] + (tail ? sep_len + tail->len[r] : 0);
-    rows++;
+  for (unsigned k = 0; k < nt; k++) {
+    if (r_bad[k]) return set_err(DCRX_E_INVALID, "decombined read without a quality string");
+    rows += r_rows[k]; need += r_need[k];
   }
   if (n_rows) *n_rows = rows;
   if (!out || need > out_cap) return (int64_t)need;
-  Out o{out, 0, field_sep, sep_len, false};
-  for (uint64_t r = 0; r < n_reads; r++) {
-    const dcrx_record_t &c = records[r];
-    if (c.status != DCRX_S_OK) continue;
-    const bool rev = c.frame == 0;
-    const char *s = vdj->text + vdj->start[r];
-    const char *q = qual->text + qual->start[r];
-    o.num(c.v); o.fs(); o.num(c.j); o.fs(); o.num(c.vdel); o.fs(); o.num(c.jdel); o.fs();
-    o.cut(s, vdj->len[r], rev, true, c.ins_start, (uint32_t)c.ins_start + c.ins_len); o.fs();
-    o.put(id->text + id->start[r], id->len[r]); o.fs();
-    o.cut(s, vdj->len[r], rev, true, c.v_start, c.j_end); o.fs();
-    o.cut(q, qual->len[r], rev, false, c.v_start, c.j_end); o.fs();
-    o.put(bc->text + bc->start[r], bc->len[r]); o.fs();
-    o.put(bcq->text + bcq->start[r], bcq->len[r]);
-    if (tail) { o.fs(); o.put(tail->text + tail->start[r], tail->len[r]); }
-    o.ch('\n');
-  }
-  if (n_rows) *n_rows = rows;
-  if (o.clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the field separator");
+  std::vector<uint64_t> r_off(nt, 0);
+  for (unsigned k = 1; k < nt; k++) r_off[k] = r_off[k - 1] + r_need[k - 1];
+  auto write_pass = [&](unsigned k) {
+    uint64_t lo, hi; range(k, lo, hi);
+    Out o{out + r_off[k], 0, field_sep, sep_len, false};
+    for (uint64_t r = lo; r < hi; r++) {
+      const dcrx_record_t &c = records[r];
+      if (c.status != DCRX_S_OK) continue;
+      const bool rev = c.frame == 0;
+      const char *s = vdj->text + vdj->start[r];
+      const char *q = qual->text + qual->start[r];
+      o.num(c.v); o.fs(); o.num(c.j); o.fs(); o.num(c.vdel); o.fs(); o.num(c.jdel); o.fs();
+      o.cut(s, vdj->len[r], rev, true, c.ins_start, (uint32_t)c.ins_start + c.ins_len); o.fs();
+      o.put(id->text + id->start[r], id->len[r]); o.fs();
+      o.cut(s, vdj->len[r], rev, true, c.v_start, c.j_end); o.fs();
+      o.cut(q, qual->len[r], rev, false, c.v_start, c.j_end); o.fs();
+      o.put(bc->text + bc->start[r], bc->len[r]); o.fs();
+      o.put(bcq->text + bcq->start[r], bcq->len[r]);
+      if (tail) { o.fs(); o.put(tail->text + tail->start[r], tail->len[r]); }
+      o.ch('\n');
+    }
+    r_clash[k] = o.clash ? 1 : 0;
+  };
+  run(write_pass);
+  bool clash = false;
+  for (unsigned k = 0; k < nt; k++) clash = clash || r_clash[k];
+  if (clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the field separator");
   return (int64_t)need;
 }
