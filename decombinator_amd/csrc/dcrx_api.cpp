@@ -50,10 +50,10 @@ struct dcrx_tables {
   uint8_t *d_blob = nullptr;
   DevTables dev{};
   LaunchPlan plan{};
-  uint32_t *d_block_counts = nullptr;
+  bool ws_dirty = true;       // work counters / exception bitmap must be zeroed before the next launch
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
-  uint32_t *d_queue = nullptr;  // [4 counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
+  uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
   uint64_t compact_reads = 0;
@@ -66,9 +66,9 @@ struct dcrx_tables {
 
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
-  (void)hipFree(t->d_blob); (void)hipFree(t->d_block_counts); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue);
+  (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue);
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
-  t->d_blob = nullptr; t->d_block_counts = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
+  t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
   t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
 }
@@ -184,7 +184,6 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
     t->plan = P;
-    HIP_TRY(hipMalloc(&t->d_block_counts, (size_t)(P.grid + P.qgrid) * DCRX_N_COUNTERS * 4));
     t->device = dev;
   }
   if (max_reads < 4096) max_reads = 4096;  // workspace exists even for empty batches
@@ -192,8 +191,16 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
     (void)hipFree(t->d_queue); t->d_queue = nullptr;
     HIP_TRY(hipMalloc(&t->d_exc_flag, ((max_reads + 31) / 32) * 4 + 16));
-    HIP_TRY(hipMalloc(&t->d_queue, (2 * max_reads + 8) * 4));  // [count, gcount, -, -][rescue queue][general queue]
+    HIP_TRY(hipMalloc(&t->d_queue, (2 * max_reads + DCRX_QUEUE_HEADER) * 4));  // [work counters][rescue queue][general queue]
     t->exc_flag_reads = max_reads;
+    t->ws_dirty = true;
+  }
+  if (t->ws_dirty) {
+    // the kernels leave the work counters and the exception bitmap zeroed; they are zeroed here
+    // only once per allocation, or after a launch that failed part-way
+    HIP_TRY(hipMemset(t->d_exc_flag, 0, ((t->exc_flag_reads + 31) / 32) * 4 + 16));
+    HIP_TRY(hipMemset(t->d_queue, 0, DCRX_QUEUE_HEADER * 4));
+    t->ws_dirty = false;
   }
   if (max_reads > t->compact_reads) {
     (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off);
@@ -244,9 +251,10 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
-  HIP_TRY(launch_decombine(t->plan, t->dev, B, C, d_records, t->d_block_counts, t->d_queue + 4, t->d_queue + 4 + t->exc_flag_reads,
-                           t->d_queue, d_counters, (hipStream_t)stream,
-                           t->ev_start, t->ev_stop));
+  const hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
+                                         t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
+                                         (hipStream_t)stream, t->ev_start, t->ev_stop);
+  if (le != hipSuccess) { t->ws_dirty = true; return hip_err(le, "launch_decombine"); }
   return DCRX_OK;
 }
 

@@ -1071,6 +1071,10 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
     if (attempt == 0) {
       const ScanOut so = scan_collect<true, TABLE_LDS>(T, lds_trans, rv, hh);
+      if (cfg.flags & DCRX_F_PROFILE_LIST_SCAN_ONLY) {   // profiling aid: price the collecting scan alone
+        rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend);
+        rec.j_end = (uint16_t)hh.cnts; status = 254; break;
+      }
       status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
       if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
     } else {

@@ -54,7 +54,7 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
 __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decombine_kernel(
-    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, uint32_t *__restrict__ block_counts,
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count) {
   constexpr int BLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
   extern __shared__ __align__(64) uint32_t smem[];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
     for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
   }
   __syncthreads();
-  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
 // List kernel: everything the fast kernel does not finish, in dense waves.  Two work lists,
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T0, BatchDev B, CfgDev cfg,
                                                                      dcrx_record_t *__restrict__ records,
-                                                                     uint32_t *__restrict__ block_counts,
+                                                                     unsigned long long *__restrict__ counters,
                                                                      const uint32_t *__restrict__ queue,
                                                                      const uint32_t *__restrict__ gqueue,
                                                                      uint32_t *__restrict__ queue_count) {
@@ -217,8 +217,17 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
   // tickets: one per 64 general reads, one per DCRX_CHUNK*64 rescue reads
   const uint32_t t_general = (n_general + 63) / 64, t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
+  // The last block to finish re-arms the work counters for the next launch (no memset between
+  // launches): by then every block has read the counts above.
+  auto leave = [&]() {
+    if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
+      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
+      __threadfence();
+      queue_count[4] = 0;
+    }
+  };
   if ((uint64_t)blockIdx.x * (DCRX_QBLOCK / 64) >= (uint64_t)t_general + t_rescue) {  // nothing left for this block
-    if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = 0;
+    leave();
     return;
   }
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   __syncthreads();
   const Counters C{lds_counts};
   const int lane = tid & 63;
+  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
   for (;;) {
     uint32_t ticket = 0;
     if (lane == 0) ticket = atomicAdd(tile_ticket, 1u);
@@ -239,9 +249,14 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     if (ticket >= t_general + t_rescue) break;
     if (ticket < t_general) {
       const uint32_t i = ticket * 64 + lane;
-      if (i < n_general)
-        decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)gqueue[i], C, records,
+      if (i < n_general) {
+        const uint32_t r = gqueue[i];
+        decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                    lds_slots + tid * DCRX_LSLOT);
+        // the read's exception flag has served its purpose: cleared here, so that the bitmap is
+        // all zero again when the launch ends (no memset per launch)
+        if (B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
+      }
     } else {
       const uint32_t first = (ticket - t_general) * (64 * DCRX_CHUNK);
       for (int c = 0; c < DCRX_CHUNK; c++) {
@@ -253,46 +268,28 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     }
   }
   __syncthreads();
-  if (tid < DCRX_N_COUNTERS) block_counts[(size_t)blockIdx.x * DCRX_N_COUNTERS + tid] = lds_counts[tid];
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+  leave();
 }
 
-// Sums the per-block tallies into the caller's uint64[DCRX_N_COUNTERS]:
-// one block of 1024 threads, 32 threads per counter.
-__global__ __launch_bounds__(1024) void reduce_counts_kernel(const uint32_t *__restrict__ block_counts, int n_blocks,
-                                                             uint64_t *__restrict__ out) {
-  __shared__ uint64_t part[1024];
-  const int c = threadIdx.x & (DCRX_N_COUNTERS - 1), part_id = threadIdx.x / DCRX_N_COUNTERS;
-  uint64_t s = 0;
-  for (int b = part_id; b < n_blocks; b += 1024 / DCRX_N_COUNTERS) s += block_counts[(size_t)b * DCRX_N_COUNTERS + c];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < DCRX_N_COUNTERS) {
-    uint64_t tot = 0;
-    for (int p = 0; p < 1024 / DCRX_N_COUNTERS; p++) tot += part[p * DCRX_N_COUNTERS + threadIdx.x];
-    out[threadIdx.x] = tot;
-  }
-}
-
-// The general kernel's work list: every read when `all` (orientation `both`, forced slow
-// reader), else each read that owns an exception byte, once.
-__global__ void build_general_queue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all,
-                                           uint64_t n_reads, uint32_t *__restrict__ gqueue,
-                                           uint32_t *__restrict__ gcount) {
+// Prologue of a launch, one thread per exception entry (or per read when `all`): zeroes the
+// caller's counters, sets the exception bit of every read on the exception list and builds the
+// general work list — every read when `all` (orientation `both`, forced slow reader), else the
+// reads that have exception entries (first entry of each read appends it).
+__global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all, uint64_t n_reads,
+                                uint32_t *__restrict__ flag, uint32_t *__restrict__ gqueue,
+                                uint32_t *__restrict__ gcount, unsigned long long *__restrict__ counters) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < DCRX_N_COUNTERS) counters[i] = 0;
+  if (i < n_exc) {
+    const uint32_t r = exc_read[i];
+    atomicOr(&flag[r >> 5], 1u << (r & 31));
+    if (!all && (i == 0 || exc_read[i - 1] != r)) gqueue[atomicAdd(gcount, 1u)] = r;
+  }
   if (all) {
     if (i < n_reads) gqueue[i] = (uint32_t)i;
     if (i == 0) *gcount = (uint32_t)n_reads;
-  } else if (i < n_exc) {
-    const uint32_t r = exc_read[i];
-    if (i == 0 || exc_read[i - 1] != r) gqueue[atomicAdd(gcount, 1u)] = r;
   }
-}
-
-// Marks reads that own at least one exception.
-__global__ void mark_exceptions_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc,
-                                       uint32_t *__restrict__ flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_exc) { const uint32_t r = exc_read[i]; atomicOr(&flag[r >> 5], 1u << (r & 31)); }
 }
 
 // ------------------------------------------------------------------------------
@@ -379,8 +376,8 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM, int NW, int ARITY>
 static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                             dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
-                             uint32_t *queue_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                             dcrx_record_t *rec, uint32_t *queue, uint32_t *gqueue, uint32_t *queue_count,
+                             unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kfast = decombine_kernel<TABLE_LDS, UNIFORM, NW, ARITY>;
   constexpr uint32_t FBLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
   auto klist = decombine_list_kernel<TABLE_LDS, UNIFORM>;
@@ -406,49 +403,35 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_list);
-  uint32_t *bc_list = block_counts + (size_t)P.grid * DCRX_N_COUNTERS;
-  if (all_general || B.n_exc > 0) {
-    const uint64_t items = all_general ? B.n_reads : B.n_exc;
-    hipLaunchKernelGGL(build_general_queue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read,
-                       B.n_exc, all_general ? 1 : 0, B.n_reads, gqueue, queue_count + 1);
+  // Three launches per batch and nothing else: the prologue zeroes the caller's counters (and marks
+  // / lists the reads with exception bytes), the kernels add their tallies with one atomic per
+  // counter and block, and the list kernel leaves the work counters and the exception bitmap
+  // zeroed for the next batch.
+  {
+    const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));
+    hipLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc,
+                       all_general ? 1 : 0, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, queue_count + 1,
+                       d_counters);
   }
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (grid) {
-    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, block_counts, queue, queue_count);
+    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, bc_list, queue, gqueue, queue_count);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  // blocks that were not launched contribute zero tallies
-  if (grid < P.grid) {
-    e = hipMemsetAsync(block_counts + (size_t)grid * DCRX_N_COUNTERS, 0, (size_t)(P.grid - grid) * DCRX_N_COUNTERS * 4, s);
-    if (e != hipSuccess) return e;
-  }
-  if (qgrid < P.qgrid)
-    e = hipMemsetAsync(bc_list + (size_t)qgrid * DCRX_N_COUNTERS, 0, (size_t)(P.qgrid - qgrid) * DCRX_N_COUNTERS * 4, s);
-  return e;
+  hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count);
+  return hipGetLastError();
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
-                            dcrx_record_t *rec, uint32_t *block_counts, uint32_t *queue, uint32_t *gqueue,
-                            uint32_t *queue_count, uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start,
-                            hipEvent_t ev_stop) {
+                            dcrx_record_t *rec, uint32_t *queue, uint32_t *gqueue, uint32_t *queue_count,
+                            uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   hipError_t e;
-  if (B.n_exc) {
-    e = hipMemsetAsync(const_cast<uint32_t *>(B.exc_flag), 0, ((B.n_reads + 31) / 32) * 4, s);
-    if (e != hipSuccess) return e;
-    const uint32_t g = (uint32_t)((B.n_exc + 255) / 256);
-    hipLaunchKernelGGL(mark_exceptions_kernel, dim3(g), dim3(256), 0, s, B.exc_read, B.n_exc,
-                       const_cast<uint32_t *>(B.exc_flag));
-  }
-  e = hipMemsetAsync(queue_count, 0, 16, s);  // rescue count, general count, fast ticket, rescue ticket
-  if (e != hipSuccess) return e;
+  unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_counters);
   const bool uniform = B.lens == nullptr;
   const bool nw10 = B.stride <= 40;  // 150-nt reads: ten words in registers instead of DCRX_NWMAX
-#define DCRX_LAUNCH(TL, UN, NW_, AR_) launch_all<TL, UN, NW_, AR_>(P, T, B, cfg, rec, block_counts, queue, gqueue, queue_count, s, ev_start, ev_stop)
+#define DCRX_LAUNCH(TL, UN, NW_, AR_) launch_all<TL, UN, NW_, AR_>(P, T, B, cfg, rec, queue, gqueue, queue_count, ctr, s, ev_start, ev_stop)
   const bool pair_scan = P.table16_in_lds && !(cfg.flags & DCRX_F_ONE_BASE_SCAN);
   if (P.table_in_lds && pair_scan) {
     if (nw10) e = uniform ? DCRX_LAUNCH(true, true, 10, 16) : DCRX_LAUNCH(true, false, 10, 16);
@@ -461,9 +444,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
     else e = uniform ? DCRX_LAUNCH(false, true, DCRX_NWMAX, 4) : DCRX_LAUNCH(false, false, DCRX_NWMAX, 4);
   }
 #undef DCRX_LAUNCH
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, (int)(P.grid + P.qgrid), d_counters);
-  return hipGetLastError();
+  return e;
 }
 
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
