@@ -22,6 +22,8 @@ DCRX_DEV int dcrx_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1;
 DCRX_DEV int dcrx_clz64(uint64_t v) { return __clzll((long long)v); }
 DCRX_DEV int dcrx_popc64(uint64_t v) { return __popcll((unsigned long long)v); }
 DCRX_DEV int dcrx_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
+DCRX_DEV int dcrx_clz32(uint32_t v) { return __clz((int)v); }
+DCRX_DEV uint32_t dcrx_brev32(uint32_t v) { return __brev(v); }
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
 }
@@ -48,6 +50,13 @@ inline int dcrx_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
 inline int dcrx_popc64(uint64_t v) { return __builtin_popcountll(v); }
 inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
+inline int dcrx_clz32(uint32_t v) { return __builtin_clz(v); }
+inline uint32_t dcrx_brev32(uint32_t v) {
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24);
+}
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
 typedef uint32_t dcrx_lds_u32;
 #define DCRX_TO_LDS(p) (p)
@@ -462,6 +471,9 @@ constexpr int HH_STRIDE = 4 * HH_K;  // dwords per lane
 struct HalfHits {
   dcrx_lds_u32 *slot;
   uint32_t cnts;
+  uint32_t keep = 0xFu;   // classes that are collected at all
+  uint32_t compact = 0;   // 1: two lists only (V classes share list 0, J classes list 1; `keep` holds one class of each)
+  DCRX_DEV int list_of(int cls4) const { return compact ? (cls4 >> 1) : cls4; }
   DCRX_DEV int count(int cls4) const { return (int)((cnts >> (8 * cls4)) & 0xFFu); }
 };
 
@@ -472,7 +484,7 @@ DCRX_DEVNI bool rescue_list(const DevTables &T, const Frame<REV> &F, const HalfH
   const int cls4 = GENE * 2 + (HALF - 1);
   const int cnt = hh.count(cls4);
   for (int h = 0; h < cnt; h++) {
-    const uint32_t t = hh.slot[cls4 * HH_K + h];
+    const uint32_t t = hh.slot[hh.list_of(cls4) * HH_K + h];
     if (rescue_at<REV>(T, F, GENE, HALF, ((t >> 9) & 0x3FFFu) - (T.row0 >> 4), (int)(t >> 23), end_of_v, out, C)) return true;
   }
   return false;
@@ -661,10 +673,12 @@ DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], cons
 // second base (then its row is the end state) or at the first (one step in the one-base table
 // in global memory gives the end state).  An odd read length leaves a last base, stepped here
 // with the one-base table.
+// `off`: frame position of the first base of pair 0 (1 when the caller consumed one base
+// before the pairs, see scan_collect16); `leftover`: a last single base follows the pairs.
 template <bool REV, bool TABLE_LDS>
-DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a) {
+DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a, const int off, const bool leftover) {
   ScanOut so;
-  so.acc = a.acc & ~((1u << TE16_V2_BIT) | (1u << TE16_J2_BIT));
+  so.acc = a.acc & 0x03FFFFFFu;      // drops the pair-table-only bits (V2 J2, second-base half classes)
   so.vcount = a.vacc & ACC16_CNT_MASK;
   if (((a.acc >> TE_VMULTI_BIT) & 1u) || (so.vcount == 0 && ((a.acc >> TE_VFULL_BIT) & 1u))) so.vcount = 2;
   so.jcount = a.jacc & ACC16_CNT_MASK;
@@ -676,18 +690,18 @@ DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc
   auto locate = [&](uint32_t accv, int full_bit, int second_bit, uint32_t &state, int &end) {
     const uint32_t rowp = accv & TE16_ROW_MASK & ~ACC16_CNT_MASK;    // row (address) of the state before the pair
     const int k = (int)((accv >> ACC16_PAIR_SHIFT) & 0xFFu);
-    const int c1 = F.code(2 * k), c2 = F.code(2 * k + 1);
+    const int c1 = F.code(off + 2 * k), c2 = F.code(off + 2 * k + 1);
     const uint32_t e16 = trans16_at<TABLE_LDS>(T, rowp | (uint32_t)((c1 * 4 + c2) << 2));
     if ((e16 >> second_bit) & 1u) {
-      state = ((e16 & TE16_ROW_MASK) - T.row16_0) >> 6; end = 2 * k + 1;
+      state = ((e16 & TE16_ROW_MASK) - T.row16_0) >> 6; end = off + 2 * k + 1;
     } else {
       const uint32_t e1 = step4((rowp - T.row16_0) >> 6, c1);
-      state = (e1 & TE_ROW_MASK) >> 4; end = 2 * k;
+      state = (e1 & TE_ROW_MASK) >> 4; end = off + 2 * k;
     }
     (void)full_bit;
   };
   bool vnew = false, jnew = false;
-  if (n & 1) {
+  if (leftover) {
     // the last base: one-base step from the state after the last pair
     const uint32_t slast = ((a.e_last & TE16_ROW_MASK) - T.row16_0) >> 6;
     const uint32_t e = step4(slast, F.code(n - 1));
@@ -708,14 +722,20 @@ DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc
   return so;
 }
 
+template <bool REV, bool TABLE_LDS>
+DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a) {
+  return finish16<REV, TABLE_LDS>(T, F, a, 0, (F.n() & 1) != 0);
+}
+
 // Collecting scan (queue kernel): scan_fast that also appends every half-tag hit to the
 // read's LDS lists.
 DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
+  hb &= hh.keep;
   while (hb) {
     const int c = dcrx_ctz32(hb);
     hb &= hb - 1u;
     const uint32_t idx = (hh.cnts >> (8 * c)) & 0xFFu;
-    if (idx < (uint32_t)HH_K) hh.slot[c * HH_K + (int)idx] = t;
+    if (idx < (uint32_t)HH_K) hh.slot[hh.list_of(c) * HH_K + (int)idx] = t;
     if (idx < 255u) hh.cnts += 1u << (8 * c);
   }
 }
@@ -1025,6 +1045,243 @@ DCRX_DEV int fast16_tail_one(const DevTables &T, const uint32_t *lds_trans, cons
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
   dcrx_store_record(records + r, rec);
   return FAST_DONE;
+}
+
+// ------------------------------------------------------------------------------
+// Rescue form (rescue kernel): clean reads the fast kernel deferred because a V or J tag
+// needs the half-tag rescue.  The half-tag hit lists that scan_collect gathers base by
+// base are produced here with the pair table:
+//   1. scan_collect16: the pair scan of the fast kernel, which also marks, one bit per pair,
+//      the pairs where some half-tag keyword ends (entry bits TE_VH1_BIT..TE_JH2_BIT);
+//   2. resolve_half_hits: for each marked pair, in scan order, both of its positions are
+//      resolved by re-running the automaton from the root over the DCRX_MINI_W bases that end
+//      there.  The state so reached carries the same half-tag outputs as the state of the
+//      full scan: every half-tag keyword that ends at a position is a suffix of that window
+//      (DCRX_MINI_W >= max_half_len), hence a suffix of the longest window suffix that is a
+//      trie prefix, and any deeper state of the full scan is longer than every half tag.
+// The lists come out exactly as scan_collect writes them (same entries, same order).
+// ------------------------------------------------------------------------------
+constexpr int DCRX_MINI_W = 16;    // bases per window: one packed word
+
+template <int NW>
+struct PairMarks {
+  uint32_t m[(NW + 3) / 4];   // byte (kk & 3) of m[kk >> 2]: bit j = pair in nibble j of read word kk (whole words below the top one)
+  uint32_t top;               // the same for the partial top word
+};
+
+#define DCRX_STEP16C(PAIR4, MARKS, SHIFT)                                                       \
+  do {                                                                                          \
+    DCRX_STEP16(PAIR4);                                                                         \
+    uint32_t h_ = e & (0xFu << TE_VH1_BIT);                                                     \
+    h_ = h_ < 1u ? h_ : 1u;                                                                     \
+    (MARKS) |= h_ << (SHIFT);                                                                   \
+  } while (0)
+
+// `off` (out): 1 when the frame's first base was consumed alone before the pairs (REV frame of an
+// odd-length read: that keeps the pairs aligned with the nibbles of the packed words), else 0.
+// An odd-length FWD read leaves its last base to finish16, like scan_fast16.
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV ScanAcc16 scan_collect16(const DevTables &T, const uint32_t (&w)[NW], const uint32_t *words, int n,
+                                  PairMarks<NW> &pm, int &off) {
+  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+#pragma unroll
+  for (int x = 0; x < (NW + 3) / 4; x++) pm.m[x] = 0;
+  pm.top = 0;
+  off = 0;
+  if (n > 0) {
+    const int top = (n - 1) >> 4;
+    const int cnt = ((n - 1) & 15) + 1;       // bases in the top word
+    if (REV) {
+      uint32_t wp = ~words[top] << (2 * (16 - cnt));
+      int c = cnt;
+      if (cnt & 1) {
+        // frame position 0 alone, with the one-base table (global memory; keywords are >= 2 long, so nothing ends here)
+        const uint32_t e4 = T.trans[wp >> 30];
+        e = T.row16_0 + ((e4 & TE_ROW_MASK) >> 4) * 64u;
+        wp <<= 2; c = cnt - 1; off = 1;
+      }
+      for (int k = 0; k < (c >> 1); k++) { DCRX_STEP16C((wp >> 28) << 2, pm.top, (c >> 1) - 1 - k); wp <<= 4; }
+#pragma unroll
+      for (int kk = NW - 1; kk >= 0; kk--) {
+        if (kk < top) {
+          const uint32_t wv = ~w[kk];
+#pragma unroll
+          for (int j = 7; j >= 0; j--) DCRX_STEP16C(dcrx_ubfe(wv, 4 * j, 4) << 2, pm.m[kk >> 2], 8 * (kk & 3) + j);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < NW; kk++) {
+        if (kk < top) {
+          const uint32_t wv = w[kk];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t nib = dcrx_ubfe(wv, 4 * j, 4);
+            DCRX_STEP16C((((nib & 3u) << 2) | (nib >> 2)) << 2, pm.m[kk >> 2], 8 * (kk & 3) + j);
+          }
+        }
+      }
+      uint32_t wp = words[top];
+      for (int k = 0; k < (cnt >> 1); k++) {
+        DCRX_STEP16C((((wp & 3u) << 2) | ((wp >> 2) & 3u)) << 2, pm.top, k);
+        wp >>= 4;
+      }
+    }
+  }
+  return ScanAcc16{acc, vacc, jacc, e};
+}
+
+// The automaton's state after frame position `end`, and the half-tag classes (bit c = class
+// K_VH1 + c) that hit there, from a scan of the last DCRX_MINI_W bases only.
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV void mini_scan(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], int end, uint32_t &state,
+                        uint32_t &classes) {
+  const int n = rv.n;
+  const int len = end + 1 < DCRX_MINI_W ? end + 1 : DCRX_MINI_W;
+  // the window's bases, oldest first, 2 bits each (frame codes)
+  const int p0 = REV ? n - 1 - end : end - len + 1;        // lowest read position of the window
+  const int wi = p0 >> 4, sh = 2 * (p0 & 15);
+  // the read's words sit in registers: a select chain instead of a (dependent, global) load
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int x = 0; x < NW; x++) { lo = (wi == x) ? w[x] : lo; hi = (wi + 1 == x) ? w[x] : hi; }
+  uint32_t fv = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+  if (REV) {
+    uint32_t x = dcrx_brev32(~fv);                                  // groups reversed, bits inside a group swapped
+    x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);        // bits inside each group back in order
+    fv = x >> (2 * (DCRX_MINI_W - len));
+  }
+  uint32_t st = 0;   // root
+  int k = 0;
+  uint32_t cls = 0;
+  if (len & 1) {     // an odd window starts at frame position 0: its first base goes through the one-base table
+    const uint32_t e4 = T.trans[fv & 3u];
+    st = (e4 & TE_ROW_MASK) >> 4;
+    cls = (e4 >> TE_VH1_BIT) & 0xFu;
+    fv >>= 2; k = 1;
+  }
+  uint32_t e = T.row16_0 + st * 64u;
+  for (; k < len; k += 2) {
+    const uint32_t nib = fv & 15u;
+    e = trans16_at<TABLE_LDS>(T, (e & TE16_ROW_MASK) | ((((nib & 3u) << 2) | (nib >> 2)) << 2));
+    cls = e >> TE16_H2_SHIFT;
+    fv >>= 4;
+  }
+  if (len > 1) st = ((e & TE16_ROW_MASK) - T.row16_0) >> 6;
+  state = st; classes = cls;
+}
+
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV void resolve_pair(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], int kk, int j, HalfHits &hh) {
+  const int pa = 16 * kk + 2 * j;                              // read positions pa, pa + 1
+  const int i1 = REV ? rv.n - 2 - pa : pa;                     // frame positions i1, i1 + 1
+#pragma unroll 1
+  for (int i = i1; i <= i1 + 1; i++) {
+    uint32_t st, cls;
+    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, i, st, cls);
+    if (cls) collect_hits(hh, cls, ((T.row0 + st * 16u) << 5) | ((uint32_t)i << ACC_POS_SHIFT) | 1u);
+  }
+}
+
+// Marked pairs in scan order.  `off`/REV as in scan_collect16.
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV void resolve_half_hits(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], const PairMarks<NW> &pm,
+                                HalfHits &hh) {
+  const int n = rv.n;
+  if (n <= 0) return;
+  const int top = (n - 1) >> 4;
+  auto word_marks = [&](int kk) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int x = 0; x < (NW + 3) / 4; x++) v = (kk >> 2) == x ? pm.m[x] : v;
+    return (v >> (8 * (kk & 3))) & 0xFFu;
+  };
+  // One flat loop over the marked pairs in scan order (REV: top word first, nibbles downwards):
+  // the wave's trip count is then the largest number of marked pairs of a lane, not the sum over
+  // the words of the per-word maxima.
+  auto marks_of = [&](int kk) { return kk == top ? pm.top : word_marks(kk); };
+  int kk = REV ? top : 0;
+  uint32_t b = marks_of(kk);
+  for (;;) {
+    while (!b) {
+      kk += REV ? -1 : 1;
+      if (kk < 0 || kk > top) return;
+      b = marks_of(kk);
+    }
+    const int jj = REV ? 31 - dcrx_clz32(b) : dcrx_ctz32(b);
+    b &= ~(1u << jj);
+    resolve_pair<REV, TABLE_LDS, NW>(T, rv, w, kk, jj, hh);
+  }
+}
+
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV int rescue16_frame(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], const CfgDev &cfg,
+                            const Counters &C, dcrx_record_t &rec, HalfHits &hh) {
+  PairMarks<NW> pm;
+  int off;
+  const ScanAcc16 a = scan_collect16<REV, TABLE_LDS, NW>(T, w, rv.words, rv.n, pm, off);
+  const Frame<REV> F(rv);
+  const bool leftover = !REV && (rv.n & 1);
+  const ScanOut so = finish16<REV, TABLE_LDS>(T, F, a, off, leftover);
+  hh.cnts = 0;
+  // dcr_frame tries half 1 of a gene when any half-1 keyword occurs, else half 2 (:294/:339,
+  // :422/:473): only those two lists are kept, in two LDS lists per lane
+  hh.keep = (((so.acc >> TE_VH1_BIT) & 1u) ? 1u : 2u) | (((so.acc >> TE_JH1_BIT) & 1u) ? 4u : 8u);
+  hh.compact = 1;
+  if (cfg.flags & DCRX_F_PROFILE_LIST_SCAN_ONLY) {   // profiling aid: price the marking scan alone
+    rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend);
+    rec.j_end = (uint16_t)(pm.top + pm.m[0] + pm.m[1]); return 254;
+  }
+  resolve_half_hits<REV, TABLE_LDS, NW>(T, rv, w, pm, hh);
+  if (cfg.flags & 32u) {                             // profiling aid: ... and the hit resolution
+    rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend);
+    rec.j_end = (uint16_t)hh.cnts; rec.ins_start = (uint16_t)hh.slot[0]; return 254;
+  }
+  if (leftover) {           // the last single base of an odd-length forward read
+    uint32_t st, cls;
+    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, rv.n - 1, st, cls);
+    if (cls) collect_hits(hh, cls, ((T.row0 + st * 16u) << 5) | ((uint32_t)(rv.n - 1) << ACC_POS_SHIFT) | 1u);
+  }
+  // TABLE_LDS false for dcr_frame: its re-scanning fallback (a class with more than HH_K hits)
+  // reads the one-base table, which this kernel keeps in global memory
+  return dcr_frame<REV, false, false>(T, nullptr, rv, so, cfg, C, rec, &hh);
+}
+
+// One clean read of the rescue queue; `slot`: this lane's 2 * HH_K dwords of LDS.
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+DCRX_DEV void decombine_rescue16_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t nw,
+                                     const Counters &C, dcrx_record_t *records, uint32_t *slot) {
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  uint32_t w[NW];
+  {
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw) t = wp2[k];
+      w[2 * k] = t.x; w[2 * k + 1] = t.y;
+    }
+  }
+  HalfHits hh;
+  hh.slot = DCRX_TO_LDS(slot);
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) { status = rescue16_frame<false, TABLE_LDS, NW>(T, rv, w, cfg, C, rec, hh); frame = 1; }
+  else { status = rescue16_frame<true, TABLE_LDS, NW>(T, rv, w, cfg, C, rec, hh); frame = 0; }
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
 }
 
 // ------------------------------------------------------------------------------

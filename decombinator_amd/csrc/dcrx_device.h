@@ -29,6 +29,7 @@ constexpr uint32_t MAX_STATES = 16383;
 // bit  24/25  two or more V / J tags end inside the pair
 // bit  26/27  the V / J tag of bit 18/19 ends at the SECOND base
 constexpr int TE16_V2_BIT = 26, TE16_J2_BIT = 27;
+constexpr int TE16_H2_SHIFT = 28;   // bits 28..31: the half-tag classes (VH1 VH2 JH1 JH2) that hit at the SECOND base of the pair
 constexpr uint32_t MAX_STATES16 = 4095;
 constexpr uint32_t MAX_TAG_LEN = 32;
 
@@ -73,6 +74,8 @@ struct DevTables {
   const uint32_t *trans16;    // [n_states*16] two-bases-per-step entries (null when the automaton has > 4095 states)
   uint32_t dfa16_bytes;
   uint32_t row16_0;           // like row0, for trans16
+  uint32_t max_half_len;      // longest half-tag keyword (the rescue kernel re-derives hit states from a window of 16 bases)
+  uint32_t pair_rescue;       // 1 when the rescue kernel's pair form applies: trans16 exists, max_half_len <= 16, every keyword >= 2 nt
   const uint32_t *st_full;    // [state - first_out] V tag | J tag << 16 ending at the state (0xFFFF none)
   const uint32_t *st_out;     // [state - first_out (+1)] CSR into outs
   const uint32_t *outs;       // per-state output list, longest keyword first

@@ -36,6 +36,7 @@ namespace dcrx {
 // LDS beyond the counters + DFA (LaunchPlan::lds_bytes): the fast kernel's per-wave deferral
 // buffers, the queue kernel's half-tag hit lists
 constexpr int DCRX_WQ_CAP = 128;
+constexpr int DCRX_GTILE = 8;  // general-list reads per ticket (one wave)
 constexpr int DCRX_CHUNK = 2;  // 64-read tiles of the rescue queue a wave claims per ticket
 constexpr uint32_t DCRX_FAST_LDS_EXTRA = (DCRX_BLOCK / 64) * DCRX_WQ_CAP * 4;
 constexpr int DCRX_TQ_CAP = 128;  // tail entries per wave (flushed at 64; 3 dwords each)
@@ -206,21 +207,24 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                                      unsigned long long *__restrict__ counters,
                                                                      const uint32_t *__restrict__ queue,
                                                                      const uint32_t *__restrict__ gqueue,
-                                                                     uint32_t *__restrict__ queue_count) {
-  uint32_t *tile_ticket = queue_count + 3;
+                                                                     uint32_t *__restrict__ queue_count, int with_rescue) {
+  // with_rescue == 0: the rescue queue belongs to decombine_rescue_kernel, which runs after this
+  // kernel and re-arms the work counters; this one then only takes the general list (ticket 2).
+  uint32_t *tile_ticket = queue_count + (with_rescue ? 3 : 2);
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_slots = smem + DCRX_N_COUNTERS;        // [DCRX_QBLOCK][DCRX_LSLOT]: hit lists + exception copy
   uint32_t *lds_trans = lds_slots + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD;
   static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
-  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
-  // tickets: one per 64 general reads, one per DCRX_CHUNK*64 rescue reads
-  const uint32_t t_general = (n_general + 63) / 64, t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
+  const uint32_t n_rescue = with_rescue ? queue_count[0] : 0u, n_general = queue_count[1];
+  // tickets: one per DCRX_GTILE general reads (few lanes per wave: these reads take long, divergent
+  // paths, and a wave runs the union of its lanes' paths), one per DCRX_CHUNK*64 rescue reads
+  const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE, t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   // The last block to finish re-arms the work counters for the next launch (no memset between
   // launches): by then every block has read the counts above.
   auto leave = [&]() {
-    if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
+    if (with_rescue && tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
       queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
       __threadfence();
       queue_count[4] = 0;
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
     ticket = __shfl(ticket, 0);
     if (ticket >= t_general + t_rescue) break;
     if (ticket < t_general) {
-      const uint32_t i = ticket * 64 + lane;
-      if (i < n_general) {
+      const uint32_t i = ticket * DCRX_GTILE + lane;
+      if (lane < DCRX_GTILE && i < n_general) {
         const uint32_t r = gqueue[i];
         decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                    lds_slots + tid * DCRX_LSLOT);
@@ -266,6 +270,83 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                      lds_slots + tid * DCRX_LSLOT);
       }
     }
+  }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+  leave();
+}
+
+// Rescue kernel (pair-table form of the list kernel's second half): the clean reads the fast
+// kernel deferred, 64 per ticket.  LDS holds what the fast kernel holds — the two-bases-per-step
+// table and the side tables — plus two hit lists (2 * HH_K dwords) per lane.  Last kernel of a
+// launch: re-arms the work counters.
+constexpr int DCRX_RBLOCK = 1024;
+constexpr int DCRX_RSLOT = (2 * HH_K) | 1;     // two hit lists per lane; odd: conflict-free
+constexpr uint32_t DCRX_RESCUE_LDS_EXTRA = ((DCRX_RBLOCK * DCRX_RSLOT * 4 + 63) / 64) * 64;
+static_assert(DCRX_GTILE * DCRX_LSLOT <= 64 * DCRX_RSLOT, "a wave's rescue slots must hold its general-list slots");
+static_assert((DCRX_N_COUNTERS * 4 + DCRX_RESCUE_LDS_EXTRA) % 64 == 0, "pair-scan rows must be 64-byte aligned");
+
+template <bool UNIFORM_LEN, int NW>
+__global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables T0, BatchDev B, CfgDev cfg,
+                                                                       dcrx_record_t *__restrict__ records,
+                                                                       unsigned long long *__restrict__ counters,
+                                                                       const uint32_t *__restrict__ queue,
+                                                                       const uint32_t *__restrict__ gqueue,
+                                                                       uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_slots = smem + DCRX_N_COUNTERS;                    // [DCRX_RBLOCK][DCRX_RSLOT]
+  uint32_t *lds_trans = smem + DCRX_N_COUNTERS + DCRX_RESCUE_LDS_EXTRA / 4;
+  const int tid = threadIdx.x;
+  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
+  const uint32_t tickets = (n_rescue + 63) / 64;
+  const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE;
+  auto leave = [&]() {
+    if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
+      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
+      __threadfence();
+      queue_count[4] = 0;
+    }
+  };
+  if ((uint64_t)blockIdx.x * (DCRX_RBLOCK / 64) >= (uint64_t)tickets + t_general) { leave(); return; }
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  const uint32_t lds_addr = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans));
+  uint32_t *lds_side = lds_trans + T0.dfa16_bytes / 4;
+  stage_lds<DCRX_RBLOCK>(reinterpret_cast<const uint8_t *>(T0.trans16), lds_trans, T0.dfa16_bytes / 16, T0.dfa16_bytes / 16,
+                         lds_addr, tid);
+  stage_lds<DCRX_RBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+  DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes);
+  T.row16_0 = lds_addr;
+  __syncthreads();
+  const Counters C{lds_counts};
+  const uint32_t nw = B.stride >> 2;
+  const int lane = tid & 63;
+  const uint32_t wave = blockIdx.x * (DCRX_RBLOCK / 64) + (uint32_t)(tid >> 6), n_waves = gridDim.x * (DCRX_RBLOCK / 64);
+  // The general list first (reads with exception bytes), DCRX_GTILE reads per wave: their scan
+  // steps the one-base table in global memory (it has no room in LDS here); these few long
+  // chains run beside the rescue tiles of the other waves.
+  if (t_general) {
+    uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
+    uint32_t *gslot = lds_slots + (tid >> 6) * (64 * DCRX_RSLOT);      // the wave's slots: room for DCRX_GTILE list-kernel slots
+    for (uint32_t g = wave; g < t_general; g += n_waves) {
+      const uint32_t i = g * DCRX_GTILE + lane;
+      if (lane < DCRX_GTILE && i < n_general) {
+        const uint32_t r = gqueue[i];
+        decombine_list_one<false, UNIFORM_LEN>(T, nullptr, B, cfg, (uint64_t)r, C, records, gslot + lane * DCRX_LSLOT);
+        if ((exc_flag[r >> 5] >> (r & 31)) & 1u) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
+      }
+    }
+  }
+  // rescue tiles through a ticket: the waves that took a general tile arrive late and take fewer
+  uint32_t *tile_ticket = queue_count + 3;
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(tile_ticket, 1u);
+    tile = __shfl(tile, 0);
+    if (tile >= tickets) break;
+    const uint32_t i = tile * 64 + lane;
+    if (i < n_rescue)
+      decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)queue[i], nw, C, records, lds_slots + tid * DCRX_RSLOT);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
@@ -420,8 +501,30 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     if (e != hipSuccess) return e;
   }
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count);
-  return hipGetLastError();
+  // What the fast kernel left: the general list (reads with exception bytes; every read for
+  // `both` / the forced slow reader) goes through the list kernel; the rescue queue through the
+  // rescue kernel when the pair table serves it, else through the list kernel as well.
+  const bool rescue16 = ARITY == 16 && T.pair_rescue && !(cfg.flags & DCRX_F_LIST_RESCUE) &&
+                        P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA <= 160u * 1024u;
+  if (!rescue16 || all_general) {
+    hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
+                       queue_count, 1);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (rescue16 && !all_general) {
+    auto kresc = decombine_rescue_kernel<UNIFORM, NW>;
+    static bool rattr_set = false;
+    if (!rattr_set) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kresc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      rattr_set = true;
+    }
+    const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
+    hipLaunchKernelGGL(kresc, dim3(P.n_cu), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count);
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,

@@ -284,6 +284,14 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
   R.n_states = S;
   R.first_out = first_out;
   R.row0 = 0;
+  R.max_half_len = 0;
+  uint32_t min_kw_len = 0xFFFFFFFFu;
+  for (int g = 0; g < 2; g++) {
+    for (const std::string &h : H.g[g].half1) { R.max_half_len = std::max<uint32_t>(R.max_half_len, (uint32_t)h.size()); min_kw_len = std::min<uint32_t>(min_kw_len, (uint32_t)h.size()); }
+    for (const std::string &h : H.g[g].half2) { R.max_half_len = std::max<uint32_t>(R.max_half_len, (uint32_t)h.size()); min_kw_len = std::min<uint32_t>(min_kw_len, (uint32_t)h.size()); }
+    for (const std::string &h : H.g[g].tags) min_kw_len = std::min<uint32_t>(min_kw_len, (uint32_t)h.size());
+  }
+  R.pair_rescue = 0;      // set below, once the pair table is known to exist
   R.dfa_bytes = H.dfa_bytes;
   R.image = as_off<uint8_t>(0);
   R.trans = as_off<uint32_t>(B.put(trans));
@@ -399,10 +407,12 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
           if (nj >= 2) e |= 1u << TE_JMULTI_BIT;
           if ((f2 >> TE_VFULL_BIT) & 1u) e |= 1u << TE16_V2_BIT;
           if ((f2 >> TE_JFULL_BIT) & 1u) e |= 1u << TE16_J2_BIT;
+          e |= ((f2 >> TE_VH1_BIT) & 0xFu) << TE16_H2_SHIFT;
           trans16[(size_t)new_id[s] * 16 + c1 * 4 + c2] = e;
         }
     R.trans16 = as_off<uint32_t>(B.put(trans16));
     R.dfa16_bytes = S * 64u;
+    R.pair_rescue = (R.max_half_len <= 16 && min_kw_len >= 2) ? 1u : 0u;
   }
   {
     // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged

@@ -25,6 +25,15 @@ static int fast_one(bool pair_scan, const DevTables &T, const BatchDev &B, const
                         : decombine_fast_one<false, UNIFORM, DCRX_NWMAX, 4>(T, nullptr, B, C, r, nw, CC, records);
 }
 
+// a deferred clean read: the rescue kernel's pair form when the launch would use it, else the list kernel's
+template <bool UNIFORM>
+static void rescue_one(bool pair_rescue, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
+                       const Counters &CC, dcrx_record_t *records, uint32_t *slot) {
+  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot); return; }
+  if (B.stride <= 40) decombine_rescue16_one<false, UNIFORM, 10>(T, B, C, r, nw, CC, records, slot);
+  else decombine_rescue16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, nw, CC, records, slot);
+}
+
 extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
                               dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
   HostTables H;
@@ -52,20 +61,21 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     uint32_t slot[HH_STRIDE + DCRX_GSLOT_EXTRA + 2];
     const uint32_t nw = b->stride / 4;
     const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
+    const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
       if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) rescue_one<false>(pair_rescue, T, B, C, r, nw, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
       if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
       else {
         const int what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
+        if (what == FAST_TO_RESCUE) rescue_one<true>(pair_rescue, T, B, C, r, nw, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     }
