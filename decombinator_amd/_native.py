@@ -41,6 +41,8 @@ ORIENTATIONS = {"reverse": 0, "forward": 1, "both": 2}
 F_FORCE_SLOW_READER = 1
 F_PROFILE_SCAN_ONLY = 2
 F_ONE_BASE_SCAN = 4
+F_PROFILE_LIST_SCAN_ONLY = 8
+F_LIST_RESCUE = 16      # rescue queue through the list kernel even when the pair form applies
 
 RECORD_DTYPE = np.dtype([
     ("v", "<u2"), ("j", "<u2"), ("v_start", "<u2"), ("j_end", "<u2"),

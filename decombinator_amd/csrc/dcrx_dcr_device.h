@@ -678,7 +678,7 @@ DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], cons
 template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a, const int off, const bool leftover) {
   ScanOut so;
-  so.acc = a.acc & 0x03FFFFFFu;      // drops the pair-table-only bits (V2 J2, second-base half classes)
+  so.acc = DCRX_ACC16_FLAGS(a.acc) & ~((1u << TE16_V2_BIT) | (1u << TE16_J2_BIT));   // one-base flag layout
   so.vcount = a.vacc & ACC16_CNT_MASK;
   if (((a.acc >> TE_VMULTI_BIT) & 1u) || (so.vcount == 0 && ((a.acc >> TE_VFULL_BIT) & 1u))) so.vcount = 2;
   so.jcount = a.jacc & ACC16_CNT_MASK;
@@ -979,7 +979,7 @@ struct TailEntry { uint32_t r, a, b; };   // read index | vacc(26)+flags(6) | ja
 DCRX_DEV TailEntry tail_pack(uint32_t r, const ScanAcc16 &s) {
   TailEntry t;
   t.r = r;
-  t.a = (s.vacc & 0x3FFFFFFu) | (((s.acc >> TE_VFULL_BIT) & 0x3Fu) << 26);   // VFULL JFULL VH1 VH2 JH1 JH2
+  t.a = (s.vacc & 0x3FFFFFFu) | (((DCRX_ACC16_FLAGS(s.acc) >> TE_VFULL_BIT) & 0x3Fu) << 26);   // VFULL JFULL VH1 VH2 JH1 JH2 (either base)
   t.b = (s.jacc & 0x3FFFFFFu) | (((s.acc >> TE_VMULTI_BIT) & 0xFu) << 26);   // VMULTI JMULTI V2 J2
   return t;
 }
@@ -1072,7 +1072,7 @@ struct PairMarks {
 #define DCRX_STEP16C(PAIR4, MARKS, SHIFT)                                                       \
   do {                                                                                          \
     DCRX_STEP16(PAIR4);                                                                         \
-    uint32_t h_ = e & (0xFu << TE_VH1_BIT);                                                     \
+    uint32_t h_ = e & ((0xFu << TE_VH1_BIT) | (0xFu << TE16_H2_SHIFT));                         \
     h_ = h_ < 1u ? h_ : 1u;                                                                     \
     (MARKS) |= h_ << (SHIFT);                                                                   \
   } while (0)
@@ -1135,7 +1135,7 @@ DCRX_DEV ScanAcc16 scan_collect16(const DevTables &T, const uint32_t (&w)[NW], c
 // K_VH1 + c) that hit there, from a scan of the last DCRX_MINI_W bases only.
 template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV void mini_scan(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], int end, uint32_t &state,
-                        uint32_t &classes) {
+                        uint32_t &classes, uint32_t &classes_before) {   // classes_before: those that end at end - 1 (0 when end == 0)
   const int n = rv.n;
   const int len = end + 1 < DCRX_MINI_W ? end + 1 : DCRX_MINI_W;
   // the window's bases, oldest first, 2 bits each (frame codes)
@@ -1167,6 +1167,7 @@ DCRX_DEV void mini_scan(const DevTables &T, const ReadView &rv, const uint32_t (
     cls = e >> TE16_H2_SHIFT;
     fv >>= 4;
   }
+  classes_before = len > 1 ? (e >> TE_VH1_BIT) & 0xFu : 0u;
   if (len > 1) st = ((e & TE16_ROW_MASK) - T.row16_0) >> 6;
   state = st; classes = cls;
 }
@@ -1175,12 +1176,16 @@ template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV void resolve_pair(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], int kk, int j, HalfHits &hh) {
   const int pa = 16 * kk + 2 * j;                              // read positions pa, pa + 1
   const int i1 = REV ? rv.n - 2 - pa : pa;                     // frame positions i1, i1 + 1
-#pragma unroll 1
-  for (int i = i1; i <= i1 + 1; i++) {
-    uint32_t st, cls;
-    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, i, st, cls);
-    if (cls) collect_hits(hh, cls, ((T.row0 + st * 16u) << 5) | ((uint32_t)i << ACC_POS_SHIFT) | 1u);
+  // one window scan ending at the second base tells which (kept) classes end at either base; a
+  // hit at the first base needs that position's own state: a second window scan, ending there
+  uint32_t st2, c2, c1, st1, x0, x1;
+  mini_scan<REV, TABLE_LDS, NW>(T, rv, w, i1 + 1, st2, c2, c1);
+  c1 &= hh.keep; c2 &= hh.keep;
+  if (c1) {
+    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, i1, st1, x0, x1);
+    collect_hits(hh, c1, ((T.row0 + st1 * 16u) << 5) | ((uint32_t)i1 << ACC_POS_SHIFT) | 1u);
   }
+  if (c2) collect_hits(hh, c2, ((T.row0 + st2 * 16u) << 5) | ((uint32_t)(i1 + 1) << ACC_POS_SHIFT) | 1u);
 }
 
 // Marked pairs in scan order.  `off`/REV as in scan_collect16.
@@ -1238,8 +1243,8 @@ DCRX_DEV int rescue16_frame(const DevTables &T, const ReadView &rv, const uint32
     rec.j_end = (uint16_t)hh.cnts; rec.ins_start = (uint16_t)hh.slot[0]; return 254;
   }
   if (leftover) {           // the last single base of an odd-length forward read
-    uint32_t st, cls;
-    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, rv.n - 1, st, cls);
+    uint32_t st, cls, before;
+    mini_scan<REV, TABLE_LDS, NW>(T, rv, w, rv.n - 1, st, cls, before);
     if (cls) collect_hits(hh, cls, ((T.row0 + st * 16u) << 5) | ((uint32_t)(rv.n - 1) << ACC_POS_SHIFT) | 1u);
   }
   // TABLE_LDS false for dcr_frame: its re-scanning fallback (a class with more than HH_K hits)

@@ -29,7 +29,10 @@ constexpr uint32_t MAX_STATES = 16383;
 // bit  24/25  two or more V / J tags end inside the pair
 // bit  26/27  the V / J tag of bit 18/19 ends at the SECOND base
 constexpr int TE16_V2_BIT = 26, TE16_J2_BIT = 27;
-constexpr int TE16_H2_SHIFT = 28;   // bits 28..31: the half-tag classes (VH1 VH2 JH1 JH2) that hit at the SECOND base of the pair
+constexpr int TE16_H2_SHIFT = 28;   // pair entries: bits 20..23 = half-tag classes (VH1 VH2 JH1 JH2) that end at the FIRST base of the
+                                    // pair, bits 28..31 = those that end at the SECOND base
+// OR-ed pair entries -> the one-base table's flag layout (half-tag classes of either base in bits 20..23)
+#define DCRX_ACC16_FLAGS(acc) (((acc) | ((((acc) >> dcrx::TE16_H2_SHIFT) & 0xFu) << dcrx::TE_VH1_BIT)) & 0x03FFFFFFu)
 constexpr uint32_t MAX_STATES16 = 4095;
 constexpr uint32_t MAX_TAG_LEN = 32;
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
       } else {
         const uint32_t vcnt = a.vacc & ACC16_CNT_MASK;
         const bool vmulti = live && !one_v && (vcnt > 1 || ((a.acc >> TE_VMULTI_BIT) & 1u) || ((a.acc >> TE_VFULL_BIT) & 1u));
-        const bool vhalf = live && !one_v && !vmulti && ((a.acc >> TE_VH1_BIT) & 3u);
+        const bool vhalf = live && !one_v && !vmulti && ((DCRX_ACC16_FLAGS(a.acc) >> TE_VH1_BIT) & 3u);
         const bool vnone = live && !one_v && !vmulti && !vhalf;
         defer = vhalf;
         if (vnone || vmulti) {

@@ -398,7 +398,7 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
           const uint32_t s1 = (uint32_t)delta[s * 4 + c1], s2 = (uint32_t)delta[s1 * 4 + c2];
           const uint32_t f1 = st_flags[s1], f2 = st_flags[s2];
           uint32_t e = new_id[s2] * 64u;
-          e |= (f1 | f2) & (0xFu << TE_VH1_BIT);
+          e |= f1 & (0xFu << TE_VH1_BIT);                            // half-tag classes that end at the FIRST base
           const uint32_t nv = cnt_bits(f1, TE_VFULL_BIT, TE_VMULTI_BIT) + cnt_bits(f2, TE_VFULL_BIT, TE_VMULTI_BIT);
           const uint32_t nj = cnt_bits(f1, TE_JFULL_BIT, TE_JMULTI_BIT) + cnt_bits(f2, TE_JFULL_BIT, TE_JMULTI_BIT);
           if (nv >= 1) e |= 1u << TE_VFULL_BIT;
@@ -407,7 +407,7 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
           if (nj >= 2) e |= 1u << TE_JMULTI_BIT;
           if ((f2 >> TE_VFULL_BIT) & 1u) e |= 1u << TE16_V2_BIT;
           if ((f2 >> TE_JFULL_BIT) & 1u) e |= 1u << TE16_J2_BIT;
-          e |= ((f2 >> TE_VH1_BIT) & 0xFu) << TE16_H2_SHIFT;
+          e |= ((f2 >> TE_VH1_BIT) & 0xFu) << TE16_H2_SHIFT;         // ... and at the SECOND base
           trans16[(size_t)new_id[s] * 16 + c1 * 4 + c2] = e;
         }
     R.trans16 = as_off<uint32_t>(B.put(trans16));

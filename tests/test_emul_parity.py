@@ -9,7 +9,8 @@ from tests import parity_util as pu
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER], ids=["pairscan", "onebase", "slowreader"])
+@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
+                         ids=["pairscan", "onebase", "slowreader", "listrescue"])
 def test_emul_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("emul", path, flags) > 500
 
@@ -17,3 +18,33 @@ def test_emul_matches_golden_and_oracle(path, flags):
 def test_emul_synthetic_orientations_and_ragged_lengths():
     from tests import emul_extended
     assert emul_extended.run(60000)
+
+
+@pytest.mark.parametrize("flags", [0, nat.F_LIST_RESCUE], ids=["rescue-form", "list-form"])
+def test_emul_ragged_lengths_forward_and_reverse_with_many_tag_errors(flags):
+    """Odd and even lengths in both frames with 3 % substitutions: the pair form of the rescue
+    (left-over last base forward, lone first base reverse) against the oracle."""
+    import numpy as np
+    from decombinator_amd import synth
+    from oracle import oracle as orc
+    ts = synth.config_tagset(2)
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=ts.half_splits[0], j_half_split=ts.half_splits[1])
+    t = pu.native_tables(d)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], *ts.half_splits)
+    be = pu.Backend("emul", d)
+    rng = np.random.default_rng(13)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=19, read_len=160, sub_rate=0.03, n_rate=0.002), 0, 30_000, stride=40)
+    reads = [orc.revcomp(r) for r in nat.unpack_reads(hb)]
+    cut = rng.integers(0, 161, size=len(reads))
+    reads = [r[:c] if i % 2 else r[len(r) - c:] for i, (r, c) in enumerate(zip(reads, cut))]
+    b = nat.pack_reads(reads, stride=40)
+    n_ok = 0
+    for orientation in ("forward", "reverse"):
+        rec, cnt = be.run(b, orientation, flags=flags)
+        orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+        pu.assert_records_equal(rec, orec, reads, orientation)
+        pu.assert_counters_equal(cnt, ocnt)
+        n_ok += int((orec["status"] == 0).sum())
+    assert n_ok > 1000

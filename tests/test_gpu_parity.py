@@ -29,7 +29,8 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER], ids=["pairscan", "onebase", "slowreader"])
+@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
+                         ids=["pairscan", "onebase", "slowreader", "listrescue"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
@@ -106,6 +107,26 @@ def test_ragged_lengths_and_empty_reads():
         orec, ocnt = pu.oracle_records(ot, reads, "reverse", allow, 130)
         pu.assert_records_equal(rec, orec, reads, "ragged")
         pu.assert_counters_equal(cnt, ocnt, "ragged")
+
+
+@pytest.mark.parametrize("flags", [0, nat.F_LIST_RESCUE], ids=["rescue-kernel", "list-kernel"])
+def test_ragged_lengths_forward_frame(flags):
+    """Odd and even lengths in the forward frame (the pair scan's left-over last base) and with
+    many tag errors, through both forms of the rescue."""
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    rng = np.random.default_rng(13)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=19, read_len=160, sub_rate=0.03, n_rate=0.002), 0, 80_000, stride=40)
+    reads = [orc.revcomp(r) for r in nat.unpack_reads(hb)]          # sense strand: decombines in the forward frame
+    cut = rng.integers(0, 161, size=len(reads))
+    reads = [r[:c] if i % 2 else r[len(r) - c:] for i, (r, c) in enumerate(zip(reads, cut))]
+    b = nat.pack_reads(reads, stride=40)
+    for orientation in ("forward", "reverse"):
+        rec, cnt = nat.decombine(t, b, orientation=orientation, flags=flags)
+        orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+        pu.assert_records_equal(rec, orec, reads, orientation)
+        pu.assert_counters_equal(cnt, ocnt, orientation)
+    assert int((orec["status"] == 0).sum()) >= 0
 
 
 def test_empty_batch_and_single_read():
