@@ -127,6 +127,8 @@ def main():
     n = args.reads
     stride = nat.stride_for(READ_LEN)
     cfg_synth = nat.synth_cfg(seed=SEED, read_len=READ_LEN)
+    if os.environ.get("DCRX_BENCH_N_RATE"):          # experiments only: share of reads with an N (default 0.0005)
+        cfg_synth = nat.synth_cfg(seed=SEED, read_len=READ_LEN, n_rate=float(os.environ["DCRX_BENCH_N_RATE"]))
     first = rank * n
 
     # inputs resident in HBM before the timed region

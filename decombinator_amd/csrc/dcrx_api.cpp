@@ -191,7 +191,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     (void)hipFree(t->d_exc_flag); t->d_exc_flag = nullptr;
     (void)hipFree(t->d_queue); t->d_queue = nullptr;
     HIP_TRY(hipMalloc(&t->d_exc_flag, ((max_reads + 31) / 32) * 4 + 16));
-    HIP_TRY(hipMalloc(&t->d_queue, (2 * max_reads + DCRX_QUEUE_HEADER) * 4));  // [work counters][rescue queue][general queue]
+    HIP_TRY(hipMalloc(&t->d_queue, (3 * max_reads + DCRX_QUEUE_HEADER) * 4));  // [work counters][rescue queue][general list][its exception-list offsets]
     t->exc_flag_reads = max_reads;
     t->ws_dirty = true;
   }

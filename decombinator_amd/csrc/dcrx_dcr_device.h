@@ -1290,6 +1290,110 @@ DCRX_DEV void decombine_rescue16_one(const DevTables &T, const BatchDev &B, cons
 }
 
 // ------------------------------------------------------------------------------
+// General form inside the rescue kernel: a read with exception bytes (non-ACGT), one frame.
+// Same results as scan_collect (one base per step, one-base table), but the state advances two
+// bases per step through the pair table in LDS; the one-base table — in global memory in this
+// kernel — is only consulted where it matters: a pair whose entry shows that some keyword ends
+// inside it is replayed base by base (full accumulator / hit-list bookkeeping of DCRX_STEP_C),
+// and a lone base before an exception byte or at the end of the read takes a single step.
+// ------------------------------------------------------------------------------
+template <bool REV, bool TABLE_LDS, int NW>
+DCRX_DEV ScanOut scan_collect16_exc(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], HalfHits &hh) {
+  const int n = rv.n;
+  uint32_t acc = 0, vacc = 0, jacc = 0;
+  hh.cnts = 0;
+  ExcCursor<REV> xc(rv);
+  auto code = [&](int i) {           // frame code of position i, from the words in registers
+    const int m = REV ? n - 1 - i : i;
+    uint32_t word = 0;
+#pragma unroll
+    for (int x = 0; x < NW; x++) word = ((m >> 4) == x) ? w[x] : word;
+    const uint32_t c = (word >> (2 * (m & 15))) & 3u;
+    return REV ? (c ^ 3u) : c;
+  };
+  // one step of the one-base table from state `st` with base c at frame position i: DCRX_STEP_C's bookkeeping
+  auto step1 = [&](uint32_t st, uint32_t c, int i) {
+    const uint32_t e = T.trans[st * 4u + c];
+    acc |= e;
+    const uint32_t t_ = ((T.row0 + (e & TE_ROW_MASK)) << 5) | ((uint32_t)i << ACC_POS_SHIFT) | 1u;
+    vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;
+    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;
+    const uint32_t hb = (e >> TE_VH1_BIT) & 0xFu;
+    if (hb) collect_hits(hh, hb, t_);
+    return (e & TE_ROW_MASK) >> 4;    // the new state
+  };
+  constexpr uint32_t INTEREST = (1u << TE_VFULL_BIT) | (1u << TE_JFULL_BIT) | (0xFu << TE_VH1_BIT) | (0xFu << TE16_H2_SHIFT) |
+                                (1u << TE_VMULTI_BIT) | (1u << TE_JMULTI_BIT);
+  uint32_t st = 0;                    // root
+  int i = 0;
+  while (i < n) {
+    if (i == xc.nextpos) { st = 0; xc.advance(); i++; continue; }   // a byte outside ACGT: back to the root
+    if (i + 1 < n && i + 1 != xc.nextpos) {
+      const uint32_t c1 = code(i), c2 = code(i + 1);
+      const uint32_t e16 = trans16_at<TABLE_LDS>(T, (T.row16_0 + st * 64u) | ((c1 * 4u + c2) << 2));
+      if (e16 & INTEREST) { st = step1(st, c1, i); st = step1(st, c2, i + 1); }
+      else st = ((e16 & TE16_ROW_MASK) - T.row16_0) >> 6;
+      i += 2;
+    } else {
+      st = step1(st, code(i), i);
+      i += 1;
+    }
+  }
+  return finish4(T, ScanAcc{acc, vacc, jacc});
+}
+
+// `e0`: index of the read's first entry in the exception list (from the prologue kernel).
+template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
+DCRX_DEV void decombine_general16_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t e0,
+                                      uint32_t nw, const Counters &C, dcrx_record_t *records, uint32_t *slot) {
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  uint64_t hi = e0;
+  while (hi < B.n_exc && B.exc_read[hi] == (uint32_t)r) hi++;
+  rv.e0 = (int)e0; rv.e1 = (int)hi;
+  if (rv.e1 - rv.e0 <= DCRX_EXC_LDS) {
+    uint16_t *xp = reinterpret_cast<uint16_t *>(slot + HH_STRIDE);
+    uint8_t *xb = reinterpret_cast<uint8_t *>(slot + HH_STRIDE + DCRX_EXC_LDS / 2);
+    const int cnt = rv.e1 - rv.e0;
+    for (int x = 0; x < cnt; x++) { xp[x] = B.exc_pos[rv.e0 + x]; xb[x] = B.exc_chr[rv.e0 + x]; }
+    rv.exc_pos = xp; rv.exc_chr = xb; rv.e0 = 0; rv.e1 = cnt;  // indices re-based onto the LDS copy
+  }
+  uint32_t w[NW];
+  {
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw) t = wp2[k];
+      w[2 * k] = t.x; w[2 * k + 1] = t.y;
+    }
+  }
+  HalfHits hh;
+  hh.slot = DCRX_TO_LDS(slot);
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {
+    const ScanOut so = scan_collect16_exc<false, TABLE_LDS, NW>(T, rv, w, hh);
+    status = dcr_frame<false, false, false>(T, nullptr, rv, so, cfg, C, rec, &hh); frame = 1;
+  } else {
+    const ScanOut so = scan_collect16_exc<true, TABLE_LDS, NW>(T, rv, w, hh);
+    status = dcr_frame<true, false, false>(T, nullptr, rv, so, cfg, C, rec, &hh); frame = 0;
+  }
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+}
+
+// ------------------------------------------------------------------------------
 // List form (list kernel): any read — exception bytes, orientation `both` with its
 // second, forward attempt (decombine.py:1005-1010), half-tag rescue.  One collecting
 // scan per frame, then dcr_frame with the rescue fed from the LDS hit lists (a class

@@ -56,7 +56,7 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
 __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decombine_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count) {
+    uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count, uint32_t qcap) {
   constexpr int BLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
   extern __shared__ __align__(64) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
@@ -93,18 +93,45 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
   // Static work distribution: block b takes tiles b, b + grid, ... (the grid is exactly the
   // resident capacity, so every block runs from the start; a global ticket per wave-tile was
   // measured slower: one atomic address sustains only ~90 tickets/us).
-  auto to_rescue = [&](bool defer, uint32_t r32) {
+  // The rescue queue can be filled from both ends — reads whose V tag needs the rescue from the
+  // front (count in queue_count[0]), reads whose J tag needs it from the back
+  // (queue_count[DCRX_QC_BACK]) — so that the waves working it off run one kind of rescue each.
+  // Measured on MI355X (10 M reads): the rescue kernel gains nothing from sorted tiles, while the
+  // second atomic per flush costs the fast kernel ~9 %; so everything goes to the front.
+  constexpr bool typed = false;
+  auto flush = [&]() {
+    if (!typed) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(queue_count, wq_n);
+      base = __shfl(base, 0);
+      for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
+      wq_n = 0;
+      return;
+    }
+    for (uint32_t i0 = 0; i0 < wq_n; i0 += 64) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool have = i < wq_n;
+      const uint32_t ent = have ? wq[i] : 0u;
+      const bool back = have && (ent >> 31);
+      const unsigned long long mb = __ballot(back), mf = __ballot(have && !back);
+      uint32_t bf = 0, bb = 0;
+      if (lane == 0) {
+        if (mf) bf = atomicAdd(queue_count, (uint32_t)__popcll(mf));
+        if (mb) bb = atomicAdd(queue_count + DCRX_QC_BACK, (uint32_t)__popcll(mb));
+      }
+      bf = __shfl(bf, 0); bb = __shfl(bb, 0);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (back) queue[qcap - 1u - (bb + (uint32_t)__popcll(mb & below))] = ent & 0x7FFFFFFFu;
+      else if (have) queue[bf + (uint32_t)__popcll(mf & below)] = ent;
+    }
+    wq_n = 0;
+  };
+  auto to_rescue = [&](bool defer, uint32_t r32, uint32_t j_kind) {
     const unsigned long long m = __ballot(defer);
     if (m) {
-      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r32;
+      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = typed ? (r32 | (j_kind << 31)) : r32;
       wq_n += (uint32_t)__popcll(m);
-      if (wq_n >= 64) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue_count, wq_n);
-        base = __shfl(base, 0);
-        for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
-        wq_n = 0;
-      }
+      if (wq_n >= 64) flush();
     }
   };
   // Pair scan, uniform even read length: the tail (hit location, walks, filters) is batched.
@@ -124,7 +151,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
         defer = fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)te.r, tail_unpack(te, T.row16_0), C,
                                                         records) == FAST_TO_RESCUE;
       }
-      to_rescue(defer, r32);
+      to_rescue(defer, r32, 1u);      // a read with its V tag in hand: the J tag needs the rescue
     };
     for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
       const uint64_t r = tile * BLOCK + tid;
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
           if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
         }
       }
-      to_rescue(defer, (uint32_t)r);
+      to_rescue(defer, (uint32_t)r, 0u);
       const unsigned long long m = __ballot(one_v);
       if (m) {
         if (one_v) {
@@ -181,17 +208,25 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
     if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW, ARITY>(T, lds_trans, B, cfg, r, nw, C, records);
     // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
     // from the exception list before this kernel starts
-    to_rescue(what == FAST_TO_RESCUE, (uint32_t)r);
+    to_rescue(what == FAST_TO_RESCUE, (uint32_t)r, 0u);
   }
   }
-  if (wq_n) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(queue_count, wq_n);
-    base = __shfl(base, 0);
-    for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
-  }
+  if (wq_n) flush();
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+
+// Read index of entry `lane` of rescue tile `tile`: tiles [0, tiles_front) walk the front part of
+// the queue, the others its back part (see the fast kernel).  0xFFFFFFFF: no entry.
+__device__ __forceinline__ uint32_t rescue_entry(const uint32_t *__restrict__ queue, uint32_t qcap, uint32_t n_front,
+                                                 uint32_t n_back, uint32_t tiles_front, uint32_t tile, uint32_t per_tile,
+                                                 uint32_t k) {
+  if (tile < tiles_front) {
+    const uint32_t i = tile * per_tile + k;
+    return i < n_front ? queue[i] : 0xFFFFFFFFu;
+  }
+  const uint32_t i = (tile - tiles_front) * per_tile + k;
+  return i < n_back ? queue[qcap - 1u - i] : 0xFFFFFFFFu;
 }
 
 // List kernel: everything the fast kernel does not finish, in dense waves.  Two work lists,
@@ -207,25 +242,26 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                                      unsigned long long *__restrict__ counters,
                                                                      const uint32_t *__restrict__ queue,
                                                                      const uint32_t *__restrict__ gqueue,
-                                                                     uint32_t *__restrict__ queue_count, int with_rescue) {
-  // with_rescue == 0: the rescue queue belongs to decombine_rescue_kernel, which runs after this
-  // kernel and re-arms the work counters; this one then only takes the general list (ticket 2).
-  uint32_t *tile_ticket = queue_count + (with_rescue ? 3 : 2);
+                                                                     uint32_t *__restrict__ queue_count, uint32_t qcap) {
+  uint32_t *tile_ticket = queue_count + 3;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_slots = smem + DCRX_N_COUNTERS;        // [DCRX_QBLOCK][DCRX_LSLOT]: hit lists + exception copy
   uint32_t *lds_trans = lds_slots + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD;
   static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
-  const uint32_t n_rescue = with_rescue ? queue_count[0] : 0u, n_general = queue_count[1];
+  const uint32_t n_front = queue_count[0], n_back = queue_count[DCRX_QC_BACK], n_general = queue_count[1];
   // tickets: one per DCRX_GTILE general reads (few lanes per wave: these reads take long, divergent
   // paths, and a wave runs the union of its lanes' paths), one per DCRX_CHUNK*64 rescue reads
-  const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE, t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
+  const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE;
+  const uint32_t tiles_front = (n_front + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
+  const uint32_t t_rescue = tiles_front + (n_back + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   // The last block to finish re-arms the work counters for the next launch (no memset between
   // launches): by then every block has read the counts above.
   auto leave = [&]() {
-    if (with_rescue && tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
-      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
+    if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
+      queue_count[0] = queue_count[1] = queue_count[3] = 0;
+      queue_count[DCRX_QC_BACK] = 0;
       __threadfence();
       queue_count[4] = 0;
     }
@@ -262,11 +298,11 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
         if (B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
       }
     } else {
-      const uint32_t first = (ticket - t_general) * (64 * DCRX_CHUNK);
       for (int c = 0; c < DCRX_CHUNK; c++) {
-        const uint32_t i = first + (uint32_t)c * 64 + lane;
-        if (i < n_rescue)
-          decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)queue[i], C, records,
+        const uint32_t r = rescue_entry(queue, qcap, n_front, n_back, tiles_front, ticket - t_general, 64 * DCRX_CHUNK,
+                                        (uint32_t)c * 64 + lane);
+        if (r != 0xFFFFFFFFu)
+          decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                      lds_slots + tid * DCRX_LSLOT);
       }
     }
@@ -292,18 +328,20 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
                                                                        unsigned long long *__restrict__ counters,
                                                                        const uint32_t *__restrict__ queue,
                                                                        const uint32_t *__restrict__ gqueue,
-                                                                       uint32_t *__restrict__ queue_count) {
+                                                                       uint32_t *__restrict__ queue_count, uint32_t qcap) {
   extern __shared__ __align__(64) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_slots = smem + DCRX_N_COUNTERS;                    // [DCRX_RBLOCK][DCRX_RSLOT]
   uint32_t *lds_trans = smem + DCRX_N_COUNTERS + DCRX_RESCUE_LDS_EXTRA / 4;
   const int tid = threadIdx.x;
-  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
-  const uint32_t tickets = (n_rescue + 63) / 64;
+  const uint32_t n_front = queue_count[0], n_back = queue_count[DCRX_QC_BACK], n_general = queue_count[1];
+  const uint32_t tiles_front = (n_front + 63) / 64;
+  const uint32_t tickets = tiles_front + (n_back + 63) / 64;
   const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE;
   auto leave = [&]() {
     if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
-      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
+      queue_count[0] = queue_count[1] = queue_count[3] = 0;
+      queue_count[DCRX_QC_BACK] = 0;
       __threadfence();
       queue_count[4] = 0;
     }
@@ -322,9 +360,9 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
   const uint32_t wave = blockIdx.x * (DCRX_RBLOCK / 64) + (uint32_t)(tid >> 6), n_waves = gridDim.x * (DCRX_RBLOCK / 64);
-  // The general list first (reads with exception bytes), DCRX_GTILE reads per wave: their scan
-  // steps the one-base table in global memory (it has no room in LDS here); these few long
-  // chains run beside the rescue tiles of the other waves.
+  // The general list first (reads with exception bytes), DCRX_GTILE reads per wave (few lanes: a
+  // wave runs the union of its lanes' paths); these longer chains run beside the rescue tiles of
+  // the other waves.
   if (t_general) {
     uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
     uint32_t *gslot = lds_slots + (tid >> 6) * (64 * DCRX_RSLOT);      // the wave's slots: room for DCRX_GTILE list-kernel slots
@@ -332,7 +370,8 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
       const uint32_t i = g * DCRX_GTILE + lane;
       if (lane < DCRX_GTILE && i < n_general) {
         const uint32_t r = gqueue[i];
-        decombine_list_one<false, UNIFORM_LEN>(T, nullptr, B, cfg, (uint64_t)r, C, records, gslot + lane * DCRX_LSLOT);
+        decombine_general16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, gqueue[qcap + i], nw, C, records,
+                                                       gslot + lane * DCRX_LSLOT);
         if ((exc_flag[r >> 5] >> (r & 31)) & 1u) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
       }
     }
@@ -344,9 +383,9 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
     if (lane == 0) tile = atomicAdd(tile_ticket, 1u);
     tile = __shfl(tile, 0);
     if (tile >= tickets) break;
-    const uint32_t i = tile * 64 + lane;
-    if (i < n_rescue)
-      decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)queue[i], nw, C, records, lds_slots + tid * DCRX_RSLOT);
+    const uint32_t r = rescue_entry(queue, qcap, n_front, n_back, tiles_front, tile, 64, (uint32_t)lane);
+    if (r != 0xFFFFFFFFu)
+      decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, nw, C, records, lds_slots + tid * DCRX_RSLOT);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
@@ -358,14 +397,18 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
 // general work list — every read when `all` (orientation `both`, forced slow reader), else the
 // reads that have exception entries (first entry of each read appends it).
 __global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all, uint64_t n_reads,
-                                uint32_t *__restrict__ flag, uint32_t *__restrict__ gqueue,
+                                uint32_t *__restrict__ flag, uint32_t *__restrict__ gqueue, uint32_t *__restrict__ gstart,
                                 uint32_t *__restrict__ gcount, unsigned long long *__restrict__ counters) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < DCRX_N_COUNTERS) counters[i] = 0;
   if (i < n_exc) {
     const uint32_t r = exc_read[i];
     atomicOr(&flag[r >> 5], 1u << (r & 31));
-    if (!all && (i == 0 || exc_read[i - 1] != r)) gqueue[atomicAdd(gcount, 1u)] = r;
+    if (!all && (i == 0 || exc_read[i - 1] != r)) {
+      const uint32_t slot = atomicAdd(gcount, 1u);
+      gqueue[slot] = r;
+      gstart[slot] = (uint32_t)i;        // where the read's entries start in the exception list
+    }
   }
   if (all) {
     if (i < n_reads) gqueue[i] = (uint32_t)i;
@@ -484,6 +527,8 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_list);
+  const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue (filled from both ends), of the general
+                                                         // list behind it, and of the list of exception-list offsets behind that
   // Three launches per batch and nothing else: the prologue zeroes the caller's counters (and marks
   // / lists the reads with exception bytes), the kernels add their tallies with one atomic per
   // counter and block, and the list kernel leaves the work counters and the exception bitmap
@@ -491,12 +536,12 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   {
     const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));
     hipLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc,
-                       all_general ? 1 : 0, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, queue_count + 1,
-                       d_counters);
+                       all_general ? 1 : 0, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
+                       queue_count + 1, d_counters);
   }
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (grid) {
-    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count);
+    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count, qcap);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -508,7 +553,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
                         P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA <= 160u * 1024u;
   if (!rescue16 || all_general) {
     hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
-                       queue_count, 1);
+                       queue_count, qcap);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -521,7 +566,8 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
       rattr_set = true;
     }
     const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
-    hipLaunchKernelGGL(kresc, dim3(P.n_cu), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count);
+    hipLaunchKernelGGL(kresc, dim3(P.n_cu), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count,
+                       qcap);
     e = hipGetLastError();
   }
   return e;

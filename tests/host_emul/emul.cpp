@@ -34,6 +34,17 @@ static void rescue_one(bool pair_rescue, const DevTables &T, const BatchDev &B, 
   else decombine_rescue16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, nw, CC, records, slot);
 }
 
+// a read with exception bytes: the rescue kernel's general form when the launch would use it
+template <bool UNIFORM>
+static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
+                        const Counters &CC, dcrx_record_t *records, uint32_t *slot) {
+  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot); return; }
+  uint32_t e0 = 0;
+  while (e0 < B.n_exc && B.exc_read[e0] < (uint32_t)r) e0++;
+  if (B.stride <= 40) decombine_general16_one<false, UNIFORM, 10>(T, B, C, r, e0, nw, CC, records, slot);
+  else decombine_general16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, e0, nw, CC, records, slot);
+}
+
 extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
                               dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
   HostTables H;
@@ -65,14 +76,14 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     if (b->lens) {
-      if (general) decombine_list_one<false, false>(T, nullptr, B, C, r, CC, records, slot);
+      if (general) general_one<false>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
       else {
         const int what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
         if (what == FAST_TO_RESCUE) rescue_one<false>(pair_rescue, T, B, C, r, nw, CC, records, slot);
         else if (what != FAST_DONE) return -100;
       }
     } else {
-      if (general) decombine_list_one<false, true>(T, nullptr, B, C, r, CC, records, slot);
+      if (general) general_one<true>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
       else {
         const int what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
         if (what == FAST_TO_RESCUE) rescue_one<true>(pair_rescue, T, B, C, r, nw, CC, records, slot);
