@@ -23,6 +23,16 @@ DCRX_DEV int dcrx_clz64(uint64_t v) { return __clzll((long long)v); }
 DCRX_DEV int dcrx_popc64(uint64_t v) { return __popcll((unsigned long long)v); }
 DCRX_DEV int dcrx_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
 DCRX_DEV int dcrx_clz32(uint32_t v) { return __clz((int)v); }
+// (byte BYTE of w) & mask in one VALU op (SDWA source-byte select)
+template <int BYTE>
+DCRX_DEV uint32_t dcrx_byte_and(uint32_t w, uint32_t mask) {
+  uint32_t r;
+  if (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(mask));
+  else if (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(mask));
+  else if (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(mask));
+  else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(mask));
+  return r;
+}
 DCRX_DEV uint32_t dcrx_brev32(uint32_t v) { return __brev(v); }
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
@@ -51,6 +61,8 @@ inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
 inline int dcrx_popc64(uint64_t v) { return __builtin_popcountll(v); }
 inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
 inline int dcrx_clz32(uint32_t v) { return __builtin_clz(v); }
+template <int BYTE>
+inline uint32_t dcrx_byte_and(uint32_t w, uint32_t mask) { return (w >> (8 * BYTE)) & mask; }
 inline uint32_t dcrx_brev32(uint32_t v) {
   v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
   v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
@@ -590,18 +602,20 @@ DCRX_DEV uint32_t trans16_at(const DevTables &T, uint32_t byte_addr) {
   return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.trans16) + byte_addr);
 }
 
-// accumulator term of a pair: count in bits 0..5 (the row's low six bits are zero), the row of
-// the state BEFORE the pair in bits 6..17, the pair index in bits 18..25.  A count that wraps
-// (>= 64 hits) is caught by the OR-ed VFULL/JFULL flag: flag seen but count 0 means "many".
+// Accumulator term of a pair = its look-up address | `it`: bits 2..5 the pair's bases (first * 4 +
+// second), bits 6..17 the row of the state BEFORE the pair, bits 18..25 the pair index, bits
+// 26..31 a count of one.  With exactly one hit the sum IS that hit.  A count that wraps (>= 64
+// hits) is caught by the OR-ed VFULL/JFULL flag: flag seen but count 0 means "many".
 constexpr int ACC16_PAIR_SHIFT = 18;
-constexpr uint32_t ACC16_CNT_MASK = 0x3Fu;
+constexpr int ACC16_CNT_SHIFT = 26;
+#define DCRX_ACC16_COUNT(x) ((x) >> dcrx::ACC16_CNT_SHIFT)
 
 #define DCRX_STEP16(PAIR4) /* PAIR4 = (first base * 4 + second base) << 2 */                   \
   do {                                                                                          \
-    const uint32_t rowp_ = e & TE16_ROW_MASK;                                                   \
-    e = trans16_at<TABLE_LDS>(T, rowp_ | (uint32_t)(PAIR4));                                    \
+    const uint32_t addr_ = (e & TE16_ROW_MASK) | (uint32_t)(PAIR4);                             \
+    e = trans16_at<TABLE_LDS>(T, addr_);                                                        \
     acc |= e;                                                                                   \
-    const uint32_t t_ = rowp_ | it;                                                             \
+    const uint32_t t_ = addr_ | it;                                                             \
     vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
     jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
     it += (1u << ACC16_PAIR_SHIFT);                                                             \
@@ -613,7 +627,7 @@ struct ScanAcc16 { uint32_t acc, vacc, jacc, e_last; };
 // caller finishes with a one-base step (finish16).
 template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], const uint32_t *words, int n) {
-  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u << ACC16_CNT_SHIFT;
   const int npairs = n >> 1;
   if (npairs > 0) {
     // The frame's bases in scan order form a bit stream; it is consumed pair by pair.  REV: the
@@ -641,9 +655,12 @@ DCRX_DEV ScanAcc16 scan_fast16(const DevTables &T, const uint32_t (&w)[NW], cons
 #pragma unroll
         for (int kk = NW - 1; kk >= 0; kk--) {
           if (kk < top) {
-            const uint32_t wv = ~w[kk];
-#pragma unroll
-            for (int j = 7; j >= 0; j--) DCRX_STEP16(dcrx_ubfe(wv, 4 * j, 4) << 2);
+            // nibble j, times four, is bits 2..5 of byte j/2 of the word shifted by two either way
+            const uint32_t wv = ~w[kk], wlo = wv << 2, whi = wv >> 2;
+            DCRX_STEP16(dcrx_byte_and<3>(whi, 0x3Cu)); DCRX_STEP16(dcrx_byte_and<3>(wlo, 0x3Cu));
+            DCRX_STEP16(dcrx_byte_and<2>(whi, 0x3Cu)); DCRX_STEP16(dcrx_byte_and<2>(wlo, 0x3Cu));
+            DCRX_STEP16(dcrx_byte_and<1>(whi, 0x3Cu)); DCRX_STEP16(dcrx_byte_and<1>(wlo, 0x3Cu));
+            DCRX_STEP16(dcrx_byte_and<0>(whi, 0x3Cu)); DCRX_STEP16(dcrx_byte_and<0>(wlo, 0x3Cu));
           }
         }
       }
@@ -679,19 +696,19 @@ template <bool REV, bool TABLE_LDS>
 DCRX_DEV ScanOut finish16(const DevTables &T, const Frame<REV> &F, const ScanAcc16 &a, const int off, const bool leftover) {
   ScanOut so;
   so.acc = DCRX_ACC16_FLAGS(a.acc) & ~((1u << TE16_V2_BIT) | (1u << TE16_J2_BIT));   // one-base flag layout
-  so.vcount = a.vacc & ACC16_CNT_MASK;
+  so.vcount = DCRX_ACC16_COUNT(a.vacc);
   if (((a.acc >> TE_VMULTI_BIT) & 1u) || (so.vcount == 0 && ((a.acc >> TE_VFULL_BIT) & 1u))) so.vcount = 2;
-  so.jcount = a.jacc & ACC16_CNT_MASK;
+  so.jcount = DCRX_ACC16_COUNT(a.jacc);
   if (((a.acc >> TE_JMULTI_BIT) & 1u) || (so.jcount == 0 && ((a.acc >> TE_JFULL_BIT) & 1u))) so.jcount = 2;
   so.vstate = so.jstate = 0; so.vend = so.jend = 0;
   const int n = F.n();
   // one-base step from state index st (new numbering) with base c, in the global one-base table
   auto step4 = [&](uint32_t st, int c) { return T.trans[st * 4 + (uint32_t)c]; };
   auto locate = [&](uint32_t accv, int full_bit, int second_bit, uint32_t &state, int &end) {
-    const uint32_t rowp = accv & TE16_ROW_MASK & ~ACC16_CNT_MASK;    // row (address) of the state before the pair
+    const uint32_t rowp = accv & TE16_ROW_MASK & ~0x3Fu;             // row (address) of the state before the pair
     const int k = (int)((accv >> ACC16_PAIR_SHIFT) & 0xFFu);
-    const int c1 = F.code(off + 2 * k), c2 = F.code(off + 2 * k + 1);
-    const uint32_t e16 = trans16_at<TABLE_LDS>(T, rowp | (uint32_t)((c1 * 4 + c2) << 2));
+    const int c1 = (int)((accv >> 4) & 3u);                          // the pair's bases ride in the accumulator
+    const uint32_t e16 = trans16_at<TABLE_LDS>(T, accv & TE16_ROW_MASK);
     if ((e16 >> second_bit) & 1u) {
       state = ((e16 & TE16_ROW_MASK) - T.row16_0) >> 6; end = off + 2 * k + 1;
     } else {
@@ -976,18 +993,21 @@ DCRX_DEV int decombine_fast_one(const DevTables &T, const uint32_t *lds_trans, c
 // ------------------------------------------------------------------------------
 struct TailEntry { uint32_t r, a, b; };   // read index | vacc(26)+flags(6) | jacc(26)+flags(4)
 
-DCRX_DEV TailEntry tail_pack(uint32_t r, const ScanAcc16 &s) {
+DCRX_DEV TailEntry tail_pack(uint32_t r, const ScanAcc16 &s) {      // only reads with exactly one V tag are packed
   TailEntry t;
   t.r = r;
   t.a = (s.vacc & 0x3FFFFFFu) | (((DCRX_ACC16_FLAGS(s.acc) >> TE_VFULL_BIT) & 0x3Fu) << 26);   // VFULL JFULL VH1 VH2 JH1 JH2 (either base)
-  t.b = (s.jacc & 0x3FFFFFFu) | (((s.acc >> TE_VMULTI_BIT) & 0xFu) << 26);   // VMULTI JMULTI V2 J2
+  uint32_t jc = DCRX_ACC16_COUNT(s.jacc);                           // 0, 1, or "several" (a wrapped count shows as JFULL with 0)
+  if (jc == 0 && ((s.acc >> TE_JFULL_BIT) & 1u)) jc = 2;
+  jc = jc < 2u ? jc : 2u;
+  t.b = (s.jacc & 0x3FFFFFFu) | (((s.acc >> TE_VMULTI_BIT) & 0xFu) << 26) | (jc << 30);       // VMULTI JMULTI V2 J2, J count
   return t;
 }
 DCRX_DEV ScanAcc16 tail_unpack(const TailEntry &t, uint32_t row16_0) {
   ScanAcc16 s;
-  s.vacc = t.a & 0x3FFFFFFu;
-  s.jacc = t.b & 0x3FFFFFFu;
-  s.acc = ((t.a >> 26) << TE_VFULL_BIT) | ((t.b >> 26) << TE_VMULTI_BIT);
+  s.vacc = (t.a & 0x3FFFFFFu) | (1u << ACC16_CNT_SHIFT);
+  s.jacc = (t.b & 0x3FFFFFFu) | ((t.b >> 30) << ACC16_CNT_SHIFT);
+  s.acc = ((t.a >> 26) << TE_VFULL_BIT) | (((t.b >> 26) & 0xFu) << TE_VMULTI_BIT);
   s.e_last = row16_0;   // only even read lengths are batched: no last single base
   return s;
 }
@@ -1083,7 +1103,7 @@ struct PairMarks {
 template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV ScanAcc16 scan_collect16(const DevTables &T, const uint32_t (&w)[NW], const uint32_t *words, int n,
                                   PairMarks<NW> &pm, int &off) {
-  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u;
+  uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u << ACC16_CNT_SHIFT;
 #pragma unroll
   for (int x = 0; x < (NW + 3) / 4; x++) pm.m[x] = 0;
   pm.top = 0;

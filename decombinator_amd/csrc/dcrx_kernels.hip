@@ -159,7 +159,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
       if (live && B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) live = false;   // on the general list already
       ScanAcc16 a{0, 0, 0, 0};
       if (live) a = fast16_scan_one<TABLE_LDS, UNIFORM_LEN, NW>(T, B, cfg, r, nw);
-      const bool one_v = live && !(cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) && (a.vacc & ACC16_CNT_MASK) == 1 &&
+      const bool one_v = live && !(cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) && DCRX_ACC16_COUNT(a.vacc) == 1 &&
                          !((a.acc >> TE_VMULTI_BIT) & 1u);
       // No single V tag: the outcome needs no walk.  No V tag and no V half tag -> NoVDetected
       // (decombine.py:393); several V tags -> MultipleVtagMatches (:278-280); V half tags only ->
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
       if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {
         if (live) fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, r, a, C, records);
       } else {
-        const uint32_t vcnt = a.vacc & ACC16_CNT_MASK;
+        const uint32_t vcnt = DCRX_ACC16_COUNT(a.vacc);
         const bool vmulti = live && !one_v && (vcnt > 1 || ((a.acc >> TE_VMULTI_BIT) & 1u) || ((a.acc >> TE_VFULL_BIT) & 1u));
         const bool vhalf = live && !one_v && !vmulti && ((DCRX_ACC16_FLAGS(a.acc) >> TE_VH1_BIT) & 3u);
         const bool vnone = live && !one_v && !vmulti && !vhalf;
