@@ -34,8 +34,11 @@ DCRX_DEV uint32_t dcrx_byte_and(uint32_t w, uint32_t mask) {
   return r;
 }
 DCRX_DEV uint32_t dcrx_brev32(uint32_t v) { return __brev(v); }
+// Records are written once and never read back by these kernels: streamed past the caches, so
+// that the L2 keeps the packed reads the batched tail comes back to.
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
-  *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&rec);
+  typedef uint32_t dcrx_v4u __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(*reinterpret_cast<const dcrx_v4u *>(&rec), reinterpret_cast<dcrx_v4u *>(dst));
 }
 // pointer into LDS with its address space spelled out (ds_read/ds_write instead of flat_*)
 typedef __attribute__((address_space(3))) uint32_t dcrx_lds_u32;
