@@ -148,6 +148,10 @@ def main():
     cfg = nat.make_cfg("reverse", False, 130, args.cfg_flags)
     nat.check(nat.lib().dcrx_reserve_device(tables.handle, n))
     gather = sharded.TupleGather(n, world, rank, dev) if use_dist else None
+    if world > 1:
+        # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that
+        # the gather of step k really runs beside the scan of step k+1
+        nat.check(nat.lib().dcrx_set_reserved_cus(tables.handle, int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))))
 
     def step(ev_pair=None):
         if ev_pair is not None:

@@ -51,6 +51,7 @@ struct dcrx_tables {
   DevTables dev{};
   LaunchPlan plan{};
   bool ws_dirty = true;       // work counters / exception bitmap must be zeroed before the next launch
+  uint32_t reserved_cus = 0;
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
@@ -183,6 +184,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     P.grid = (uint32_t)prop.multiProcessorCount * std::max<uint32_t>(per_cu, 1);  // upper bound for either fast kernel
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
+    P.reserved_cus = t->reserved_cus;
     t->plan = P;
     t->device = dev;
   }
@@ -319,11 +321,11 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
   return DCRX_OK;
 }
 
-int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
-                             dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits, void *stream) {
+static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index, dcrx_record_t *d_hits,
+                        uint64_t *d_hit_index, uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
   // workspace lives in a process-wide slot keyed by device: compaction does not need tables
   static thread_local struct { int dev = -1; uint32_t *tc = nullptr; uint64_t *to = nullptr; uint64_t cap = 0; } ws;
-  if (!d_n_hits || (n_reads && (!d_records || !d_hits || !d_hit_index))) return set_err(DCRX_E_INVALID, "null argument");
+  if (!d_n_hits || (n_reads && (!d_records || !d_hits || (!d_hit_index && !d_ok_bitmap)))) return set_err(DCRX_E_INVALID, "null argument");
   int dev = -1; HIP_TRY(hipGetDevice(&dev));
   if (ws.dev != dev || n_reads > ws.cap) {
     if (ws.dev == dev) { (void)hipFree(ws.tc); (void)hipFree(ws.to); }
@@ -332,7 +334,27 @@ int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, u
     HIP_TRY(hipMalloc(&ws.to, tiles * 8));
     ws.dev = dev; ws.cap = n_reads;
   }
-  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_n_hits, ws.tc, ws.to, (hipStream_t)stream));
+  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_ok_bitmap, d_n_hits, ws.tc, ws.to,
+                         (hipStream_t)stream));
+  return DCRX_OK;
+}
+
+int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
+                             dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits, void *stream) {
+  if (n_reads && !d_hit_index) return set_err(DCRX_E_INVALID, "null argument");
+  return compact_hits(d_records, n_reads, first_index, d_hits, d_hit_index, nullptr, d_n_hits, stream);
+}
+
+int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_reads, dcrx_record_t *d_hits,
+                                    uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
+  if (n_reads && !d_ok_bitmap) return set_err(DCRX_E_INVALID, "null argument");
+  return compact_hits(d_records, n_reads, 0, d_hits, nullptr, d_ok_bitmap, d_n_hits, stream);
+}
+
+int dcrx_set_reserved_cus(dcrx_tables_t *t, uint32_t n_cus) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  t->reserved_cus = n_cus;
+  t->plan.reserved_cus = n_cus;
   return DCRX_OK;
 }
 

@@ -466,7 +466,8 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
                                                                     uint64_t first_index,
                                                                     const uint64_t *__restrict__ tile_off,
                                                                     dcrx_record_t *__restrict__ hits,
-                                                                    uint64_t *__restrict__ hit_index) {
+                                                                    uint64_t *__restrict__ hit_index,
+                                                                    uint64_t *__restrict__ ok_bitmap) {
   __shared__ uint32_t s_wave[CP_PER_THREAD][CP_BLOCK / 64];
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -477,7 +478,12 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
     ok[k] = i < n && rec[i].status == DCRX_S_OK;
     const unsigned long long m = __ballot(ok[k]);
     rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[k][wave] = (uint32_t)__popcll(m);
+    if (lane == 0) {
+      s_wave[k][wave] = (uint32_t)__popcll(m);
+      // bit (i & 63) of word i >> 6: read i decombined.  A wave covers 64 consecutive reads from a multiple of 64.
+      const uint64_t i0 = base + (uint64_t)k * CP_BLOCK + (uint64_t)wave * 64;
+      if (ok_bitmap && i0 < n) ok_bitmap[i0 >> 6] = m;
+    }
   }
   __syncthreads();
   uint64_t off = tile_off[blockIdx.x];
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
       const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
       const uint64_t dst = off + before + rank[k];
       reinterpret_cast<uint4 *>(hits)[dst] = reinterpret_cast<const uint4 *>(rec)[i];
-      hit_index[dst] = first_index + i;
+      if (hit_index) hit_index[dst] = first_index + i;
     }
   }
 }
@@ -525,8 +531,10 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   if (e != hipSuccess) return e;
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
-  const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, P.n_cu * (uint32_t)occ_fast);
-  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, P.n_cu * (uint32_t)occ_list);
+  // reserved_cus: compute units left to other streams (an RCCL gather running beside the scan)
+  const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
+  const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, cus * (uint32_t)occ_fast);
+  const uint32_t qgrid = std::min<uint32_t>(P.qgrid, cus * (uint32_t)occ_list);
   const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue (filled from both ends), of the general
                                                          // list behind it, and of the list of exception-list offsets behind that
   // Three launches per batch and nothing else: the prologue zeroes the caller's counters (and marks
@@ -566,7 +574,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
       rattr_set = true;
     }
     const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
-    hipLaunchKernelGGL(kresc, dim3(P.n_cu), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count,
+    hipLaunchKernelGGL(kresc, dim3(cus), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count,
                        qcap);
     e = hipGetLastError();
   }
@@ -597,15 +605,15 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
 }
 
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
-                          uint64_t *hit_index, uint64_t *d_total, uint32_t *tile_count, uint64_t *tile_off,
-                          hipStream_t s) {
+                          uint64_t *hit_index, uint64_t *ok_bitmap, uint64_t *d_total, uint32_t *tile_count,
+                          uint64_t *tile_off, hipStream_t s) {
   const uint32_t n_tiles = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
   if (n_tiles)
     hipLaunchKernelGGL(compact_count_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, tile_count);
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, n_tiles, tile_off, d_total);
   if (n_tiles)
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, first_index, tile_off,
-                       hits, hit_index);
+                       hits, hit_index, ok_bitmap);
   return hipGetLastError();
 }
 

@@ -66,11 +66,13 @@ def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
 
 class TupleGather:
     """Per-step fixed-capacity gather for the benchmark loop: no host sync inside the timed
-    region.  Every rank compacts its step's tuples on the device and sends the first `cap`
-    of them (cap = reads/2 covers the synthetic mixture's ~42 % decombined reads; `check`
-    verifies that after the run).  The gathers are issued asynchronously on RCCL's stream
-    with `depth` rotating buffer sets, so the gather of step k overlaps the scan of step
-    k+1; a buffer set is reused only after its previous gather has completed."""
+    region.  Every rank compacts its step's tuples on the device — the 16-byte records in read
+    order plus one bit per read saying which reads they belong to (a third fewer bytes than
+    8-byte indices) — and sends the first `cap` records (cap = reads/2 covers the synthetic
+    mixture's ~42 % decombined reads; `check` verifies that after the run) and the bitmap.  The
+    gathers are issued asynchronously on RCCL's stream with `depth` rotating buffer sets, so the
+    gather of step k overlaps the scan of step k+1; a buffer set is reused only after its previous
+    gather has completed."""
 
     def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5,
                  depth: int = 2):
@@ -78,18 +80,19 @@ class TupleGather:
         self.nat = nat
         self.world, self.rank = world, rank
         self.cap = int(n_reads * cap_fraction) + 1024
+        self.words = (n_reads + 63) // 64
         self.k = 0
         self.slots = []
         for _ in range(depth):
             slot = {
                 "hits": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
-                "idx": torch.empty(n_reads, dtype=torch.int64, device=device),
+                "bitmap": torch.zeros(self.words, dtype=torch.int64, device=device),
                 "n": torch.zeros(1, dtype=torch.int64, device=device),
                 "work": [],
             }
             if rank == 0:
                 slot["g_hits"] = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
-                slot["g_idx"] = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(world)]
+                slot["g_bitmap"] = [torch.empty(self.words, dtype=torch.int64, device=device) for _ in range(world)]
                 slot["g_n"] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
             self.slots.append(slot)
 
@@ -99,17 +102,17 @@ class TupleGather:
         self.k += 1
         for w in s["work"]:          # the compute stream waits for this set's previous gather
             w.wait()
-        nat.check(nat.lib().dcrx_compact_hits_device(d_rec.data_ptr(), n_reads, first_index, s["hits"].data_ptr(),
-                                                     s["idx"].data_ptr(), s["n"].data_ptr(), stream_ptr))
-        h, i = s["hits"][:self.cap * 16], s["idx"][:self.cap]
+        nat.check(nat.lib().dcrx_compact_hits_bitmap_device(d_rec.data_ptr(), n_reads, s["hits"].data_ptr(),
+                                                            s["bitmap"].data_ptr(), s["n"].data_ptr(), stream_ptr))
+        h = s["hits"][:self.cap * 16]
         if self.rank == 0:
             s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
                          dist.gather(h, s["g_hits"], dst=0, async_op=True),
-                         dist.gather(i, s["g_idx"], dst=0, async_op=True)]
+                         dist.gather(s["bitmap"], s["g_bitmap"], dst=0, async_op=True)]
         else:
             s["work"] = [dist.gather(s["n"], None, dst=0, async_op=True),
                          dist.gather(h, None, dst=0, async_op=True),
-                         dist.gather(i, None, dst=0, async_op=True)]
+                         dist.gather(s["bitmap"], None, dst=0, async_op=True)]
 
     def finish(self) -> None:
         """Makes the current stream wait for every gather still in flight."""
@@ -117,6 +120,14 @@ class TupleGather:
             for w in s["work"]:
                 w.wait()
             s["work"] = []
+
+    @staticmethod
+    def _popcount(words: torch.Tensor) -> int:
+        b = words.view(torch.uint8).to(torch.int32)
+        total = 0
+        for k in range(8):
+            total += int(((b >> k) & 1).sum().item())
+        return total
 
     def check(self, n_hits_local: int) -> None:
         self.finish()
@@ -127,8 +138,7 @@ class TupleGather:
             got = [int(x.item()) for x in last["g_n"]]
             if got[0] != n_hits_local or any(g <= 0 or g > self.cap for g in got):
                 raise RuntimeError(f"gathered tuple counts look wrong: {got}")
-            # rank order = read order: every rank's indices lie in its own shard, ascending
+            # every rank's bitmap marks exactly as many reads as it sent tuples (rank order = read order)
             for r in range(self.world):
-                idx = last["g_idx"][r][:got[r]]
-                if got[r] > 1 and not bool((idx[1:] > idx[:-1]).all()):
-                    raise RuntimeError(f"tuples of rank {r} are not in read order")
+                if self._popcount(last["g_bitmap"][r]) != got[r]:
+                    raise RuntimeError(f"bitmap of rank {r} does not match its {got[r]} tuples")

@@ -248,6 +248,17 @@ int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, u
                              dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits,
                              void *hip_stream);
 
+/* Same compaction with the read indices as a bitmap instead of a list: bit (i & 63) of
+ * d_ok_bitmap[i >> 6] is set when read i decombined ((n_reads + 63) / 64 words; the k-th record
+ * of d_hits belongs to the k-th set bit).  A third fewer bytes to gather than 8-byte indices. */
+int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_reads,
+                                    dcrx_record_t *d_hits, uint64_t *d_ok_bitmap, uint64_t *d_n_hits,
+                                    void *hip_stream);
+
+/* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
+ * them are left free from the next call on (for a collective running on another stream). */
+int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);
+
 /* ---- device plumbing for callers without a HIP binding of their own ---- */
 int dcrx_device_count(void);
 int dcrx_set_device(int device);

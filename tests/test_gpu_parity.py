@@ -237,3 +237,13 @@ def test_compact_hits_matches_numpy():
     assert k == len(ok)
     assert d_hits.to_host(nat.RECORD_DTYPE, k).tobytes() == rec[ok].tobytes()
     assert (d_idx.to_host(np.uint64, k) == ok.astype(np.uint64) + 5_000_000).all()
+    # bitmap form: same records, positions as one bit per read
+    words = (n + 63) // 64
+    d_bm = nat.DeviceBuffer(words * 8)
+    d_hits2 = nat.DeviceBuffer(n * 16)
+    nat.compact_hits_bitmap_device(d_rec, n, d_hits2, d_bm, d_n)
+    nat.synchronize()
+    assert int(d_n.to_host(np.uint64, 1)[0]) == k
+    assert d_hits2.to_host(nat.RECORD_DTYPE, k).tobytes() == rec[ok].tobytes()
+    bits = np.unpackbits(d_bm.to_host(np.uint64, words).view(np.uint8), bitorder="little")
+    assert (np.nonzero(bits)[0] == ok).all()
