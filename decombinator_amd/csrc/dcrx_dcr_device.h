@@ -1095,7 +1095,7 @@ struct PairMarks {
 #define DCRX_STEP16C(PAIR4, MARKS, SHIFT)                                                       \
   do {                                                                                          \
     DCRX_STEP16(PAIR4);                                                                         \
-    uint32_t h_ = e & ((0xFu << TE_VH1_BIT) | (0xFu << TE16_H2_SHIFT));                         \
+    uint32_t h_ = e & hmask;                                                                    \
     h_ = h_ < 1u ? h_ : 1u;                                                                     \
     (MARKS) |= h_ << (SHIFT);                                                                   \
   } while (0)
@@ -1105,7 +1105,7 @@ struct PairMarks {
 // An odd-length FWD read leaves its last base to finish16, like scan_fast16.
 template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV ScanAcc16 scan_collect16(const DevTables &T, const uint32_t (&w)[NW], const uint32_t *words, int n,
-                                  PairMarks<NW> &pm, int &off) {
+                                  uint32_t hmask, PairMarks<NW> &pm, int &off) {   // hmask: the half-tag class bits (both bases) that count
   uint32_t e = T.row16_0, acc = 0, vacc = 0, jacc = 0, it = 1u << ACC16_CNT_SHIFT;
 #pragma unroll
   for (int x = 0; x < (NW + 3) / 4; x++) pm.m[x] = 0;
@@ -1244,24 +1244,27 @@ DCRX_DEV void resolve_half_hits(const DevTables &T, const ReadView &rv, const ui
 
 template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV int rescue16_frame(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], const CfgDev &cfg,
-                            const Counters &C, dcrx_record_t &rec, HalfHits &hh) {
+                            const uint32_t hints, const Counters &C, dcrx_record_t &rec, HalfHits &hh) {
+  // hints (from the fast kernel): bit 1 = the V tag needs the rescue, bit 0 = the J tag may need it
+  const uint32_t genes = ((hints & 2u) ? 3u : 0u) | ((hints & 1u) ? 12u : 0u);          // as half-tag classes
   PairMarks<NW> pm;
   int off;
-  const ScanAcc16 a = scan_collect16<REV, TABLE_LDS, NW>(T, w, rv.words, rv.n, pm, off);
+  const ScanAcc16 a = scan_collect16<REV, TABLE_LDS, NW>(T, w, rv.words, rv.n, (genes << TE_VH1_BIT) | (genes << TE16_H2_SHIFT),
+                                                         pm, off);
   const Frame<REV> F(rv);
   const bool leftover = !REV && (rv.n & 1);
   const ScanOut so = finish16<REV, TABLE_LDS>(T, F, a, off, leftover);
   hh.cnts = 0;
   // dcr_frame tries half 1 of a gene when any half-1 keyword occurs, else half 2 (:294/:339,
   // :422/:473): only those two lists are kept, in two LDS lists per lane
-  hh.keep = (((so.acc >> TE_VH1_BIT) & 1u) ? 1u : 2u) | (((so.acc >> TE_JH1_BIT) & 1u) ? 4u : 8u);
+  hh.keep = ((((so.acc >> TE_VH1_BIT) & 1u) ? 1u : 2u) | (((so.acc >> TE_JH1_BIT) & 1u) ? 4u : 8u)) & genes;
   hh.compact = 1;
   if (cfg.flags & DCRX_F_PROFILE_LIST_SCAN_ONLY) {   // profiling aid: price the marking scan alone
     rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend);
     rec.j_end = (uint16_t)(pm.top + pm.m[0] + pm.m[1]); return 254;
   }
   resolve_half_hits<REV, TABLE_LDS, NW>(T, rv, w, pm, hh);
-  if (cfg.flags & 32u) {                             // profiling aid: ... and the hit resolution
+  if (cfg.flags & DCRX_F_PROFILE_RESCUE_HITS_ONLY) {   // profiling aid: ... and the hit resolution
     rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend);
     rec.j_end = (uint16_t)hh.cnts; rec.ins_start = (uint16_t)hh.slot[0]; return 254;
   }
@@ -1277,8 +1280,8 @@ DCRX_DEV int rescue16_frame(const DevTables &T, const ReadView &rv, const uint32
 
 // One clean read of the rescue queue; `slot`: this lane's 2 * HH_K dwords of LDS.
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
-DCRX_DEV void decombine_rescue16_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t nw,
-                                     const Counters &C, dcrx_record_t *records, uint32_t *slot) {
+DCRX_DEV void decombine_rescue16_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t hints,
+                                     uint32_t nw, const Counters &C, dcrx_record_t *records, uint32_t *slot) {
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
@@ -1301,8 +1304,8 @@ DCRX_DEV void decombine_rescue16_one(const DevTables &T, const BatchDev &B, cons
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
   int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) { status = rescue16_frame<false, TABLE_LDS, NW>(T, rv, w, cfg, C, rec, hh); frame = 1; }
-  else { status = rescue16_frame<true, TABLE_LDS, NW>(T, rv, w, cfg, C, rec, hh); frame = 0; }
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) { status = rescue16_frame<false, TABLE_LDS, NW>(T, rv, w, cfg, hints, C, rec, hh); frame = 1; }
+  else { status = rescue16_frame<true, TABLE_LDS, NW>(T, rv, w, cfg, hints, C, rec, hh); frame = 0; }
   C.add(DCRX_C_READ_COUNT);                                           // :991
   if (status == DCRX_S_OK) {
     C.add(DCRX_C_VJ_COUNT);                                           // :1013

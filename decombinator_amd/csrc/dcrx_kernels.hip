@@ -56,7 +56,7 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
 __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decombine_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count, uint32_t qcap) {
+    uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_count) {
   constexpr int BLOCK = ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK;
   extern __shared__ __align__(64) uint32_t smem[];
   uint32_t *lds_counts = smem;                        // [DCRX_N_COUNTERS]
@@ -93,43 +93,21 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
   // Static work distribution: block b takes tiles b, b + grid, ... (the grid is exactly the
   // resident capacity, so every block runs from the start; a global ticket per wave-tile was
   // measured slower: one atomic address sustains only ~90 tickets/us).
-  // The rescue queue can be filled from both ends — reads whose V tag needs the rescue from the
-  // front (count in queue_count[0]), reads whose J tag needs it from the back
-  // (queue_count[DCRX_QC_BACK]) — so that the waves working it off run one kind of rescue each.
-  // Measured on MI355X (10 M reads): the rescue kernel gains nothing from sorted tiles, while the
-  // second atomic per flush costs the fast kernel ~9 %; so everything goes to the front.
-  constexpr bool typed = false;
+  // Queue entries carry two hints in their top bits when the batch allows (< 2^30 reads): bit 31 =
+  // the V tag needs the rescue, bit 30 = the J tag may need it.  The rescue kernel then only
+  // marks and resolves the half-tag hits of the gene(s) concerned.  Hints err on the side of 1.
+  const bool tagged = B.n_reads < (1ull << 30);
   auto flush = [&]() {
-    if (!typed) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(queue_count, wq_n);
-      base = __shfl(base, 0);
-      for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
-      wq_n = 0;
-      return;
-    }
-    for (uint32_t i0 = 0; i0 < wq_n; i0 += 64) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      const bool have = i < wq_n;
-      const uint32_t ent = have ? wq[i] : 0u;
-      const bool back = have && (ent >> 31);
-      const unsigned long long mb = __ballot(back), mf = __ballot(have && !back);
-      uint32_t bf = 0, bb = 0;
-      if (lane == 0) {
-        if (mf) bf = atomicAdd(queue_count, (uint32_t)__popcll(mf));
-        if (mb) bb = atomicAdd(queue_count + DCRX_QC_BACK, (uint32_t)__popcll(mb));
-      }
-      bf = __shfl(bf, 0); bb = __shfl(bb, 0);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (back) queue[qcap - 1u - (bb + (uint32_t)__popcll(mb & below))] = ent & 0x7FFFFFFFu;
-      else if (have) queue[bf + (uint32_t)__popcll(mf & below)] = ent;
-    }
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(queue_count, wq_n);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < wq_n; i += 64) queue[base + i] = wq[i];
     wq_n = 0;
   };
-  auto to_rescue = [&](bool defer, uint32_t r32, uint32_t j_kind) {
+  auto to_rescue = [&](bool defer, uint32_t r32, uint32_t hints) {
     const unsigned long long m = __ballot(defer);
     if (m) {
-      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = typed ? (r32 | (j_kind << 31)) : r32;
+      if (defer) wq[wq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = tagged ? (r32 | (hints << 30)) : r32;
       wq_n += (uint32_t)__popcll(m);
       if (wq_n >= 64) flush();
     }
@@ -151,7 +129,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
         defer = fast16_tail_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)te.r, tail_unpack(te, T.row16_0), C,
                                                         records) == FAST_TO_RESCUE;
       }
-      to_rescue(defer, r32, 1u);      // a read with its V tag in hand: the J tag needs the rescue
+      to_rescue(defer, r32, 1u);      // a read with its V tag in hand: only the J tag needs the rescue
     };
     for (uint64_t tile = blockIdx.x; tile * BLOCK < B.n_reads; tile += gridDim.x) {
       const uint64_t r = tile * BLOCK + tid;
@@ -188,7 +166,8 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
           if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
         }
       }
-      to_rescue(defer, (uint32_t)r, 0u);
+      // V needs the rescue; J may need it unless exactly one J tag was seen
+      to_rescue(defer, (uint32_t)r, 2u | (DCRX_ACC16_COUNT(a.jacc) != 1u ? 1u : 0u));
       const unsigned long long m = __ballot(one_v);
       if (m) {
         if (one_v) {
@@ -208,7 +187,7 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
     if (r < B.n_reads) what = decombine_fast_one<TABLE_LDS, UNIFORM_LEN, NW, ARITY>(T, lds_trans, B, cfg, r, nw, C, records);
     // FAST_TO_GENERAL reads (exception bytes) are already on the general list, which is built
     // from the exception list before this kernel starts
-    to_rescue(what == FAST_TO_RESCUE, (uint32_t)r, 0u);
+    to_rescue(what == FAST_TO_RESCUE, (uint32_t)r, 3u);
   }
   }
   if (wq_n) flush();
@@ -216,17 +195,17 @@ __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decom
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
-// Read index of entry `lane` of rescue tile `tile`: tiles [0, tiles_front) walk the front part of
-// the queue, the others its back part (see the fast kernel).  0xFFFFFFFF: no entry.
-__device__ __forceinline__ uint32_t rescue_entry(const uint32_t *__restrict__ queue, uint32_t qcap, uint32_t n_front,
-                                                 uint32_t n_back, uint32_t tiles_front, uint32_t tile, uint32_t per_tile,
-                                                 uint32_t k) {
-  if (tile < tiles_front) {
-    const uint32_t i = tile * per_tile + k;
-    return i < n_front ? queue[i] : 0xFFFFFFFFu;
-  }
-  const uint32_t i = (tile - tiles_front) * per_tile + k;
-  return i < n_back ? queue[qcap - 1u - i] : 0xFFFFFFFFu;
+// Entry k of rescue tile `tile` (per_tile entries each), 0xFFFFFFFF past the end.  With `tagged`
+// the top two bits are the fast kernel's hints (see there); *hints gets them (3 when untagged).
+__device__ __forceinline__ uint32_t rescue_entry(const uint32_t *__restrict__ queue, uint32_t n_rescue, uint32_t tile,
+                                                 uint32_t per_tile, uint32_t k, bool tagged, uint32_t *hints) {
+  const uint32_t i = tile * per_tile + k;
+  *hints = 3u;
+  if (i >= n_rescue) return 0xFFFFFFFFu;
+  const uint32_t ent = queue[i];
+  if (!tagged) return ent;
+  *hints = ent >> 30;
+  return ent & 0x3FFFFFFFu;
 }
 
 // List kernel: everything the fast kernel does not finish, in dense waves.  Two work lists,
@@ -242,7 +221,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                                      unsigned long long *__restrict__ counters,
                                                                      const uint32_t *__restrict__ queue,
                                                                      const uint32_t *__restrict__ gqueue,
-                                                                     uint32_t *__restrict__ queue_count, uint32_t qcap) {
+                                                                     uint32_t *__restrict__ queue_count) {
   uint32_t *tile_ticket = queue_count + 3;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
@@ -250,18 +229,17 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   uint32_t *lds_trans = lds_slots + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD;
   static_assert(((DCRX_N_COUNTERS + DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT_PAD) % 4) == 0, "DFA rows must stay 16-byte aligned");
   const int tid = threadIdx.x;
-  const uint32_t n_front = queue_count[0], n_back = queue_count[DCRX_QC_BACK], n_general = queue_count[1];
+  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
+  const bool tagged = B.n_reads < (1ull << 30);
   // tickets: one per DCRX_GTILE general reads (few lanes per wave: these reads take long, divergent
   // paths, and a wave runs the union of its lanes' paths), one per DCRX_CHUNK*64 rescue reads
   const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE;
-  const uint32_t tiles_front = (n_front + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
-  const uint32_t t_rescue = tiles_front + (n_back + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
+  const uint32_t t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   // The last block to finish re-arms the work counters for the next launch (no memset between
   // launches): by then every block has read the counts above.
   auto leave = [&]() {
     if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
-      queue_count[0] = queue_count[1] = queue_count[3] = 0;
-      queue_count[DCRX_QC_BACK] = 0;
+      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
       __threadfence();
       queue_count[4] = 0;
     }
@@ -299,8 +277,9 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
       }
     } else {
       for (int c = 0; c < DCRX_CHUNK; c++) {
-        const uint32_t r = rescue_entry(queue, qcap, n_front, n_back, tiles_front, ticket - t_general, 64 * DCRX_CHUNK,
-                                        (uint32_t)c * 64 + lane);
+        uint32_t hints;
+        const uint32_t r = rescue_entry(queue, n_rescue, ticket - t_general, 64 * DCRX_CHUNK, (uint32_t)c * 64 + lane, tagged,
+                                        &hints);
         if (r != 0xFFFFFFFFu)
           decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                      lds_slots + tid * DCRX_LSLOT);
@@ -334,14 +313,13 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
   uint32_t *lds_slots = smem + DCRX_N_COUNTERS;                    // [DCRX_RBLOCK][DCRX_RSLOT]
   uint32_t *lds_trans = smem + DCRX_N_COUNTERS + DCRX_RESCUE_LDS_EXTRA / 4;
   const int tid = threadIdx.x;
-  const uint32_t n_front = queue_count[0], n_back = queue_count[DCRX_QC_BACK], n_general = queue_count[1];
-  const uint32_t tiles_front = (n_front + 63) / 64;
-  const uint32_t tickets = tiles_front + (n_back + 63) / 64;
+  const uint32_t n_rescue = queue_count[0], n_general = queue_count[1];
+  const bool tagged = B.n_reads < (1ull << 30);
+  const uint32_t tickets = (n_rescue + 63) / 64;
   const uint32_t t_general = (n_general + DCRX_GTILE - 1) / DCRX_GTILE;
   auto leave = [&]() {
     if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
-      queue_count[0] = queue_count[1] = queue_count[3] = 0;
-      queue_count[DCRX_QC_BACK] = 0;
+      queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
       __threadfence();
       queue_count[4] = 0;
     }
@@ -383,9 +361,10 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
     if (lane == 0) tile = atomicAdd(tile_ticket, 1u);
     tile = __shfl(tile, 0);
     if (tile >= tickets) break;
-    const uint32_t r = rescue_entry(queue, qcap, n_front, n_back, tiles_front, tile, 64, (uint32_t)lane);
+    uint32_t hints;
+    const uint32_t r = rescue_entry(queue, n_rescue, tile, 64, (uint32_t)lane, tagged, &hints);
     if (r != 0xFFFFFFFFu)
-      decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, nw, C, records, lds_slots + tid * DCRX_RSLOT);
+      decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, hints, nw, C, records, lds_slots + tid * DCRX_RSLOT);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
@@ -535,7 +514,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, cus * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, cus * (uint32_t)occ_list);
-  const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue (filled from both ends), of the general
+  const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue, of the general
                                                          // list behind it, and of the list of exception-list offsets behind that
   // Three launches per batch and nothing else: the prologue zeroes the caller's counters (and marks
   // / lists the reads with exception bytes), the kernels add their tallies with one atomic per
@@ -549,7 +528,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   }
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (grid) {
-    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count, qcap);
+    hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -561,7 +540,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
                         P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA <= 160u * 1024u;
   if (!rescue16 || all_general) {
     hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
-                       queue_count, qcap);
+                       queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -10,8 +10,7 @@
 #define DCRX_BLOCK 512   /* fast kernel, one base per step */
 #define DCRX_BLOCK16 1024 /* fast kernel, two bases per step (one block per CU: the table takes most of the LDS) */
 #define DCRX_QBLOCK 512  /* list kernel */
-#define DCRX_QC_BACK 32      /* index of the back count: its own cache line (two atomic streams, not one) */
-#define DCRX_QUEUE_HEADER 64 /* work counters in front of the queues: rescue count (front), general count, rescue count (back), ticket, blocks done */
+#define DCRX_QUEUE_HEADER 8 /* work counters in front of the queues: rescue count, general count, -, ticket, blocks done */
 #define DCRX_EXC_LDS 4    /* exception entries of a read the list kernel keeps in LDS */
 /* extra dwords of a general-kernel lane slot after the hit lists: exception positions (u16) + bytes (u8) */
 #define DCRX_GSLOT_EXTRA (DCRX_EXC_LDS / 2 + DCRX_EXC_LDS / 4)

@@ -114,6 +114,7 @@ typedef struct dcrx_cfg {
 #define DCRX_F_FORCE_SLOW_READER 1u /* tests: route every read through the exception-aware reader */
 #define DCRX_F_PROFILE_SCAN_ONLY 2u  /* profiling: fast kernel stops after the DFA scan (records are NOT results) */
 #define DCRX_F_PROFILE_LIST_SCAN_ONLY 8u /* profiling: list kernel stops after its collecting scan (records are NOT results) */
+#define DCRX_F_PROFILE_RESCUE_HITS_ONLY 32u /* profiling: rescue kernel stops after resolving the half-tag hit lists (records are NOT results) */
 #define DCRX_F_LIST_RESCUE 16u       /* rescue queue through the list kernel (one-base collecting scan) even when the pair form applies (A/B, tests) */
 #define DCRX_F_ONE_BASE_SCAN 4u      /* use the one-base-per-step fast kernel even when the two-base table fits LDS (A/B, tests) */
 

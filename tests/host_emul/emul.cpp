@@ -30,8 +30,8 @@ template <bool UNIFORM>
 static void rescue_one(bool pair_rescue, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
                        const Counters &CC, dcrx_record_t *records, uint32_t *slot) {
   if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot); return; }
-  if (B.stride <= 40) decombine_rescue16_one<false, UNIFORM, 10>(T, B, C, r, nw, CC, records, slot);
-  else decombine_rescue16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, nw, CC, records, slot);
+  if (B.stride <= 40) decombine_rescue16_one<false, UNIFORM, 10>(T, B, C, r, 3u, nw, CC, records, slot);
+  else decombine_rescue16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, 3u, nw, CC, records, slot);
 }
 
 // a read with exception bytes: the rescue kernel's general form when the launch would use it
