@@ -1077,10 +1077,10 @@ DCRX_DEV int fast16_tail_one(const DevTables &T, const uint32_t *lds_trans, cons
 //   1. scan_collect16: the pair scan of the fast kernel, which also marks, one bit per pair,
 //      the pairs where some half-tag keyword ends (entry bits TE_VH1_BIT..TE_JH2_BIT);
 //   2. resolve_half_hits: for each marked pair, in scan order, both of its positions are
-//      resolved by re-running the automaton from the root over the DCRX_MINI_W bases that end
-//      there.  The state so reached carries the same half-tag outputs as the state of the
+//      resolved by re-running the automaton from the root over the W bases that end there
+//      (W = the longest half tag + 1, rounded up to even; at most DCRX_MINI_W = 16).  The state so reached carries the same half-tag outputs as the state of the
 //      full scan: every half-tag keyword that ends at a position is a suffix of that window
-//      (DCRX_MINI_W >= max_half_len), hence a suffix of the longest window suffix that is a
+//      (W > max_half_len), hence a suffix of the longest window suffix that is a
 //      trie prefix, and any deeper state of the full scan is longer than every half tag.
 // The lists come out exactly as scan_collect writes them (same entries, same order).
 // ------------------------------------------------------------------------------
@@ -1160,7 +1160,10 @@ template <bool REV, bool TABLE_LDS, int NW>
 DCRX_DEV void mini_scan(const DevTables &T, const ReadView &rv, const uint32_t (&w)[NW], int end, uint32_t &state,
                         uint32_t &classes, uint32_t &classes_before) {   // classes_before: those that end at end - 1 (0 when end == 0)
   const int n = rv.n;
-  const int len = end + 1 < DCRX_MINI_W ? end + 1 : DCRX_MINI_W;
+  // even, <= DCRX_MINI_W (pair_rescue), and one base longer than every half tag: the classes reported for
+  // end - 1 come from the window without its last base
+  const int W = (int)((T.max_half_len + 2u) & ~1u);
+  const int len = end + 1 < W ? end + 1 : W;
   // the window's bases, oldest first, 2 bits each (frame codes)
   const int p0 = REV ? n - 1 - end : end - len + 1;        // lowest read position of the window
   const int wi = p0 >> 4, sh = 2 * (p0 & 15);

@@ -78,7 +78,7 @@ struct DevTables {
   uint32_t dfa16_bytes;
   uint32_t row16_0;           // like row0, for trans16
   uint32_t max_half_len;      // longest half-tag keyword (the rescue kernel re-derives hit states from a window of 16 bases)
-  uint32_t pair_rescue;       // 1 when the rescue kernel's pair form applies: trans16 exists, max_half_len <= 16, every keyword >= 2 nt
+  uint32_t pair_rescue;       // 1 when the rescue kernel's pair form applies: trans16 exists, max_half_len <= 15, every keyword >= 2 nt
   const uint32_t *st_full;    // [state - first_out] V tag | J tag << 16 ending at the state (0xFFFF none)
   const uint32_t *st_out;     // [state - first_out (+1)] CSR into outs
   const uint32_t *outs;       // per-state output list, longest keyword first

@@ -412,7 +412,7 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
         }
     R.trans16 = as_off<uint32_t>(B.put(trans16));
     R.dfa16_bytes = S * 64u;
-    R.pair_rescue = (R.max_half_len <= 16 && min_kw_len >= 2) ? 1u : 0u;
+    R.pair_rescue = (R.max_half_len <= 15 && min_kw_len >= 2) ? 1u : 0u;   // the rescue kernel's window: 16 bases, one more than any half tag
   }
   {
     // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged

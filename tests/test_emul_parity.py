@@ -48,3 +48,34 @@ def test_emul_ragged_lengths_forward_and_reverse_with_many_tag_errors(flags):
         pu.assert_counters_equal(cnt, ocnt)
         n_ok += int((orec["status"] == 0).sum())
     assert n_ok > 1000
+
+
+@pytest.mark.parametrize("tag_len", [21, 22], ids=["half15-pair-rescue", "half16-list-rescue"])
+def test_emul_long_half_tags_at_the_window_limit(tag_len):
+    """Half tags of 15 nt are the longest the rescue kernel's 16-base window serves; 16-nt ones go
+    through the list form.  3 % substitutions so that many reads need the rescue."""
+    _long_half_tags("emul", tag_len, 20_000)
+
+
+def _long_half_tags(kind, tag_len, n):
+    from decombinator_amd import synth
+    from oracle import oracle as orc
+    ts = synth.make_tagset("human", "original", "b", n_v=30, n_j=8, seed=77 + tag_len, tag_len=tag_len)
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=ts.half_splits[0], j_half_split=ts.half_splits[1])
+    t = pu.native_tables(d)
+    assert t.info()["pair_scan_bytes"] > 0
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], *ts.half_splits)
+    be = pu.Backend(kind, d)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=5, sub_rate=0.03, n_rate=0.002), 0, n)
+    reads = nat.unpack_reads(hb)
+    for orientation in ("reverse", "forward"):
+        rs = reads if orientation == "reverse" else [orc.revcomp(r) for r in reads]
+        b = nat.pack_reads(rs)
+        rec, cnt = be.run(b, orientation)
+        orec, ocnt = pu.oracle_records(ot, rs, orientation, False, 130)
+        pu.assert_records_equal(rec, orec, rs, orientation)
+        pu.assert_counters_equal(cnt, ocnt)
+    rescued = int(ocnt[nat.COUNTER_NAMES.index("verr1")] + ocnt[nat.COUNTER_NAMES.index("verr2")]) if "verr1" in nat.COUNTER_NAMES else 1
+    assert rescued > 0

@@ -247,3 +247,9 @@ def test_compact_hits_matches_numpy():
     assert d_hits2.to_host(nat.RECORD_DTYPE, k).tobytes() == rec[ok].tobytes()
     bits = np.unpackbits(d_bm.to_host(np.uint64, words).view(np.uint8), bitorder="little")
     assert (np.nonzero(bits)[0] == ok).all()
+
+
+@pytest.mark.parametrize("tag_len", [21, 22], ids=["half15-pair-rescue", "half16-list-rescue"])
+def test_long_half_tags_at_the_rescue_window_limit(tag_len):
+    from tests.test_emul_parity import _long_half_tags
+    _long_half_tags("hip", tag_len, 200_000)
