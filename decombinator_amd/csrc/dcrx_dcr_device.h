@@ -278,7 +278,9 @@ DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const Fram
   const int n = F.n();
   // fast path: both slices are whole 10-mers inside their sequences, nothing but ACGT involved
   if (ga >= 0 && gb <= Lg && gb - ga == rb - ra && ra >= 0 && rb <= n && gb - ga <= 16 && gb > ga &&
-      G.reg_clean[g] && F.clean(ra, rb)) {
+      G.reg_clean[g]) {
+    // a read window that holds a byte outside ACGT cannot equal a stretch of a pure-ACGT germline
+    if (!F.clean(ra, rb)) return false;
     int len = gb - ga;
     uint32_t rw = F.window(ra, len);
     uint32_t gw = REV ? packed_window(G.reg_pk_rc + G.reg_pk_off[g], Lg - ga - len, len)
@@ -1372,6 +1374,9 @@ DCRX_DEV ScanOut scan_collect16_exc(const DevTables &T, const ReadView &rv, cons
 }
 
 // `e0`: index of the read's first entry in the exception list (from the prologue kernel).
+// `slot`: DCRX_GENERAL_SLOT dwords of LDS for this lane: hit lists, exception copy, the read's words.
+constexpr int DCRX_GENERAL_WORDS_AT = 24;                       // after HH_STRIDE + the exception copy
+constexpr int DCRX_GENERAL_SLOT = DCRX_GENERAL_WORDS_AT + DCRX_NWMAX;
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW>
 DCRX_DEV void decombine_general16_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, uint64_t r, uint32_t e0,
                                       uint32_t nw, const Counters &C, dcrx_record_t *records, uint32_t *slot) {
@@ -1400,6 +1405,12 @@ DCRX_DEV void decombine_general16_one(const DevTables &T, const BatchDev &B, con
       w[2 * k] = t.x; w[2 * k + 1] = t.y;
     }
   }
+  // the walks and comparisons of a read with exception bytes go character by character: they read
+  // the packed words from this lane's LDS copy, not from global memory
+  uint32_t *lw = slot + DCRX_GENERAL_WORDS_AT;
+#pragma unroll
+  for (int x = 0; x < NW; x++) lw[x] = w[x];
+  rv.words = lw;
   HalfHits hh;
   hh.slot = DCRX_TO_LDS(slot);
   __align__(16) dcrx_record_t rec;

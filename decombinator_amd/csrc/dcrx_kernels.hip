@@ -298,7 +298,8 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
 constexpr int DCRX_RBLOCK = 1024;
 constexpr int DCRX_RSLOT = (2 * HH_K) | 1;     // two hit lists per lane; odd: conflict-free
 constexpr uint32_t DCRX_RESCUE_LDS_EXTRA = ((DCRX_RBLOCK * DCRX_RSLOT * 4 + 63) / 64) * 64;
-static_assert(DCRX_GTILE * DCRX_LSLOT <= 64 * DCRX_RSLOT, "a wave's rescue slots must hold its general-list slots");
+static_assert(DCRX_GTILE * DCRX_GENERAL_SLOT <= 64 * DCRX_RSLOT, "a wave's rescue slots must hold its general-list slots");
+static_assert(HH_STRIDE + DCRX_GSLOT_EXTRA <= DCRX_GENERAL_WORDS_AT, "hit lists and exception copy come before the words");
 static_assert((DCRX_N_COUNTERS * 4 + DCRX_RESCUE_LDS_EXTRA) % 64 == 0, "pair-scan rows must be 64-byte aligned");
 
 template <bool UNIFORM_LEN, int NW>
@@ -349,22 +350,32 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
       if (lane < DCRX_GTILE && i < n_general) {
         const uint32_t r = gqueue[i];
         decombine_general16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, gqueue[qcap + i], nw, C, records,
-                                                       gslot + lane * DCRX_LSLOT);
+                                                       gslot + lane * DCRX_GENERAL_SLOT);
         if ((exc_flag[r >> 5] >> (r & 31)) & 1u) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
       }
     }
   }
-  // rescue tiles through a ticket: the waves that took a general tile arrive late and take fewer
-  uint32_t *tile_ticket = queue_count + 3;
-  for (;;) {
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(tile_ticket, 1u);
-    tile = __shfl(tile, 0);
-    if (tile >= tickets) break;
+  // Rescue tiles: whole rounds by static striding (a ticket per tile would serialise: one atomic
+  // address sustains ~90 tickets/us and there are ~13 000 tiles in 10 M reads), the last, partial
+  // round through a ticket, so that waves that come late (a general tile, slower reads) take fewer.
+  auto rescue_tile = [&](uint32_t tile) {
     uint32_t hints;
     const uint32_t r = rescue_entry(queue, n_rescue, tile, 64, (uint32_t)lane, tagged, &hints);
     if (r != 0xFFFFFFFFu)
       decombine_rescue16_one<true, UNIFORM_LEN, NW>(T, B, cfg, (uint64_t)r, hints, nw, C, records, lds_slots + tid * DCRX_RSLOT);
+  };
+  // the waves that took a general tile stay out of the static rounds
+  const uint32_t g_waves = t_general < n_waves / 2 ? t_general : 0u, s_waves = n_waves - g_waves;
+  const uint32_t static_tiles = (tickets / s_waves) * s_waves;
+  if (wave >= g_waves)
+    for (uint32_t tile = wave - g_waves; tile < static_tiles; tile += s_waves) rescue_tile(tile);
+  uint32_t *tile_ticket = queue_count + 3;
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(tile_ticket, 1u);
+    tile = static_tiles + __shfl(tile, 0);
+    if (tile >= tickets) break;
+    rescue_tile(tile);
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);

@@ -69,7 +69,7 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     // what the launch does: reads of the general list (exception bytes; every read for `both` /
     // forced slow reader) take the general kernel's form; the rest go through the fast kernel and,
     // when deferred, the rescue kernel's form.
-    uint32_t slot[HH_STRIDE + DCRX_GSLOT_EXTRA + 2];
+    uint32_t slot[DCRX_GENERAL_SLOT + 2];
     const uint32_t nw = b->stride / 4;
     const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
     const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
