@@ -10,18 +10,25 @@
 // compared against a pre-reverse-complemented packed copy of the region.
 //
 // Per read (decombine.py:534-585, dcr()):
-//   scan    one pass of the DFA over the frame: V/J full-tag hit count, the
-//           single hit's (state, position), and "any half-tag hit" flags
-//           (replaces the findall() calls at :275, :399 and tells whether the
-//           ones at :294, :339, :422, :473 would be non-empty)
-//   V       full hit -> get_v_deletions walk (:749-785); no hit -> half-tag
-//           rescue by re-scanning and testing candidates in findall order with
-//           Hamming <= 1 (:294-390)
+//   scan    one pass of the DFA over the frame, two bases per LDS look-up when the
+//           pair table fits: V/J full-tag hit count, the single hit's location, and
+//           "any half-tag hit" flags (replaces the findall() calls at :275, :399 and
+//           tells whether the ones at :294, :339, :422, :473 would be non-empty)
+//   V       full hit -> get_v_deletions walk (:749-785); no hit -> half-tag rescue:
+//           candidates in findall order, tested with Hamming <= 1 (:294-390)
 //   J       same (:397-531, walk :788-817), only when V succeeded (:544-548)
 //   filters :553-569, then the 16-byte record
 //
-// Integer/byte work only; no MFMA.  Bound: LDS look-ups and VALU issue for the
-// scan, HBM for the packed reads (40 B) and records (16 B).
+// Three launches per batch:
+//   prologue_kernel          zeroes the counters, marks / lists the reads with non-ACGT bytes
+//   decombine_kernel         every clean read: scan; reads with one V tag are ballot-compacted
+//                            and finished in full waves; reads that need a half-tag rescue are
+//                            queued
+//   decombine_rescue_kernel  the queue and the listed reads (decombine_list_kernel instead when
+//                            there is no pair table, for orientation `both`, or on request)
+//
+// Integer/byte work only; no MFMA.  Bound: VALU issue and LDS look-ups of the scan;
+// HBM carries the packed reads (40 B) and the records (16 B).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,7 +41,7 @@
 namespace dcrx {
 
 // LDS beyond the counters + DFA (LaunchPlan::lds_bytes): the fast kernel's per-wave deferral
-// buffers, the queue kernel's half-tag hit lists
+// buffers, the list kernel's half-tag hit lists
 constexpr int DCRX_WQ_CAP = 128;
 constexpr int DCRX_GTILE = 8;  // general-list reads per ticket (one wave)
 constexpr int DCRX_CHUNK = 2;  // 64-read tiles of the rescue queue a wave claims per ticket
@@ -49,9 +56,10 @@ constexpr uint32_t DCRX_QUEUE_LDS_EXTRA = (DCRX_QBLOCK * DCRX_LSLOT + DCRX_LSLOT
 // ------------------------------------------------------------------------------
 // Fast kernel: persistent blocks, each stages the DFA into LDS once and then
 // strides over tiles of DCRX_BLOCK reads.  Reads that need the general path
-// (half-tag rescue, exception bytes, orientation `both`) are compacted with a
-// wavefront ballot into a queue of read indices for the queue kernel, so that the
-// rare, long, divergent work runs in dense waves instead of stalling this one.
+// (half-tag rescue) are compacted with a wavefront ballot into a queue of read
+// indices for the rescue kernel, so that the rare, long, divergent work runs in
+// dense waves instead of stalling this one; reads with exception bytes are
+// skipped here (the prologue put them on the general list).
 // ------------------------------------------------------------------------------
 template <bool TABLE_LDS, bool UNIFORM_LEN, int NW, int ARITY>
 __global__ __launch_bounds__(ARITY == 16 ? DCRX_BLOCK16 : DCRX_BLOCK) void decombine_kernel(
