@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_listprof.sh [flags...]  (on the GPU box): kernel times per profiling flag set
+# usage: tools/listprof.sh [flags...]  (on the GPU box): kernel times per profiling flag set
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for f in ${@:-0 8}; do

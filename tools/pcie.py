@@ -1,6 +1,8 @@
 """PCIe-inclusive rate of the host-buffer entry point (dcrx_decombine: H2D + kernels + D2H),
 for DESIGN.md; never the benchmark's `value`."""
 import time
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root
 import numpy as np
 from decombinator_amd import _native as nat, synth
 

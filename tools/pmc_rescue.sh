@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc_rescue.sh (GPU box): instruction / cycle counters of the kernels of one bench run
+# usage: tools/pmc_rescue.sh (GPU box): instruction / cycle counters of the kernels of one bench run
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmcr1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmcr1.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag>   (runs on the GPU box through gpurun)
+# usage: tools/prof.sh <tag>   (runs on the GPU box through gpurun)
 TAG=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
@@ -12,4 +12,4 @@ timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS S
 timeout 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/$TAG/pmc3 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$TAG/pmc3.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/$TAG/pmc4 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$TAG/pmc4.log 2>&1
 find $R/gpurun_out/$TAG -name "*.csv" | head -30
-python3 $R/tools_prof_summary.py $R/gpurun_out/$TAG
+python3 $R/tools/prof_summary.py $R/gpurun_out/$TAG

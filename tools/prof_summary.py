@@ -1,4 +1,4 @@
-"""Condenses the rocprofv3 output of tools_prof.sh into the small files kept under profiles/:
+"""Condenses the rocprofv3 output of tools/prof.sh into the small files kept under profiles/:
 kernel_stats.csv (from --kernel-trace --stats) and pmc_per_launch.json (every counter of the
 --pmc passes, averaged per launch and kernel).  usage: tools_prof_summary.py <gpurun_out/TAG>"""
 import collections
@@ -30,7 +30,7 @@ for p in glob.glob(os.path.join(tag, "pmc*", "**", "*counter_collection.csv"), r
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 res = {k: {c: v / max(len(launches[k][c]), 1) for c, v in cs.items()} for k, cs in per.items()}
-json.dump({"note": "rocprofv3 --pmc, separate passes (tools_prof.sh), bench.py --steps 3 --warmup 1; values are per launch",
+json.dump({"note": "rocprofv3 --pmc, separate passes (tools/prof.sh), bench.py --steps 3 --warmup 1; values are per launch",
            "kernels": res}, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
 for k, cs in res.items():
     if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:

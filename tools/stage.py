@@ -7,6 +7,8 @@ import gzip
 import os
 import tempfile
 import time
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root
 
 import numpy as np
 

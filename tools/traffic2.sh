@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_traffic2.sh (GPU box): raw L2 memory-side request counters, normal run and scan-only run
+# usage: tools/traffic2.sh (GPU box): raw L2 memory-side request counters, normal run and scan-only run
 # (the scan-only run moves a known byte count: 40 B read + 16 B written per read -> calibration)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
