@@ -79,3 +79,8 @@ def _long_half_tags(kind, tag_len, n):
         pu.assert_counters_equal(cnt, ocnt)
     rescued = int(ocnt[nat.COUNTER_NAMES.index("verr1")] + ocnt[nat.COUNTER_NAMES.index("verr2")]) if "verr1" in nat.COUNTER_NAMES else 1
     assert rescued > 0
+
+
+def test_emul_randomised_configurations():
+    from tests import fuzz_util
+    assert fuzz_util.run("emul", 16, 3000, seed=424242) > 1000

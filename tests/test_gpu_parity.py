@@ -253,3 +253,8 @@ def test_compact_hits_matches_numpy():
 def test_long_half_tags_at_the_rescue_window_limit(tag_len):
     from tests.test_emul_parity import _long_half_tags
     _long_half_tags("hip", tag_len, 200_000)
+
+
+def test_randomised_configurations():
+    from tests import fuzz_util
+    assert fuzz_util.run("hip", 30, 40_000, seed=20261002) > 50_000
