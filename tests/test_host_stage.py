@@ -252,3 +252,25 @@ def test_fasta_record_raises_like_the_reference(tmp_path, monkeypatch):
             (tmp_path / "F_1.fq").write_text(">b\nACGT\n@a\nACGT\n+\nIIII\n")
         with pytest.raises(TypeError):
             dec.decombinator(args)
+
+
+def test_n12rows_behaves_like_the_reference_list():
+    """decombinator() returns N12Rows: iteration, len, indexing, slicing and == with a list of lists;
+    blobs (native assembly) and lists (per-row path) can be mixed; write_text gives the .n12 text."""
+    rows = dec.N12Rows()
+    assert len(rows) == 0 and list(rows) == [] and rows == []
+    rows._add_blob(bytearray(b"1, 2, 0, 3, AC, id1, ACGT, IIII, AAA, III\n4, 5, 1, 0, , id2, GG, II, CCC, III\n"), 2)
+    rows.extend([["7", "8", "0", "0", "T", "id3", "TT", "II", "GGG", "III"]])
+    rows.append(["9", "1", "2", "3", "", "id4", "A", "I", "TTT", "III"])
+    expect = [["1", "2", "0", "3", "AC", "id1", "ACGT", "IIII", "AAA", "III"],
+              ["4", "5", "1", "0", "", "id2", "GG", "II", "CCC", "III"],
+              ["7", "8", "0", "0", "T", "id3", "TT", "II", "GGG", "III"],
+              ["9", "1", "2", "3", "", "id4", "A", "I", "TTT", "III"]]
+    assert len(rows) == 4 and rows == expect and expect == rows and list(rows) == expect
+    assert rows[1] == expect[1] and rows[-1] == expect[-1] and rows[1:3] == expect[1:3]
+    assert rows != expect[:3]
+    buf = _io.BytesIO()
+    text = _io.TextIOWrapper(buf, encoding="utf-8", newline="")
+    rows.write_text(text, ", ")
+    text.flush()
+    assert buf.getvalue().decode() == "".join(", ".join(r) + "\n" for r in expect)
