@@ -237,14 +237,18 @@ int dcrx_fastq_next(dcrx_fastq_t *f, uint64_t max_records, dcrx_fastq_batch_t *o
       f->ahead_valid = false;
       f->cur ^= 1;
     } else {
-      rc = f->parse(f->st[f->cur], max_records);
+      try { rc = f->parse(f->st[f->cur], max_records); }
+      catch (...) { f->err_msg = "out of memory while reading the FASTQ file"; rc = DCRX_E_NOMEM; }
     }
     if (rc != DCRX_OK) return set_err(rc, f->err_msg ? f->err_msg : "FASTQ reader failed");
     f->cur_valid = true;
     f->cursor = 0;
     if (!f->finished) {      // read ahead while the caller works on this chunk
       dcrx_fastq::Store *other = &f->st[f->cur ^ 1];
-      f->ahead = std::async(std::launch::async, [f, other, max_records] { return f->parse(*other, max_records); });
+      f->ahead = std::async(std::launch::async, [f, other, max_records]() -> int {
+        try { return f->parse(*other, max_records); }
+        catch (...) { f->err_msg = "out of memory while reading the FASTQ file"; return DCRX_E_NOMEM; }
+      });
       f->ahead_valid = true;
     }
   }
