@@ -453,14 +453,18 @@ int64_t dcrx_pack_reads(const char *ascii, const uint64_t *offsets, uint64_t n_r
                         uint8_t *packed, uint16_t *lens, uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
                         uint64_t exc_cap) {
   if (n_reads && !offsets) return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads");
-  return pack_all(ascii, SpanOffsets{offsets}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
+  try {
+    return pack_all(ascii, SpanOffsets{offsets}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
+  } catch (...) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_pack_reads"); }
 }
 
 int64_t dcrx_pack_reads_span(const char *ascii, const uint64_t *start, const uint32_t *len, uint64_t n_reads, uint32_t stride,
                              uint8_t *packed, uint16_t *lens, uint32_t *exc_read, uint16_t *exc_pos, uint8_t *exc_chr,
                              uint64_t exc_cap) {
   if (n_reads && (!start || !len)) return set_err(DCRX_E_INVALID, "bad argument to dcrx_pack_reads_span");
-  return pack_all(ascii, SpanStartLen{start, len}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
+  try {
+    return pack_all(ascii, SpanStartLen{start, len}, n_reads, stride, packed, lens, exc_read, exc_pos, exc_chr, exc_cap);
+  } catch (...) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_pack_reads_span"); }
 }
 
 int dcrx_unpack_reads(const dcrx_batch_t *b, const uint64_t *offsets, char *ascii) {

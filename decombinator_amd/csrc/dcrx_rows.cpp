@@ -68,7 +68,7 @@ struct Out {
 };
 }  // namespace
 
-extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
+static int64_t assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
                                       const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
                                       const dcrx_spans_t *bcq, const dcrx_spans_t *tail, const char *field_sep, char *out,
                                       uint64_t out_cap, uint64_t *n_rows) {
@@ -144,4 +144,13 @@ extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_r
   for (unsigned k = 0; k < nt; k++) clash = clash || r_clash[k];
   if (clash) return set_err(DCRX_E_UNSUPPORTED, "a field contains the field separator");
   return (int64_t)need;
+}
+
+extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_reads, const dcrx_spans_t *vdj,
+                                      const dcrx_spans_t *qual, const dcrx_spans_t *id, const dcrx_spans_t *bc,
+                                      const dcrx_spans_t *bcq, const dcrx_spans_t *tail, const char *field_sep, char *out,
+                                      uint64_t out_cap, uint64_t *n_rows) {
+  try {
+    return assemble_rows(records, n_reads, vdj, qual, id, bc, bcq, tail, field_sep, out, out_cap, n_rows);
+  } catch (...) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_assemble_rows"); }
 }
