@@ -78,7 +78,7 @@ extern "C" {
 
 int dcrx_abi_version(void) { return DCRX_ABI_VERSION; }
 const char *dcrx_last_error(void) { return g_err.c_str(); }
-const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; block " "512" "; fast-scan reads <= 320 nt"; }
+const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; pair-scan block 1024, one-base block 512; reads <= 320 nt"; }
 
 int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
   if (!out) return set_err(DCRX_E_INVALID, "out is null");
@@ -86,7 +86,9 @@ int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
   dcrx_tables *t = new (std::nothrow) dcrx_tables();
   if (!t) return set_err(DCRX_E_NOMEM, "out of memory");
   std::string err;
-  int rc = compile_tables(tagset, &t->host, &err);
+  int rc;
+  try { rc = compile_tables(tagset, &t->host, &err); }
+  catch (...) { rc = DCRX_E_NOMEM; err = "out of memory while compiling the tag tables"; }
   if (rc != DCRX_OK) { delete t; return set_err(rc, err); }
   *out = t;
   return DCRX_OK;
