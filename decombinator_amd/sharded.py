@@ -69,9 +69,11 @@ class TupleGather:
     region.  Every rank compacts its step's tuples on the device — the 16-byte records in read
     order plus one bit per read saying which reads they belong to (a third fewer bytes than
     8-byte indices) — and sends the first `cap` records (cap = reads/2 covers the synthetic
-    mixture's ~42 % decombined reads; `check` verifies that after the run) and the bitmap.  The
-    gathers are issued asynchronously on RCCL's stream with `depth` rotating buffer sets, so the
-    gather of step k overlaps the scan of step k+1; a buffer set is reused only after its previous
+    mixture's ~42 % decombined reads; `check` verifies that after the run) and the bitmap.
+
+    Compaction and gather run on a side stream, beside the scan of the following step: the caller
+    alternates between `depth` record buffers (`records(k)`), the scan of step k+depth waits for
+    the compaction of step k (`before_scan`), and a buffer set is reused only after its previous
     gather has completed."""
 
     def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5,
@@ -82,13 +84,16 @@ class TupleGather:
         self.cap = int(n_reads * cap_fraction) + 1024
         self.words = (n_reads + 63) // 64
         self.k = 0
+        self.side = torch.cuda.Stream(device=device)
         self.slots = []
         for _ in range(depth):
             slot = {
+                "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
                 "hits": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
                 "bitmap": torch.zeros(self.words, dtype=torch.int64, device=device),
                 "n": torch.zeros(1, dtype=torch.int64, device=device),
                 "work": [],
+                "compacted": None,     # event: the compaction that read this slot's records is done
             }
             if rank == 0:
                 slot["g_hits"] = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
@@ -96,30 +101,47 @@ class TupleGather:
                 slot["g_n"] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
             self.slots.append(slot)
 
-    def step(self, d_rec: torch.Tensor, n_reads: int, first_index: int, stream_ptr) -> None:
+    def records(self) -> torch.Tensor:
+        """The record buffer the next scan writes (call before_scan() first)."""
+        return self.slots[self.k % len(self.slots)]["rec"]
+
+    def before_scan(self) -> None:
+        """The current stream waits until the slot's previous compaction has read its records."""
+        ev = self.slots[self.k % len(self.slots)]["compacted"]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def step(self, n_reads: int) -> None:
+        """After the scan of this step has been queued on the current stream."""
         nat = self.nat
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
-        for w in s["work"]:          # the compute stream waits for this set's previous gather
-            w.wait()
-        nat.check(nat.lib().dcrx_compact_hits_bitmap_device(d_rec.data_ptr(), n_reads, s["hits"].data_ptr(),
-                                                            s["bitmap"].data_ptr(), s["n"].data_ptr(), stream_ptr))
-        h = s["hits"][:self.cap * 16]
-        if self.rank == 0:
-            s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
-                         dist.gather(h, s["g_hits"], dst=0, async_op=True),
-                         dist.gather(s["bitmap"], s["g_bitmap"], dst=0, async_op=True)]
-        else:
-            s["work"] = [dist.gather(s["n"], None, dst=0, async_op=True),
-                         dist.gather(h, None, dst=0, async_op=True),
-                         dist.gather(s["bitmap"], None, dst=0, async_op=True)]
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            for w in s["work"]:          # this set's previous gather must be done before its buffers are rewritten
+                w.wait()
+            nat.check(nat.lib().dcrx_compact_hits_bitmap_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
+                                                                s["bitmap"].data_ptr(), s["n"].data_ptr(),
+                                                                self.side.cuda_stream))
+            s["compacted"] = self.side.record_event()
+            h = s["hits"][:self.cap * 16]
+            if self.rank == 0:
+                s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
+                             dist.gather(h, s["g_hits"], dst=0, async_op=True),
+                             dist.gather(s["bitmap"], s["g_bitmap"], dst=0, async_op=True)]
+            else:
+                s["work"] = [dist.gather(s["n"], None, dst=0, async_op=True),
+                             dist.gather(h, None, dst=0, async_op=True),
+                             dist.gather(s["bitmap"], None, dst=0, async_op=True)]
 
     def finish(self) -> None:
-        """Makes the current stream wait for every gather still in flight."""
-        for s in self.slots:
-            for w in s["work"]:
-                w.wait()
-            s["work"] = []
+        """Makes the current stream wait for every compaction and gather still in flight."""
+        with torch.cuda.stream(self.side):
+            for s in self.slots:
+                for w in s["work"]:
+                    w.wait()
+                s["work"] = []
+        torch.cuda.current_stream().wait_stream(self.side)
 
     @staticmethod
     def _popcount(words: torch.Tensor) -> int:
@@ -131,6 +153,7 @@ class TupleGather:
 
     def check(self, n_hits_local: int) -> None:
         self.finish()
+        torch.cuda.synchronize()
         if n_hits_local > self.cap:
             raise RuntimeError(f"rank {self.rank}: {n_hits_local} tuples exceed the gather capacity {self.cap}")
         if self.rank == 0:
