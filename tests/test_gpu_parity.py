@@ -258,3 +258,17 @@ def test_long_half_tags_at_the_rescue_window_limit(tag_len):
 def test_randomised_configurations():
     from tests import fuzz_util
     assert fuzz_util.run("hip", 30, 40_000, seed=20261002) > 50_000
+
+
+def test_reserved_compute_units_do_not_change_results():
+    """dcrx_set_reserved_cus shrinks the persistent grids (bench.py leaves CUs to RCCL): same records."""
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=21, sub_rate=0.01, n_rate=0.002), 0, 400_000)
+    reads = nat.unpack_reads(hb)
+    orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+    for reserved in (16, 200, 0):
+        nat.check(nat.lib().dcrx_set_reserved_cus(t.handle, reserved))
+        rec, cnt = nat.decombine(t, hb)
+        pu.assert_records_equal(rec, orec, reads, f"reserved {reserved}")
+        pu.assert_counters_equal(cnt, ocnt, f"reserved {reserved}")
