@@ -111,7 +111,7 @@ EXPORTS = [
     "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
     "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
-    "dcrx_compact_hits_bitmap_device", "dcrx_set_reserved_cus",
+    "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
@@ -153,6 +153,7 @@ def lib():
         "dcrx_reserve_device": (i32, [vp, u64]),
         "dcrx_compact_hits_device": (i32, [vp, u64, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_bitmap_device": (i32, [vp, u64, vp, vp, vp, vp]),
+        "dcrx_compact_hits_packed_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
         "dcrx_device_count": (i32, []),
         "dcrx_set_device": (i32, [i32]),
@@ -668,6 +669,22 @@ def compact_hits_bitmap_device(d_records: DeviceBuffer, n_reads: int, d_hits: De
                                d_n_hits: DeviceBuffer, stream=None):
     """Decombined records in input order + a bitmap of which reads they belong to ((n_reads+63)//64 uint64)."""
     check(lib().dcrx_compact_hits_bitmap_device(d_records.ptr, n_reads, d_hits.ptr, d_ok_bitmap.ptr, d_n_hits.ptr, stream))
+
+
+def unpack_tuples12(words: np.ndarray) -> np.ndarray:
+    """(k, 3) uint32 tuples of dcrx_compact_hits_packed_device -> RECORD_DTYPE records (status OK)."""
+    w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 3)
+    rec = np.zeros(len(w), dtype=RECORD_DTYPE)
+    rec["v"] = w[:, 0] & 0xFFF
+    rec["j"] = (w[:, 0] >> 12) & 0xFFF
+    rec["vdel"] = (w[:, 0] >> 24) & 0xFF
+    rec["v_start"] = w[:, 1] & 0x1FF
+    rec["j_end"] = (w[:, 1] >> 9) & 0x1FF
+    rec["ins_start"] = (w[:, 1] >> 18) & 0x1FF
+    rec["ins_len"] = w[:, 2] & 0x1FF
+    rec["jdel"] = (w[:, 2] >> 9) & 0xFF
+    rec["frame"] = (w[:, 2] >> 17) & 1
+    return rec
 
 
 def compact_hits_device(d_records: DeviceBuffer, n_reads: int, first_index: int, d_hits: DeviceBuffer,

@@ -324,7 +324,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
 }
 
 static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index, dcrx_record_t *d_hits,
-                        uint64_t *d_hit_index, uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
+                        uint64_t *d_hit_index, uint64_t *d_ok_bitmap, int packed12, uint64_t *d_n_hits, void *stream) {
   // workspace lives in a process-wide slot keyed by device: compaction does not need tables
   static thread_local struct { int dev = -1; uint32_t *tc = nullptr; uint64_t *to = nullptr; uint64_t cap = 0; } ws;
   if (!d_n_hits || (n_reads && (!d_records || !d_hits || (!d_hit_index && !d_ok_bitmap)))) return set_err(DCRX_E_INVALID, "null argument");
@@ -336,7 +336,7 @@ static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64
     HIP_TRY(hipMalloc(&ws.to, tiles * 8));
     ws.dev = dev; ws.cap = n_reads;
   }
-  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_ok_bitmap, d_n_hits, ws.tc, ws.to,
+  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_ok_bitmap, packed12, d_n_hits, ws.tc, ws.to,
                          (hipStream_t)stream));
   return DCRX_OK;
 }
@@ -344,13 +344,19 @@ static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64
 int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
                              dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits, void *stream) {
   if (n_reads && !d_hit_index) return set_err(DCRX_E_INVALID, "null argument");
-  return compact_hits(d_records, n_reads, first_index, d_hits, d_hit_index, nullptr, d_n_hits, stream);
+  return compact_hits(d_records, n_reads, first_index, d_hits, d_hit_index, nullptr, 0, d_n_hits, stream);
 }
 
 int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_reads, dcrx_record_t *d_hits,
                                     uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
   if (n_reads && !d_ok_bitmap) return set_err(DCRX_E_INVALID, "null argument");
-  return compact_hits(d_records, n_reads, 0, d_hits, nullptr, d_ok_bitmap, d_n_hits, stream);
+  return compact_hits(d_records, n_reads, 0, d_hits, nullptr, d_ok_bitmap, 0, d_n_hits, stream);
+}
+
+int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples12,
+                                    uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
+  if (n_reads && !d_ok_bitmap) return set_err(DCRX_E_INVALID, "null argument");
+  return compact_hits(d_records, n_reads, 0, reinterpret_cast<dcrx_record_t *>(d_tuples12), nullptr, d_ok_bitmap, 1, d_n_hits, stream);
 }
 
 int dcrx_set_reserved_cus(dcrx_tables_t *t, uint32_t n_cus) {

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
                                                                     const uint64_t *__restrict__ tile_off,
                                                                     dcrx_record_t *__restrict__ hits,
                                                                     uint64_t *__restrict__ hit_index,
-                                                                    uint64_t *__restrict__ ok_bitmap) {
+                                                                    uint64_t *__restrict__ ok_bitmap, int packed12) {
   __shared__ uint32_t s_wave[CP_PER_THREAD][CP_BLOCK / 64];
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -493,7 +493,15 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
     if (ok[k]) {
       const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
       const uint64_t dst = off + before + rank[k];
-      reinterpret_cast<uint4 *>(hits)[dst] = reinterpret_cast<const uint4 *>(rec)[i];
+      if (packed12) {      // the 12-byte tuple of include/dcrx.h (dcrx_compact_hits_packed_device)
+        const dcrx_record_t r = rec[i];
+        uint32_t *o = reinterpret_cast<uint32_t *>(hits) + dst * 3;
+        o[0] = (uint32_t)r.v | ((uint32_t)r.j << 12) | ((uint32_t)r.vdel << 24);
+        o[1] = (uint32_t)r.v_start | ((uint32_t)r.j_end << 9) | ((uint32_t)r.ins_start << 18);
+        o[2] = (uint32_t)r.ins_len | ((uint32_t)r.jdel << 9) | ((uint32_t)r.frame << 17);
+      } else {
+        reinterpret_cast<uint4 *>(hits)[dst] = reinterpret_cast<const uint4 *>(rec)[i];
+      }
       if (hit_index) hit_index[dst] = first_index + i;
     }
   }
@@ -603,7 +611,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
 }
 
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
-                          uint64_t *hit_index, uint64_t *ok_bitmap, uint64_t *d_total, uint32_t *tile_count,
+                          uint64_t *hit_index, uint64_t *ok_bitmap, int packed12, uint64_t *d_total, uint32_t *tile_count,
                           uint64_t *tile_off, hipStream_t s) {
   const uint32_t n_tiles = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
   if (n_tiles)
@@ -611,7 +619,7 @@ hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_i
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, n_tiles, tile_off, d_total);
   if (n_tiles)
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, first_index, tile_off,
-                       hits, hit_index, ok_bitmap);
+                       hits, hit_index, ok_bitmap, packed12);
   return hipGetLastError();
 }
 

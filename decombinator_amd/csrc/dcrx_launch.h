@@ -27,7 +27,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
                             dcrx_record_t *rec, uint32_t *queue, uint32_t *gqueue, uint32_t *queue_count,
                             uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
-                          uint64_t *hit_index, uint64_t *ok_bitmap, uint64_t *d_total, uint32_t *tile_count,
+                          uint64_t *hit_index, uint64_t *ok_bitmap, int packed12, uint64_t *d_total, uint32_t *tile_count,
                           uint64_t *tile_off, hipStream_t s);
 uint32_t compact_tiles(uint64_t n);
 

@@ -66,15 +66,17 @@ def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
 
 class TupleGather:
     """Per-step fixed-capacity gather for the benchmark loop: no host sync inside the timed
-    region.  Every rank compacts its step's tuples on the device — the 16-byte records in read
-    order plus one bit per read saying which reads they belong to (a third fewer bytes than
-    8-byte indices) — and sends the first `cap` records (cap = reads/2 covers the synthetic
+    region.  Every rank compacts its step's tuples on the device — each decombined record squeezed
+    into 12 bytes, in read order, plus one bit per read saying which reads they belong to (half the
+    bytes of 16-byte records with 8-byte indices) — and sends the first `cap` records (cap = reads/2 covers the synthetic
     mixture's ~42 % decombined reads; `check` verifies that after the run) and the bitmap.
 
     Compaction and gather run on a side stream, beside the scan of the following step: the caller
     alternates between `depth` record buffers (`records(k)`), the scan of step k+depth waits for
     the compaction of step k (`before_scan`), and a buffer set is reused only after its previous
     gather has completed."""
+
+    TUPLE_BYTES = 12     # dcrx_compact_hits_packed_device: the record's fields in three uint32
 
     def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5,
                  depth: int = 2):
@@ -89,14 +91,14 @@ class TupleGather:
         for _ in range(depth):
             slot = {
                 "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
-                "hits": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
+                "hits": torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=device),
                 "bitmap": torch.zeros(self.words, dtype=torch.int64, device=device),
                 "n": torch.zeros(1, dtype=torch.int64, device=device),
                 "work": [],
                 "compacted": None,     # event: the compaction that read this slot's records is done
             }
             if rank == 0:
-                slot["g_hits"] = [torch.empty(self.cap * 16, dtype=torch.uint8, device=device) for _ in range(world)]
+                slot["g_hits"] = [torch.empty(self.cap * self.TUPLE_BYTES, dtype=torch.uint8, device=device) for _ in range(world)]
                 slot["g_bitmap"] = [torch.empty(self.words, dtype=torch.int64, device=device) for _ in range(world)]
                 slot["g_n"] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
             self.slots.append(slot)
@@ -120,11 +122,11 @@ class TupleGather:
         with torch.cuda.stream(self.side):
             for w in s["work"]:          # this set's previous gather must be done before its buffers are rewritten
                 w.wait()
-            nat.check(nat.lib().dcrx_compact_hits_bitmap_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
+            nat.check(nat.lib().dcrx_compact_hits_packed_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
                                                                 s["bitmap"].data_ptr(), s["n"].data_ptr(),
                                                                 self.side.cuda_stream))
             s["compacted"] = self.side.record_event()
-            h = s["hits"][:self.cap * 16]
+            h = s["hits"][:self.cap * self.TUPLE_BYTES]
             if self.rank == 0:
                 s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
                              dist.gather(h, s["g_hits"], dst=0, async_op=True),

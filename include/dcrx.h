@@ -256,6 +256,15 @@ int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_r
                                     dcrx_record_t *d_hits, uint64_t *d_ok_bitmap, uint64_t *d_n_hits,
                                     void *hip_stream);
 
+/* The same with each decombined record squeezed into 12 bytes (three little-endian uint32):
+ *   word 0: v (bits 0-11) | j (12-23) | vdel (24-31)
+ *   word 1: v_start (0-8) | j_end (9-17) | ins_start (18-26)
+ *   word 2: ins_len (0-8) | jdel (9-16) | frame (17)
+ * status is DCRX_S_OK by construction.  Requires < 4096 V and J tags (any real tag set); positions
+ * are < 512 by the 320-nt read limit.  d_tuples12: 12 bytes per record. */
+int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples12,
+                                    uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
+
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */
 int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);

@@ -247,6 +247,13 @@ def test_compact_hits_matches_numpy():
     assert d_hits2.to_host(nat.RECORD_DTYPE, k).tobytes() == rec[ok].tobytes()
     bits = np.unpackbits(d_bm.to_host(np.uint64, words).view(np.uint8), bitorder="little")
     assert (np.nonzero(bits)[0] == ok).all()
+    # 12-byte tuples: same records again
+    d_t12 = nat.DeviceBuffer(n * 12)
+    nat.check(nat.lib().dcrx_compact_hits_packed_device(d_rec.ptr, n, d_t12.ptr, d_bm.ptr, d_n.ptr, None))
+    nat.synchronize()
+    assert int(d_n.to_host(np.uint64, 1)[0]) == k
+    back = nat.unpack_tuples12(d_t12.to_host(np.uint32, 3 * k))
+    assert back.tobytes() == rec[ok].tobytes()
 
 
 @pytest.mark.parametrize("tag_len", [21, 22], ids=["half15-pair-rescue", "half16-list-rescue"])
