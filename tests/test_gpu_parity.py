@@ -279,3 +279,19 @@ def test_reserved_compute_units_do_not_change_results():
         rec, cnt = nat.decombine(t, hb)
         pu.assert_records_equal(rec, orec, reads, f"reserved {reserved}")
         pu.assert_counters_equal(cnt, ocnt, f"reserved {reserved}")
+
+
+@pytest.mark.parametrize("n_v", [60, 62, 66], ids=["pair-scan+rescue-kernel", "pair-scan+list-kernel", "one-base-kernels"])
+def test_table_sizes_around_the_lds_limits(n_v):
+    """1 753 / 1 809 / 1 897 states: the pair table with the rescue kernel's hit lists fits LDS, fits
+    only with the fast kernel's buffers (the list kernel then works the rescue queue off), does not
+    fit (one-base kernels).  Same reads-vs-oracle check on each side of the two limits."""
+    ts = synth.make_tagset("human", "original", "b", n_v=n_v, n_j=13, seed=4242, tag_len=20)
+    t, ot = _tables(ts)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=n_v, sub_rate=0.02, n_rate=0.002), 0, 300_000)
+    reads = nat.unpack_reads(hb)
+    rec, cnt = nat.decombine(t, hb)
+    orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+    pu.assert_records_equal(rec, orec, reads, f"n_v {n_v}")
+    pu.assert_counters_equal(cnt, ocnt, f"n_v {n_v}")
+    assert int(ocnt[nat.COUNTER_NAMES.index("verr1")]) + int(ocnt[nat.COUNTER_NAMES.index("verr2")]) > 1000
