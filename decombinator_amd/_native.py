@@ -41,6 +41,13 @@ ORIENTATIONS = {"reverse": 0, "forward": 1, "both": 2}
 F_FORCE_SLOW_READER = 1
 F_PROFILE_SCAN_ONLY = 2
 F_ONE_BASE_SCAN = 4
+F_V1_KERNELS = 64        # the three-launch form even where the v2 kernel applies
+
+
+def F_V2_SHAPE(k):
+    """v2 kernel launch shape (A/B): 1 = one read per lane, two blocks per CU; 2 = two reads per lane; 3 = one read, one block."""
+    return int(k) << 8
+
 F_PROFILE_LIST_SCAN_ONLY = 8
 F_LIST_RESCUE = 16      # rescue queue through the list kernel even when the pair form applies
 

@@ -55,6 +55,8 @@ struct dcrx_tables {
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
+  void *d_v2_tail = nullptr, *d_v2_events = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
+  uint32_t *d_v2_counts = nullptr;
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
   uint64_t compact_reads = 0;
@@ -67,7 +69,8 @@ struct dcrx_tables {
 
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
-  (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue);
+  (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
+  t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr;
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
   t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
@@ -159,7 +162,7 @@ int dcrx_event_elapsed_ms(void *a, void *b, float *ms) {
 }  // extern "C"
 
 // ---- per-device state -------------------------------------------------------------
-static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
+static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 40) {
   int dev = -1;
   HIP_TRY(hipGetDevice(&dev));
   if (t->device != dev) {
@@ -198,6 +201,22 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads) {
     HIP_TRY(hipMalloc(&t->d_queue, (3 * max_reads + DCRX_QUEUE_HEADER) * 4));  // [work counters][rescue queue][general list][its exception-list offsets]
     t->exc_flag_reads = max_reads;
     t->ws_dirty = true;
+  }
+  if (t->host.rel.v2_ok) {
+    // the lists between the v2 kernels: every wave of the scan kernel (16 per CU) owns a region of tail and of event
+    // entries; an entry carries the read's packed words, so the size follows the stride
+    uint64_t tr = 0, er = 0;
+    v2_list_rows(max_reads, stride, t->plan.n_cu, &tr, &er);
+    if (tr > t->plan.v2_tail_rows || er > t->plan.v2_event_rows) {
+      (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
+      t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr;
+      t->plan.v2_tail = nullptr; t->plan.v2_events = nullptr; t->plan.v2_tail_rows = t->plan.v2_event_rows = 0;
+      HIP_TRY(hipMalloc(&t->d_v2_tail, tr * 16));
+      HIP_TRY(hipMalloc(&t->d_v2_events, er * 16));
+      HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 8));
+      t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
+      t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er;
+    }
   }
   if (t->ws_dirty) {
     // the kernels leave the work counters and the exception bitmap zeroed; they are zeroed here
@@ -248,7 +267,7 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   if (rc) return rc;
   if (b->n_reads && !d_records) return set_err(DCRX_E_INVALID, "d_records is null");
   if (cfg->orientation < 0 || cfg->orientation > 2) return set_err(DCRX_E_INVALID, "orientation must be 0, 1 or 2");
-  rc = ensure_device(t, b->n_reads);
+  rc = ensure_device(t, b->n_reads, b->stride);
   if (rc) return rc;
   BatchDev B;
   B.packed = b->packed; B.stride = b->stride; B.read_len = b->read_len; B.lens = b->lens;

@@ -38,7 +38,14 @@ DCRX_DEV uint32_t dcrx_brev32(uint32_t v) { return __brev(v); }
 // that the L2 keeps the packed reads the batched tail comes back to.
 DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   typedef uint32_t dcrx_v4u __attribute__((ext_vector_type(4)));
-  __builtin_nontemporal_store(*reinterpret_cast<const dcrx_v4u *>(&rec), reinterpret_cast<dcrx_v4u *>(dst));
+  // composed from the fields (the record's little-endian layout): reading the struct through a
+  // vector pointer would keep it in scratch memory
+  dcrx_v4u v;
+  v.x = (uint32_t)rec.v | ((uint32_t)rec.j << 16);
+  v.y = (uint32_t)rec.v_start | ((uint32_t)rec.j_end << 16);
+  v.z = (uint32_t)rec.ins_start | ((uint32_t)rec.ins_len << 16);
+  v.w = (uint32_t)rec.vdel | ((uint32_t)rec.jdel << 8) | ((uint32_t)rec.status << 16) | ((uint32_t)rec.frame << 24);
+  __builtin_nontemporal_store(v, reinterpret_cast<dcrx_v4u *>(dst));
 }
 // pointer into LDS with its address space spelled out (ds_read/ds_write instead of flat_*)
 typedef __attribute__((address_space(3))) uint32_t dcrx_lds_u32;
@@ -144,8 +151,19 @@ struct ReadView {
 
 template <bool REV>
 struct Frame {
+  static constexpr bool kRev = REV;
   const ReadView &r;
   DCRX_DEVNI explicit Frame(const ReadView &rv) : r(rv) {}
+  // an exception byte 'N' (as the frame shows it) at frame positions [lo, hi)
+  DCRX_DEVNI bool has_N(int lo, int hi) const {
+    bool hasN = false;
+    for (int x = r.e0; x < r.e1; x++) {
+      const int i = REV ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
+      const uint8_t b = REV ? r.comp[r.exc_chr[x]] : r.exc_chr[x];
+      if (i >= lo && i < hi && b == (uint8_t)'N') hasN = true;
+    }
+    return hasN;
+  }
   DCRX_DEV int n() const { return r.n; }
   DCRX_DEV int fpos(int i) const { return REV ? r.n - 1 - i : i; }
   DCRX_DEV int code(int i) const {
@@ -272,8 +290,9 @@ DCRX_DEV uint32_t packed_window(const uint32_t *pk, int base_pos, int len) {
 
 // G[ga:gb] == read[ra:rb] with Python slice semantics (the comparisons at
 // decombine.py:769-772 and :802-805).
-template <bool REV>
-DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const Frame<REV> &F, int ra, int rb) {
+template <class FR>
+DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const FR &F, int ra, int rb) {
+  constexpr bool REV = FR::kRev;
   const int Lg = (int)G.reg_len[g];
   const int n = F.n();
   // fast path: both slices are whole 10-mers inside their sequences, nothing but ACGT involved
@@ -298,9 +317,10 @@ DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const Fram
 }
 
 // get_v_deletions — decombine.py:749-785
-template <bool REV>
-DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v_match, int temp_end_v,
+template <class FR>
+DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const FR &F, int v_match, int temp_end_v,
                                 int &end_v, int &deletions_v, const Counters &C) {
+  constexpr bool REV = FR::kRev;
   const int n = F.n();
   int f = temp_end_v;                                       // :753
   const int Lg = (int)G.reg_len[v_match];
@@ -317,7 +337,7 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v
   }
   int num_del = 0;                                          // :765
   while (0 <= f && f < n) {                                 // :767
-    if (slice_eq<REV>(G, v_match, pos, pos + 10, F, f - 10, f)) {  // :769-772
+    if (slice_eq(G, v_match, pos, pos + 10, F, f - 10, f)) {  // :769-772
       deletions_v = num_del;                                // :774
       end_v = temp_end_v - num_del;                         // :775
       return true;
@@ -329,9 +349,10 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int v
 }
 
 // get_j_deletions — decombine.py:788-817
-template <bool REV>
-DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j_match, int temp_start_j,
+template <class FR>
+DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const FR &F, int j_match, int temp_start_j,
                                 int end_of_v, int &start_j, int &deletions_j, const Counters &C) {
+  constexpr bool REV = FR::kRev;
   const int n = F.n();
   int f = temp_start_j;                                     // :792
   int pos = 0;                                              // :793
@@ -346,7 +367,7 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j
   }
   while (0 <= f + 2 && f + 2 < n) {                         // :795
     if (f < end_of_v) { pos += 1; f += 1; }                 // :798-800
-    else if (slice_eq<REV>(G, j_match, pos, pos + 10, F, f, f + 10)) {  // :802-805
+    else if (slice_eq(G, j_match, pos, pos + 10, F, f, f + 10)) {  // :802-805
       deletions_j = pos; start_j = f;                       // :807-808
       return true;
     } else { pos += 1; f += 1; }                            // :810-811
@@ -357,8 +378,9 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const Frame<REV> &F, int j
 
 // Levenshtein.hamming(tag k, read[lo:hi]) <= 1 (decombine.py:308-317 and siblings);
 // a length difference counts like rapidfuzz's padding.
-template <bool REV>
-DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const Frame<REV> &F, int lo, int hi) {
+template <class FR>
+DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const FR &F, int lo, int hi) {
+  constexpr bool REV = FR::kRev;
   const int Lt = (int)G.tag_len[k];
   const int n = F.n();
   // packed form: the slice is the whole tag-long window, pure ACGT, and a 32-base load covers it
@@ -399,51 +421,60 @@ DCRX_DEV uint32_t trans_at(const uint32_t *lds_trans, const DevTables &T, uint32
 // rescue different classes side by side.  Returns true with `out` filled on success;
 // otherwise the caller bumps the "found half not other half" counter.
 // ------------------------------------------------------------------------------
+// Candidates of one half-tag hit (keyword `gk` = global keyword id of class (GENE, HALF), `hlen`
+// long, starting at frame position p): its tags in ascending index — the `indices`
+// comprehension of decombine.py:298-300 / :342-346 / :425-427 / :476-480.
+template <class FR>
+DCRX_DEVNI bool rescue_candidates(const DevTables &T, const FR &F, const int GENE, const int HALF, const uint32_t gk,
+                                  const int hlen, const int p, const int end_of_v, XDat &out, const Counters &C) {
+  const GeneDevPtrs &G = T.g[GENE];
+  const int n = F.n();
+  const int split = G.split;
+  const int k0 = (int)T.kw_first[gk];                  // half_seqs.index(...)
+  const int L0 = (int)G.tag_len[k0];
+  for (uint32_t x = T.kw_begin[gk]; x < T.kw_begin[gk + 1]; x++) {
+    const int k = (int)T.kw_tags[x];                   // indices, ascending
+    const int Lk = (int)G.tag_len[k];
+    const int q = (HALF == 1) ? p : p - split;         // window start
+    int lo, hi;
+    pyslice(n, q, q + L0, lo, hi);                     // :302-307 / :348-357 / :429-434 / :482-491
+    if (Lk != hi - lo) continue;
+    pyslice(n, q, (HALF == 1) ? p + Lk : p + Lk - split, lo, hi);  // :311-314 / :361-366
+    if (!hamming_le1(G, k, F, lo, hi)) continue;
+    if (GENE == 0) {
+      C.add(HALF == 1 ? DCRX_C_VERR2 : DCRX_C_VERR1);  // :318 / :370
+      const int te = (HALF == 1) ? p + G.jump[k] - 1 : p + G.jump[k] - split - 1;  // :320-322 / :372-377
+      int end_v, dels;
+      if (get_v_deletions(G, F, k, te, end_v, dels, C)) {
+        out.match = k; out.pos = end_v; out.dels = dels; out.tagpos = q;  // :327-333 / :382-388
+        return true;
+      }
+    } else {
+      C.add(HALF == 1 ? DCRX_C_JERR2 : DCRX_C_JERR1);  // :445 / :504
+      const int ts = (HALF == 1) ? p - G.jump[k] : p - G.jump[k] - split;  // :447-449 / :506-510
+      const int jend = (HALF == 1) ? p + hlen + split : p + hlen;          // :450-454 / :511
+      int start_j, dels;
+      if (get_j_deletions(G, F, k, ts, end_of_v, start_j, dels, C)) {
+        out.match = k; out.pos = start_j; out.dels = dels; out.tagpos = jend;  // :463-468 / :520-525
+        return true;
+      }
+    }
+  }
+  return false;
+}
+
 // Candidates of one half-tag hit: every keyword of class (GENE, HALF) that ends at
 // state `st` reached after frame position `i`, each with its tags in ascending index.
 template <bool REV>
 DCRX_DEVNI bool rescue_at(const DevTables &T, const Frame<REV> &F, const int GENE, const int HALF, const uint32_t st,
                           const int i, const int end_of_v, XDat &out, const Counters &C) {
   const int CLS = (GENE == 0) ? (HALF == 1 ? K_VH1 : K_VH2) : (HALF == 1 ? K_JH1 : K_JH2);
-  const GeneDevPtrs &G = T.g[GENE];
-  const int n = F.n();
-  const int split = G.split;
   for (uint32_t o = T.st_out[st - T.first_out];; o++) {
     const uint32_t ent = T.outs[o];
     if ((int)(ent & 7u) == CLS) {
       const int hlen = (int)((ent >> 3) & 63u);
       const uint32_t gk = T.kw_base[CLS] + ((ent >> 9) & 0xFFFFu);
-      const int p = i + 1 - hlen;                          // hold_x[i][1]
-      const int k0 = (int)T.kw_first[gk];                  // half_seqs.index(...)
-      const int L0 = (int)G.tag_len[k0];
-      for (uint32_t x = T.kw_begin[gk]; x < T.kw_begin[gk + 1]; x++) {
-        const int k = (int)T.kw_tags[x];                   // indices, ascending
-        const int Lk = (int)G.tag_len[k];
-        const int q = (HALF == 1) ? p : p - split;         // window start
-        int lo, hi;
-        pyslice(n, q, q + L0, lo, hi);                     // :302-307 / :348-357 / :429-434 / :482-491
-        if (Lk != hi - lo) continue;
-        pyslice(n, q, (HALF == 1) ? p + Lk : p + Lk - split, lo, hi);  // :311-314 / :361-366
-        if (!hamming_le1<REV>(G, k, F, lo, hi)) continue;
-        if (GENE == 0) {
-          C.add(HALF == 1 ? DCRX_C_VERR2 : DCRX_C_VERR1);  // :318 / :370
-          const int te = (HALF == 1) ? p + G.jump[k] - 1 : p + G.jump[k] - split - 1;  // :320-322 / :372-377
-          int end_v, dels;
-          if (get_v_deletions<REV>(G, F, k, te, end_v, dels, C)) {
-            out.match = k; out.pos = end_v; out.dels = dels; out.tagpos = q;  // :327-333 / :382-388
-            return true;
-          }
-        } else {
-          C.add(HALF == 1 ? DCRX_C_JERR2 : DCRX_C_JERR1);  // :445 / :504
-          const int ts = (HALF == 1) ? p - G.jump[k] : p - G.jump[k] - split;  // :447-449 / :506-510
-          const int jend = (HALF == 1) ? p + hlen + split : p + hlen;          // :450-454 / :511
-          int start_j, dels;
-          if (get_j_deletions<REV>(G, F, k, ts, end_of_v, start_j, dels, C)) {
-            out.match = k; out.pos = start_j; out.dels = dels; out.tagpos = jend;  // :463-468 / :520-525
-            return true;
-          }
-        }
-      }
+      if (rescue_candidates(T, F, GENE, HALF, gk, hlen, i + 1 - hlen, end_of_v, out, C)) return true;   // p = hold_x[i][1]
     }
     if (ent >> 31) break;
   }
@@ -810,6 +841,36 @@ DCRX_DEV ScanOut scan_collect(const DevTables &T, const uint32_t *lds_trans, con
   return finish4(T, ScanAcc{acc, vacc, jacc});
 }
 
+// The four filters of dcr() (decombine.py:553-569) and the record of a decombined read (:572-581).
+template <class FR>
+DCRX_DEVNI int dcr_filters(const DevTables &T, const FR &F, const XDat &vdat, const XDat &jdat, const dcrx::CfgDev &cfg,
+                           const Counters &C, dcrx_record_t &rec) {
+  const int n = F.n();
+  const GeneDevPtrs &GV = T.g[0];
+  const GeneDevPtrs &GJ = T.g[1];
+  if (F.has_exc() && !cfg.allow_ns) {
+    int lo, hi;
+    pyslice(n, vdat.tagpos, jdat.tagpos, lo, hi);            // "N" in read[vdat[3]:jdat[3]]
+    if (F.has_N(lo, hi)) { C.add(DCRX_C_DCRFILTER_INTERTAGN); return DCRX_S_F_INTERTAG_N; }
+  }
+  if ((vdat.tagpos - jdat.tagpos) >= cfg.lenthreshold) {     // :557-560
+    C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG); return DCRX_S_F_TOOLONG;
+  }
+  if (vdat.dels > (GV.jump[vdat.match] - (int)GV.tag_len[vdat.match]) || jdat.dels > GJ.jump[jdat.match]) {  // :561-565
+    C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION); return DCRX_S_F_IMPOSS_DEL;
+  }
+  if ((vdat.tagpos + (int)GV.tag_len[vdat.match]) > (jdat.tagpos + (int)GJ.tag_len[jdat.match])) {  // :566-569
+    C.add(DCRX_C_DCRFILTER_TAG_OVERLAP); return DCRX_S_F_OVERLAP;
+  }
+  int lo, hi;
+  pyslice(n, vdat.pos + 1, jdat.pos, lo, hi);                // read[vdat[1]+1 : jdat[1]] :577
+  rec.v = (uint16_t)vdat.match; rec.j = (uint16_t)jdat.match;
+  rec.v_start = (uint16_t)vdat.tagpos; rec.j_end = (uint16_t)jdat.tagpos;
+  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
+  rec.vdel = (uint8_t)vdat.dels; rec.jdel = (uint8_t)jdat.dels;
+  return DCRX_S_OK;
+}
+
 // ------------------------------------------------------------------------------
 // dcr() for one frame — decombine.py:534-585 with vanalysis :273-394 and
 // janalysis :397-531 folded around the single scan.  Returns the status and
@@ -840,7 +901,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
       const int p = iend + 1 - (int)GV.tag_len[v];           // hold_v[0][1]
       const int te = p + GV.jump[v] - 1;                     // :283-285
       int end_v, dels;
-      if (!get_v_deletions<REV>(GV, F, v, te, end_v, dels, C))                      // :288-290
+      if (!get_v_deletions(GV, F, v, te, end_v, dels, C))                      // :288-290
         return (te >= n) ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;         // :760-762 / :783-785
       vdat = XDat{v, end_v, dels, p};
     } else if ((so.acc >> TE_VH1_BIT) & 3u) {                // a V half1 (:294-335) or half2 (:339-390) keyword occurs
@@ -870,7 +931,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
       const int p = iend + 1 - Lj;
       const int ts = p - GJ.jump[j];                         // :407-409
       int start_j, dels;
-      if (get_j_deletions<REV>(GJ, F, j, ts, end_of_v, start_j, dels, C)) jdat = XDat{j, start_j, dels, p + Lj};  // :411-418
+      if (get_j_deletions(GJ, F, j, ts, end_of_v, start_j, dels, C)) jdat = XDat{j, start_j, dels, p + Lj};  // :411-418
       else jstatus = DCRX_S_J_WALK_FAIL;
     } else if ((so.acc >> TE_JH1_BIT) & 3u) {                // a J half1 (:422-470) or half2 (:473-527) keyword occurs
       if (DEFER) return DCRX_S_DEFER;                        // nothing has been counted for this read yet
@@ -886,34 +947,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
   }
   if (jstatus != DCRX_S_OK) { C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); return jstatus; }  // :583-585
 
-  // ---- filters :553-569 --------------------------------------------------------
-  if (F.has_exc() && !cfg.allow_ns) {
-    int lo, hi;
-    pyslice(n, vdat.tagpos, jdat.tagpos, lo, hi);            // "N" in read[vdat[3]:jdat[3]]
-    bool hasN = false;
-    for (int x = rv.e0; x < rv.e1; x++) {
-      const int i = REV ? n - 1 - (int)rv.exc_pos[x] : (int)rv.exc_pos[x];
-      const uint8_t b = REV ? rv.comp[rv.exc_chr[x]] : rv.exc_chr[x];
-      if (i >= lo && i < hi && b == (uint8_t)'N') hasN = true;
-    }
-    if (hasN) { C.add(DCRX_C_DCRFILTER_INTERTAGN); return DCRX_S_F_INTERTAG_N; }
-  }
-  if ((vdat.tagpos - jdat.tagpos) >= cfg.lenthreshold) {     // :557-560
-    C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG); return DCRX_S_F_TOOLONG;
-  }
-  if (vdat.dels > (GV.jump[vdat.match] - (int)GV.tag_len[vdat.match]) || jdat.dels > GJ.jump[jdat.match]) {  // :561-565
-    C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION); return DCRX_S_F_IMPOSS_DEL;
-  }
-  if ((vdat.tagpos + (int)GV.tag_len[vdat.match]) > (jdat.tagpos + (int)GJ.tag_len[jdat.match])) {  // :566-569
-    C.add(DCRX_C_DCRFILTER_TAG_OVERLAP); return DCRX_S_F_OVERLAP;
-  }
-  int lo, hi;
-  pyslice(n, vdat.pos + 1, jdat.pos, lo, hi);                // read[vdat[1]+1 : jdat[1]] :577
-  rec.v = (uint16_t)vdat.match; rec.j = (uint16_t)jdat.match;
-  rec.v_start = (uint16_t)vdat.tagpos; rec.j_end = (uint16_t)jdat.tagpos;
-  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
-  rec.vdel = (uint8_t)vdat.dels; rec.jdel = (uint8_t)jdat.dels;
-  return DCRX_S_OK;
+  return dcr_filters(T, F, vdat, jdat, cfg, C, rec);
 }
 
 // ------------------------------------------------------------------------------

@@ -41,6 +41,44 @@ inline uint32_t out_pack(int cls, int len, int kw, bool last) {
   return (uint32_t)cls | ((uint32_t)len << 3) | ((uint32_t)kw << 9) | (last ? 0x80000000u : 0u);
 }
 
+// ---- v2 scan (dcrx_v2_device.h): forward-only filter automaton + event log -------------------
+// One table per frame.  The stored (FASTQ-frame) read is always scanned forwards from its first
+// base: for the forward frame the automaton holds the keywords themselves, for the reverse frame
+// their reverse complements (a keyword K occurs in revcomp(read) exactly where revcomp(K) occurs
+// in the read).  Entry (uint16) for (state, raw nibble of the packed read = first base | second
+// base << 2): next state << 4 | V2_F_* flags "a keyword of that group ends at the first or the
+// second base of the pair".  The flags select the reads and positions that are then resolved by
+// comparing the read's window with the packed keywords (bucket tables below): the automaton is
+// the filter, the comparison is what decides.
+constexpr uint32_t V2_MAX_STATES = 4095;
+constexpr uint32_t V2_F_VF = 1u, V2_F_JF = 2u, V2_F_VH = 4u, V2_F_JH = 8u;
+constexpr int V2_NB = 64;            // buckets per keyword class
+// bucket of a packed keyword / read window (2 bits per base, first base lowest)
+inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t v2_hash(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  return ((lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ (lo >> 15)) >> 26;
+}
+
+struct V2Ori {
+  const uint16_t *trans;          // [n_states][16]
+  uint32_t trans_bytes;
+  uint32_t n_states;
+  uint32_t narrow;                // 1: entries are state << 5 | flags (<= 2047 states: the state bits are the row's byte offset); 0: state << 4 | flags
+  const uint8_t *bk;              // bucket image (staged in LDS behind the side tables)
+  uint32_t bk_bytes;
+  // byte offsets inside bk, per keyword class: bucket starts (uint16[V2_NB + 1]), the class-local
+  // keyword index of each slot (uint16[n_kw]) and the slot's packed keyword as the stored read
+  // shows it (uint64[n_kw]); slots are sorted by bucket
+  uint32_t bk_start_off[K_NCLASS];
+  uint32_t bk_kw_off[K_NCLASS];
+  uint32_t bk_pk_off[K_NCLASS];
+  uint32_t bk_tag_off[K_NCLASS];  // uint16[n_kw]: the first tag that holds the slot's keyword (list.index, decombine.py:282 / :406)
+};
+
 struct GeneDevPtrs {
   uint32_t n;
   int32_t split;               // v_half_split / j_half_split (decombine.py:657-661)
@@ -88,6 +126,10 @@ struct DevTables {
   const uint32_t *kw_tags;    // tag indices holding the keyword, ascending
   const uint8_t *comp;        // [256] Biopython ambiguous-DNA complement, both cases (decombine.py:184)
   GeneDevPtrs g[2];           // 0 = V, 1 = J
+  // v2 scan: built when every class has keywords of one length and each frame's automaton has <= V2_MAX_STATES states
+  uint32_t v2_ok;
+  uint32_t kw_len[K_NCLASS];  // the common keyword length of each class (v2_ok)
+  V2Ori v2[2];                // [0] forward frame, [1] reverse frame
 };
 
 }  // namespace dcrx

@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../../include/dcrx.h"
 #include "dcrx_device.h"
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(DCRX_RBLOCK) void decombine_rescue_kernel(DevTables
 // caller's counters, sets the exception bit of every read on the exception list and builds the
 // general work list — every read when `all` (orientation `both`, forced slow reader), else the
 // reads that have exception entries (first entry of each read appends it).
-__global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all, uint64_t n_reads,
+__global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, int all, int list, uint64_t n_reads,
                                 uint32_t *__restrict__ flag, uint32_t *__restrict__ gqueue, uint32_t *__restrict__ gstart,
                                 uint32_t *__restrict__ gcount, unsigned long long *__restrict__ counters) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -402,7 +404,7 @@ __global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t 
   if (i < n_exc) {
     const uint32_t r = exc_read[i];
     atomicOr(&flag[r >> 5], 1u << (r & 31));
-    if (!all && (i == 0 || exc_read[i - 1] != r)) {
+    if (!all && list && (i == 0 || exc_read[i - 1] != r)) {    // list == 0: the v2 kernels resolve these reads themselves
       const uint32_t slot = atomicAdd(gcount, 1u);
       gqueue[slot] = r;
       gstart[slot] = (uint32_t)i;        // where the read's entries start in the exception list
@@ -510,6 +512,15 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // ------------------------------------------------------------------------------
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
+// per-device "attribute already set" marks (one process may drive several devices)
+bool first_use_on_device(bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const bool first = !seen[dev];
+  seen[dev] = true;
+  return first;
+}
+
 template <bool TABLE_LDS, bool UNIFORM, int NW, int ARITY>
 static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
                              dcrx_record_t *rec, uint32_t *queue, uint32_t *gqueue, uint32_t *queue_count,
@@ -522,13 +533,12 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   hipError_t e;
   // persistent grids: as many blocks as are resident at once for THIS table size (queried per
   // launch: a host-side call, and tables of different sizes share the kernel instantiations)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_seen[64];
+  if (first_use_on_device(attr_seen)) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(klist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   int occ_fast = 0, occ_list = 0;
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, FBLOCK, lds_fast);
@@ -537,6 +547,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   if (e != hipSuccess) return e;
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER);
+  const bool v2 = v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);   // (the v2 entries keep two flags above a 30-bit read index)
   // reserved_cus: compute units left to other streams (an RCCL gather running beside the scan)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, cus * (uint32_t)occ_fast);
@@ -550,20 +561,33 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   {
     const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));
     hipLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc,
-                       all_general ? 1 : 0, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
+                       all_general ? 1 : 0, v2 ? 0 : 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
                        queue_count + 1, d_counters);
   }
-  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
-  if (grid) {
+  if (v2) {
+    e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop);
+    if (e != hipSuccess) return e;
+  }
+  if (v2 && getenv("DCRX_DEBUG_HANDOVER")) {      // developer aid: how many reads the v2 kernels handed over
+    uint32_t qc[2] = {0, 0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(qc, queue_count, sizeof qc, hipMemcpyDeviceToHost);
+    fprintf(stderr, "dcrx: v2 handed over %u clean reads and %u reads with exception bytes\n", qc[0], qc[1]);
+    if (getenv("DCRX_DEBUG_SKIP_TRAILING")) { (void)hipMemset(queue_count, 0, 8); return hipSuccess; }
+  }
+  if (!v2 && ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
+  if (!v2 && grid) {
     hipLaunchKernelGGL(kfast, dim3(grid), dim3(FBLOCK), lds_fast, s, T, B, cfg, rec, d_counters, queue, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  if (!v2 && ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
   // What the fast kernel left: the general list (reads with exception bytes; every read for
   // `both` / the forced slow reader) goes through the list kernel; the rescue queue through the
   // rescue kernel when the pair table serves it, else through the list kernel as well.
-  const bool rescue16 = ARITY == 16 && T.pair_rescue && !(cfg.flags & DCRX_F_LIST_RESCUE) &&
+  // (behind the v2 kernels only the few reads they hand over are left: the list kernel, whose blocks
+  // leave at once when there is nothing to do)
+  const bool rescue16 = !v2 && ARITY == 16 && T.pair_rescue && !(cfg.flags & DCRX_F_LIST_RESCUE) &&
                         P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA <= 160u * 1024u;
   if (!rescue16 || all_general) {
     hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
@@ -573,11 +597,10 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   }
   if (rescue16 && !all_general) {
     auto kresc = decombine_rescue_kernel<UNIFORM, NW>;
-    static bool rattr_set = false;
-    if (!rattr_set) {
+    static bool rattr_seen[64];
+    if (first_use_on_device(rattr_seen)) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(kresc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
-      rattr_set = true;
     }
     const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
     hipLaunchKernelGGL(kresc, dim3(cus), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count,

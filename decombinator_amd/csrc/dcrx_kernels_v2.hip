@@ -1,0 +1,504 @@
+// dcrx_kernels_v2.hip — the v2 decombine kernels for gfx950 (CDNA4) and their launcher.
+// Per-read code: dcrx_v2_device.h.  The three-launch form (dcrx_kernels.hip) stays for
+// orientation `both`, tag sets the v2 tables do not express, and the few reads these kernels
+// hand over (more flagged pairs than an entry holds).
+//
+// Two launches per batch:
+//
+//   scan2_kernel    persistent, one 1024-thread block per CU.  LDS holds the frame's 16-bit pair
+//                   table (at LDS address 0) and nothing else.  Per tile of 1024 * RPL reads: the
+//                   next tile's words are requested, this tile is scanned (RPL independent chains
+//                   per lane, one ds_read_u16 + one v_alignbit per two bases), the flag log is
+//                   digested, and by ballot a read is
+//                     - finished at once (no V tag and no V half tag / several V tags),
+//                     - appended to the wave's TAIL list (read, V pair, J pair: 8 bytes), or
+//                     - appended to the wave's EVENT list (read, up to six flagged pairs: 16 bytes).
+//                   Each wave owns a region of both lists (no atomics) and leaves its counts.
+//   finish2_kernel  one wave per region, 256-thread blocks, the side tables and keyword buckets in
+//                   LDS, four such blocks per CU.  Tail entries take the lean form (tail2_fast),
+//                   event entries and whatever the lean form does not settle the general form
+//                   (dcr_frame3) on a read held in registers.  Reads with exception bytes arrive
+//                   here as event entries and are resolved with their exception list.
+//
+// The scan has its registers to itself (no finishing code in that kernel), and the finishing,
+// which waits on memory, runs at twice the scan kernel's wave count.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/dcrx.h"
+#include "dcrx_device.h"
+#include "dcrx_launch.h"
+#include "dcrx_dcr_device.h"
+#include "dcrx_v2_device.h"
+
+namespace dcrx {
+
+bool first_use_on_device(bool (&seen)[64]);
+
+constexpr int DCRX_V2_BLOCK = 1024;
+constexpr int DCRX_V2_FBLOCK = 256;
+#ifndef DCRX_V2_TSPLIT
+#define DCRX_V2_TSPLIT 2    /* waves of the tail kernel per region */
+#endif
+
+// ---- the lists: per wave of the scan kernel one region of tail entries and one of event entries ----
+// An entry carries the read's packed words (the scan kernel has them in registers), so that the
+// finishing kernels never gather from the read array: their loads are the entries, structure of
+// arrays inside a region (row k of slot i at rows[k * cap + i], 16 bytes each), one lane one slot,
+// fully coalesced.  Tail entry: read, digest (tail2_pack), words; event entry: read | flags, three
+// dwords of events, words.
+struct V2Lists {
+  uint4 *tail;        // [regions][rows_t][tcap]
+  uint4 *events;      // [regions][rows_e][ecap]
+  uint32_t *counts;   // [regions][2]
+  uint32_t tcap, ecap;
+};
+template <int NW>
+struct V2Rows {
+  static constexpr int T = (2 + NW + 3) / 4, E = (4 + NW + 3) / 4;
+};
+// dwords x[0 .. N) of slot `at` into the rows of a region (cap slots per row)
+template <int N>
+__device__ __forceinline__ void v2_put_rows(uint4 *rows, const uint32_t cap, const uint32_t at, const uint32_t (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < (N + 3) / 4; k++)
+    rows[(size_t)k * cap + at] = make_uint4(x[4 * k], 4 * k + 1 < N ? x[4 * k + 1] : 0u, 4 * k + 2 < N ? x[4 * k + 2] : 0u,
+                                            4 * k + 3 < N ? x[4 * k + 3] : 0u);
+}
+template <int N>
+__device__ __forceinline__ void v2_get_rows(const uint4 *rows, const uint32_t cap, const uint32_t at, const bool live, uint32_t (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < (N + 3) / 4; k++) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (live) v = rows[(size_t)k * cap + at];
+    x[4 * k] = v.x;
+    if (4 * k + 1 < N) x[4 * k + 1] = v.y;
+    if (4 * k + 2 < N) x[4 * k + 2] = v.z;
+    if (4 * k + 3 < N) x[4 * k + 3] = v.w;
+  }
+}
+
+// a read the v2 kernels hand to the three-launch form: clean reads to its rescue queue, reads
+// with exception bytes to its general list (with the offset of their exception entries)
+__device__ __forceinline__ void v2_hand_over(const BatchDev &B, uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
+                                             const bool tagged, const uint32_t r, const bool exc) {
+  if (!exc) {
+    const uint32_t at = atomicAdd(queue_count, 1u);
+    queue[at] = tagged ? (r | (3u << 30)) : r;
+    return;
+  }
+  uint64_t lo = 0, hi = B.n_exc;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+  const uint32_t at = atomicAdd(queue_count + 1, 1u);
+  gqueue[at] = r;
+  gqueue[qcap + at] = (uint32_t)lo;
+}
+
+// counters of a wave's lean-tail statuses: one ballot per status, one LDS atomic per counter and wave
+__device__ __forceinline__ void v2_tally(uint32_t *lds_counts, const int lane, const int status, const bool forward) {
+  const unsigned long long m_ok = __ballot(status == DCRX_S_OK), m_jn = __ballot(status == DCRX_S_J_NONE),
+                           m_jm = __ballot(status == DCRX_S_J_MULTI), m_tl = __ballot(status == DCRX_S_F_TOOLONG),
+                           m_im = __ballot(status == DCRX_S_F_IMPOSS_DEL), m_ov = __ballot(status == DCRX_S_F_OVERLAP);
+  if (lane == 0) {
+    const uint32_t n_ok = (uint32_t)__popcll(m_ok), n_jn = (uint32_t)__popcll(m_jn), n_jm = (uint32_t)__popcll(m_jm),
+                   n_tl = (uint32_t)__popcll(m_tl), n_im = (uint32_t)__popcll(m_im), n_ov = (uint32_t)__popcll(m_ov);
+    const uint32_t all = n_ok + n_jn + n_jm + n_tl + n_im + n_ov;
+    if (all) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], all);
+    if (n_ok) { atomicAdd(&lds_counts[DCRX_C_VJ_COUNT], n_ok); if (forward) atomicAdd(&lds_counts[DCRX_C_FRAME_FORWARD], n_ok); }
+    if (n_jn) atomicAdd(&lds_counts[DCRX_C_NO_J_ASSIGNED], n_jn);
+    if (n_jm) atomicAdd(&lds_counts[DCRX_C_MULTIPLE_J_MATCHES], n_jm);
+    if (n_jn + n_jm) atomicAdd(&lds_counts[DCRX_C_VJ_ASSIGNMENT_FAILED], n_jn + n_jm);
+    if (n_tl) atomicAdd(&lds_counts[DCRX_C_DCRFILTER_TOOLONG_INTERTAG], n_tl);
+    if (n_im) atomicAdd(&lds_counts[DCRX_C_DCRFILTER_IMPOSS_DELETION], n_im);
+    if (n_ov) atomicAdd(&lds_counts[DCRX_C_DCRFILTER_TAG_OVERLAP], n_ov);
+  }
+}
+
+template <int NW, int RPL>
+__device__ __forceinline__ void v2_load_tile(const BatchDev &B, const uint32_t nw, const uint64_t first_read, const int tid,
+                                             uint32_t (&w)[RPL][NW]) {
+#pragma unroll
+  for (int q = 0; q < RPL; q++) {
+    const uint64_t r = first_read + (uint64_t)q * DCRX_V2_BLOCK + tid;
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(B.packed + (r < B.n_reads ? r : 0) * B.stride);
+#pragma unroll
+    for (int k = 0; k < NW / 2; k++) {
+      uint2 t = make_uint2(0u, 0u);
+      if ((uint32_t)(2 * k) < nw && r < B.n_reads) t = wp2[k];
+      w[q][2 * k] = t.x; w[q][2 * k + 1] = t.y;
+    }
+  }
+}
+
+template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW>
+__global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  V2Ori V0 = T0.v2[0];
+  if (o) V0 = T0.v2[1];
+  uint32_t *lds_trans = smem;                                         // the pair table, at LDS address 0
+  uint32_t *lds_counts = smem + V0.trans_bytes / 4;
+  const int tid = threadIdx.x;
+  if (dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans)) != 0u) __builtin_trap();   // v2_entry reads the table at absolute LDS addresses
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  stage_lds<DCRX_V2_BLOCK>(reinterpret_cast<const uint8_t *>(V0.trans), lds_trans, V0.trans_bytes / 16, 0, 0, tid);
+  const V2Tab tab{};
+  __syncthreads();
+  const uint32_t nw = B.stride >> 2;
+  const int lane = tid & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const bool tagged = B.n_reads < (1ull << 30);
+  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
+
+  const size_t region = (size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6);
+  uint4 *tq = Q.tail + region * Q.tcap * V2Rows<NW>::T;
+  uint4 *eq = Q.events + region * Q.ecap * V2Rows<NW>::E;
+  uint32_t tn = 0, en = 0;
+
+  constexpr uint64_t TILE = (uint64_t)DCRX_V2_BLOCK * RPL;
+  const int npairs = UNIFORM_LEN ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
+  uint32_t w[RPL][NW];
+  uint64_t tile = blockIdx.x;
+  if (tile * TILE < B.n_reads) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
+  for (; tile * TILE < B.n_reads; tile += gridDim.x) {
+    uint32_t wn[RPL][NW];
+    const bool more = (tile + gridDim.x) * TILE < B.n_reads;
+    if (more) v2_load_tile<NW, RPL>(B, nw, (tile + gridDim.x) * TILE, tid, wn);     // in flight while this tile is scanned
+    uint32_t lg[RPL][NW];
+    scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const uint64_t r = tile * TILE + (uint64_t)q * DCRX_V2_BLOCK + tid;
+      const bool live = r < B.n_reads;
+      const bool exc = live && B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u);
+      const int n = UNIFORM_LEN ? (int)B.read_len : (live ? (int)B.lens[r] : 0);
+      if (!UNIFORM_LEN) mask_log2<NW>(lg[q], n);
+      const Digest2 d = digest2<NW>(lg[q]);
+      if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {        // profiling aid: price the scan alone (records are NOT results)
+        if (live) {
+          __align__(16) dcrx_record_t rec;
+          rec.v = (uint16_t)d.any; rec.j = (uint16_t)d.vf_n; rec.v_start = (uint16_t)d.vf_pair; rec.j_end = (uint16_t)d.jf_n;
+          rec.ins_start = (uint16_t)d.jf_pair; rec.ins_len = 0; rec.vdel = rec.jdel = 0; rec.status = 254; rec.frame = 0;
+          dcrx_store_record(records + r, rec);
+        }
+        continue;
+      }
+      // A read with exception bytes was scanned with those bytes packed as A: its flags hold every
+      // keyword that really occurs (and possibly more), so "no V flag" still means "no V keyword";
+      // anything else is resolved from its events against its exception list.
+      const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg[q], n >> 1) : 0u;
+      int what = live ? classify2(d, bnd) : -1;
+      if (exc && what != V2_VNONE) what = V2_EVENTS;
+      const bool vnone = what == V2_VNONE, vmulti = what == V2_VMULTI;
+      if (vnone || vmulti) {
+        __align__(16) dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+        rec.vdel = rec.jdel = 0;
+        rec.status = (uint8_t)(vnone ? DCRX_S_V_NONE : DCRX_S_V_MULTI);
+        rec.frame = (uint8_t)(o == 0 ? 1 : 0);
+        dcrx_store_record(records + r, rec);
+        if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));   // the flag has served: the bitmap is all zero again when the batch ends
+      }
+      const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
+      if (lane == 0) {
+        if (mn) atomicAdd(&lds_counts[DCRX_C_NO_VTAGS_FOUND], (uint32_t)__popcll(mn));
+        if (mm) atomicAdd(&lds_counts[DCRX_C_MULTIPLE_V_MATCHES], (uint32_t)__popcll(mm));
+        if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
+      }
+      if (cfg.flags & DCRX_F_PROFILE_NO_FINISH) continue;
+      bool to_tail = what == V2_TAIL;
+      const unsigned long long mt0 = __ballot(to_tail);
+      if (mt0) {
+        const uint32_t at = tn + (uint32_t)__popcll(mt0 & lt_mask);
+        if (to_tail && at >= Q.tcap) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, false); to_tail = false; }
+        if (to_tail) {
+          uint32_t x[2 + NW];
+          x[0] = (uint32_t)r; x[1] = tail2_pack(d);
+#pragma unroll
+          for (int k = 0; k < NW; k++) x[2 + k] = w[q][k];
+          v2_put_rows<2 + NW>(tq, Q.tcap, at, x);
+        }
+        tn = min(tn + (uint32_t)__popcll(mt0), Q.tcap);
+      }
+      bool to_ev = what == V2_EVENTS;
+      if (__ballot(to_ev)) {
+        uint32_t ev[3] = {0u, 0u, 0u};
+        bool fits = true;
+        if (to_ev) fits = events2<NW>(lg[q], d, exc ? 0xFu : bnd, ev);     // a read with exception bytes keeps every flag (none is certain)
+        if (to_ev && !fits) {      // more flagged pairs than an entry holds: the three-launch form
+          v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
+          to_ev = false;
+        }
+        const unsigned long long me0 = __ballot(to_ev);
+        const uint32_t at = en + (uint32_t)__popcll(me0 & lt_mask);
+        if (to_ev && at >= Q.ecap) {                 // a full region (its last lanes): the three-launch form
+          v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
+          to_ev = false;
+        }
+        if (to_ev) {
+          uint32_t x[4 + NW];
+          x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u); x[1] = ev[0]; x[2] = ev[1]; x[3] = ev[2];
+#pragma unroll
+          for (int k = 0; k < NW; k++) x[4 + k] = w[q][k];
+          v2_put_rows<4 + NW>(eq, Q.ecap, at, x);
+        }
+        en = min(en + (uint32_t)__popcll(me0), Q.ecap);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < RPL; q++)
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[q][k] = wn[q][k];
+    }
+  }
+  if (lane == 0) { Q.counts[2 * region] = tn; Q.counts[2 * region + 1] = en; }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+
+// LDS of the finishing kernel: counters, side tables, the frame's keyword buckets
+static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
+  return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
+}
+
+// The tail kernel: one wave per region, 256-thread blocks at eight waves per SIMD (the lean form
+// needs few registers, and what it waits for is memory).  Software pipeline over the batches of 64:
+// the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
+// hand finds everything in registers.  What the lean form does not settle joins the region's
+// event entries (full waves in the event kernel, not two lanes here).
+template <bool UNIFORM_LEN, int NW>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, 8) void tail2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  V2Ori V = T0.v2[0];
+  if (o) V = T0.v2[1];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_side = smem + DCRX_N_COUNTERS;
+  uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
+  const int tid = threadIdx.x;
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+  stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
+  const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1);
+  __syncthreads();
+  const int lane = tid & 63;
+  const bool tagged = B.n_reads < (1ull << 30);
+  // DCRX_V2_TSPLIT waves share a region: wave k of them takes the batches k, k + DCRX_V2_TSPLIT, ...
+  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
+  for (uint32_t job = gwave; job < n_regions * DCRX_V2_TSPLIT; job += n_gwaves) {
+    const uint32_t region = job / DCRX_V2_TSPLIT, part = job % DCRX_V2_TSPLIT;
+    const uint32_t tn = Q.counts[2 * region];
+    const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
+    uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
+    constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
+    uint32_t x1[2 + NW];
+    v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
+    for (uint32_t first = 64 * part; first < tn && !(cfg.flags & DCRX_F_PROFILE_NO_TAIL); first += STEP) {
+      uint32_t x[2 + NW];
+#pragma unroll
+      for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
+      v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
+      uint32_t w[NW];
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = x[2 + k];
+      int status = -2;
+      const uint32_t r = x[0], dg = x[1];
+      if (first + lane < tn) {
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+        status = o ? tail2_fast<true, NW>(tt, w, n, dg, cfg, rec) : tail2_fast<false, NW>(tt, w, n, dg, cfg, rec);
+        if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
+      }
+      v2_tally(lds_counts, lane, status, o == 0);
+      const unsigned long long ms = __ballot(status == TAIL2_SLOW);
+      if (ms) {      // the region's event list is shared by the waves of the region: one atomic per batch that has such reads
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&Q.counts[2 * region + 1], (uint32_t)__popcll(ms));
+        base = __shfl(base, 0);
+        const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+        if (status == TAIL2_SLOW) {
+          uint32_t ev[3];
+          bool jmulti;
+          tail2_events(dg, ev, jmulti);
+          if (at < Q.ecap) {
+            uint32_t y[4 + NW];
+            y[0] = r | (jmulti ? V2_R_JMULTI : 0u); y[1] = ev[0]; y[2] = ev[1]; y[3] = ev[2];
+#pragma unroll
+            for (int k = 0; k < NW; k++) y[4 + k] = w[k];
+            v2_put_rows<4 + NW>(eq, Q.ecap, at, y);
+          } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+
+// The event kernel: one wave per region; the general form (dcr_frame3) on reads held in registers,
+// their words loaded one batch ahead.  Reads with exception bytes are resolved against their slice
+// of the exception list.
+template <bool UNIFORM_LEN, int NW>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  V2Ori V = T0.v2[0];
+  if (o) V = T0.v2[1];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_side = smem + DCRX_N_COUNTERS;
+  uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
+  const int tid = threadIdx.x;
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+  stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
+  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes);
+  V.bk = reinterpret_cast<const uint8_t *>(lds_bk);
+  __syncthreads();
+  const Counters C{lds_counts};
+  const int lane = tid & 63;
+  const bool tagged = B.n_reads < (1ull << 30);
+  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
+  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
+  for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
+    const uint32_t en = min(Q.counts[2 * region + 1], Q.ecap);      // (the tail kernel's appends may have run past the region's end)
+    const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
+    uint32_t x1[4 + NW];
+    v2_get_rows<4 + NW>(eq, Q.ecap, lane, (uint32_t)lane < en, x1);
+    for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
+      uint32_t x[4 + NW];
+#pragma unroll
+      for (int k = 0; k < 4 + NW; k++) x[k] = x1[k];
+      v2_get_rows<4 + NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);        // the next batch, in flight during this one
+      uint32_t w[NW];
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = x[4 + k];
+      const uint4 e = make_uint4(x[0], x[1], x[2], x[3]);
+      if (first + lane < en) {
+        const uint32_t r = e.x & V2_R_MASK;
+        const uint32_t ev[3] = {e.y, e.z, e.w};
+        int x0 = 0, x1 = 0;
+        const bool exc = (e.x & V2_R_EXC) != 0u;
+        if (exc) {                      // the read's slice of the (sorted) exception list
+          uint64_t lo = 0, hi = B.n_exc;
+          while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+          x0 = (int)lo;
+          while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
+          x1 = (int)lo;
+        }
+        if (finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1, C, records)) {
+          if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
+        } else {
+          v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+
+// ---- launcher ------------------------------------------------------------------------------------
+// LDS the scan kernel needs for frame o: the pair table and the block's counters
+static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].trans_bytes + DCRX_N_COUNTERS * 4; }
+
+// The v2 kernels serve one frame; the A/B switches of the three-launch form, the forced slow
+// reader and orientation `both` keep that form.
+bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
+  if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events) return false;
+  if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY |
+                   DCRX_F_PROFILE_RESCUE_HITS_ONLY)) return false;
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) <= 64u * 1024u;
+}
+
+template <bool UNIFORM, int NW, int RPL, bool NARROW>
+static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
+                            uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
+                            unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW>;
+  auto kt = tail2_kernel<UNIFORM, NW>;
+  auto ke = events2_kernel<UNIFORM, NW>;
+  static bool seen[64];
+  hipError_t e;
+  if (first_use_on_device(seen)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  if (B.n_reads == 0) return hipSuccess;       // the prologue has zeroed the counters
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
+  const uint64_t tile = (uint64_t)DCRX_V2_BLOCK * RPL;
+  const uint64_t n_tiles = (B.n_reads + tile - 1) / tile;
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, n_tiles));
+  // each wave of the scan kernel owns a region of the two lists sized for the reads it can meet
+  const uint64_t per_wave = ((n_tiles + grid - 1) / grid) * 64ull * RPL;
+  V2Lists Q;
+  Q.tail = P.v2_tail; Q.events = P.v2_events; Q.counts = P.v2_counts;
+  const uint32_t n_regions = grid * (DCRX_V2_BLOCK / 64);
+  Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions);
+  Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions);
+  if (Q.tcap < 64 || Q.ecap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, queue, gqueue, qcap,
+                     queue_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
+  if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
+    const uint32_t fgrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    hipLaunchKernelGGL(kt, dim3(fgrid * DCRX_V2_TSPLIT), dim3(DCRX_V2_FBLOCK), v2_finish_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, n_regions,
+                       queue, gqueue, qcap, queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), v2_finish_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, n_regions,
+                       queue, gqueue, qcap, queue_count);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
+                         uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
+                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  const bool uniform = B.lens == nullptr, nw10 = B.stride <= 40, narrow = T.v2[o].narrow != 0;
+  int shape = (int)((cfg.flags >> 8) & 3u);
+  if (shape == 0) shape = 2;      // two reads per lane (two independent chains per wave): measured faster than one
+#define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
+#define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : DCRX_V2A(UN, NW_, 2, NA))
+  if (nw10) {
+    if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);
+    return narrow ? DCRX_V2(false, 10, true) : DCRX_V2(false, 10, false);
+  }
+  if (uniform) return narrow ? DCRX_V2(true, DCRX_NWMAX, true) : DCRX_V2(true, DCRX_NWMAX, false);
+  return narrow ? DCRX_V2(false, DCRX_NWMAX, true) : DCRX_V2(false, DCRX_NWMAX, false);
+#undef DCRX_V2
+#undef DCRX_V2A
+}
+
+// 16-byte rows the two lists need for batches of up to max_reads reads of `stride` bytes on n_cu compute units:
+// a tail entry per read (every read can be one) and half as many event entries
+void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *tail_rows, uint64_t *event_rows) {
+  const bool nw10 = stride <= 40;
+  const uint64_t rt = nw10 ? V2Rows<10>::T : V2Rows<DCRX_NWMAX>::T, re = nw10 ? V2Rows<10>::E : V2Rows<DCRX_NWMAX>::E;
+  const uint64_t entries = max_reads + max_reads / 8 + (uint64_t)n_cu * 16 * 256;
+  *tail_rows = entries * rt;
+  *event_rows = (entries / 2) * re;
+}
+
+}  // namespace dcrx

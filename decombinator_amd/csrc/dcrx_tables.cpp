@@ -84,6 +84,7 @@ DevTables HostTables::resolve(const uint8_t *base) const {
     fix(d.g[g].reg_len); fix(d.g[g].reg_bytes); fix(d.g[g].reg_pk_off); fix(d.g[g].reg_pk);
     fix(d.g[g].reg_pk_rc); fix(d.g[g].reg_clean); fix(d.g[g].w64_fwd); fix(d.g[g].w64_rc); fix(d.g[g].w64_ok);
   }
+  if (d.v2_ok) for (int o = 0; o < 2; o++) { fix(d.v2[o].trans); fix(d.v2[o].bk); }
   return d;
 }
 
@@ -413,6 +414,97 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     R.trans16 = as_off<uint32_t>(B.put(trans16));
     R.dfa16_bytes = S * 64u;
     R.pair_rescue = (R.max_half_len <= 15 && min_kw_len >= 2) ? 1u : 0u;   // the rescue kernel's window: 16 bases, one more than any half tag
+  }
+  // ---- v2 scan tables (dcrx_v2_device.h): per frame a filter automaton over the keywords as the
+  // STORED read shows them (forward frame: the keywords; reverse frame: their reverse complements),
+  // two bases per 16-bit entry, and per class a bucket table of the packed keywords ------------------
+  R.v2_ok = 0;
+  for (int c = 0; c < K_NCLASS; c++) R.kw_len[c] = kw_str[c].empty() ? 0u : (uint32_t)kw_str[c][0].size();
+  for (int o = 0; o < 2; o++) { R.v2[o] = V2Ori{}; }
+  if (H.equal_len_per_automaton) {
+    bool ok = true;
+    for (int o = 0; o < 2 && ok; o++) {
+      auto shown = [&](const std::string &k) {        // the keyword as it appears in the stored read
+        if (o == 0) return k;
+        std::string r(k.rbegin(), k.rend());
+        for (char &ch : r) ch = "TGCA"[base_code(ch)];
+        return r;
+      };
+      struct N2 { int next[4] = {-1, -1, -1, -1}; int fail = 0; uint32_t fl = 0; };
+      std::vector<N2> nd(1);
+      const uint32_t group[K_NCLASS] = {V2_F_VF, V2_F_JF, V2_F_VH, V2_F_VH, V2_F_JH, V2_F_JH};
+      for (int cls = 0; cls < K_NCLASS; cls++)
+        for (const std::string &k0 : kw_str[cls]) {
+          const std::string k = shown(k0);
+          int s = 0;
+          for (char ch : k) {
+            const int c = base_code(ch);
+            if (nd[s].next[c] < 0) { nd[s].next[c] = (int)nd.size(); nd.push_back(N2()); }
+            s = nd[s].next[c];
+          }
+          nd[s].fl |= group[cls];
+        }
+      const uint32_t S2 = (uint32_t)nd.size();
+      if (S2 > V2_MAX_STATES) { ok = false; break; }
+      std::vector<int> d2(S2 * 4, 0);
+      {
+        std::queue<int> q;
+        for (int c = 0; c < 4; c++) {
+          const int t = nd[0].next[c];
+          if (t >= 0) { d2[c] = t; nd[t].fail = 0; q.push(t); }
+        }
+        while (!q.empty()) {
+          const int s = q.front(); q.pop();
+          const int f = nd[s].fail;
+          nd[s].fl |= nd[f].fl;                      // everything that ends at a suffix state ends here too (BFS: f is final)
+          for (int c = 0; c < 4; c++) {
+            const int t = nd[s].next[c];
+            if (t >= 0) { d2[s * 4 + c] = t; nd[t].fail = d2[f * 4 + c]; q.push(t); }
+            else d2[s * 4 + c] = d2[f * 4 + c];
+          }
+        }
+      }
+      std::vector<uint16_t> tr((size_t)S2 * 16);
+      const bool narrow = S2 <= 2047;
+      for (uint32_t s = 0; s < S2; s++)
+        for (int x = 0; x < 16; x++) {               // x: raw nibble, first base in its low two bits
+          const uint32_t s1 = (uint32_t)d2[s * 4 + (x & 3)], s2 = (uint32_t)d2[s1 * 4 + (x >> 2)];
+          tr[(size_t)s * 16 + x] = (uint16_t)((s2 << (narrow ? 5 : 4)) | nd[s1].fl | nd[s2].fl);
+        }
+      // buckets
+      Blob K;
+      V2Ori &V = R.v2[o];
+      for (int cls = 0; cls < K_NCLASS; cls++) {
+        const size_t nk = kw_str[cls].size();
+        std::vector<uint64_t> pk(nk);
+        std::vector<uint32_t> hb(nk);
+        for (size_t i = 0; i < nk; i++) {
+          const std::string k = shown(kw_str[cls][i]);
+          uint64_t v = 0;
+          for (size_t x = 0; x < k.size(); x++) v |= (uint64_t)base_code(k[x]) << (2 * x);
+          pk[i] = v; hb[i] = v2_hash(v);
+        }
+        std::vector<uint16_t> start(V2_NB + 1, 0), slot_kw(nk), slot_tag(nk);
+        std::vector<uint64_t> slot_pk(nk);
+        for (size_t i = 0; i < nk; i++) start[hb[i] + 1]++;
+        for (int b = 0; b < V2_NB; b++) start[b + 1] = (uint16_t)(start[b + 1] + start[b]);
+        std::vector<uint16_t> fill(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < nk; i++) { const uint16_t at = fill[hb[i]]++; slot_kw[at] = (uint16_t)i; slot_pk[at] = pk[i]; slot_tag[at] = (uint16_t)kw_idx[cls][i][0]; }
+        V.bk_start_off[cls] = (uint32_t)K.put(start);
+        V.bk_kw_off[cls] = (uint32_t)K.put(slot_kw);
+        V.bk_pk_off[cls] = (uint32_t)K.put(slot_pk);
+        V.bk_tag_off[cls] = (uint32_t)K.put(slot_tag);
+      }
+      K.reserve(16);
+      V.n_states = S2;
+      V.narrow = narrow ? 1u : 0u;
+      V.trans_bytes = S2 * 32u;
+      V.trans = as_off<uint16_t>(B.put(tr));
+      V.bk_bytes = (uint32_t)K.bytes.size();
+      V.bk = as_off<uint8_t>(B.put(K.bytes));
+    }
+    if (ok) R.v2_ok = 1;
+    else for (int o = 0; o < 2; o++) R.v2[o] = V2Ori{};
   }
   {
     // Bio.Seq complement table (ambiguous DNA, both cases, U like T); other bytes unchanged

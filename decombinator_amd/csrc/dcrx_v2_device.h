@@ -1,0 +1,732 @@
+// dcrx_v2_device.h — per-read code of the v2 decombine kernel (dcrx_kernels.hip,
+// decombine2_kernel) and of its test-only host build (tests/host_emul).
+//
+// What changes against dcrx_dcr_device.h's scan:
+//   * the stored read is always scanned FORWARDS, from its first base and the root state; the
+//     reverse frame (decombine.py:1000, revcomp :182-184) is served by an automaton over the
+//     reverse-complemented keywords, so no frame needs a backwards walk and read lengths never
+//     shape the scan;
+//   * two bases per 16-bit entry (32 bytes per state: automata of up to 4095 states fit the LDS);
+//     an entry carries the next state and four flags: a V tag / J tag / V half tag / J half tag
+//     ends inside the pair;
+//   * the scan keeps nothing but a log of those flags, four bits per pair (one v_alignbit per
+//     step).  Flags of pairs that lie inside the read are exact (the scan starts at the root at
+//     base 0: no context precedes the read); what the automaton saw is then resolved by comparing
+//     the read's window with the packed keywords of the class (bucket tables, V2Ori) — the
+//     automaton is the filter, the comparison decides which keyword ends where;
+//   * half-tag hits (the findall() lists at decombine.py:294, :339, :422, :473) come out of the
+//     same log, so a read that needs the half-tag rescue is never scanned twice.
+#pragma once
+
+#include "dcrx_dcr_device.h"
+
+namespace dcrx {
+
+#ifndef DCRX_HOST_EMUL
+DCRX_DEV uint32_t dcrx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+typedef __attribute__((address_space(3))) uint16_t dcrx_lds_u16;
+struct V2Tab {};                      // the staged pair table starts at LDS address 0 (the kernel checks)
+DCRX_DEV uint32_t v2_entry(const V2Tab &, uint32_t byte_off) {
+  return *reinterpret_cast<const dcrx_lds_u16 *>(static_cast<uintptr_t>(byte_off));
+}
+#else
+inline uint32_t dcrx_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+struct V2Tab { const uint16_t *base; };
+inline uint32_t v2_entry(const V2Tab &tab, uint32_t byte_off) { return tab.base[byte_off >> 1]; }
+#endif
+
+// Typed access to the staged tables and to the reads: on the device an LDS address (32 bits) read
+// with ds_read, and a global-memory pointer read with global_load — never a flat access, which
+// would wait for both memory counters; in the host build plain pointers.
+#ifndef DCRX_HOST_EMUL
+typedef uint32_t dcrx_ldsaddr;
+template <typename T>
+DCRX_DEV T dcrx_lds_at(dcrx_ldsaddr a, uint32_t i) {
+  return reinterpret_cast<const __attribute__((address_space(3))) T *>(static_cast<uintptr_t>(a))[i];
+}
+DCRX_DEV dcrx_ldsaddr dcrx_ldsaddr_of(const void *p) { return dcrx_lds_address(reinterpret_cast<const uint8_t *>(p)); }
+typedef const __attribute__((address_space(1))) uint32_t *dcrx_gwords;
+DCRX_DEV dcrx_gwords dcrx_gwords_of(const uint8_t *p) { return reinterpret_cast<dcrx_gwords>(reinterpret_cast<uintptr_t>(p)); }
+#else
+typedef uintptr_t dcrx_ldsaddr;
+template <typename T>
+inline T dcrx_lds_at(dcrx_ldsaddr a, uint32_t i) { return reinterpret_cast<const T *>(a)[i]; }
+inline dcrx_ldsaddr dcrx_ldsaddr_of(const void *p) { return reinterpret_cast<uintptr_t>(p); }
+typedef const uint32_t *dcrx_gwords;
+inline dcrx_gwords dcrx_gwords_of(const uint8_t *p) { return reinterpret_cast<const uint32_t *>(p); }
+#endif
+
+// One step: two bases.  NIB2 = raw nibble of the packed read (first base | second base << 2) times two.
+// NARROW (<= 2047 states): entry = state << 5 | flags, the entry's state bits ARE the row's byte offset.
+#define DCRX_V2_STEP(NARROW, E, LOG, NIB2)                                                       \
+  do {                                                                                            \
+    const uint32_t off_ = (NARROW) ? (((E) & 0xFFE0u) | (uint32_t)(NIB2))                         \
+                                   : ((((E) & 0xFFF0u) << 1) | (uint32_t)(NIB2));                 \
+    (E) = v2_entry(tab, off_);                                                                    \
+    (LOG) = dcrx_alignbit((E), (LOG), 4);                                                         \
+  } while (0)
+
+// The scan of RPL reads side by side (independent chains in one instruction stream).
+// w[q][kk]: word kk of read q.  lg[q][kk]: nibble j = flags of the pair at bases 16kk+2j, 16kk+2j+1.
+// npairs: pairs to scan (wave-uniform): (n + 1) / 2 for a batch of one length, 8 * words otherwise.
+template <int NW, int RPL, bool NARROW>
+DCRX_DEV void scan2(const V2Tab &tab, const uint32_t (&w)[RPL][NW], uint32_t (&lg)[RPL][NW], const int npairs) {
+  uint32_t e[RPL];
+#pragma unroll
+  for (int q = 0; q < RPL; q++) e[q] = 0;      // root
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    const int cnt = npairs - 8 * kk;             // pairs of this word that are scanned
+    if (cnt >= 8) {
+      uint32_t lo[RPL], hi[RPL], l[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) { lo[q] = w[q][kk] << 1; hi[q] = w[q][kk] >> 3; l[q] = 0; }
+      // nibble j, times two: bits 1..4 of byte j/2 of the word shifted left by one (even j) or right by three (odd j)
+#define DCRX_V2_BYTE(BY)                                                                          \
+  _Pragma("unroll") for (int q = 0; q < RPL; q++) DCRX_V2_STEP(NARROW, e[q], l[q], dcrx_byte_and<BY>(lo[q], 0x1Eu));  \
+  _Pragma("unroll") for (int q = 0; q < RPL; q++) DCRX_V2_STEP(NARROW, e[q], l[q], dcrx_byte_and<BY>(hi[q], 0x1Eu));
+      DCRX_V2_BYTE(0) DCRX_V2_BYTE(1) DCRX_V2_BYTE(2) DCRX_V2_BYTE(3)
+#undef DCRX_V2_BYTE
+#pragma unroll
+      for (int q = 0; q < RPL; q++) lg[q][kk] = l[q];
+    } else if (cnt > 0) {
+      uint32_t wv[RPL], l[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) { wv[q] = w[q][kk]; l[q] = 0; }
+      for (int j = 0; j < cnt; j++) {
+#pragma unroll
+        for (int q = 0; q < RPL; q++) { DCRX_V2_STEP(NARROW, e[q], l[q], (wv[q] & 15u) << 1); wv[q] >>= 4; }
+      }
+#pragma unroll
+      for (int q = 0; q < RPL; q++) lg[q][kk] = l[q] >> (4 * (8 - cnt));
+    } else {
+#pragma unroll
+      for (int q = 0; q < RPL; q++) lg[q][kk] = 0;
+    }
+  }
+}
+
+// What the dispatch after the scan needs from a read's log.
+struct Digest2 {
+  uint32_t any;            // OR of all flags (V2_F_*)
+  uint32_t vf_n, vf_pair;  // pairs with a V tag ending inside, and the first such pair (8 * word + nibble)
+  uint32_t jf_n, jf_pair;
+};
+
+// Clears the flags of pairs that start at or beyond base n (batches of mixed lengths scan whole words).
+template <int NW>
+DCRX_DEV void mask_log2(uint32_t (&lg)[NW], const int n) {
+  const int pairs = (n + 1) >> 1;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    const int c = pairs - 8 * kk;
+    const uint32_t m = c >= 8 ? 0xFFFFFFFFu : (c <= 0 ? 0u : ((1u << (4 * c)) - 1u));
+    lg[kk] &= m;
+  }
+}
+
+template <int NW>
+DCRX_DEV Digest2 digest2(const uint32_t (&lg)[NW]) {
+  Digest2 d;
+  uint32_t o = 0, vn = 0, jn = 0, vp = 0xFFFFFFFFu, jp = 0xFFFFFFFFu;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    const uint32_t l = lg[kk];
+    o |= l;
+    const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
+    vn += (uint32_t)dcrx_popc64(tv);
+    jn += (uint32_t)dcrx_popc64(tj);
+    // lowest set bit (all ones when none) | word index: the minimum over the words is the first pair
+    const uint32_t qv = tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu, qj = tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu;
+    vp = min(vp, qv | ((uint32_t)kk << 5));
+    jp = min(jp, qj | ((uint32_t)kk << 5));
+  }
+  o |= o >> 16; o |= o >> 8; o |= o >> 4;
+  d.any = o & 0xFu;
+  d.vf_n = vn; d.vf_pair = vp >> 2;
+  d.jf_n = jn; d.jf_pair = jp >> 2;
+  return d;
+}
+
+// flags of pair index `pair` (any lane-varying index: a select chain over the words)
+template <int NW>
+DCRX_DEV uint32_t log_nibble(const uint32_t (&lg)[NW], const int pair) {
+  uint32_t l = 0;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) l = ((pair >> 3) == kk) ? lg[kk] : l;
+  return (l >> (4 * (pair & 7))) & 0xFu;
+}
+
+// ---- what a read needs after the scan -----------------------------------------------------------
+//   V2_VNONE   no V tag and no V half tag: NoVDetected (decombine.py:393), the record is final
+//   V2_VMULTI  two or more V tags: MultipleVtagMatches (:278-280), final
+//   V2_TAIL    exactly one pair holds a V tag and the J side needs no half-tag rescue: the tail
+//              resolves both tags from their pairs (entry: TailEntry2)
+//   V2_EVENTS  anything else (half-tag rescue of V or of J, a flag on the half pair at the end of an
+//              odd-length read): resolved from the read's event list (entry: events, up to V2_MAX_EVENTS)
+enum { V2_VNONE = 0, V2_VMULTI = 1, V2_TAIL = 2, V2_EVENTS = 3 };
+constexpr int V2_MAX_EVENTS = 8;      // 12 bits each: pair (8) | flags (4) << 8; 96 bits in three dwords
+
+// `bnd`: flags of the pair that holds the last base of an odd-length read beside a base that is not
+// part of the read (0 for even lengths): those flags may be set by a keyword that runs over the end.
+DCRX_DEV int classify2(const Digest2 &d, const uint32_t bnd) {
+  if (!(d.any & (V2_F_VF | V2_F_VH))) return V2_VNONE;
+  if (bnd & (V2_F_VF | V2_F_JF)) return V2_EVENTS;
+  if (d.vf_n >= 2) return V2_VMULTI;
+  if (d.vf_n == 1) return (d.jf_n >= 1 || !(d.any & V2_F_JH)) ? V2_TAIL : V2_EVENTS;
+  return V2_EVENTS;                      // V half tags only
+}
+
+// tail entry, second dword: V pair | J pair << 8 | J class << 16 (0 none, 1 one pair, 2 several pairs)
+DCRX_DEV uint32_t tail2_pack(const Digest2 &d) {
+  const uint32_t jc = d.jf_n < 2u ? d.jf_n : 2u;
+  return (d.vf_pair & 0xFFu) | ((jc ? (d.jf_pair & 0xFFu) : 0u) << 8) | (jc << 16);
+}
+
+// An event list: up to V2_MAX_EVENTS entries of 12 bits (pair | flags << 8; flags 0 = empty), entry i
+// at bits 12 i of the 96-bit string lo (64) : hi (32).
+struct Events2 {
+  uint64_t lo; uint32_t hi;
+  DCRX_DEV void put(int i, uint32_t x) {
+    const int bp = 12 * i;
+    if (bp < 64) lo |= (uint64_t)x << bp;
+    if (bp < 64 && bp + 12 > 64) hi |= x >> (64 - bp);
+    if (bp >= 64) hi |= x << (bp - 64);
+  }
+  DCRX_DEV uint32_t get(int i) const {
+    const int bp = 12 * i;
+    uint64_t v = bp < 64 ? (lo >> bp) : 0ull;
+    if (bp < 64 && bp + 12 > 64) v |= (uint64_t)hi << (64 - bp);
+    if (bp >= 64) v = hi >> (bp - 64);
+    return (uint32_t)v & 0xFFFu;
+  }
+  DCRX_DEV int count() const {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < V2_MAX_EVENTS; i++) n += (get(i) & 0xF00u) ? 1 : 0;
+    return n;
+  }
+};
+
+// The event list of a read: every pair with a flag that can matter, ascending.  V half-tag flags
+// are dropped when a V tag was seen (the half tags are only consulted without one, :292), J likewise;
+// `bnd` keeps them (the full-tag flag may then not stand).  Returns false when the read has more
+// than V2_MAX_EVENTS such pairs.
+template <int NW>
+DCRX_DEV bool events2(const uint32_t (&lg)[NW], const Digest2 &d, const uint32_t bnd, uint32_t (&ev)[3]) {
+  uint32_t keep = 0xFu;
+  if (!bnd) {
+    if (d.vf_n) keep &= ~V2_F_VH;
+    if (d.jf_n) keep &= ~V2_F_JH;
+  }
+  Events2 E{0, 0};
+  int ne = 0;
+  const uint32_t keep8 = keep * 0x11111111u;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    uint32_t m = lg[kk] & keep8;
+    while (m) {
+      const int j = dcrx_ctz32(m) >> 2;
+      const uint32_t fl = (m >> (4 * j)) & 0xFu;
+      m &= ~(0xFu << (4 * j));
+      if (ne < V2_MAX_EVENTS) E.put(ne, (uint32_t)(kk * 8 + j) | (fl << 8));
+      ne++;
+    }
+  }
+  ev[0] = (uint32_t)E.lo; ev[1] = (uint32_t)(E.lo >> 32); ev[2] = E.hi;
+  return ne <= V2_MAX_EVENTS;
+}
+
+// events of a tail entry: its V pair and (one J pair) its J pair
+// flags that travel in the top bits of an entry's read index (batches of fewer than 2^30 reads)
+constexpr uint32_t V2_R_JMULTI = 0x80000000u;    // several pairs hold a J tag (they are not listed)
+constexpr uint32_t V2_R_EXC = 0x40000000u;       // the read has exception bytes
+constexpr uint32_t V2_R_MASK = 0x3FFFFFFFu;
+DCRX_DEV void tail2_events(const uint32_t t, uint32_t (&ev)[3], bool &jmulti) {
+  const uint32_t vp = t & 0xFFu, jp = (t >> 8) & 0xFFu, jc = (t >> 16) & 3u;
+  jmulti = jc == 2u;
+  const uint32_t ve = vp | (V2_F_VF << 8), je = jp | (V2_F_JF << 8);
+  Events2 E{0, 0};
+  if (jc != 1u) E.put(0, ve);
+  else if (jp == vp) E.put(0, vp | ((V2_F_VF | V2_F_JF) << 8));
+  else if (jp > vp) { E.put(0, ve); E.put(1, je); }
+  else { E.put(0, je); E.put(1, ve); }
+  ev[0] = (uint32_t)E.lo; ev[1] = (uint32_t)(E.lo >> 32); ev[2] = E.hi;
+}
+
+// ------------------------------------------------------------------------------
+// A read whose packed words sit in registers, seen in one frame: the interface of Frame<REV>
+// (dcrx_dcr_device.h) without a memory access — a lane-varying word index is a select chain over
+// the NW registers.  The finishing code of the v2 kernel works on this: one round of loads per
+// read, then no load at all.
+// ------------------------------------------------------------------------------
+template <bool REV_, int NW>
+struct FrameReg {
+  static constexpr bool kRev = REV_;
+  const uint32_t (&w)[NW];
+  const ReadView &r;       // length and exception list (r.words is not used)
+  DCRX_DEVNI FrameReg(const uint32_t (&words)[NW], const ReadView &rv) : w(words), r(rv) {}
+  DCRX_DEV int n() const { return r.n; }
+  DCRX_DEV int fpos(int i) const { return REV_ ? r.n - 1 - i : i; }
+  DCRX_DEV uint32_t word(int idx) const {        // 0 beyond the registers
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) v = (idx == k) ? w[k] : v;
+    return v;
+  }
+  DCRX_DEV int code(int i) const {
+    const int m = fpos(i);
+    const int c = (int)((word(m >> 4) >> ((m & 15) * 2)) & 3u);
+    return REV_ ? (c ^ 3) : c;
+  }
+  DCRX_DEVNI int exc_index(int i) const {
+    const int m = fpos(i);
+    for (int x = r.e0; x < r.e1; x++)
+      if ((int)r.exc_pos[x] == m) return x;
+    return -1;
+  }
+  DCRX_DEV bool has_exc() const { return r.e1 > r.e0; }
+  DCRX_DEV bool clean(int a, int b) const {
+    for (int x = r.e0; x < r.e1; x++) {
+      const int i = REV_ ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
+      if (i >= a && i < b) return false;
+    }
+    return true;
+  }
+  DCRX_DEVNI bool has_N(int lo, int hi) const {
+    bool hasN = false;
+    for (int x = r.e0; x < r.e1; x++) {
+      const int i = REV_ ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
+      const uint8_t b = REV_ ? r.comp[r.exc_chr[x]] : r.exc_chr[x];
+      if (i >= lo && i < hi && b == (uint8_t)'N') hasN = true;
+    }
+    return hasN;
+  }
+  DCRX_DEVNI uint8_t chr(int i) const {
+    if (has_exc()) {
+      const int x = exc_index(i);
+      if (x >= 0) { const uint8_t b = r.exc_chr[x]; return REV_ ? r.comp[b] : b; }
+    }
+    return (uint8_t)("ACGT"[code(i)]);
+  }
+  // 32 bases of the stored read from base s >= 0 (one select chain per word, the three share their compares)
+  DCRX_DEV uint64_t stored64(int s) const {
+    const int i = s >> 4, sh = (s & 15) * 2;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const bool at = i == k;
+      w0 = at ? w[k] : w0;
+      if (k + 1 < NW) w1 = at ? w[k + 1] : w1;
+      if (k + 2 < NW) w2 = at ? w[k + 2] : w2;
+    }
+    return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+  }
+  DCRX_DEV uint32_t window(int a, int len) const {
+    const int lo = REV_ ? r.n - a - len : a;
+    const uint32_t v = (uint32_t)stored64(lo);
+    return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
+  }
+  DCRX_DEV uint64_t load64(int b) const { return stored64(b); }
+};
+
+// the same window for a read in memory
+template <bool REV>
+DCRX_DEV uint64_t frame_stored64(const Frame<REV> &F, const int nwords, const int s);
+template <bool REV, int NW>
+DCRX_DEV uint64_t frame_stored64(const FrameReg<REV, NW> &F, const int, const int s) { return F.stored64(s); }
+
+// ---- resolving events: window of the stored read against the packed keywords of a class ----------
+// 32 bases of the packed read from base s >= 0 (bases beyond the allocated words read as A)
+DCRX_DEV uint64_t win64(const uint32_t *words, const int nwords, const int s) {
+  const int i = s >> 4, sh = (s & 15) * 2;
+  const uint32_t w0 = i < nwords ? words[i] : 0u;
+  const uint32_t w1 = i + 1 < nwords ? words[i + 1] : 0u;
+  const uint32_t w2 = (sh && i + 2 < nwords) ? words[i + 2] : 0u;
+  return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+}
+
+template <bool REV>
+DCRX_DEV uint64_t frame_stored64(const Frame<REV> &F, const int nwords, const int s) { return win64(F.r.words, nwords, s); }
+
+// class-local index of the keyword whose packed form (as the stored read shows it) is `val`, or -1
+// (the per-class members are picked with constant indices: a lane-varying index into a struct that
+// lives in registers would send the struct to scratch memory)
+#define DCRX_V2_PICK(ARR, CLS) ((CLS) == 0 ? (ARR)[0] : (CLS) == 1 ? (ARR)[1] : (CLS) == 2 ? (ARR)[2] : (CLS) == 3 ? (ARR)[3] : (CLS) == 4 ? (ARR)[4] : (ARR)[5])
+DCRX_DEVNI int v2_lookup(const V2Ori &V, const int cls, const uint64_t val) {
+  const uint16_t *st = reinterpret_cast<const uint16_t *>(V.bk + DCRX_V2_PICK(V.bk_start_off, cls));
+  const uint16_t *kw = reinterpret_cast<const uint16_t *>(V.bk + DCRX_V2_PICK(V.bk_kw_off, cls));
+  const uint64_t *pk = reinterpret_cast<const uint64_t *>(V.bk + DCRX_V2_PICK(V.bk_pk_off, cls));
+  const uint32_t h = v2_hash(val);
+  const uint32_t a = st[h], b = st[h + 1];
+  for (uint32_t i = a; i < b; i++)
+    if (pk[i] == val) return (int)kw[i];
+  return -1;
+}
+
+// ------------------------------------------------------------------------------
+// dcr() for one frame from a read's events — decombine.py:534-585 with vanalysis :273-394 and
+// janalysis :397-531 — in two stages, so that a wave runs each piece of work once:
+//   1. one sweep over the events in the frame's findall order (ascending end position); per
+//      event one 32-base window of the stored read, out of which every keyword class its flags
+//      name is tested at both bases of the pair (window slice -> bucket -> compare).  The hits
+//      go to short per-class lists (the findall() lists, in order);
+//   2. vanalysis from the V lists, then janalysis from the J lists, exactly as the reference
+//      walks them.
+// Returns DCRX_S_DEFER, having counted nothing, when a half-tag list does not fit its registers
+// (the caller hands the read to the three-launch form).
+// jmulti: several pairs hold a J tag (tail entries; their pairs are not listed).
+// ------------------------------------------------------------------------------
+constexpr int V2_MAX_HITS = 8;
+struct Hits2 {            // hits of one class in findall order: 32 bits each, keyword (class-local) << 16 | stored end base
+  uint64_t a, b, c, d;    // slots 0-1, 2-3, 4-5, 6-7
+  int n;
+  DCRX_DEV void add(int kw, int f) {
+    const uint64_t h = ((uint64_t)(uint32_t)kw << 16) | (uint64_t)(uint32_t)f;
+    const uint64_t x = h << (32 * (n & 1));
+    if ((n >> 1) == 0) a |= x; else if ((n >> 1) == 1) b |= x; else if ((n >> 1) == 2) c |= x; else if ((n >> 1) == 3) d |= x;
+    n++;
+  }
+  DCRX_DEV uint32_t at(int i) const {
+    const uint64_t w = (i >> 1) == 0 ? a : ((i >> 1) == 1 ? b : ((i >> 1) == 2 ? c : d));
+    return (uint32_t)(w >> (32 * (i & 1)));
+  }
+};
+
+template <class FR>
+DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const int nwords, const uint32_t (&ev_in)[3],
+                          const bool jmulti, const CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
+  const Events2 E{(uint64_t)ev_in[0] | ((uint64_t)ev_in[1] << 32), ev_in[2]};   // scalars: an array picked with a lane-varying index would live in scratch memory
+  constexpr bool REV = FR::kRev;
+  const int n = F.n();
+  const GeneDevPtrs &GV = T.g[0];
+  const GeneDevPtrs &GJ = T.g[1];
+  const int ne = E.count();
+  const int Lvf = (int)T.kw_len[K_VFULL], Ljf = (int)T.kw_len[K_JFULL], Lv1 = (int)T.kw_len[K_VH1], Lv2 = (int)T.kw_len[K_VH2],
+            Lj1 = (int)T.kw_len[K_JH1], Lj2 = (int)T.kw_len[K_JH2];
+  Hits2 hvf{0, 0, 0, 0, 0}, hjf{0, 0, 0, 0, 0}, hv1{0, 0, 0, 0, 0}, hv2{0, 0, 0, 0, 0}, hj1{0, 0, 0, 0, 0}, hj2{0, 0, 0, 0, 0};
+  // ---- stage 1: the sweep ----
+  for (int x = 0; x < ne; x++) {
+    const int i = REV ? ne - 1 - x : x;
+    const uint32_t e = E.get(i);
+    const uint32_t fl = e >> 8;
+    const int f1 = 2 * (int)(e & 0xFFu) + 1;                 // the pair's second stored base
+    const int xs = f1 >= 31 ? f1 - 31 : 0;                   // the window: stored bases [xs, xs + 32)
+    const uint64_t X = frame_stored64(F, nwords, xs);
+    for (int y = 0; y < 2; y++) {
+      const int f = REV ? f1 - y : f1 - 1 + y;               // ascending end position in the frame
+      // keyword of class cls (L long) whose occurrence in the stored read ends at base f
+      auto test = [&](const int cls, const int L, Hits2 &h) {
+        const int s = f - L + 1;
+        if (s < 0 || f >= n) return;
+        const int p = REV ? n - s - L : s;
+        if (F.has_exc() && !F.clean(p, p + L)) return;         // an exception byte sends the automata back to their roots
+        const uint64_t mask = L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull);
+        const int kw = v2_lookup(V, cls, (X >> (2 * (s - xs))) & mask);
+        if (kw >= 0) h.add(kw, f);
+      };
+      if (fl & V2_F_VF) test(K_VFULL, Lvf, hvf);
+      if (fl & V2_F_VH) { test(K_VH1, Lv1, hv1); test(K_VH2, Lv2, hv2); }
+      if (fl & V2_F_JF) test(K_JFULL, Ljf, hjf);
+      if (fl & V2_F_JH) { test(K_JH1, Lj1, hj1); test(K_JH2, Lj2, hj2); }
+    }
+  }
+  // a half-tag list that will be walked and does not fit: nothing has been counted yet
+  if ((hvf.n == 0 && (hv1.n > V2_MAX_HITS || (hv1.n == 0 && hv2.n > V2_MAX_HITS))) ||
+      (hjf.n == 0 && !jmulti && (hj1.n > V2_MAX_HITS || (hj1.n == 0 && hj2.n > V2_MAX_HITS))))
+    return DCRX_S_DEFER;
+  auto frame_start = [&](const int f, const int L) { const int s = f - L + 1; return REV ? n - s - L : s; };
+  XDat vdat{0, 0, 0, 0}, jdat{0, 0, 0, 0};
+
+  // ---- stage 2: vanalysis ----
+  if (hvf.n > 1) { C.add(DCRX_C_MULTIPLE_V_MATCHES); return DCRX_S_V_MULTI; }      // :278-280
+  if (hvf.n == 1) {
+    const uint32_t h = hvf.at(0);
+    const int v = (int)T.kw_first[T.kw_base[K_VFULL] + (h >> 16)];                 // v_seqs.index(tag) :282
+    const int vp = frame_start((int)(h & 0xFFFFu), Lvf);
+    const int te = vp + GV.jump[v] - 1;                                            // :283-285
+    int end_v, dels;
+    if (!get_v_deletions(GV, F, v, te, end_v, dels, C))                            // :288-290
+      return (te >= n) ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;
+    vdat = XDat{v, end_v, dels, vp};
+  } else {
+    const int half = hv1.n ? 1 : 2;                          // half 2 only when no half-1 keyword occurs (:292-294, :337-339)
+    const Hits2 hh{hv1.n ? hv1.a : hv2.a, hv1.n ? hv1.b : hv2.b, hv1.n ? hv1.c : hv2.c, hv1.n ? hv1.d : hv2.d, hv1.n ? hv1.n : hv2.n};   // by value: a reference picked at run time would put both lists in memory
+    if (hh.n == 0) { C.add(DCRX_C_NO_VTAGS_FOUND); return DCRX_S_V_NONE; }         // :393-394
+    const int cls = half == 1 ? K_VH1 : K_VH2, L = half == 1 ? Lv1 : Lv2;
+    bool done = false;
+    for (int k = 0; k < hh.n && !done; k++) {
+      const uint32_t h = hh.at(k);
+      done = rescue_candidates(T, F, 0, half, T.kw_base[cls] + (h >> 16), L, frame_start((int)(h & 0xFFFFu), L), 0, vdat, C);
+    }
+    if (!done) {
+      C.add(half == 1 ? DCRX_C_FOUNDV1NOTV2 : DCRX_C_FOUNDV2NOTV1);                 // :334 / :389
+      return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : DCRX_S_V_HALF2_EXHAUSTED;
+    }
+  }
+  const int end_of_v = vdat.pos + 1;                                               // :547
+
+  // ---- janalysis ----
+  int jstatus = DCRX_S_OK;
+  const int jcount = jmulti ? 2 : hjf.n;
+  if (jcount > 1) { C.add(DCRX_C_MULTIPLE_J_MATCHES); jstatus = DCRX_S_J_MULTI; }  // :402-404
+  else if (jcount == 1) {
+    const uint32_t h = hjf.at(0);
+    const int j = (int)T.kw_first[T.kw_base[K_JFULL] + (h >> 16)];                 // j_seqs.index(tag) :406
+    const int jp = frame_start((int)(h & 0xFFFFu), Ljf);
+    const int Lj = (int)GJ.tag_len[j];
+    const int ts = jp - GJ.jump[j];                                                // :407-409
+    int start_j, dels;
+    if (get_j_deletions(GJ, F, j, ts, end_of_v, start_j, dels, C)) jdat = XDat{j, start_j, dels, jp + Lj};  // :411-418
+    else jstatus = DCRX_S_J_WALK_FAIL;
+  } else {
+    const int half = hj1.n ? 1 : 2;
+    const Hits2 hh{hj1.n ? hj1.a : hj2.a, hj1.n ? hj1.b : hj2.b, hj1.n ? hj1.c : hj2.c, hj1.n ? hj1.d : hj2.d, hj1.n ? hj1.n : hj2.n};
+    if (hh.n == 0) { C.add(DCRX_C_NO_J_ASSIGNED); jstatus = DCRX_S_J_NONE; }       // :530-531
+    else {
+      const int cls = half == 1 ? K_JH1 : K_JH2, L = half == 1 ? Lj1 : Lj2;
+      bool done = false;
+      for (int k = 0; k < hh.n && !done; k++) {
+        const uint32_t h = hh.at(k);
+        done = rescue_candidates(T, F, 1, half, T.kw_base[cls] + (h >> 16), L, frame_start((int)(h & 0xFFFFu), L), end_of_v, jdat, C);
+      }
+      if (!done) {
+        C.add(half == 1 ? DCRX_C_FOUNDJ1NOTJ2 : DCRX_C_FOUNDV2NOTV1);               // :469 / :526 (the reference bumps the V key)
+        jstatus = half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : DCRX_S_J_HALF2_EXHAUSTED;
+      }
+    }
+  }
+  if (jstatus != DCRX_S_OK) { C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); return jstatus; }  // :583-585
+  return dcr_filters(T, F, vdat, jdat, cfg, C, rec);
+}
+
+// One read from its events to its record, the read's words loaded into registers once (NW words;
+// typed global loads on the device).  false: the read goes to the three-launch form (see dcr_frame3).  [x0, x1): the read's slice of the exception list (x0 == x1: a clean read).
+template <bool UNIFORM_LEN, int NW>
+DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
+                            const uint32_t (&w)[NW], const uint32_t (&ev)[3], const bool jmulti, const int x0, const int x1,
+                            const Counters &C, dcrx_record_t *records);
+
+// the first NW packed words of read r into registers: typed global loads on the device, two words
+// per load (reads start on 8-byte boundaries: stride is a multiple of 8).  Lanes of a wave hold
+// scattered reads, so every load instruction visits about as many cache lines as there are lanes:
+// few, wide loads.
+template <int NW>
+DCRX_DEV void load_words(const BatchDev &B, const uint64_t r, uint32_t (&w)[NW]) {
+  const uint32_t nw = B.stride >> 2;
+#ifndef DCRX_HOST_EMUL
+  typedef uint32_t dcrx_v2u __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(1))) dcrx_v2u *gw =
+      reinterpret_cast<const __attribute__((address_space(1))) dcrx_v2u *>(reinterpret_cast<uintptr_t>(B.packed + r * B.stride));
+#pragma unroll
+  for (int k = 0; k < NW / 2; k++) {
+    dcrx_v2u t = {0u, 0u};
+    if ((uint32_t)(2 * k) < nw) t = gw[k];
+    w[2 * k] = t.x; w[2 * k + 1] = t.y;
+  }
+#else
+  const dcrx_gwords gw = dcrx_gwords_of(B.packed + r * B.stride);
+#pragma unroll
+  for (int k = 0; k < NW; k++) w[k] = (uint32_t)k < nw ? gw[k] : 0u;
+#endif
+}
+
+template <bool UNIFORM_LEN, int NW>
+DCRX_DEV bool finish2_reg(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
+                          const uint32_t (&ev)[3], const bool jmulti, const int x0, const int x1, const Counters &C,
+                          dcrx_record_t *records) {
+  uint32_t w[NW];
+  load_words<NW>(B, r, w);
+  return finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, r, w, ev, jmulti, x0, x1, C, records);
+}
+
+template <bool UNIFORM_LEN, int NW>
+DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
+                            const uint32_t (&w)[NW], const uint32_t (&ev)[3], const bool jmulti, const int x0, const int x1,
+                            const Counters &C, dcrx_record_t *records) {
+  const uint32_t nw = B.stride >> 2;
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = nullptr;
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = x0; rv.e1 = x1;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  int status, frame;
+  if (cfg.orientation == DCRX_ORIENT_FORWARD) {
+    status = dcr_frame3(T, V, FrameReg<false, NW>(w, rv), (int)nw, ev, jmulti, cfg, C, rec); frame = 1;
+  } else {
+    status = dcr_frame3(T, V, FrameReg<true, NW>(w, rv), (int)nw, ev, jmulti, cfg, C, rec); frame = 0;
+  }
+  if (status == DCRX_S_DEFER) return false;                           // to the three-launch form; nothing counted, nothing written
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+  return true;
+}
+
+// ------------------------------------------------------------------------------
+// The lean tail: a read with exactly one V-tag pair whose J side is one J-tag pair, several,
+// or none, finished in straight-line code — two rounds of loads (the two tag windows, then the
+// two walk windows), keyword look-up by window comparison, the bit-parallel germline walks of
+// get_v_deletions / get_j_deletions, the filters.  Whatever does not fit that mould (a window
+// that leaves the read, a walk the 32-base form does not settle, two tags inside one pair, ...)
+// returns TAIL2_SLOW and takes the general form (dcr_frame3) from the event stack.
+// ------------------------------------------------------------------------------
+struct Tail2Tabs {       // where the lean tail finds its tables (frame in use); index 0 = V, 1 = J
+  dcrx_ldsaddr bk_start[2], bk_tag[2], bk_pk[2];   // full-tag buckets: starts (uint16[V2_NB + 1]), first tag per slot (uint16), packed keyword per slot (uint64)
+  dcrx_ldsaddr jump[2];                            // int32 per tag
+  dcrx_ldsaddr w64[2];                             // uint64 per tag: the walk window as the stored read shows it in this frame
+  dcrx_ldsaddr w64_ok[2];                          // uint8 per tag
+  uint32_t L[2];                                   // tag length of the class
+};
+
+// `side` / `bk`: where the side tables (image[dfa_bytes ..)) and the frame's bucket image were staged
+DCRX_DEV Tail2Tabs tail2_tabs(const DevTables &T0, const V2Ori &V0, const uint8_t *side, const uint8_t *bk, const bool rev) {
+  Tail2Tabs t;
+  auto at_side = [&](const void *p) { return dcrx_ldsaddr_of(side + ((reinterpret_cast<const uint8_t *>(p) - T0.image) - T0.dfa_bytes)); };
+  for (int g = 0; g < 2; g++) {
+    const int cls = g == 0 ? K_VFULL : K_JFULL;
+    t.bk_start[g] = dcrx_ldsaddr_of(bk + V0.bk_start_off[cls]);
+    t.bk_tag[g] = dcrx_ldsaddr_of(bk + V0.bk_tag_off[cls]);
+    t.bk_pk[g] = dcrx_ldsaddr_of(bk + V0.bk_pk_off[cls]);
+    t.jump[g] = at_side(T0.g[g].jump);
+    t.w64[g] = at_side(rev ? T0.g[g].w64_rc : T0.g[g].w64_fwd);
+    t.w64_ok[g] = at_side(T0.g[g].w64_ok);
+    t.L[g] = T0.kw_len[cls];
+  }
+  return t;
+}
+
+constexpr int TAIL2_SLOW = -1;
+
+// 32 bases of the stored read from base s; caller guarantees 0 <= s and s + 32 <= n
+DCRX_DEV uint64_t tail2_load64(const dcrx_gwords words, const int s) {
+  const int i = s >> 4, sh = (s & 15) * 2;
+  const uint32_t w0 = words[i], w1 = words[i + 1];
+  const uint32_t w2 = sh ? words[i + 2] : 0u;
+  return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+}
+
+// first tag holding the full-tag keyword whose packed form is `val`, or -1
+DCRX_DEV int tail2_lookup(const Tail2Tabs &tt, const int g, const uint64_t val) {
+  const uint32_t h = v2_hash(val);
+  const uint32_t a = dcrx_lds_at<uint16_t>(tt.bk_start[g], h), b = dcrx_lds_at<uint16_t>(tt.bk_start[g], h + 1);
+  int tag = -1;
+  for (uint32_t i = a; i < b; i++)
+    if (dcrx_lds_at<uint64_t>(tt.bk_pk[g], i) == val) tag = (int)dcrx_lds_at<uint16_t>(tt.bk_tag[g], i);
+  return tag;
+}
+
+// 32 bases of a read held in registers (NW words) from stored base s >= 0: one select chain per
+// word, the three chains share their compares
+template <int NW>
+DCRX_DEV uint64_t reg_stored64(const uint32_t (&w)[NW], const int s) {
+  const int i = s >> 4, sh = (s & 15) * 2;
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    const bool at = i == k;
+    w0 = at ? w[k] : w0;
+    if (k + 1 < NW) w1 = at ? w[k + 1] : w1;
+    if (k + 2 < NW) w2 = at ? w[k + 2] : w2;
+  }
+  return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+}
+
+// One tail entry (`digest`: tail2_pack) on a read whose words sit in registers (the finishing
+// kernel loads them one batch ahead: nothing here waits for global memory).  Returns the read's
+// status with `rec` filled (status and frame left to the caller), or TAIL2_SLOW with nothing
+// decided.  No counter is touched here: the caller tallies by status (each status of this form
+// implies its counters).
+template <bool REV, int NW>
+DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const uint32_t (&w)[NW], const int n, const uint32_t digest, const CfgDev &cfg,
+                        dcrx_record_t &rec) {
+  const int vpair = (int)(digest & 0xFFu), jpair = (int)((digest >> 8) & 0xFFu), jc = (int)((digest >> 16) & 3u);
+  const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
+  if (n < 32 || Lv > 31 || Lj > 31) return TAIL2_SLOW;
+  // ---- the windows that hold the tags (both candidate ends of a pair share one window) ----
+  const int sva = 2 * vpair - Lv + 1;                      // the V tag starts here (ends at the pair's first base) or one base on
+  const int wsv = min(max(sva, 0), n - 32);
+  const uint64_t Wv = reg_stored64<NW>(w, wsv);
+  const int sja = 2 * jpair - Lj + 1;
+  const int wsj = min(max(sja, 0), n - 32);
+  const uint64_t Wj = reg_stored64<NW>(w, wsj);
+  const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
+  int v = -1, sv = 0;
+  {
+    const bool oka = sva >= 0, okb = sva + 1 + Lv <= n;
+    const int ta = oka ? tail2_lookup(tt, 0, (Wv >> (2 * (sva - wsv))) & mv) : -1;
+    const int tb = okb ? tail2_lookup(tt, 0, (Wv >> (2 * (sva + 1 - wsv))) & mv) : -1;
+    if ((ta >= 0) == (tb >= 0)) return TAIL2_SLOW;        // none (cannot be) or two V tags inside the pair
+    v = ta >= 0 ? ta : tb; sv = ta >= 0 ? sva : sva + 1;
+  }
+  int j = -1, sj = 0;
+  if (jc == 1) {
+    const bool oka = sja >= 0, okb = sja + 1 + Lj <= n;
+    const int ta = oka ? tail2_lookup(tt, 1, (Wj >> (2 * (sja - wsj))) & mj) : -1;
+    const int tb = okb ? tail2_lookup(tt, 1, (Wj >> (2 * (sja + 1 - wsj))) & mj) : -1;
+    if ((ta >= 0) == (tb >= 0)) return TAIL2_SLOW;
+    j = ta >= 0 ? ta : tb; sj = ta >= 0 ? sja : sja + 1;
+  }
+  // ---- the walk windows ----
+  const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
+  const int vp = REV ? n - sv - Lv : sv;                   // where the tag starts in the frame (hold_v[0][1])
+  const int te = vp + jumpv - 1;                           // decombine.py:283-285
+  const int fv = te + 1;
+  if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return TAIL2_SLOW;
+  const uint64_t rwv = reg_stored64<NW>(w, REV ? n - fv : fv - 32);
+  int jumpj = 0, jp = 0, ts = 0;
+  uint64_t rwj = 0;
+  if (jc == 1) {
+    jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
+    jp = REV ? n - sj - Lj : sj;
+    ts = jp - jumpj;                                       // :407-409
+    if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return TAIL2_SLOW;
+    rwj = reg_stored64<NW>(w, REV ? n - ts - 32 : ts);
+  }
+  // get_v_deletions (:749-785), the 32-base form
+  const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
+  const int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  if (kv < 0) return TAIL2_SLOW;
+  const int end_v = te - kv;
+  if (jc == 0) return DCRX_S_J_NONE;                       // :530-531 (no J tag, no J half tag)
+  if (jc == 2) return DCRX_S_J_MULTI;                      // :402-404
+  // get_j_deletions (:788-817), the 32-base form
+  const int end_of_v = end_v + 1;                          // :547
+  const int k0 = end_of_v > ts ? end_of_v - ts : 0;
+  const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
+  const int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  if (kj < 0) return TAIL2_SLOW;
+  const int start_j = ts + kj, jend = jp + Lj;
+  // filters :553-569 (a clean read holds no N)
+  if ((vp - jend) >= cfg.lenthreshold) return DCRX_S_F_TOOLONG;
+  if (kv > jumpv - Lv || kj > jumpj) return DCRX_S_F_IMPOSS_DEL;
+  if (vp + Lv > jend + Lj) return DCRX_S_F_OVERLAP;
+  int lo, hi;
+  pyslice(n, end_v + 1, start_j, lo, hi);                  // read[vdat[1]+1 : jdat[1]] :577
+  rec.v = (uint16_t)v; rec.j = (uint16_t)j;
+  rec.v_start = (uint16_t)vp; rec.j_end = (uint16_t)jend;
+  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
+  rec.vdel = (uint8_t)kv; rec.jdel = (uint8_t)kj;
+  return DCRX_S_OK;
+}
+
+// the counters a status of the lean tail stands for (besides read_count)
+DCRX_DEV void tail2_count(const Counters &C, const int status, const bool forward) {
+  C.add(DCRX_C_READ_COUNT);
+  if (status == DCRX_S_OK) { C.add(DCRX_C_VJ_COUNT); if (forward) C.add(DCRX_C_FRAME_FORWARD); return; }
+  if (status == DCRX_S_J_NONE) { C.add(DCRX_C_NO_J_ASSIGNED); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); }
+  else if (status == DCRX_S_J_MULTI) { C.add(DCRX_C_MULTIPLE_J_MATCHES); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); }
+  else if (status == DCRX_S_F_TOOLONG) C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG);
+  else if (status == DCRX_S_F_IMPOSS_DEL) C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION);
+  else if (status == DCRX_S_F_OVERLAP) C.add(DCRX_C_DCRFILTER_TAG_OVERLAP);
+}
+
+}  // namespace dcrx

@@ -116,6 +116,11 @@ typedef struct dcrx_cfg {
 #define DCRX_F_PROFILE_LIST_SCAN_ONLY 8u /* profiling: list kernel stops after its collecting scan (records are NOT results) */
 #define DCRX_F_PROFILE_RESCUE_HITS_ONLY 32u /* profiling: rescue kernel stops after resolving the half-tag hit lists (records are NOT results) */
 #define DCRX_F_LIST_RESCUE 16u       /* rescue queue through the list kernel (one-base collecting scan) even when the pair form applies (A/B, tests) */
+#define DCRX_F_PROFILE_NO_FINISH 128u /* profiling: the v2 kernel scans and sorts reads onto its stacks but finishes none of them (records are NOT results) */
+#define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
+#define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
+#define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
+#define DCRX_F_V2_SHAPE(k) ((uint32_t)(k) << 8) /* v2 kernel launch shape, A/B: 0 default, 2 = two reads per lane, 3 = one read per lane (one 1024-thread block per CU either way) */
 #define DCRX_F_ONE_BASE_SCAN 4u      /* use the one-base-per-step fast kernel even when the two-base table fits LDS (A/B, tests) */
 
 /* A batch of reads, 2-bit packed: base i of read r is bits [2(i%4), 2(i%4)+1] of

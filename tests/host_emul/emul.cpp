@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../decombinator_amd/csrc/dcrx_dcr_device.h"
+#include "../../decombinator_amd/csrc/dcrx_v2_device.h"
 #include "../../decombinator_amd/csrc/dcrx_tables.h"
 
 using namespace dcrx;
@@ -45,6 +46,68 @@ static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B,
   else decombine_general16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, e0, nw, CC, records, slot);
 }
 
+static uint64_t g_v2_lean = 0;    // ... of them settled by the lean tail
+extern "C" uint64_t emul_v2_lean(void) { const uint64_t v = g_v2_lean; g_v2_lean = 0; return v; }
+static uint64_t g_v2_reads = 0;   // reads that took the v2 form since the last emul_v2_reads() call
+extern "C" uint64_t emul_v2_reads(void) { const uint64_t v = g_v2_reads; g_v2_reads = 0; return v; }
+
+// What one lane of the v2 kernel does with a clean read: scan, digest, classification, and the
+// finishing of tail / event entries (the kernel batches those in stacks; here they run at once).
+// Returns FAST_TO_RESCUE for a read with more flagged pairs than an event entry holds.
+// [x0, x1): the read's slice of the exception list (x0 == x1: a clean read).  A read with exception bytes the v2 kernels
+// hand over returns FAST_TO_GENERAL.
+template <bool UNIFORM, int NW>
+static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, int x0, int x1, const Counters &CC,
+                  dcrx_record_t *records) {
+  const bool exc = x1 > x0;
+  const int o = C.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  const V2Ori &V = T.v2[o];
+  const V2Tab tab{V.trans};
+  g_v2_reads++;
+  const uint32_t nw = B.stride >> 2;
+  uint32_t w[1][NW], lg[1][NW];
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  for (int k = 0; k < NW; k++) w[0][k] = (uint32_t)k < nw ? words[k] : 0u;
+  const int n = UNIFORM ? (int)B.read_len : (int)B.lens[r];
+  const int npairs = UNIFORM ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
+  if (V.narrow) scan2<NW, 1, true>(tab, w, lg, npairs); else scan2<NW, 1, false>(tab, w, lg, npairs);
+  if (!UNIFORM) mask_log2<NW>(lg[0], n);
+  const Digest2 d = digest2<NW>(lg[0]);
+  const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg[0], n >> 1) : 0u;
+  int what = classify2(d, bnd);
+  if (exc && what != V2_VNONE) what = V2_EVENTS;
+  if (what == V2_VNONE || what == V2_VMULTI) {
+    dcrx_record_t rec;
+    std::memset(&rec, 0, sizeof rec);
+    rec.status = (uint8_t)(what == V2_VNONE ? DCRX_S_V_NONE : DCRX_S_V_MULTI);
+    rec.frame = (uint8_t)(o == 0 ? 1 : 0);
+    records[r] = rec;
+    CC.add(what == V2_VNONE ? DCRX_C_NO_VTAGS_FOUND : DCRX_C_MULTIPLE_V_MATCHES);
+    CC.add(DCRX_C_READ_COUNT);
+    return FAST_DONE;
+  }
+  uint32_t ev[3];
+  bool jmulti = false;
+  if (what == V2_TAIL) {
+    // the lean tail first; what it does not settle takes the general form from the same entry
+    const Tail2Tabs tt = tail2_tabs(T, V, T.image + T.dfa_bytes, V.bk, o == 1);
+    dcrx_record_t rec;
+    std::memset(&rec, 0, sizeof rec);
+    const int st = o ? tail2_fast<true, NW>(tt, w[0], n, tail2_pack(d), C, rec) : tail2_fast<false, NW>(tt, w[0], n, tail2_pack(d), C, rec);
+    if (st != TAIL2_SLOW) {
+      rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
+      records[r] = rec;
+      tail2_count(CC, st, o == 0);
+      g_v2_lean++;
+      return FAST_DONE;
+    }
+    tail2_events(tail2_pack(d), ev, jmulti);
+    return finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, jmulti, 0, 0, CC, records) ? FAST_DONE : FAST_TO_RESCUE;
+  }
+  if (!events2<NW>(lg[0], d, exc ? 0xFu : bnd, ev)) return exc ? FAST_TO_GENERAL : FAST_TO_RESCUE;
+  return finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, false, x0, x1, CC, records) ? FAST_DONE : (exc ? FAST_TO_GENERAL : FAST_TO_RESCUE);
+}
+
 extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, const dcrx_batch_t *b,
                               dcrx_record_t *records, uint64_t *counters, char *err, int err_cap) {
   HostTables H;
@@ -75,20 +138,31 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
     const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
+    // the launch's choice of kernels (dcrx_kernels.hip, v2_applies)
+    const bool v2 = T.v2_ok && !all_general &&
+                    !(C.flags & (DCRX_F_V1_KERNELS | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY |
+                                 DCRX_F_PROFILE_RESCUE_HITS_ONLY));
+    // the v2 kernels take every read of the batch, those with exception bytes included (with their slice of the list)
+    int x0 = 0, x1 = 0;
+    if (v2 && general) {
+      while ((uint64_t)x0 < B.n_exc && B.exc_read[x0] < (uint32_t)r) x0++;
+      x1 = x0;
+      while ((uint64_t)x1 < B.n_exc && B.exc_read[x1] == (uint32_t)r) x1++;
+    }
     if (b->lens) {
-      if (general) general_one<false>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
-      else {
-        const int what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) rescue_one<false>(pair_rescue, T, B, C, r, nw, CC, records, slot);
-        else if (what != FAST_DONE) return -100;
-      }
+      int what = FAST_TO_GENERAL;
+      if (v2) what = B.stride <= 40 ? v2_one<false, 10>(T, B, C, r, x0, x1, CC, records) : v2_one<false, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records);
+      else if (!general) what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
+      if (what == FAST_TO_GENERAL) general_one<false>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
+      else if (what == FAST_TO_RESCUE) rescue_one<false>(pair_rescue, T, B, C, r, nw, CC, records, slot);
+      else if (what != FAST_DONE) return -100;
     } else {
-      if (general) general_one<true>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
-      else {
-        const int what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
-        if (what == FAST_TO_RESCUE) rescue_one<true>(pair_rescue, T, B, C, r, nw, CC, records, slot);
-        else if (what != FAST_DONE) return -100;
-      }
+      int what = FAST_TO_GENERAL;
+      if (v2) what = B.stride <= 40 ? v2_one<true, 10>(T, B, C, r, x0, x1, CC, records) : v2_one<true, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records);
+      else if (!general) what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
+      if (what == FAST_TO_GENERAL) general_one<true>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
+      else if (what == FAST_TO_RESCUE) rescue_one<true>(pair_rescue, T, B, C, r, nw, CC, records, slot);
+      else if (what != FAST_DONE) return -100;
     }
     for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
   }
