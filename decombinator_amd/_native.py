@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libdcrx.so")
 
 N_COUNTERS = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum dcrx_counter order; the strings are the reference's Counter keys
 # (reference decombine.py:598 and the increments cited in include/dcrx_codes.h)
@@ -80,6 +80,7 @@ class TablesInfoC(C.Structure):
         ("n_v", C.c_uint32), ("n_j", C.c_uint32), ("n_states", C.c_uint32), ("dfa_bytes", C.c_uint32),
         ("n_keywords", C.c_uint32 * 6), ("max_tag_len", C.c_uint32), ("tables_in_lds", C.c_uint32),
         ("equal_len_per_automaton", C.c_uint32), ("pair_scan_bytes", C.c_uint32),
+        ("v2_tables", C.c_uint32), ("v2_states", C.c_uint32 * 2), ("v2_scan_bytes", C.c_uint32 * 2), ("max_read_len", C.c_uint32),
     ]
 
 
@@ -117,7 +118,7 @@ class SynthCfgC(C.Structure):
 EXPORTS = [
     "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
     "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
-    "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
+    "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_set_step_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
     "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
@@ -157,6 +158,7 @@ def lib():
         "dcrx_decombine": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp]),
         "dcrx_decombine_device": (i32, [vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp, vp]),
         "dcrx_set_timing_events": (i32, [vp, vp, vp]),
+        "dcrx_set_step_events": (i32, [vp, vp, vp]),
         "dcrx_reserve_device": (i32, [vp, u64]),
         "dcrx_compact_hits_device": (i32, [vp, u64, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_bitmap_device": (i32, [vp, u64, vp, vp, vp, vp]),
@@ -237,7 +239,9 @@ class Tables:
         return {"n_v": inf.n_v, "n_j": inf.n_j, "n_states": inf.n_states, "dfa_bytes": inf.dfa_bytes,
                 "n_keywords": list(inf.n_keywords), "max_tag_len": inf.max_tag_len,
                 "tables_in_lds": bool(inf.tables_in_lds),
-                "equal_len_per_automaton": bool(inf.equal_len_per_automaton), "pair_scan_bytes": inf.pair_scan_bytes}
+                "equal_len_per_automaton": bool(inf.equal_len_per_automaton), "pair_scan_bytes": inf.pair_scan_bytes,
+                "v2_tables": bool(inf.v2_tables), "v2_states": list(inf.v2_states), "v2_scan_bytes": max(inf.v2_scan_bytes),
+                "max_read_len": inf.max_read_len}
 
     def close(self):
         if self._h is not None:

@@ -64,7 +64,8 @@ struct dcrx_tables {
   uint8_t *d_stage = nullptr;
   size_t stage_bytes = 0;
   bool constants_ready = false;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // around the dominant kernel
+  hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;  // around every launch of a call
 };
 
 static void free_device_state(dcrx_tables *t) {
@@ -120,6 +121,9 @@ int dcrx_tables_info(const dcrx_tables_t *t, dcrx_tables_info_t *info) {
   info->tables_in_lds = t->host.rel.lds_image_bytes + 128 <= 120 * 1024;
   info->equal_len_per_automaton = t->host.equal_len_per_automaton ? 1 : 0;
   info->pair_scan_bytes = t->host.rel.dfa16_bytes;
+  info->v2_tables = t->host.rel.v2_ok;
+  for (int o = 0; o < 2; o++) { info->v2_states[o] = t->host.rel.v2[o].n_states; info->v2_scan_bytes[o] = t->host.rel.v2[o].trans_bytes; }
+  info->max_read_len = DCRX_MAX_READ_LEN;
   return DCRX_OK;
 }
 
@@ -162,7 +166,7 @@ int dcrx_event_elapsed_ms(void *a, void *b, float *ms) {
 }  // extern "C"
 
 // ---- per-device state -------------------------------------------------------------
-static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 40) {
+static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 40, hipStream_t stream = nullptr) {
   int dev = -1;
   HIP_TRY(hipGetDevice(&dev));
   if (t->device != dev) {
@@ -221,8 +225,9 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
   if (t->ws_dirty) {
     // the kernels leave the work counters and the exception bitmap zeroed; they are zeroed here
     // only once per allocation, or after a launch that failed part-way
-    HIP_TRY(hipMemset(t->d_exc_flag, 0, ((t->exc_flag_reads + 31) / 32) * 4 + 16));
-    HIP_TRY(hipMemset(t->d_queue, 0, DCRX_QUEUE_HEADER * 4));
+    // on the stream the kernels will run on (a non-blocking stream does not order against the null stream)
+    HIP_TRY(hipMemsetAsync(t->d_exc_flag, 0, ((t->exc_flag_reads + 31) / 32) * 4 + 16, stream));
+    HIP_TRY(hipMemsetAsync(t->d_queue, 0, DCRX_QUEUE_HEADER * 4, stream));
     t->ws_dirty = false;
   }
   if (max_reads > t->compact_reads) {
@@ -255,6 +260,12 @@ int dcrx_set_timing_events(dcrx_tables_t *t, void *start_event, void *stop_event
   return DCRX_OK;
 }
 
+int dcrx_set_step_events(dcrx_tables_t *t, void *start_event, void *stop_event) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  t->ev_step_start = (hipEvent_t)start_event; t->ev_step_stop = (hipEvent_t)stop_event;
+  return DCRX_OK;
+}
+
 int dcrx_reserve_device(dcrx_tables_t *t, uint64_t max_reads) {
   if (!t) return set_err(DCRX_E_INVALID, "tables is null");
   return ensure_device(t, max_reads);
@@ -267,17 +278,19 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   if (rc) return rc;
   if (b->n_reads && !d_records) return set_err(DCRX_E_INVALID, "d_records is null");
   if (cfg->orientation < 0 || cfg->orientation > 2) return set_err(DCRX_E_INVALID, "orientation must be 0, 1 or 2");
-  rc = ensure_device(t, b->n_reads, b->stride);
+  rc = ensure_device(t, b->n_reads, b->stride, (hipStream_t)stream);
   if (rc) return rc;
   BatchDev B;
   B.packed = b->packed; B.stride = b->stride; B.read_len = b->read_len; B.lens = b->lens;
   B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
+  if (t->ev_step_start) HIP_TRY(hipEventRecord(t->ev_step_start, (hipStream_t)stream));
   const hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
                                          t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
                                          (hipStream_t)stream, t->ev_start, t->ev_stop);
   if (le != hipSuccess) { t->ws_dirty = true; return hip_err(le, "launch_decombine"); }
+  if (t->ev_step_stop) HIP_TRY(hipEventRecord(t->ev_step_stop, (hipStream_t)stream));
   return DCRX_OK;
 }
 

@@ -46,8 +46,9 @@ constexpr int DCRX_V2_FBLOCK = 256;
 // An entry carries the read's packed words (the scan kernel has them in registers), so that the
 // finishing kernels never gather from the read array: their loads are the entries, structure of
 // arrays inside a region (row k of slot i at rows[k * cap + i], 16 bytes each), one lane one slot,
-// fully coalesced.  Tail entry: read, digest (tail2_pack), words; event entry: read | flags, three
-// dwords of events, words.
+// fully coalesced.  Tail entry: read, digest (tail2_pack), words; event entry: read | flags, the
+// read's flag log, words (the event list is drawn from the log by the event kernel, where every
+// lane has one to draw).
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
   uint4 *events;      // [regions][rows_e][ecap]
@@ -56,7 +57,7 @@ struct V2Lists {
 };
 template <int NW>
 struct V2Rows {
-  static constexpr int T = (2 + NW + 3) / 4, E = (4 + NW + 3) / 4;
+  static constexpr int T = (2 + NW + 3) / 4, E = (1 + 2 * NW + 3) / 4;
 };
 // dwords x[0 .. N) of slot `at` into the rows of a region (cap slots per row)
 template <int N>
@@ -224,26 +225,19 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         tn = min(tn + (uint32_t)__popcll(mt0), Q.tcap);
       }
       bool to_ev = what == V2_EVENTS;
-      if (__ballot(to_ev)) {
-        uint32_t ev[3] = {0u, 0u, 0u};
-        bool fits = true;
-        if (to_ev) fits = events2<NW>(lg[q], d, exc ? 0xFu : bnd, ev);     // a read with exception bytes keeps every flag (none is certain)
-        if (to_ev && !fits) {      // more flagged pairs than an entry holds: the three-launch form
-          v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
-          to_ev = false;
-        }
-        const unsigned long long me0 = __ballot(to_ev);
+      const unsigned long long me0 = __ballot(to_ev);
+      if (me0) {
         const uint32_t at = en + (uint32_t)__popcll(me0 & lt_mask);
         if (to_ev && at >= Q.ecap) {                 // a full region (its last lanes): the three-launch form
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
           to_ev = false;
         }
         if (to_ev) {
-          uint32_t x[4 + NW];
-          x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u); x[1] = ev[0]; x[2] = ev[1]; x[3] = ev[2];
+          uint32_t x[1 + 2 * NW];
+          x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
 #pragma unroll
-          for (int k = 0; k < NW; k++) x[4 + k] = w[q][k];
-          v2_put_rows<4 + NW>(eq, Q.ecap, at, x);
+          for (int k = 0; k < NW; k++) { x[1 + k] = lg[q][k]; x[1 + NW + k] = w[q][k]; }
+          v2_put_rows<1 + 2 * NW>(eq, Q.ecap, at, x);
         }
         en = min(en + (uint32_t)__popcll(me0), Q.ecap);
       }
@@ -325,15 +319,18 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 8) void tail2_kernel(
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == TAIL2_SLOW) {
-          uint32_t ev[3];
-          bool jmulti;
-          tail2_events(dg, ev, jmulti);
           if (at < Q.ecap) {
-            uint32_t y[4 + NW];
-            y[0] = r | (jmulti ? V2_R_JMULTI : 0u); y[1] = ev[0]; y[2] = ev[1]; y[3] = ev[2];
+            // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
+            const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
+            uint32_t y[1 + 2 * NW];
+            y[0] = r | (jc == 2u ? V2_R_JMULTI : 0u);
 #pragma unroll
-            for (int k = 0; k < NW; k++) y[4 + k] = w[k];
-            v2_put_rows<4 + NW>(eq, Q.ecap, at, y);
+            for (int k = 0; k < NW; k++) {
+              uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
+              if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
+              y[1 + k] = l; y[1 + NW + k] = w[k];
+            }
+            v2_put_rows<1 + 2 * NW>(eq, Q.ecap, at, y);
           } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
         }
       }
@@ -373,30 +370,36 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
     const uint32_t en = min(Q.counts[2 * region + 1], Q.ecap);      // (the tail kernel's appends may have run past the region's end)
     const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
-    uint32_t x1[4 + NW];
-    v2_get_rows<4 + NW>(eq, Q.ecap, lane, (uint32_t)lane < en, x1);
+    uint32_t x1[1 + 2 * NW];
+    v2_get_rows<1 + 2 * NW>(eq, Q.ecap, lane, (uint32_t)lane < en, x1);
     for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
-      uint32_t x[4 + NW];
+      uint32_t x[1 + 2 * NW];
 #pragma unroll
-      for (int k = 0; k < 4 + NW; k++) x[k] = x1[k];
-      v2_get_rows<4 + NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);        // the next batch, in flight during this one
-      uint32_t w[NW];
+      for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
+      v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);        // the next batch, in flight during this one
+      uint32_t lg[NW], w[NW];
 #pragma unroll
-      for (int k = 0; k < NW; k++) w[k] = x[4 + k];
-      const uint4 e = make_uint4(x[0], x[1], x[2], x[3]);
+      for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
       if (first + lane < en) {
-        const uint32_t r = e.x & V2_R_MASK;
-        const uint32_t ev[3] = {e.y, e.z, e.w};
-        int x0 = 0, x1 = 0;
-        const bool exc = (e.x & V2_R_EXC) != 0u;
+        const uint32_t r = x[0] & V2_R_MASK;
+        const bool exc = (x[0] & V2_R_EXC) != 0u;
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        // the read's event list, from its flag log (a read with exception bytes keeps every flag: none is certain)
+        const Digest2 d = digest2<NW>(lg);
+        const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg, n >> 1) : 0u;
+        uint32_t ev[3];
+        const bool fits = events2<NW>(lg, d, exc ? 0xFu : bnd, ev);
+        const uint4 e = make_uint4(x[0], ev[0], ev[1], ev[2]);
+        if (!fits) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc); continue; }   // more flagged pairs than a list holds: the three-launch form
+        int x0 = 0, x1e = 0;
         if (exc) {                      // the read's slice of the (sorted) exception list
           uint64_t lo = 0, hi = B.n_exc;
           while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
           x0 = (int)lo;
           while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
-          x1 = (int)lo;
+          x1e = (int)lo;
         }
-        if (finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1, C, records)) {
+        if (finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1e, C, records)) {
           if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
         } else {
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
@@ -416,8 +419,7 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // reader and orientation `both` keep that form.
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
   if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events) return false;
-  if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY |
-                   DCRX_F_PROFILE_RESCUE_HITS_ONLY)) return false;
+  if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) <= 64u * 1024u;
 }
@@ -478,7 +480,7 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   const bool uniform = B.lens == nullptr, nw10 = B.stride <= 40, narrow = T.v2[o].narrow != 0;
   int shape = (int)((cfg.flags >> 8) & 3u);
-  if (shape == 0) shape = 2;      // two reads per lane (two independent chains per wave): measured faster than one
+  if (shape == 0) shape = nw10 ? 2 : 3;      // two reads per lane (two independent chains per wave) where the registers allow: measured faster than one
 #define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : DCRX_V2A(UN, NW_, 2, NA))
   if (nw10) {

@@ -405,31 +405,70 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
   const int Lvf = (int)T.kw_len[K_VFULL], Ljf = (int)T.kw_len[K_JFULL], Lv1 = (int)T.kw_len[K_VH1], Lv2 = (int)T.kw_len[K_VH2],
             Lj1 = (int)T.kw_len[K_JH1], Lj2 = (int)T.kw_len[K_JH2];
   Hits2 hvf{0, 0, 0, 0, 0}, hjf{0, 0, 0, 0, 0}, hv1{0, 0, 0, 0, 0}, hv2{0, 0, 0, 0, 0}, hj1{0, 0, 0, 0, 0}, hj2{0, 0, 0, 0, 0};
-  // ---- stage 1: the sweep ----
-  for (int x = 0; x < ne; x++) {
-    const int i = REV ? ne - 1 - x : x;
-    const uint32_t e = E.get(i);
-    const uint32_t fl = e >> 8;
-    const int f1 = 2 * (int)(e & 0xFFu) + 1;                 // the pair's second stored base
-    const int xs = f1 >= 31 ? f1 - 31 : 0;                   // the window: stored bases [xs, xs + 32)
-    const uint64_t X = frame_stored64(F, nwords, xs);
-    for (int y = 0; y < 2; y++) {
-      const int f = REV ? f1 - y : f1 - 1 + y;               // ascending end position in the frame
-      // keyword of class cls (L long) whose occurrence in the stored read ends at base f
-      auto test = [&](const int cls, const int L, Hits2 &h) {
-        const int s = f - L + 1;
-        if (s < 0 || f >= n) return;
-        const int p = REV ? n - s - L : s;
-        if (F.has_exc() && !F.clean(p, p + L)) return;         // an exception byte sends the automata back to their roots
-        const uint64_t mask = L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull);
-        const int kw = v2_lookup(V, cls, (X >> (2 * (s - xs))) & mask);
-        if (kw >= 0) h.add(kw, f);
-      };
-      if (fl & V2_F_VF) test(K_VFULL, Lvf, hvf);
-      if (fl & V2_F_VH) { test(K_VH1, Lv1, hv1); test(K_VH2, Lv2, hv2); }
-      if (fl & V2_F_JF) test(K_JFULL, Ljf, hjf);
-      if (fl & V2_F_JH) { test(K_JH1, Lj1, hj1); test(K_JH2, Lj2, hj2); }
+  // ---- stage 1: the sweep, V flags first, then J flags.  Per flagged pair one window of the stored
+  // read; per base of the pair two look-ups at most: the full tag or (no full-tag flag) the first
+  // half tag — one piece of code, the class picked per lane — and the second half tag. ----
+  auto sweep = [&](const uint32_t f_full, const uint32_t f_half, const int c_full, const int c_h1, const int c_h2, const int Lf,
+                   const int L1, const int L2, Hits2 &hf, Hits2 &h1, Hits2 &h2) {
+    // where the three classes' buckets are (picked per lane below between the full tag's and the first half tag's)
+    const uint32_t so_f = V.bk_start_off[c_full], ko_f = V.bk_kw_off[c_full], po_f = V.bk_pk_off[c_full];
+    const uint32_t so_1 = V.bk_start_off[c_h1], ko_1 = V.bk_kw_off[c_h1], po_1 = V.bk_pk_off[c_h1];
+    const uint32_t so_2 = V.bk_start_off[c_h2], ko_2 = V.bk_kw_off[c_h2], po_2 = V.bk_pk_off[c_h2];
+    auto lookup = [&](const uint32_t so, const uint32_t ko, const uint32_t po, const uint64_t val) {
+      const uint16_t *st = reinterpret_cast<const uint16_t *>(V.bk + so);
+      const uint32_t h = v2_hash(val);
+      const uint32_t a = st[h], b = st[h + 1];
+      int kw = -1;
+      for (uint32_t i = a; i < b; i++)
+        if (reinterpret_cast<const uint64_t *>(V.bk + po)[i] == val) kw = (int)reinterpret_cast<const uint16_t *>(V.bk + ko)[i];
+      return kw;
+    };
+    for (int x = 0; x < ne; x++) {
+      const int i = REV ? ne - 1 - x : x;
+      const uint32_t e = E.get(i);
+      const uint32_t fl = e >> 8;
+      if (!(fl & (f_full | f_half))) continue;
+      const bool full = (fl & f_full) != 0u, half = (fl & f_half) != 0u;
+      const int f1 = 2 * (int)(e & 0xFFu) + 1;               // the pair's second stored base
+      const int xs = f1 >= 31 ? f1 - 31 : 0;                 // the window: stored bases [xs, xs + 32)
+      const uint64_t X = frame_stored64(F, nwords, xs);
+      for (int y = 0; y < 2; y++) {
+        const int f = REV ? f1 - y : f1 - 1 + y;             // ascending end position in the frame
+        // keyword (L long) whose occurrence in the stored read ends at base f: its packed form, or ~0 when it cannot be there
+        auto slice = [&](const int L) -> uint64_t {
+          const int s = f - L + 1;
+          if (s < 0 || f >= n) return ~0ull;
+          const int p = REV ? n - s - L : s;
+          if (F.has_exc() && !F.clean(p, p + L)) return ~0ull;   // an exception byte sends the automata back to their roots
+          const uint64_t mask = L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull);
+          return (X >> (2 * (s - xs))) & mask;
+        };
+        {   // the full tag where the pair carries its flag; else the first half tag
+          const int L = full ? Lf : L1;
+          const uint64_t val = slice(L);
+          const bool can = L >= 32 || val != ~0ull;            // (a 32-base keyword of all T packs to ~0: let it through)
+          const int kw = can ? lookup(full ? so_f : so_1, full ? ko_f : ko_1, full ? po_f : po_1, val) : -1;
+          if (kw >= 0) { if (full) hf.add(kw, f); else h1.add(kw, f); }
+        }
+        if (half) {
+          const uint64_t val = slice(L2);
+          const bool can = L2 >= 32 || val != ~0ull;
+          const int kw = can ? lookup(so_2, ko_2, po_2, val) : -1;
+          if (kw >= 0) h2.add(kw, f);
+          if (full) {                                          // full-tag and half-tag flags on one pair: the first half tag as well
+            const uint64_t v1 = slice(L1);
+            const int k1 = (L1 >= 32 || v1 != ~0ull) ? lookup(so_1, ko_1, po_1, v1) : -1;
+            if (k1 >= 0) h1.add(k1, f);
+          }
+        }
+      }
     }
+  };
+  sweep(V2_F_VF, V2_F_VH, K_VFULL, K_VH1, K_VH2, Lvf, Lv1, Lv2, hvf, hv1, hv2);
+  sweep(V2_F_JF, V2_F_JH, K_JFULL, K_JH1, K_JH2, Ljf, Lj1, Lj2, hjf, hj1, hj2);
+  if (cfg.flags & DCRX_F_PROFILE_RESCUE_HITS_ONLY) {   // profiling aid: price the sweep alone (records are NOT results)
+    rec.v = (uint16_t)(hvf.n + hjf.n + hv1.n + hv2.n + hj1.n + hj2.n); rec.j = (uint16_t)(hvf.a ^ hjf.a ^ hv1.a ^ hv2.a ^ hj1.a ^ hj2.a);
+    return 254;
   }
   // a half-tag list that will be walked and does not fit: nothing has been counted yet
   if ((hvf.n == 0 && (hv1.n > V2_MAX_HITS || (hv1.n == 0 && hv2.n > V2_MAX_HITS))) ||

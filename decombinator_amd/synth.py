@@ -151,6 +151,13 @@ def config_tagset(config: int) -> TagSet:
     raise ValueError(f"no synthetic tag set for config {config}")
 
 
+def config5_tagsets():
+    """Mouse gamma and delta: the two chains of BASELINE config 5 (both take the `original` tag set:
+    the reference rewrites inputargs["tags"] for mouse and for gamma/delta, decombine.py:640-654)."""
+    return (make_tagset("mouse", "original", "g", n_v=12, n_j=4, seed=20260106, n_shared_groups=2),
+            make_tagset("mouse", "original", "d", n_v=16, n_j=2, seed=20260107, n_shared_groups=2))
+
+
 def config3_tagsets():
     return (make_tagset("human", "extended", "a", n_v=104, n_j=61, seed=20260104, n_shared_groups=5),
             make_tagset("human", "extended", "b", n_v=88, n_j=14, seed=20260105, n_shared_groups=4))

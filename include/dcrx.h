@@ -17,7 +17,9 @@
  *   - every function returns 0 on success or a negative dcrx_error; the text of
  *     the last failure on the calling thread is dcrx_last_error();
  *   - nothing throws, aborts or prints;
- *   - a dcrx_tables_t is not thread-safe: serialise calls that share one;
+ *   - a dcrx_tables_t is not thread-safe: serialise calls that share one, and launch the
+ *     asynchronous entry points that share one on ONE stream (the handle owns a workspace
+ *     that consecutive launches reuse);
  *   - "device" pointers are HIP device memory on the current device
  *     (dcrx_set_device), "host" pointers ordinary process memory.
  */
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCRX_ABI_VERSION 1
+#define DCRX_ABI_VERSION 2
 
 enum dcrx_error {
   DCRX_OK = 0,
@@ -74,6 +76,11 @@ typedef struct dcrx_tables_info {
   uint32_t equal_len_per_automaton; /* 1 when every automaton's keywords share one length (acora tie order then irrelevant) */
   uint32_t pair_scan_bytes;  /* bytes of the two-bases-per-step table of the fast kernel; 0 = not built (> 4095 states,
                                 or tags that overlap themselves at shifts 1..4) */
+  uint32_t v2_tables;        /* 1 when the v2 kernels serve this tag set (every keyword class of one length, each
+                                frame's automaton within 4095 states); else the three-launch form runs */
+  uint32_t v2_states[2];     /* states of the forward- / reverse-frame automaton of the v2 scan */
+  uint32_t v2_scan_bytes[2]; /* bytes of its 16-bit two-bases-per-step table (what the scan kernel keeps in LDS) */
+  uint32_t max_read_len;     /* longest read a batch may hold (DCRX_E_UNSUPPORTED beyond) */
 } dcrx_tables_info_t;
 
 /* Compiles the six Aho-Corasick automata of decombine.py:722-746 into one merged
@@ -238,10 +245,14 @@ int dcrx_decombine_device(dcrx_tables_t *tables, const dcrx_cfg_t *cfg,
                           uint64_t *d_counters, void *hip_stream);
 
 /* Profiling aid: the following dcrx_decombine_device calls on `tables` record
- * start_event right before and stop_event right after the main decombine kernel,
+ * start_event right before and stop_event right after the dominant kernel (the scan),
  * on the stream that kernel is launched on (hipEvent_t handles, e.g. from
  * dcrx_event_create).  NULL, NULL switches it off. */
 int dcrx_set_timing_events(dcrx_tables_t *tables, void *start_event, void *stop_event);
+
+/* The same around EVERY launch of a dcrx_decombine_device call (prologue, scan, finishing kernels):
+ * the time the whole hot path takes on the device for one batch. */
+int dcrx_set_step_events(dcrx_tables_t *tables, void *start_event, void *stop_event);
 
 /* Uploads the tables to the current device and sizes the per-launch workspace
  * for batches of up to max_reads reads. */

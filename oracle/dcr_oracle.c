@@ -565,6 +565,52 @@ void dcro_decombine_batch(const dcro_tables *t, const char *ascii, const uint64_
                         allow_ns, lenthreshold, &res[r], counts);
 }
 
+/* The same over n_threads POSIX threads (contiguous slices of the reads; per-thread counters
+ * summed at the end): the checker for full-size batches on the GPU box and bench.py's CPU
+ * baseline.  passes > 1 repeats each slice (timing only: results and counters are those of one
+ * pass). */
+#include <pthread.h>
+typedef struct {
+  const dcro_tables *t; const char *ascii; const uint64_t *offsets; uint64_t lo, hi;
+  int orientation, allow_ns, lenthreshold, passes; dcro_result *res; uint64_t counts[DCRX_N_COUNTERS];
+} dcro_job;
+static void *dcro_worker(void *arg) {
+  dcro_job *j = (dcro_job *)arg;
+  for (int p = 0; p < j->passes; p++) {
+    memset(j->counts, 0, sizeof j->counts);
+    for (uint64_t r = j->lo; r < j->hi; r++)
+      dcro_decombine_read(j->t, j->ascii + j->offsets[r], (int)(j->offsets[r + 1] - j->offsets[r]), j->orientation,
+                          j->allow_ns, j->lenthreshold, &j->res[r], j->counts);
+  }
+  return NULL;
+}
+int dcro_decombine_batch_mt(const dcro_tables *t, const char *ascii, const uint64_t *offsets,
+                            uint64_t n_reads, int orientation, int allow_ns, int lenthreshold,
+                            dcro_result *res, uint64_t *counts, int n_threads, int passes) {
+  if (n_threads < 1) n_threads = 1;
+  if (passes < 1) passes = 1;
+  dcro_job *jobs = (dcro_job *)calloc((size_t)n_threads, sizeof *jobs);
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof *th);
+  if (!jobs || !th) { free(jobs); free(th); return -1; }
+  int started = 0;
+  for (int k = 0; k < n_threads; k++) {
+    jobs[k].t = t; jobs[k].ascii = ascii; jobs[k].offsets = offsets; jobs[k].res = res;
+    jobs[k].lo = n_reads * (uint64_t)k / (uint64_t)n_threads; jobs[k].hi = n_reads * (uint64_t)(k + 1) / (uint64_t)n_threads;
+    jobs[k].orientation = orientation; jobs[k].allow_ns = allow_ns; jobs[k].lenthreshold = lenthreshold; jobs[k].passes = passes;
+    if (pthread_create(&th[k], NULL, dcro_worker, &jobs[k]) != 0) break;
+    started++;
+  }
+  for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+  for (int k = started; k < n_threads; k++) dcro_worker(&jobs[k]);      /* threads that could not start: here */
+  for (int c = 0; c < DCRX_N_COUNTERS; c++) {
+    uint64_t s = 0;
+    for (int k = 0; k < n_threads; k++) s += jobs[k].counts[c];
+    counts[c] += s;
+  }
+  free(jobs); free(th);
+  return 0;
+}
+
 /* findall exposed for the acora-contract tests: which = 0 key, 1 half1, 2 half2; gene 0 V, 1 J.
  * Writes (index of the first tag holding the keyword, start) pairs; returns the hit count. */
 int dcro_findall(const dcro_tables *t, int gene, int which, const char *text, int n,

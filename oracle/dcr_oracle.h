@@ -44,6 +44,11 @@ void dcro_decombine_batch(const dcro_tables *t, const char *ascii, const uint64_
                           uint64_t n_reads, int orientation, int allow_ns, int lenthreshold,
                           dcro_result *res, uint64_t *counts);
 
+/* n_threads POSIX threads over contiguous slices; passes > 1 repeats the work (timing only). 0 or -1. */
+int dcro_decombine_batch_mt(const dcro_tables *t, const char *ascii, const uint64_t *offsets,
+                            uint64_t n_reads, int orientation, int allow_ns, int lenthreshold,
+                            dcro_result *res, uint64_t *counts, int n_threads, int passes);
+
 int dcro_findall(const dcro_tables *t, int gene, int which, const char *text, int n,
                  int *first_idx, int *start, int cap);
 

@@ -67,6 +67,9 @@ def lib():
         L.dcro_decombine_batch.restype = None
         L.dcro_decombine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.dcro_decombine_batch_mt.restype = C.c_int
+        L.dcro_decombine_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.dcro_findall.restype = C.c_int
         L.dcro_findall.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
@@ -146,6 +149,25 @@ class OracleTables:
         lib().dcro_decombine_batch(self._h, ascii_buf.ctypes.data, offsets.ctypes.data, n,
                                    int(orientation), int(allow_ns), int(lenthreshold),
                                    res.ctypes.data, counts.ctypes.data)
+        return res, counts
+
+    def decombine_batch_mt(self, ascii_buf: np.ndarray, offsets: np.ndarray, orientation: int = 0,
+                           allow_ns: bool = False, lenthreshold: int = 130, n_threads: int = 0, passes: int = 1):
+        """decombine_batch over POSIX threads inside the C library (n_threads 0 = every host core);
+        passes > 1 repeats the work for timing."""
+        import os
+        ascii_buf = np.ascontiguousarray(ascii_buf, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        counts = np.zeros(N_COUNTERS, dtype=np.uint64)
+        if n_threads <= 0:
+            n_threads = os.cpu_count() or 1
+        rc = lib().dcro_decombine_batch_mt(self._h, ascii_buf.ctypes.data, offsets.ctypes.data, n,
+                                           int(orientation), int(allow_ns), int(lenthreshold),
+                                           res.ctypes.data, counts.ctypes.data, int(n_threads), int(passes))
+        if rc:
+            raise MemoryError("dcro_decombine_batch_mt")
         return res, counts
 
     def findall(self, gene: int, which: int, text: str, cap: int = 4096):

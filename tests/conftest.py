@@ -14,6 +14,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests need a GPU and the built library.  On a host without one a plain `pytest tests`
+    skips them (the product itself fails loudly there: tests/test_cabi.py); DCRX_EXPECT_GPU=1 — set on
+    the GPU box by the drivers that must not pass vacuously — turns the skip into a failure."""
+    if os.environ.get("DCRX_EXPECT_GPU") == "1":
+        return
+    try:
+        from decombinator_amd import _native as nat
+        have = nat.device_count() > 0
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no GPU on this host (set DCRX_EXPECT_GPU=1 to fail instead)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
