@@ -62,7 +62,8 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     ot.decombine_batch_mt(buf, offsets[:n1 + 1], n_threads=1)
     t1 = time.perf_counter() - t0
     rate1 = n1 / t1
-    cores = os.cpu_count() or 1
+    # the cores this process may run on (a container's share of the host), not every core of the box
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     passes = max(1, int(round(rate1 * 1.0 / max(1, sample_reads // cores))))      # ~1 s of work per thread
     passes = min(passes, 64)
     t0 = time.perf_counter()
@@ -71,7 +72,8 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     return {
         "value": round(sample_reads * passes / tn / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
         "sample": f"first {sample_reads} reads of the same synthetic workload x {passes} passes, oracle/dcr_oracle.c "
-                  f"(C port of the reference's Python path), {cores} POSIX threads, {tn:.2f} s",
+                  f"(C port of the reference's Python path), {cores} POSIX threads (cores this process may use; the box reports "
+                  f"{os.cpu_count()}), {tn:.2f} s",
         "value_1thread": round(rate1 / 1e6, 4), "sample_1thread": f"first {n1} reads, 1 thread, {t1:.2f} s",
     }
 

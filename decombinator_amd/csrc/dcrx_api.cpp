@@ -82,7 +82,7 @@ extern "C" {
 
 int dcrx_abi_version(void) { return DCRX_ABI_VERSION; }
 const char *dcrx_last_error(void) { return g_err.c_str(); }
-const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; pair-scan block 1024, one-base block 512; reads <= 320 nt"; }
+const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; v2 scan block 1024 (16-bit pair table), finishing blocks 256; reads <= 511 nt (register-resident scans <= 320 nt)"; }
 
 int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
   if (!out) return set_err(DCRX_E_INVALID, "out is null");
@@ -245,7 +245,8 @@ static int check_batch(const dcrx_batch_t *b) {
   if (!b) return set_err(DCRX_E_INVALID, "batch is null");
   if (b->n_reads >= (1ull << 32)) return set_err(DCRX_E_INVALID, "more than 2^32-1 reads in one call");
   if (b->stride == 0 || (b->stride & 7u)) return set_err(DCRX_E_INVALID, "stride must be a positive multiple of 8");
-  if (b->stride > 4 * DCRX_NWMAX) return set_err(DCRX_E_UNSUPPORTED, "stride > 80 bytes: reads longer than 320 nt are not supported");
+  if (b->stride > DCRX_MAX_STRIDE) return set_err(DCRX_E_UNSUPPORTED, "stride > 128 bytes: reads longer than 511 nt are not supported");
+  if (!b->lens && b->read_len > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "reads longer than 511 nt are not supported");
   if (!b->lens && b->read_len > 4 * b->stride) return set_err(DCRX_E_INVALID, "read_len exceeds 4*stride");
   if (b->n_reads && !b->packed) return set_err(DCRX_E_INVALID, "packed is null");
   if (b->n_exc && (!b->exc_read || !b->exc_pos || !b->exc_chr)) return set_err(DCRX_E_INVALID, "exception arrays are null");
@@ -305,6 +306,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
   if (hb->lens)
     for (uint64_t r = 0; r < n; r++)
       if (hb->lens[r] > 4 * hb->stride) return set_err(DCRX_E_INVALID, "a read is longer than 4*stride");
+      else if (hb->lens[r] > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt");
   for (uint64_t i = 0; i < hb->n_exc; i++) {
     const uint8_t c = hb->exc_chr[i];
     if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return set_err(DCRX_E_INVALID, "exception byte is one of ACGT");

@@ -6,7 +6,11 @@
 
 // words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
 #define DCRX_NWMAX 20
-#define DCRX_MAX_READ_LEN (16 * DCRX_NWMAX)
+#define DCRX_FAST_READ_LEN (16 * DCRX_NWMAX)
+// longer reads (up to 511 nt: strides of up to 128 bytes) go through the list kernel, which walks the packed words
+// in memory; its hit positions have nine bits
+#define DCRX_MAX_STRIDE 128
+#define DCRX_MAX_READ_LEN 511
 #define DCRX_BLOCK 512   /* fast kernel, one base per step */
 #define DCRX_BLOCK16 1024 /* fast kernel, two bases per step (one block per CU: the table takes most of the LDS) */
 #define DCRX_QBLOCK 512  /* list kernel */

@@ -225,6 +225,7 @@ class ChainTables:
         self.tables = nat.Tables(self.v_seqs, self.jump_to_end_v, self.v_regions[:len(self.v_seqs)],
                                  self.j_seqs, self.jump_to_start_j, self.j_regions[:len(self.j_seqs)],
                                  v_half_split, j_half_split)
+        self.max_read_len = int(self.tables.info()["max_read_len"])
 
 
 def import_tcr_info(inputargs) -> ChainTables:
@@ -618,6 +619,12 @@ def decombinator(inputargs: dict) -> list:
                 if inputargs["dontcount"] == False and counts["read_count"] // 100000 > before // 100000:  # noqa: E712
                     print("\t read", (counts["read_count"] // 100000) * 100000)
                 t1 = time()
+                longest = int(spans.v_len.max()) if n else 0
+                if longest > tcr.max_read_len:
+                    # the reference has no length limit (decombine.py:534-585); this build's kernels do, and
+                    # there is no CPU path to fall back to: say so before anything of this batch is processed
+                    raise ValueError(f"a read of {longest} nt exceeds the {tcr.max_read_len} nt this build decombines "
+                                     f"(dcrx_tables_info.max_read_len); trim or split the reads")
                 batch = nat.pack_reads_span(spans.v_text, spans.v_start, spans.v_len)
                 t2 = time()
                 rec, cnt = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])

@@ -64,43 +64,79 @@ def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
     return None, None
 
 
+def pack_tuples12(rec):
+    """Host-side twin of dcrx_compact_hits_packed_device: the status-OK records of `rec` (RECORD_DTYPE) as
+    (k, 3) uint32 tuples in read order, and the bitmap of the reads they belong to ((n + 63) // 64 uint64)."""
+    import numpy as np
+    ok = rec["status"] == 0
+    r = rec[ok]
+    w = np.zeros((len(r), 3), dtype=np.uint32)
+    w[:, 0] = r["v"].astype(np.uint32) | (r["j"].astype(np.uint32) << 12) | (r["vdel"].astype(np.uint32) << 24)
+    w[:, 1] = r["v_start"].astype(np.uint32) | (r["j_end"].astype(np.uint32) << 9) | (r["ins_start"].astype(np.uint32) << 18)
+    w[:, 2] = r["ins_len"].astype(np.uint32) | (r["jdel"].astype(np.uint32) << 9) | (r["frame"].astype(np.uint32) << 17)
+    bits = np.zeros(((len(rec) + 63) // 64) * 64, dtype=np.uint8)
+    bits[:len(rec)] = ok
+    bitmap = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1, 8).view(np.uint64).reshape(-1)
+    return w, bitmap
+
+
+def bitmap_indices(bitmap, n_reads: int):
+    """Read indices (ascending) whose bit is set."""
+    import numpy as np
+    bits = np.unpackbits(np.ascontiguousarray(bitmap, dtype=np.uint64).view(np.uint8), bitorder="little")[:n_reads]
+    return np.nonzero(bits)[0]
+
+
 class TupleGather:
-    """Per-step fixed-capacity gather for the benchmark loop: no host sync inside the timed
-    region.  Every rank compacts its step's tuples on the device — each decombined record squeezed
-    into 12 bytes, in read order, plus one bit per read saying which reads they belong to (half the
-    bytes of 16-byte records with 8-byte indices) — and sends the first `cap` records (cap = reads/2 covers the synthetic
-    mixture's ~42 % decombined reads; `check` verifies that after the run) and the bitmap.
+    """Per-step gather of the DCR tuples on rank 0, exact sizes, nothing truncated.
 
-    Compaction and gather run on a side stream, beside the scan of the following step: the caller
-    alternates between `depth` record buffers (`records(k)`), the scan of step k+depth waits for
-    the compaction of step k (`before_scan`), and a buffer set is reused only after its previous
-    gather has completed."""
+    A tuple travels as 12 bytes (dcrx_compact_hits_packed_device: the record's fields in three uint32,
+    in read order) plus one bit per read saying which reads decombined.  Per step, on a side stream
+    beside the scan of the following step:
 
-    TUPLE_BYTES = 12     # dcrx_compact_hits_packed_device: the record's fields in three uint32
+      1. compaction of the step's records -> tuples, bitmap, count (on the device);
+      2. count exchange: all_gather of the ranks' counts, copied to pinned host memory;
+      3. one step later, when the counts have arrived: exact-size point-to-point transfers
+         (rank r sends count_r tuples and its bitmap; rank 0 receives them, rank order = read order).
 
-    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, cap_fraction: float = 0.5,
-                 depth: int = 2):
+    The caller alternates between `depth` record buffers (`records()`), the scan of step k + depth waits for
+    the compaction of step k (`before_scan`), and a buffer set is reused only after its transfers completed.
+    `compact` replaces step 1 (tests feed tuples made on the host); device None or CPU runs without streams
+    (gloo), else on a CUDA side stream (RCCL)."""
+
+    TUPLE_BYTES = 12
+
+    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None):
         from . import _native as nat
         self.nat = nat
-        self.world, self.rank = world, rank
-        self.cap = int(n_reads * cap_fraction) + 1024
+        self.world, self.rank, self.n_reads = world, rank, n_reads
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.device = device if self.cuda else torch.device("cpu")
         self.words = (n_reads + 63) // 64
         self.k = 0
-        self.side = torch.cuda.Stream(device=device)
+        self.side = torch.cuda.Stream(device=device) if self.cuda else None
+        self.compact = compact
         self.slots = []
+        dev = self.device
         for _ in range(depth):
             slot = {
-                "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=device),
-                "hits": torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=device),
-                "bitmap": torch.zeros(self.words, dtype=torch.int64, device=device),
-                "n": torch.zeros(1, dtype=torch.int64, device=device),
-                "work": [],
+                "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=dev),
+                "hits": torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=dev),
+                "bitmap": torch.zeros(self.words, dtype=torch.int64, device=dev),
+                "n": torch.zeros(1, dtype=torch.int64, device=dev),
+                "counts": [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)],
+                "counts_host": torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda),
+                "counted": None,       # event: counts_host is filled
                 "compacted": None,     # event: the compaction that read this slot's records is done
+                "posted": True,        # the transfers of the slot's last use have been posted
+                "work": [],
+                "step": -1,
             }
             if rank == 0:
-                slot["g_hits"] = [torch.empty(self.cap * self.TUPLE_BYTES, dtype=torch.uint8, device=device) for _ in range(world)]
-                slot["g_bitmap"] = [torch.empty(self.words, dtype=torch.int64, device=device) for _ in range(world)]
-                slot["g_n"] = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+                slot["g_hits"] = [slot["hits"] if r == 0 else torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=dev)
+                                  for r in range(world)]
+                slot["g_bitmap"] = [slot["bitmap"] if r == 0 else torch.empty(self.words, dtype=torch.int64, device=dev)
+                                    for r in range(world)]
             self.slots.append(slot)
 
     def records(self) -> torch.Tensor:
@@ -110,60 +146,108 @@ class TupleGather:
     def before_scan(self) -> None:
         """The current stream waits until the slot's previous compaction has read its records."""
         ev = self.slots[self.k % len(self.slots)]["compacted"]
-        if ev is not None:
+        if ev is not None and self.cuda:
             torch.cuda.current_stream().wait_event(ev)
+
+    def _side(self):
+        return torch.cuda.stream(self.side) if self.cuda else _NullCtx()
+
+    def _post(self, s) -> None:
+        """Exact-size transfers of a slot whose counts have arrived."""
+        if s["posted"]:
+            return
+        if s["counted"] is not None:
+            s["counted"].synchronize()       # the host waits for the counts (a few bytes, one step old)
+        counts = [int(x) for x in s["counts_host"].tolist()]
+        s["posted"] = True
+        with self._side():
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    if counts[r]:
+                        s["work"].append(dist.irecv(s["g_hits"][r][:counts[r] * self.TUPLE_BYTES], src=r))
+                    s["work"].append(dist.irecv(s["g_bitmap"][r], src=r))
+            else:
+                if counts[self.rank]:
+                    s["work"].append(dist.isend(s["hits"][:counts[self.rank] * self.TUPLE_BYTES], dst=0))
+                s["work"].append(dist.isend(s["bitmap"], dst=0))
 
     def step(self, n_reads: int) -> None:
         """After the scan of this step has been queued on the current stream."""
         nat = self.nat
         s = self.slots[self.k % len(self.slots)]
-        self.k += 1
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            for w in s["work"]:          # this set's previous gather must be done before its buffers are rewritten
+        prev = self.slots[(self.k - 1) % len(self.slots)] if self.k else None
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+        with self._side():
+            self._post(s)                # (a slot is reused only when its last transfers were posted ...)
+            for w in s["work"]:          # ... and are done
                 w.wait()
-            nat.check(nat.lib().dcrx_compact_hits_packed_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
-                                                                s["bitmap"].data_ptr(), s["n"].data_ptr(),
-                                                                self.side.cuda_stream))
-            s["compacted"] = self.side.record_event()
-            h = s["hits"][:self.cap * self.TUPLE_BYTES]
-            if self.rank == 0:
-                s["work"] = [dist.gather(s["n"], s["g_n"], dst=0, async_op=True),
-                             dist.gather(h, s["g_hits"], dst=0, async_op=True),
-                             dist.gather(s["bitmap"], s["g_bitmap"], dst=0, async_op=True)]
+            s["work"] = []
+            if self.compact is not None:
+                self.compact(s, n_reads)
             else:
-                s["work"] = [dist.gather(s["n"], None, dst=0, async_op=True),
-                             dist.gather(h, None, dst=0, async_op=True),
-                             dist.gather(s["bitmap"], None, dst=0, async_op=True)]
+                nat.check(nat.lib().dcrx_compact_hits_packed_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
+                                                                    s["bitmap"].data_ptr(), s["n"].data_ptr(),
+                                                                    self.side.cuda_stream))
+            if self.cuda:
+                s["compacted"] = self.side.record_event()
+            if self.world > 1:
+                dist.all_gather(s["counts"], s["n"])
+            else:
+                s["counts"][0].copy_(s["n"])
+            s["counts_host"].copy_(torch.cat(s["counts"]), non_blocking=True)
+            s["counted"] = self.side.record_event() if self.cuda else None
+            s["posted"] = False
+            s["step"] = self.k
+        self.k += 1
+        if prev is not None and prev is not s:
+            self._post(prev)             # the previous step's counts are one step old by now
 
     def finish(self) -> None:
-        """Makes the current stream wait for every compaction and gather still in flight."""
-        with torch.cuda.stream(self.side):
+        """Posts what is still to be posted and makes the current stream wait for every transfer."""
+        for s in self.slots:
+            self._post(s)
+        with self._side():
             for s in self.slots:
                 for w in s["work"]:
                     w.wait()
                 s["work"] = []
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
 
-    @staticmethod
-    def _popcount(words: torch.Tensor) -> int:
-        b = words.view(torch.uint8).to(torch.int32)
-        total = 0
-        for k in range(8):
-            total += int(((b >> k) & 1).sum().item())
-        return total
+    def gathered(self, step: int):
+        """On rank 0, after finish(): the tuples of `step` (one of the last `depth` steps) as (records, read index
+        within the rank, rank) per rank, re-expanded from the 12-byte form and the bitmaps."""
+        import numpy as np
+        s = next(x for x in self.slots if x["step"] == step)
+        if self.cuda:
+            torch.cuda.synchronize()
+        counts = [int(x) for x in s["counts_host"].tolist()]
+        out = []
+        for r in range(self.world):
+            w = s["g_hits"][r][:counts[r] * self.TUPLE_BYTES].cpu().numpy().view(np.uint32).reshape(-1, 3)
+            idx = bitmap_indices(s["g_bitmap"][r].cpu().numpy().view(np.uint64), self.n_reads)
+            out.append((self.nat.unpack_tuples12(w), idx, r))
+        return out
 
     def check(self, n_hits_local: int) -> None:
+        """After the run: the last step's counts and bitmaps are consistent on rank 0."""
         self.finish()
-        torch.cuda.synchronize()
-        if n_hits_local > self.cap:
-            raise RuntimeError(f"rank {self.rank}: {n_hits_local} tuples exceed the gather capacity {self.cap}")
+        if self.cuda:
+            torch.cuda.synchronize()
+        last = self.slots[(self.k - 1) % len(self.slots)]
+        counts = [int(x) for x in last["counts_host"].tolist()]
+        if counts[self.rank] != n_hits_local:
+            raise RuntimeError(f"rank {self.rank}: exchanged count {counts[self.rank]} != {n_hits_local} decombined reads")
         if self.rank == 0:
-            last = self.slots[(self.k - 1) % len(self.slots)]
-            got = [int(x.item()) for x in last["g_n"]]
-            if got[0] != n_hits_local or any(g <= 0 or g > self.cap for g in got):
-                raise RuntimeError(f"gathered tuple counts look wrong: {got}")
-            # every rank's bitmap marks exactly as many reads as it sent tuples (rank order = read order)
-            for r in range(self.world):
-                if self._popcount(last["g_bitmap"][r]) != got[r]:
-                    raise RuntimeError(f"bitmap of rank {r} does not match its {got[r]} tuples")
+            for r, (rec, idx, _) in enumerate(self.gathered(self.k - 1)):
+                if len(rec) != counts[r] or len(idx) != counts[r]:
+                    raise RuntimeError(f"rank {r}: {len(rec)} tuples, {len(idx)} bitmap bits, {counts[r]} announced")
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -135,8 +135,10 @@ typedef struct dcrx_cfg {
  * are not one of "ACGT" (N, IUPAC codes, lower case) are packed as 0 and listed
  * as exceptions sorted by (read, pos); the device treats them exactly as the
  * reference treats the original byte.  stride is a multiple of
- * 8 with 4*stride >= the longest read and stride <= 80: reads of up to 320 nt
- * (DCRX_E_UNSUPPORTED beyond). */
+ * 8 with 4*stride >= the longest read and stride <= 128: reads of up to 511 nt
+ * (DCRX_E_UNSUPPORTED beyond; dcrx_tables_info.max_read_len).  Batches with stride <= 80
+ * (reads of up to 320 nt) take the register-resident scan kernels, longer ones a kernel
+ * that walks the packed words in memory. */
 typedef struct dcrx_batch {
   uint64_t n_reads;         /* < 2^32 per call */
   const uint8_t *packed;

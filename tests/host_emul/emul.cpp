@@ -136,7 +136,7 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const uint32_t nw = b->stride / 4;
     const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
     const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
-    const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER);
+    const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
     // the launch's choice of kernels (dcrx_kernels.hip, v2_applies)
     const bool v2 = T.v2_ok && !all_general &&

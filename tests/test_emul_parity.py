@@ -84,3 +84,41 @@ def _long_half_tags(kind, tag_len, n):
 def test_emul_randomised_configurations():
     from tests import fuzz_util
     assert fuzz_util.run("emul", 16, 3000, seed=424242) > 1000
+
+
+def _long_reads(kind, n):
+    """Reads of 321..511 nt (merged 2x250 amplicons): beyond the register-resident scans, through the kernel that walks
+    the packed words in memory."""
+    import numpy as np
+    from decombinator_amd import synth
+    from oracle import oracle as orc
+    ts = synth.config_tagset(2)
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=ts.half_splits[0], j_half_split=ts.half_splits[1])
+    t = pu.native_tables(d)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], *ts.half_splits)
+    be = pu.Backend(kind, d)
+    rng = np.random.default_rng(5)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=77, read_len=300, sub_rate=0.01, n_rate=0.002), 0, n, stride=nat.stride_for(300))
+    reads = nat.unpack_reads(hb)
+    # pad to 321..511 nt with random flanks on either side (the rearrangement sits anywhere inside)
+    out = []
+    for i, r in enumerate(reads):
+        extra = int(rng.integers(21, 212))
+        left = int(rng.integers(0, extra + 1))
+        fl = "".join("ACGT"[k] for k in rng.integers(0, 4, size=extra))
+        out.append(fl[:left] + r + fl[left:])
+    assert 321 <= min(map(len, out)) and max(map(len, out)) <= 511
+    b = nat.pack_reads(out, stride=128)
+    for orientation in ("reverse", "forward"):
+        rec, cnt = be.run(b, orientation)
+        orec, ocnt = pu.oracle_records(ot, out, orientation, False, 130)
+        pu.assert_records_equal(rec, orec, out, orientation)
+        pu.assert_counters_equal(cnt, ocnt)
+    assert int((orec["status"] == 0).sum()) >= 0
+    return int(ocnt[nat.COUNTER_NAMES.index("read_count")])
+
+
+def test_emul_reads_of_321_to_511_nt():
+    assert _long_reads("emul", 3000) == 3000

@@ -29,24 +29,59 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
-                         ids=["pairscan", "onebase", "slowreader", "listrescue"])
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
+                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "onebase", "slowreader", "listrescue"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
 
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS], ids=["v2", "v1"])
 @pytest.mark.parametrize("config,seed,sub,n", [(2, 2, 0.005, 1_000_000), (5, 5, 0.02, 300_000)])
-def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n):
+def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n, flags):
     ts = synth.config_tagset(config)
     t, ot = _tables(ts)
     cfg = nat.synth_cfg(seed=seed, sub_rate=sub, n_rate=0.0005)
     hb = nat.synth_reads_host(t, cfg, 0, n)
-    rec, cnt = nat.decombine(t, hb)
+    rec, cnt = nat.decombine(t, hb, flags=flags)
     reads = nat.unpack_reads(hb)
     orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
     pu.assert_records_equal(rec, orec, reads, f"config {config}")
     pu.assert_counters_equal(cnt, ocnt, f"config {config}")
     assert 0.3 < int(cnt[19]) / n < 0.46
+
+
+def test_config5_delta_chain_bit_exact_vs_oracle():
+    """The delta chain of BASELINE config 5 (mouse gamma/delta; `original` tag set by the rewrite rule of
+    decombine.py:640-654), 2 % substitutions."""
+    g, d = synth.config5_tagsets()
+    t, ot = _tables(d)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=55, sub_rate=0.02, n_rate=0.0005), 0, 300_000)
+    rec, cnt = nat.decombine(t, hb)
+    reads = nat.unpack_reads(hb)
+    orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+    pu.assert_records_equal(rec, orec, reads, "delta")
+    pu.assert_counters_equal(cnt, ocnt, "delta")
+    assert int(cnt[19]) > 50_000
+
+
+def test_reads_of_321_to_511_nt():
+    from tests.test_emul_parity import _long_reads
+    assert _long_reads("hip", 50_000) == 50_000
+
+
+def test_reads_longer_than_the_limit_are_refused_explicitly():
+    """dcrx_tables_info names the longest read a batch may hold; a longer one is DCRX_E_UNSUPPORTED, nothing else."""
+    ts = synth.config_tagset(2)
+    t, _ = _tables(ts)
+    lim = t.info()["max_read_len"]
+    assert lim == 511
+    ok = nat.pack_reads(["ACGT" * (lim // 4)], stride=nat.stride_for(lim))
+    rec, cnt = nat.decombine(t, ok)
+    assert len(rec) == 1 and int(cnt[20]) == 1
+    too_long = nat.pack_reads(["ACGT" * (lim // 4 + 8)], stride=nat.stride_for(lim + 32))
+    with pytest.raises(nat.DcrxError) as ei:
+        nat.decombine(t, too_long)
+    assert ei.value.code == -2
 
 
 def test_config3_both_chains_bit_exact_vs_oracle():
@@ -171,25 +206,29 @@ def test_full_size_10M_properties_and_sampled_blocks():
         assert d_r.to_host(nat.RECORD_DTYPE, q).tobytes() == rec[k * q:(k + 1) * q].tobytes()
         tot += d_c.to_host(np.uint64, nat.N_COUNTERS)
     assert (tot == cnt).all()
-    # sampled blocks against the oracle
-    rng = np.random.default_rng(1)
-    blk = 65_536
-    for b0 in rng.integers(0, n // blk, size=16):
-        first = int(b0) * blk
-        hb = nat.synth_reads_host(t, cfg, first, blk)
-        reads = nat.unpack_reads(hb)
-        orec, _ = pu.oracle_records(ot, reads, "reverse", False, 130)
-        pu.assert_records_equal(rec[first:first + blk], orec, reads, f"block {b0}")
+    # every record and every counter against the oracle (threaded in C over the host cores), 2 M reads at a time
+    tot_o = np.zeros(nat.N_COUNTERS, dtype=np.uint64)
+    step = 2_000_000
+    for first in range(0, n, step):
+        hb = nat.synth_reads_host(t, cfg, first, step)
+        buf, offsets = nat.unpack_reads_raw(hb)
+        ores, ocnt = ot.decombine_batch_mt(buf, offsets)
+        orec = pu.oracle_to_records(ores)
+        if rec[first:first + step].tobytes() != orec.tobytes():
+            pu.assert_records_equal(rec[first:first + step], orec, nat.unpack_reads(hb), f"reads {first}..")
+        tot_o += ocnt
+    pu.assert_counters_equal(cnt, tot_o, "all 10 M reads")
 
 
-@pytest.mark.parametrize("which", ["config3_alpha", "config3_beta", "config5_mouse_gd"])
+@pytest.mark.parametrize("which", ["config3_alpha", "config3_beta", "config5_mouse_g", "config5_mouse_d"])
 def test_100M_reads_sampled_blocks(which):
     """BASELINE configs 3 and 5 at their full 100 M reads, device-resident: status histogram vs
     counters, and 16 sampled 64k-read blocks bit-exact against the oracle (SURVEY.md §8(d)
     "parity at scale").  Config 3 runs its two chains as two passes over the same reads."""
     n = 100_000_000
-    if which == "config5_mouse_gd":
-        ts, seed, sub = synth.config_tagset(5), 5, 0.02
+    if which.startswith("config5"):
+        g, d = synth.config5_tagsets()
+        ts, seed, sub = (g if which.endswith("_g") else d), 5, 0.02
     else:
         a, b = synth.config3_tagsets()
         ts, seed, sub = (a, 3, 0.005) if which.endswith("alpha") else (b, 3, 0.005)
@@ -211,11 +250,101 @@ def test_100M_reads_sampled_blocks(which):
         nat.check(nat.lib().dcrx_memcpy_d2h(part.ctypes.data, d_rec.ptr + first * 16, blk * 16))
         hb = nat.synth_reads_host(t, cfg, first, blk)
         reads = nat.unpack_reads(hb)
-        orec, _ = pu.oracle_records(ot, reads, "reverse", False, 130)
+        orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
         pu.assert_records_equal(part, orec, reads, f"{which} block {b0}")
+        # the block's counters too: the same reads as their own launch (counters are additive over reads)
+        sub = nat.synth_reads_device(t, cfg, first, blk)
+        d_r, d_c = nat.DeviceBuffer(blk * 16), nat.DeviceBuffer(nat.N_COUNTERS * 8)
+        nat.decombine_device(t, sub, d_r, d_c)
+        nat.synchronize()
+        pu.assert_counters_equal(d_c.to_host(np.uint64, nat.N_COUNTERS), ocnt, f"{which} block {b0} counters")
         hist_ok += int((part["status"] == 0).sum())
     # the sampled blocks' decombined fraction must match the whole run's within sampling noise
     assert abs(hist_ok / (16 * blk) - int(cnt[19]) / n) < 0.01
+
+
+def test_config4_one_rank_shard_of_the_billion_reads():
+    """BASELINE config 4 as one of its eight ranks sees it: rank 3's 125 M-read shard of the 1 B reads (seed 4,
+    sharded.shard_range), device-resident: sampled blocks bit-exact against the oracle with their counters, the status
+    histogram against the counters."""
+    from decombinator_amd import sharded
+    lo, hi = sharded.shard_range(10**9, 8, 3)
+    n = hi - lo
+    assert n == 125_000_000
+    ts = synth.config_tagset(4)
+    t, ot = _tables(ts)
+    cfg = nat.synth_cfg(seed=4)
+    db = nat.synth_reads_device(t, cfg, lo, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    cnt = d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+    assert int(cnt[20]) == n
+    rng = np.random.default_rng(4)
+    blk = 65_536
+    ok = 0
+    for b0 in rng.integers(0, n // blk, size=16):
+        first = int(b0) * blk
+        part = np.zeros(blk, dtype=nat.RECORD_DTYPE)
+        nat.check(nat.lib().dcrx_memcpy_d2h(part.ctypes.data, d_rec.ptr + first * 16, blk * 16))
+        hb = nat.synth_reads_host(t, cfg, lo + first, blk)
+        reads = nat.unpack_reads(hb)
+        orec, _ = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(part, orec, reads, f"shard block {b0}")
+        ok += int((part["status"] == 0).sum())
+    assert abs(ok / (16 * blk) - int(cnt[19]) / n) < 0.01
+
+
+def test_rccl_tuple_gather_single_rank_tuple_for_tuple():
+    """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
+    transfers) with one rank on this GPU, several steps with different reads: what rank 0 holds for every step equals a
+    synchronous compaction of that step's records, tuple for tuple and bit for bit of the bitmap."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from decombinator_amd import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 400_000
+        ts = synth.config_tagset(2)
+        t, _ = _tables(ts)
+        dev = torch.device("cuda", 0)
+        g = sharded.TupleGather(n, 1, 0, dev)
+        stream = torch.cuda.current_stream()
+        d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
+        batches = []
+        for step in range(5):
+            p = [0.45, 0.95, 0.02, 0.7, 0.3][step]
+            db = nat.synth_reads_device(t, nat.synth_cfg(seed=40 + step, p_rearranged=p), step * n, n)
+            batches.append(db)
+        cfg = nat.make_cfg("reverse", False, 130, 0)
+        want = []
+        for step, db in enumerate(batches):
+            g.before_scan()
+            rec = g.records()
+            b = db.as_c()
+            nat.check(nat.lib().dcrx_decombine_device(t.handle, nat.C.byref(cfg), nat.C.byref(b), rec.data_ptr(),
+                                                      d_cnt.data_ptr(), stream.cuda_stream))
+            g.step(n)
+            # the same records through a synchronous compaction, for comparison
+            torch.cuda.synchronize()
+            r = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+            want.append(r[r["status"] == 0].copy())
+            if step >= 1:
+                g.finish()
+                (grec, gidx, _), = g.gathered(step - 1)
+                assert grec.tobytes() == want[step - 1].tobytes(), f"step {step - 1}"
+        g.finish()
+        (grec, gidx, _), = g.gathered(4)
+        assert grec.tobytes() == want[4].tobytes()
+        g.check(len(want[4]))
+        assert len(want[1]) > 0.8 * n and len(want[2]) < 0.05 * n       # far above and far below any fixed fraction
+    finally:
+        dist.destroy_process_group()
 
 
 def test_compact_hits_matches_numpy():

@@ -71,6 +71,92 @@ def test_two_rank_gloo_gather_matches_unsharded(tmp_path):
     assert "SHARDED_OK" in outs[0]
 
 
+GATHER_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["DCRX_ROOT"])
+    from decombinator_amd import sharded, synth, _native as nat
+    from oracle import oracle as orc
+    from tests import parity_util as pu
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, STEPS = 5000, 5
+    ts = synth.config_tagset(2)
+    vs, js = ts.half_splits
+    t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, vs, js)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], vs, js)
+
+    def shard_records(step, r):
+        """What rank r's device would hold after the scan of `step`: here from the oracle (p_rearranged differs per step
+        and rank, so that the counts do: 5 % .. 95 % decombined, above any fixed fraction)."""
+        p = [0.05, 0.95, 0.5, 0.0, 0.7][step] if r == 0 else [0.9, 0.1, 0.45, 0.6, 0.0][step]
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=100 + step, p_rearranged=p), r * N, N)
+        rec, _ = pu.oracle_records(ot, nat.unpack_reads(hb), "reverse", False, 130)
+        return rec
+
+    def compact(slot, n_reads):       # stands in for dcrx_compact_hits_packed_device: same layout, made on the host
+        rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+        w, bm = sharded.pack_tuples12(rec)
+        slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
+        slot["bitmap"][:] = torch.from_numpy(bm.view(np.int64).copy())
+        slot["n"][0] = len(w)
+
+    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact)
+    checked = 0
+    for step in range(STEPS):
+        g.before_scan()
+        rec = shard_records(step, rank)
+        g.records()[:] = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())     # "the scan wrote the records"
+        g.step(N)
+        if step >= 1 and rank == 0:
+            # the previous step is complete on rank 0 once its transfers are waited for: compare it in full
+            g.finish()
+            for r, (grec, gidx, _) in enumerate(g.gathered(step - 1)):
+                want = shard_records(step - 1, r)
+                ok = np.nonzero(want["status"] == 0)[0]
+                assert (gidx == ok).all(), (step, r, "bitmap")
+                w = want[ok].copy()
+                assert grec.tobytes() == w.tobytes(), (step, r, "tuples")
+                checked += len(ok)
+        elif step >= 1:
+            g.finish()
+    g.finish()
+    if rank == 0:
+        for r, (grec, gidx, _) in enumerate(g.gathered(STEPS - 1)):
+            want = shard_records(STEPS - 1, r)
+            ok = np.nonzero(want["status"] == 0)[0]
+            assert (gidx == ok).all() and grec.tobytes() == want[ok].tobytes()
+        print("GATHER_OK", checked)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path):
+    """The gather bench.py runs between ranks (count exchange, exact-size transfers of 12-byte tuples + bitmap,
+    alternating slots), over gloo with two ranks and five steps whose decombined fractions range from 0 to 95 %:
+    rank 0 re-expands every rank's tuples and they equal that rank's records."""
+    script = tmp_path / "gworker.py"
+    script.write_text(GATHER_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCRX_ROOT=ROOT, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
+
+
 def test_shard_range_covers_everything():
     from decombinator_amd import sharded
     for n in (0, 1, 7, 1000, 10**9 + 7):
