@@ -296,55 +296,70 @@ def test_config4_one_rank_shard_of_the_billion_reads():
     assert abs(ok / (16 * blk) - int(cnt[19]) / n) < 0.01
 
 
-def test_rccl_tuple_gather_single_rank_tuple_for_tuple():
-    """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
-    transfers) with one rank on this GPU, several steps with different reads: what rank 0 holds for every step equals a
-    synchronous compaction of that step's records, tuple for tuple and bit for bit of the bitmap."""
-    import os
-    import torch
-    import torch.distributed as dist
-    from decombinator_amd import sharded
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        n = 400_000
-        ts = synth.config_tagset(2)
-        t, _ = _tables(ts)
-        dev = torch.device("cuda", 0)
-        g = sharded.TupleGather(n, 1, 0, dev)
-        stream = torch.cuda.current_stream()
-        d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
-        batches = []
-        for step in range(5):
-            p = [0.45, 0.95, 0.02, 0.7, 0.3][step]
-            db = nat.synth_reads_device(t, nat.synth_cfg(seed=40 + step, p_rearranged=p), step * n, n)
-            batches.append(db)
-        cfg = nat.make_cfg("reverse", False, 130, 0)
-        want = []
-        for step, db in enumerate(batches):
-            g.before_scan()
-            rec = g.records()
-            b = db.as_c()
-            nat.check(nat.lib().dcrx_decombine_device(t.handle, nat.C.byref(cfg), nat.C.byref(b), rec.data_ptr(),
-                                                      d_cnt.data_ptr(), stream.cuda_stream))
-            g.step(n)
-            # the same records through a synchronous compaction, for comparison
-            torch.cuda.synchronize()
-            r = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=nat.RECORD_DTYPE)
-            want.append(r[r["status"] == 0].copy())
-            if step >= 1:
-                g.finish()
-                (grec, gidx, _), = g.gathered(step - 1)
-                assert grec.tobytes() == want[step - 1].tobytes(), f"step {step - 1}"
+RCCL_GATHER_WORKER = '''
+import os, sys
+import torch                      # first: its bundled HIP runtime must be the one libdcrx binds to
+import torch.distributed as dist
+import numpy as np
+sys.path.insert(0, os.environ["DCRX_ROOT"])
+from decombinator_amd import _native as nat, sharded, synth
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+nat.check(nat.lib().dcrx_set_device(0))
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n = 400_000
+ts = synth.config_tagset(2)
+t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
+dev = torch.device("cuda", 0)
+g = sharded.TupleGather(n, 1, 0, dev)
+stream = torch.cuda.current_stream()
+d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
+cfg = nat.make_cfg("reverse", False, 130, 0)
+want = []
+for step in range(5):
+    p = [0.45, 0.95, 0.02, 0.7, 0.3][step]
+    db = nat.synth_reads_device(t, nat.synth_cfg(seed=40 + step, p_rearranged=p), step * n, n)
+    g.before_scan()
+    rec = g.records()
+    b = db.as_c()
+    nat.check(nat.lib().dcrx_decombine_device(t.handle, nat.C.byref(cfg), nat.C.byref(b), rec.data_ptr(),
+                                              d_cnt.data_ptr(), stream.cuda_stream))
+    g.step(n)
+    torch.cuda.synchronize()      # the same records through the host, for comparison
+    r = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+    ok = np.nonzero(r["status"] == 0)[0]
+    want.append((r[ok].copy(), ok))
+    if step >= 1:
         g.finish()
-        (grec, gidx, _), = g.gathered(4)
-        assert grec.tobytes() == want[4].tobytes()
-        g.check(len(want[4]))
-        assert len(want[1]) > 0.8 * n and len(want[2]) < 0.05 * n       # far above and far below any fixed fraction
-    finally:
-        dist.destroy_process_group()
+        (grec, gidx, _), = g.gathered(step - 1)
+        assert grec.tobytes() == want[step - 1][0].tobytes(), f"tuples of step {step - 1}"
+        assert (gidx == want[step - 1][1]).all(), f"bitmap of step {step - 1}"
+g.finish()
+(grec, gidx, _), = g.gathered(4)
+assert grec.tobytes() == want[4][0].tobytes() and (gidx == want[4][1]).all()
+g.check(len(want[4][0]))
+assert len(want[1][0]) > 0.8 * n and len(want[2][0]) < 0.05 * n       # far above and far below any fixed fraction
+print("RCCL_GATHER_OK", [len(w[0]) for w in want])
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path):
+    """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
+    transfers) with one rank on this GPU, five steps with different reads: what rank 0 holds for every step equals the
+    decombined records of that step, tuple for tuple and bit for bit of the bitmap.  In a child process: torch has to
+    be imported before libdcrx there."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_GATHER_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, DCRX_ROOT=root), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_GATHER_OK" in out.stdout, out.stdout[-3000:]
 
 
 def test_compact_hits_matches_numpy():
