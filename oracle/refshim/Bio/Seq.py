@@ -44,3 +44,16 @@ class Seq:
 
     def reverse_complement(self):
         return Seq(self._data.translate(_TABLE)[::-1])
+
+    def translate(self):
+        """Standard table (NCBI 1), as Bio.Seq.translate() without arguments: '*' for stop codons, 'X' for a codon
+        with an ambiguous base that does not determine the residue, a trailing partial codon dropped (Biopython warns
+        and does the same)."""
+        s = self._data.upper().replace("U", "T")
+        bases = "TCAG"
+        aas = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+        table = {a + b + c: aas[16 * i + 4 * j + k] for i, a in enumerate(bases) for j, b in enumerate(bases) for k, c in enumerate(bases)}
+        out = []
+        for i in range(0, len(s) - len(s) % 3, 3):
+            out.append(table.get(s[i:i + 3], "X"))
+        return Seq("".join(out))
