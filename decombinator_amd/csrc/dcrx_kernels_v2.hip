@@ -132,7 +132,7 @@ __device__ __forceinline__ void v2_load_tile(const BatchDev &B, const uint32_t n
   }
 }
 
-template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW>
+template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count) {
@@ -163,11 +163,12 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   const int npairs = UNIFORM_LEN ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   uint32_t w[RPL][NW];
   uint64_t tile = blockIdx.x;
-  if (tile * TILE < B.n_reads) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
+  if (PREFETCH && tile * TILE < B.n_reads) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
   for (; tile * TILE < B.n_reads; tile += gridDim.x) {
     uint32_t wn[RPL][NW];
-    const bool more = (tile + gridDim.x) * TILE < B.n_reads;
-    if (more) v2_load_tile<NW, RPL>(B, nw, (tile + gridDim.x) * TILE, tid, wn);     // in flight while this tile is scanned
+    const bool more = PREFETCH && (tile + gridDim.x) * TILE < B.n_reads;
+    if (!PREFETCH) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
+    if (PREFETCH) { if (more) v2_load_tile<NW, RPL>(B, nw, (tile + gridDim.x) * TILE, tid, wn); }     // in flight while this tile is scanned
     uint32_t lg[RPL][NW];
     scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
 #pragma unroll
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         en = min(en + (uint32_t)__popcll(me0), Q.ecap);
       }
     }
-    if (more) {
+    if (PREFETCH && more) {
 #pragma unroll
       for (int q = 0; q < RPL; q++)
 #pragma unroll
@@ -265,7 +266,7 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
 // hand finds everything in registers.  What the lean form does not settle joins the region's
 // event entries (full waves in the event kernel, not two lanes here).
 template <bool UNIFORM_LEN, int NW>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, 8) void tail2_kernel(
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
@@ -370,13 +371,11 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
     const uint32_t en = min(Q.counts[2 * region + 1], Q.ecap);      // (the tail kernel's appends may have run past the region's end)
     const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
-    uint32_t x1[1 + 2 * NW];
-    v2_get_rows<1 + 2 * NW>(eq, Q.ecap, lane, (uint32_t)lane < en, x1);
+    // (no look-ahead here: this kernel needs its registers, and a spilled one would make every reload wait for
+    // the loads in flight; the other waves of the CU cover the entry loads)
     for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
       uint32_t x[1 + 2 * NW];
-#pragma unroll
-      for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
-      v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);        // the next batch, in flight during this one
+      v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + lane, first + lane < en, x);
       uint32_t lg[NW], w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
@@ -424,11 +423,11 @@ bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
   return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) <= 64u * 1024u;
 }
 
-template <bool UNIFORM, int NW, int RPL, bool NARROW>
+template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                             uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
                             unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW>;
+  auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
   auto kt = tail2_kernel<UNIFORM, NW>;
   auto ke = events2_kernel<UNIFORM, NW>;
   static bool seen[64];
@@ -482,7 +481,8 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
   int shape = (int)((cfg.flags >> 8) & 3u);
   if (shape == 0) shape = nw10 ? 2 : 3;      // two reads per lane (two independent chains per wave) where the registers allow: measured faster than one
 #define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
-#define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : DCRX_V2A(UN, NW_, 2, NA))
+#define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
+#define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
   if (nw10) {
     if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);
     return narrow ? DCRX_V2(false, 10, true) : DCRX_V2(false, 10, false);
@@ -491,6 +491,7 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
   return narrow ? DCRX_V2(false, DCRX_NWMAX, true) : DCRX_V2(false, DCRX_NWMAX, false);
 #undef DCRX_V2
 #undef DCRX_V2A
+#undef DCRX_V2X
 }
 
 // 16-byte rows the two lists need for batches of up to max_reads reads of `stride` bytes on n_cu compute units:
