@@ -55,7 +55,8 @@ struct dcrx_tables {
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
-  void *d_v2_tail = nullptr, *d_v2_events = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
+  void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
+  hipStream_t v2_side = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr;
   uint32_t *d_v2_counts = nullptr;
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
@@ -71,7 +72,12 @@ struct dcrx_tables {
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
-  t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr;
+  (void)hipFree(t->d_v2_slow);
+  if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
+  if (t->v2_ev_fork) (void)hipEventDestroy(t->v2_ev_fork);
+  if (t->v2_ev_join) (void)hipEventDestroy(t->v2_ev_join);
+  t->v2_side = nullptr; t->v2_ev_fork = t->v2_ev_join = nullptr;
+  t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
   t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
@@ -211,15 +217,27 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     // entries; an entry carries the read's packed words, so the size follows the stride
     uint64_t tr = 0, er = 0;
     v2_list_rows(max_reads, stride, t->plan.n_cu, &tr, &er);
-    if (tr > t->plan.v2_tail_rows || er > t->plan.v2_event_rows) {
-      (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
-      t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr;
-      t->plan.v2_tail = nullptr; t->plan.v2_events = nullptr; t->plan.v2_tail_rows = t->plan.v2_event_rows = 0;
+    if (tr > t->plan.v2_tail_rows || er > t->plan.v2_event_rows || v2_slow_rows(max_reads, stride, t->plan.n_cu) > t->plan.v2_slow_rows) {
+      (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts); (void)hipFree(t->d_v2_slow);
+      t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
+      t->plan.v2_tail = nullptr; t->plan.v2_events = nullptr; t->plan.v2_slow = nullptr;
+      t->plan.v2_tail_rows = t->plan.v2_event_rows = t->plan.v2_slow_rows = 0;
+      const uint64_t sr = v2_slow_rows(max_reads, stride, t->plan.n_cu);
       HIP_TRY(hipMalloc(&t->d_v2_tail, tr * 16));
       HIP_TRY(hipMalloc(&t->d_v2_events, er * 16));
-      HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 8));
+      HIP_TRY(hipMalloc(&t->d_v2_slow, sr * 16));
+      HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 16));
       t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
-      t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er;
+      t->plan.v2_slow = reinterpret_cast<uint4 *>(t->d_v2_slow);
+      t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;
+      if (!t->v2_side) {     // the event kernel's stream and the two events that fork it off the caller's stream and join it back
+        if (hipStreamCreateWithFlags(&t->v2_side, hipStreamNonBlocking) != hipSuccess) t->v2_side = nullptr;
+        if (t->v2_side && (hipEventCreateWithFlags(&t->v2_ev_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&t->v2_ev_join, hipEventDisableTiming) != hipSuccess)) {
+          (void)hipStreamDestroy(t->v2_side); t->v2_side = nullptr;
+        }
+      }
+      t->plan.v2_side = t->v2_side; t->plan.v2_ev_fork = t->v2_ev_fork; t->plan.v2_ev_join = t->v2_ev_join;
     }
   }
   if (t->ws_dirty) {

@@ -52,8 +52,9 @@ constexpr int DCRX_V2_FBLOCK = 256;
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
   uint4 *events;      // [regions][rows_e][ecap]
-  uint32_t *counts;   // [regions][2]
-  uint32_t tcap, ecap;
+  uint4 *slow;        // [regions][rows_e][scap]: event entries the tail kernel makes of what its lean form does not settle
+  uint32_t *counts;   // [regions][4]: tail entries, event entries, slow entries, -
+  uint32_t tcap, ecap, scap;
 };
 template <int NW>
 struct V2Rows {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         for (int k = 0; k < NW; k++) w[q][k] = wn[q][k];
     }
   }
-  if (lane == 0) { Q.counts[2 * region] = tn; Q.counts[2 * region + 1] = en; }
+  if (lane == 0) { Q.counts[4 * region] = tn; Q.counts[4 * region + 1] = en; Q.counts[4 * region + 2] = 0u; }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -260,11 +261,11 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
   return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
 }
 
-// The tail kernel: one wave per region, 256-thread blocks at eight waves per SIMD (the lean form
-// needs few registers, and what it waits for is memory).  Software pipeline over the batches of 64:
+// The tail kernel: DCRX_V2_TSPLIT waves per region, 256-thread blocks, no register spills (a spill
+// reload would wait for the loads in flight).  Software pipeline over the batches of 64:
 // the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
-// hand finds everything in registers.  What the lean form does not settle joins the region's
-// event entries (full waves in the event kernel, not two lanes here).
+// hand finds everything in registers.  What the lean form does not settle becomes an entry of the
+// region's slow list (full waves in a later event-kernel launch, not two lanes here).
 template <bool UNIFORM_LEN, int NW>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
@@ -289,9 +290,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
   for (uint32_t job = gwave; job < n_regions * DCRX_V2_TSPLIT; job += n_gwaves) {
     const uint32_t region = job / DCRX_V2_TSPLIT, part = job % DCRX_V2_TSPLIT;
-    const uint32_t tn = Q.counts[2 * region];
+    const uint32_t tn = Q.counts[4 * region];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
-    uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
+    uint4 *eq = Q.slow + (size_t)region * Q.scap * V2Rows<NW>::E;
     constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
@@ -314,13 +315,13 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
       }
       v2_tally(lds_counts, lane, status, o == 0);
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
-      if (ms) {      // the region's event list is shared by the waves of the region: one atomic per batch that has such reads
+      if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[2 * region + 1], (uint32_t)__popcll(ms));
+        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 2], (uint32_t)__popcll(ms));
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == TAIL2_SLOW) {
-          if (at < Q.ecap) {
+          if (at < Q.scap) {
             // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
             const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
             uint32_t y[1 + 2 * NW];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
               if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
               y[1 + k] = l; y[1 + NW + k] = w[k];
             }
-            v2_put_rows<1 + 2 * NW>(eq, Q.ecap, at, y);
+            v2_put_rows<1 + 2 * NW>(eq, Q.scap, at, y);
           } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
         }
       }
@@ -347,12 +348,15 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
 template <bool UNIFORM_LEN, int NW>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, int which, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   V2Ori V = T0.v2[0];
   if (o) V = T0.v2[1];
+  // which: 0 = the scan kernel's event entries, 1 = the tail kernel's slow entries
+  const uint4 *list = which ? Q.slow : Q.events;
+  const uint32_t lcap = which ? Q.scap : Q.ecap;
   uint32_t *lds_counts = smem;
   uint32_t *lds_side = smem + DCRX_N_COUNTERS;
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
@@ -369,13 +373,13 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
   for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
-    const uint32_t en = min(Q.counts[2 * region + 1], Q.ecap);      // (the tail kernel's appends may have run past the region's end)
-    const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
+    const uint32_t en = min(Q.counts[4 * region + 1 + which], lcap);      // (the tail kernel's appends may have run past the region's end)
+    const uint4 *eq = list + (size_t)region * lcap * V2Rows<NW>::E;
     // (no look-ahead here: this kernel needs its registers, and a spilled one would make every reload wait for
     // the loads in flight; the other waves of the CU cover the entry loads)
     for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
       uint32_t x[1 + 2 * NW];
-      v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + lane, first + lane < en, x);
+      v2_get_rows<1 + 2 * NW>(eq, lcap, first + lane, first + lane < en, x);
       uint32_t lg[NW], w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
@@ -417,7 +421,7 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // The v2 kernels serve one frame; the A/B switches of the three-launch form, the forced slow
 // reader and orientation `both` keep that form.
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
-  if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events) return false;
+  if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) <= 64u * 1024u;
@@ -449,11 +453,12 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // each wave of the scan kernel owns a region of the two lists sized for the reads it can meet
   const uint64_t per_wave = ((n_tiles + grid - 1) / grid) * 64ull * RPL;
   V2Lists Q;
-  Q.tail = P.v2_tail; Q.events = P.v2_events; Q.counts = P.v2_counts;
+  Q.tail = P.v2_tail; Q.events = P.v2_events; Q.slow = P.v2_slow; Q.counts = P.v2_counts;
   const uint32_t n_regions = grid * (DCRX_V2_BLOCK / 64);
   Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions);
   Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions);
-  if (Q.tcap < 64 || Q.ecap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  Q.scap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_slow_rows / V2Rows<NW>::E / n_regions);
+  if (Q.tcap < 64 || Q.ecap < 64 || Q.scap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, queue, gqueue, qcap,
                      queue_count);
@@ -461,13 +466,29 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (e != hipSuccess) return e;
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
+    // Event kernel, tail kernel, then the slow entries the tail kernel made through the event kernel again.  (Running
+    // the first two side by side — the event kernel on the handle's side stream, DCRX_F_V2_FORK — was measured
+    // slower: 0.70 against 0.63 ms per step; kept for A/B.)
     const uint32_t fgrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-    hipLaunchKernelGGL(kt, dim3(fgrid * DCRX_V2_TSPLIT), dim3(DCRX_V2_FBLOCK), v2_finish_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, n_regions,
-                       queue, gqueue, qcap, queue_count);
+    const uint32_t flds = v2_finish_lds_bytes(T, o);
+    const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
+    hipStream_t se = fork ? P.v2_side : s;
+    if (fork) {
+      e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(se, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, se, T, B, cfg, rec, d_counters, Q, 0, n_regions, queue, gqueue, qcap,
+                       queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), v2_finish_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, n_regions,
-                       queue, gqueue, qcap, queue_count);
+    if (fork) { e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kt, dim3(fgrid * DCRX_V2_TSPLIT), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue,
+                       qcap, queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (fork) { e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, 1, n_regions, queue, gqueue, qcap,
+                       queue_count);
     e = hipGetLastError();
   }
   return e;
@@ -502,6 +523,11 @@ void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *
   const uint64_t entries = max_reads + max_reads / 8 + (uint64_t)n_cu * 16 * 256;
   *tail_rows = entries * rt;
   *event_rows = (entries / 2) * re;
+}
+// ... and for the tail kernel's slow list: an eighth of the reads, at least 256 entries per region
+uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu) {
+  const uint64_t re = stride <= 40 ? V2Rows<10>::E : V2Rows<DCRX_NWMAX>::E;
+  return (max_reads / 8 + (uint64_t)n_cu * 16 * 256) * re;
 }
 
 }  // namespace dcrx

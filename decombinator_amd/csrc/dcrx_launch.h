@@ -23,7 +23,10 @@ struct LaunchPlan {
   uint32_t reserved_cus = 0; // compute units the persistent grids leave free (dcrx_set_reserved_cus)
   // v2 kernels: the per-wave lists between the scan and the finishing kernel (device memory of the tables handle)
   uint4 *v2_tail = nullptr; uint4 *v2_events = nullptr; uint32_t *v2_counts = nullptr;
-  uint64_t v2_tail_rows = 0, v2_event_rows = 0;       // 16-byte rows allocated for either list
+  uint4 *v2_slow = nullptr;
+  uint64_t v2_tail_rows = 0, v2_event_rows = 0, v2_slow_rows = 0;       // 16-byte rows allocated for each list
+  hipStream_t v2_side = nullptr;                      // the event kernel runs here, beside the tail kernel
+  hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr;
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
@@ -31,6 +34,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
                             uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 // dcrx_kernels_v2.hip
 void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *tail_rows, uint64_t *event_rows);
+uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu);
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg);
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                          uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
