@@ -48,6 +48,8 @@ static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B,
 
 static uint64_t g_v2_lean = 0;    // ... of them settled by the lean tail
 extern "C" uint64_t emul_v2_lean(void) { const uint64_t v = g_v2_lean; g_v2_lean = 0; return v; }
+static uint64_t g_v2_stats[64];  // [what] ; 8 + min(#events, 15) ; 24 + kind of event entry; 32 + status of event entries
+extern "C" void emul_v2_stats(uint64_t *out) { for (int i = 0; i < 64; i++) { out[i] = g_v2_stats[i]; g_v2_stats[i] = 0; } }
 static uint64_t g_v2_reads = 0;   // reads that took the v2 form since the last emul_v2_reads() call
 extern "C" uint64_t emul_v2_reads(void) { const uint64_t v = g_v2_reads; g_v2_reads = 0; return v; }
 
@@ -76,6 +78,7 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
   const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg[0], n >> 1) : 0u;
   int what = classify2(d, bnd);
   if (exc && what != V2_VNONE) what = V2_EVENTS;
+  g_v2_stats[what]++;
   if (what == V2_VNONE || what == V2_VMULTI) {
     dcrx_record_t rec;
     std::memset(&rec, 0, sizeof rec);
@@ -105,6 +108,14 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     return finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, jmulti, 0, 0, CC, records) ? FAST_DONE : FAST_TO_RESCUE;
   }
   if (!events2<NW>(lg[0], d, exc ? 0xFu : bnd, ev)) return exc ? FAST_TO_GENERAL : FAST_TO_RESCUE;
+  {
+    const Events2 E{(uint64_t)ev[0] | ((uint64_t)ev[1] << 32), ev[2]};
+    g_v2_stats[8 + E.count()]++;
+    g_v2_stats[24 + (d.vf_n == 1 ? 0 : 1) + (d.jf_n == 1 ? 0 : (d.jf_n == 0 ? 2 : 4))]++;   // 24 V1 J1(bnd) ; 25 V0 J1 ; 26 V1 J0 ; 27 V0 J0 ; 28/29 J multi
+    const bool ok = finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, false, x0, x1, CC, records);
+    if (ok) g_v2_stats[32 + (records[r].status < 30 ? records[r].status : 30)]++; else g_v2_stats[63]++;
+    return ok ? FAST_DONE : (exc ? FAST_TO_GENERAL : FAST_TO_RESCUE);
+  }
   return finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, false, x0, x1, CC, records) ? FAST_DONE : (exc ? FAST_TO_GENERAL : FAST_TO_RESCUE);
 }
 
