@@ -96,13 +96,15 @@ namespace dcrx {
 // The side-table pointers of `T`, re-pointed at an LDS copy: `lds_side` holds the bytes
 // image[side_off .. lds_image_bytes) (side_off = 0: the whole image, DFA first; side_off =
 // dfa_bytes: only the side tables, as the two-bases-per-step kernel stages them).
-DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_side, uint32_t side_off) {
+// `ext`: the extended image (up to lds_image2_bytes: the packed germline regions) was staged as well.
+DCRX_DEV DevTables tables_in_lds(const DevTables &T, const uint8_t *lds_side, uint32_t side_off, bool ext = false) {
   DevTables L = T;
 #define DCRX_MV(p) L.p = reinterpret_cast<decltype(L.p)>(lds_side + ((reinterpret_cast<const uint8_t *>(T.p) - T.image) - side_off))
   DCRX_MV(st_full); DCRX_MV(st_out); DCRX_MV(outs); DCRX_MV(kw_base); DCRX_MV(kw_first); DCRX_MV(kw_begin); DCRX_MV(kw_tags);
   for (int g = 0; g < 2; g++) {
     DCRX_MV(g[g].tag_len); DCRX_MV(g[g].jump); DCRX_MV(g[g].tag_pk_fwd); DCRX_MV(g[g].tag_pk_rc);
     DCRX_MV(g[g].w64_fwd); DCRX_MV(g[g].w64_rc); DCRX_MV(g[g].w64_ok); DCRX_MV(g[g].reg_len);
+    if (ext) { DCRX_MV(g[g].reg_pk_off); DCRX_MV(g[g].reg_clean); DCRX_MV(g[g].reg_pk); DCRX_MV(g[g].reg_pk_rc); }
   }
 #undef DCRX_MV
   return L;
@@ -152,6 +154,7 @@ struct ReadView {
 template <bool REV>
 struct Frame {
   static constexpr bool kRev = REV;
+  static constexpr bool kWindowedWalks = false;   // the walks go window by window past the first 23 steps (the v2 event kernel's frame does; here the code is not worth its registers)
   const ReadView &r;
   DCRX_DEVNI explicit Frame(const ReadView &rv) : r(rv) {}
   // an exception byte 'N' (as the frame shows it) at frame positions [lo, hi)
@@ -194,6 +197,15 @@ struct Frame {
       if (x >= 0) { uint8_t b = r.exc_chr[x]; return REV ? r.comp[b] : b; }
     }
     return (uint8_t)("ACGT"[code(i)]);
+  }
+  // the exception bytes among the stored bases [b, b + 32): bit 2s for base b + s (the slots of load64(b))
+  DCRX_DEV uint64_t exc_slots(int b) const {
+    uint64_t m = 0;
+    for (int x = r.e0; x < r.e1; x++) {
+      const int d = (int)r.exc_pos[x] - b;
+      if (d >= 0 && d < 32) m |= 1ull << (2 * d);
+    }
+    return m;
   }
   // 2*len bits of the packed forward read covering frame positions [a, a+len);
   // caller guarantees 0 <= a, a+len <= n, len <= 16, no exception inside.
@@ -249,6 +261,22 @@ DCRX_DEV int first_clean_down(uint64_t z, int k0) {
   return cand ? 31 - ((63 - dcrx_clz64(cand)) >> 1) : -1;
 }
 
+// the same with an upper bound: smallest k in [k0, k1] (k1 <= 22)
+DCRX_DEV int first_clean_up_range(uint64_t z, int k0, int k1) {
+  if (k0 > k1 || k0 > 22) return -1;
+  const uint64_t allowed = (0x5555555555555555ull >> (2 * k0) << (2 * k0)) & ((1ull << (2 * (k1 + 1))) - 1ull);
+  const uint64_t cand = ~z & allowed;
+  return cand ? (dcrx_ctz64(cand) >> 1) : -1;
+}
+DCRX_DEV int first_clean_down_range(uint64_t z, int k0, int k1) {
+  if (k0 > k1 || k0 > 22) return -1;
+  // window k = slots 22-k .. 31-k: its top slot 31-k runs from 31-k0 down to 31-k1 (>= 9)
+  const uint64_t upto = (k0 == 0) ? ~0ull : ((1ull << (2 * (32 - k0))) - 1ull);
+  const uint64_t allowed = 0x5555555555555555ull & upto & ~((1ull << (2 * (31 - k1))) - 1ull);
+  const uint64_t cand = ~z & allowed;
+  return cand ? 31 - ((63 - dcrx_clz64(cand)) >> 1) : -1;
+}
+
 // Walks a read's exception list in frame order while a scan advances: hit(i) is true
 // exactly when frame position i holds an exception byte.  One list load per exception,
 // none per symbol.
@@ -288,6 +316,14 @@ DCRX_DEV uint32_t packed_window(const uint32_t *pk, int base_pos, int len) {
   return v & ((len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u));
 }
 
+// 32 bases of a packed region from base b (b + 32 <= region length)
+DCRX_DEV uint64_t packed_window64(const uint32_t *pk, int b) {
+  const int i = b >> 4, sh = (b & 15) * 2;
+  const uint32_t w0 = pk[i], w1 = pk[i + 1];
+  const uint32_t w2 = sh ? pk[i + 2] : 0u;
+  return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+}
+
 // G[ga:gb] == read[ra:rb] with Python slice semantics (the comparisons at
 // decombine.py:769-772 and :802-805).
 template <class FR>
@@ -316,6 +352,12 @@ DCRX_DEVNI bool slice_eq(const GeneDevPtrs &G, int g, int ga, int gb, const FR &
   return true;
 }
 
+#if defined(DCRX_HOST_EMUL) && defined(DCRX_R2_REASONS)
+extern unsigned long long g_walk_steps[2];
+#define DCRX_WALK_STEP(g) (g_walk_steps[g]++)
+#else
+#define DCRX_WALK_STEP(g) ((void)0)
+#endif
 // get_v_deletions — decombine.py:749-785
 template <class FR>
 DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const FR &F, int v_match, int temp_end_v,
@@ -327,6 +369,7 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const FR &F, int v_match, 
   int pos = Lg - 10;                                        // :754-756
   if (f >= n) { C.add(DCRX_C_V_DEL_FAILED_TAG_AT_END); return false; }  // :760-762
   f += 1;                                                   // :764
+  int num_del0 = 0;
   // Bit-parallel form of the loop below for the common geometry: the first 23 iterations
   // only touch read[f-32:f] and the last 32 germline bases, all whole 10-mers of pure ACGT.
   if (f >= 32 && f < n && G.w64_ok[v_match] && F.clean(f - 32, f)) {
@@ -334,9 +377,48 @@ DCRX_DEVNI bool get_v_deletions(const GeneDevPtrs &G, const FR &F, int v_match, 
     const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[v_match] : G.w64_fwd[v_match]);
     const int k = REV ? first_clean_up(or10_up(y), 0) : first_clean_down(or10_down(y), 0);
     if (k >= 0) { deletions_v = k; end_v = temp_end_v - k; return true; }
+    num_del0 = 23;                                          // the 23 steps that window stands for have failed
   }
-  int num_del = 0;                                          // :765
+  // Further windows of 32 read bases along the same diagonal (read position x faces region position
+  // x + Lg - f): 23 steps each while a window fits between the read's start and the current position;
+  // then one window aligned with the read's start for the steps that are left (only its slots below the
+  // current position count).  An exception byte in a window is a mismatch (the region is pure ACGT).  What
+  // remains for the loop below are the steps whose slices leave the read or the region (Python's slice
+  // rules decide those) — a walk that runs far costs a few loads, not one round of loads per step.
+  if (FR::kWindowedWalks && f < n && Lg >= 32 && n >= 32 && G.reg_clean[v_match]) {
+    const uint32_t *gp = (REV ? G.reg_pk_rc : G.reg_pk) + G.reg_pk_off[v_match];
+    int d0 = num_del0;
+    for (;;) {
+      const int ft = f - d0;                               // the 10-mer of step d0 ends here
+      if (ft < 10 || Lg - d0 - 10 < 0) break;
+      const int we = ft >= 32 ? ft : 32;                   // window: frame positions [we - 32, we)
+      const int k0 = we - ft;
+      // region bases facing the window: [we - 32 + Lg - f, we + Lg - f), clamped into the region and shifted
+      uint64_t gw;
+      if (!REV) {
+        const int base = we - 32 + Lg - f;
+        if (base < 0) break;                               // the region's start: the loop below
+        const int b = base < Lg - 32 ? base : Lg - 32;
+        gw = packed_window64(gp, b) >> (2 * (base - b));
+      } else {
+        const int base = f - we;                           // in the reverse-complemented region
+        if (base + 32 > Lg) break;
+        const int b = base > 0 ? base : 0;
+        gw = packed_window64(gp, b) << (2 * (b - base));
+      }
+      const int sb = REV ? n - we : we - 32;               // the window in the stored read
+      const uint64_t y2 = mismatch_slots(F.load64(sb), gw) | (F.has_exc() ? F.exc_slots(sb) : 0ull);
+      const int k2 = REV ? first_clean_up(or10_up(y2), k0) : first_clean_down(or10_down(y2), k0);
+      if (k2 >= 0) { deletions_v = d0 + (k2 - k0); end_v = temp_end_v - deletions_v; return true; }
+      d0 += 23 - k0;
+      if (k0 > 0) break;                                   // that was the window at the read's start
+    }
+    num_del0 = d0;
+  }
+  int num_del = num_del0;                                   // :765 (the steps the windows above have settled are not repeated)
+  pos -= num_del0; f -= num_del0;
   while (0 <= f && f < n) {                                 // :767
+    DCRX_WALK_STEP(0);
     if (slice_eq(G, v_match, pos, pos + 10, F, f - 10, f)) {  // :769-772
       deletions_v = num_del;                                // :774
       end_v = temp_end_v - num_del;                         // :775
@@ -356,6 +438,7 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const FR &F, int j_match, 
   const int n = F.n();
   int f = temp_start_j;                                     // :792
   int pos = 0;                                              // :793
+  int p0 = 0;                                               // steps settled by the windows below
   // Bit-parallel form of the loop below while it stays inside read[ts:ts+32] and the first
   // 32 germline bases: skipped steps (f < end_of_v, :798-800) only raise the first position tried.
   if (f >= 0 && f + 32 <= n && G.w64_ok[j_match] && F.clean(f, f + 32)) {
@@ -364,8 +447,36 @@ DCRX_DEVNI bool get_j_deletions(const GeneDevPtrs &G, const FR &F, int j_match, 
     const uint64_t y = mismatch_slots(rw, REV ? G.w64_rc[j_match] : G.w64_fwd[j_match]);
     const int k = REV ? first_clean_down(or10_down(y), k0) : first_clean_up(or10_up(y), k0);
     if (k >= 0) { deletions_j = k; start_j = f + k; return true; }
+    p0 = 23;                                                // the 23 steps that window stands for have failed (or were skipped)
   }
+  // Further windows, as in get_v_deletions: read position x faces region position x - temp_start_j.  Only steps
+  // whose 10-mers lie inside the read and the region are settled here (a window that would pass the read's or
+  // the region's end is aligned with that end, and only its steps from the current one on count).
+  const int Lg = (int)G.reg_len[j_match];
+  if (FR::kWindowedWalks && f >= 0 && Lg >= 32 && n >= 32 && G.reg_clean[j_match]) {
+    const uint32_t *gp = (REV ? G.reg_pk_rc : G.reg_pk) + G.reg_pk_off[j_match];
+    const int last = (n - 10 - f < Lg - 10) ? n - 10 - f : Lg - 10;        // the last step with both 10-mers whole
+    while (p0 <= last) {
+      int ws = f + p0;                                     // window: frame positions [ws, ws + 32)
+      if (ws + 32 > n) ws = n - 32;
+      if (ws - f + 32 > Lg) ws = f + Lg - 32;              // ... and region positions [ws - f, ws - f + 32)
+      if (ws < 0 || ws + 32 > n) break;
+      const int k0a = f + p0 - ws;                         // the window's step of p0
+      const int k0b = end_of_v > ws ? end_of_v - ws : 0;   // steps before the end of V are passed over (:798-800)
+      const int k0 = k0a > k0b ? k0a : k0b;
+      const int k1 = last - (ws - f) < 22 ? last - (ws - f) : 22;
+      const uint64_t gw = packed_window64(gp, REV ? Lg - 32 - (ws - f) : ws - f);
+      const int sb = REV ? n - ws - 32 : ws;
+      const uint64_t y2 = mismatch_slots(F.load64(sb), gw) | (F.has_exc() ? F.exc_slots(sb) : 0ull);
+      const int k2 = REV ? first_clean_down_range(or10_down(y2), k0, k1) : first_clean_up_range(or10_up(y2), k0, k1);
+      if (k2 >= 0) { deletions_j = (ws - f) + k2; start_j = ws + k2; return true; }
+      p0 = (ws - f) + k1 + 1;
+    }
+  }
+  pos = p0; f += p0;
   while (0 <= f + 2 && f + 2 < n) {                         // :795
+    DCRX_WALK_STEP(1);
+    if (pos >= Lg && f >= 0) break;                         // region[pos:pos+10] is empty from here on and read[f:f+10] never is (f + 2 < n): no step can succeed
     if (f < end_of_v) { pos += 1; f += 1; }                 // :798-800
     else if (slice_eq(G, j_match, pos, pos + 10, F, f, f + 10)) {  // :802-805
       deletions_j = pos; start_j = f;                       // :807-808

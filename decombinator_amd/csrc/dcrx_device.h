@@ -110,6 +110,7 @@ struct DevTables {
                               // the staged table's LDS address inside a kernel
   uint32_t dfa_bytes;
   uint32_t lds_image_bytes;   // image[0 .. lds_image_bytes) = DFA + side tables: what the kernels stage in LDS
+  uint32_t lds_image2_bytes;  // image[lds_image_bytes .. lds_image2_bytes) = packed germline regions (+ offsets, purity flags) of both genes
   const uint8_t *image;       // start of the table blob (== trans)
   const uint32_t *trans;      // [n_states*4] transition entries
   const uint32_t *trans16;    // [n_states*16] two-bases-per-step entries (null when the automaton has > 4095 states)

@@ -25,12 +25,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "../../include/dcrx.h"
 #include "dcrx_device.h"
 #include "dcrx_launch.h"
 #include "dcrx_dcr_device.h"
 #include "dcrx_v2_device.h"
+#ifdef DCRX_DEBUG_PHASES
+namespace dcrx { __device__ unsigned long long g_dbg_phase2[16]; }
+#endif
 
 namespace dcrx {
 
@@ -41,6 +47,9 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #ifndef DCRX_V2_TSPLIT
 #define DCRX_V2_TSPLIT 2    /* waves of the tail kernel per region */
 #endif
+__device__ unsigned long long g_dbg_phase[8];   // debugging aid (DCRX_DEBUG_PHASES): longest time a wave of the event kernel spent per phase, in clock ticks
+constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
+constexpr uint32_t DCRX_V2_SLOW_GROUP_DEFAULT = 4;  // ... and what it takes of the slow list
 
 // ---- the lists: per wave of the scan kernel one region of tail entries and one of event entries ----
 // An entry carries the read's packed words (the scan kernel has them in registers), so that the
@@ -52,9 +61,10 @@ constexpr int DCRX_V2_FBLOCK = 256;
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
   uint4 *events;      // [regions][rows_e][ecap]
-  uint4 *slow;        // [regions][rows_e][scap]: event entries the tail kernel makes of what its lean form does not settle
-  uint32_t *counts;   // [regions][4]: tail entries, event entries, slow entries, -
-  uint32_t tcap, ecap, scap;
+  uint4 *slow;        // [regions][rows_e][scap]: slow list 1, the event entries the lean rescue does not settle
+  uint4 *slow2;       // [regions][rows_e][s2cap]: slow list 2, event entries the tail kernel makes of what its lean form does not settle
+  uint32_t *counts;   // [regions][4]: tail entries, event entries, entries of slow list 1, of slow list 2
+  uint32_t tcap, ecap, scap, s2cap;
 };
 template <int NW>
 struct V2Rows {
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         for (int k = 0; k < NW; k++) w[q][k] = wn[q][k];
     }
   }
-  if (lane == 0) { Q.counts[4 * region] = tn; Q.counts[4 * region + 1] = en; Q.counts[4 * region + 2] = 0u; }
+  if (lane == 0) { Q.counts[4 * region] = tn; Q.counts[4 * region + 1] = en; Q.counts[4 * region + 2] = 0u; Q.counts[4 * region + 3] = 0u; }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
     const uint32_t region = job / DCRX_V2_TSPLIT, part = job % DCRX_V2_TSPLIT;
     const uint32_t tn = Q.counts[4 * region];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
-    uint4 *eq = Q.slow + (size_t)region * Q.scap * V2Rows<NW>::E;
+    uint4 *eq = Q.slow2 + (size_t)region * Q.s2cap * V2Rows<NW>::E;
     constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
@@ -317,11 +327,11 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
       if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 2], (uint32_t)__popcll(ms));
+        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 3], (uint32_t)__popcll(ms));
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == TAIL2_SLOW) {
-          if (at < Q.scap) {
+          if (at < Q.s2cap) {
             // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
             const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
             uint32_t y[1 + 2 * NW];
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
               if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
               y[1 + k] = l; y[1 + NW + k] = w[k];
             }
-            v2_put_rows<1 + 2 * NW>(eq, Q.scap, at, y);
+            v2_put_rows<1 + 2 * NW>(eq, Q.s2cap, at, y);
           } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
         }
       }
@@ -342,21 +352,48 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
-// The event kernel: one wave per region; the general form (dcr_frame3) on reads held in registers,
-// their words loaded one batch ahead.  Reads with exception bytes are resolved against their slice
-// of the exception list.
+// counters of a wave's lean-rescue statuses (rescue2_count, by ballot)
+__device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int lane, const int status, const uint32_t errs, const bool forward) {
+  const bool done = status >= 0;
+  const unsigned long long m_all = __ballot(done);
+  if (!m_all) return;
+  auto cnt = [&](const bool c) { return (uint32_t)__popcll(__ballot(done && c)); };
+  const uint32_t n_ok = cnt(status == DCRX_S_OK), n_v1 = cnt(status == DCRX_S_V_HALF1_EXHAUSTED), n_v2 = cnt(status == DCRX_S_V_HALF2_EXHAUSTED),
+                 n_vn = cnt(status == DCRX_S_V_NONE), n_jm = cnt(status == DCRX_S_J_MULTI), n_jn = cnt(status == DCRX_S_J_NONE),
+                 n_j1 = cnt(status == DCRX_S_J_HALF1_EXHAUSTED), n_j2 = cnt(status == DCRX_S_J_HALF2_EXHAUSTED),
+                 n_tl = cnt(status == DCRX_S_F_TOOLONG), n_im = cnt(status == DCRX_S_F_IMPOSS_DEL), n_ov = cnt(status == DCRX_S_F_OVERLAP),
+                 e_v1 = cnt((errs & 1u) != 0u), e_v2 = cnt((errs & 2u) != 0u), e_j1 = cnt((errs & 4u) != 0u), e_j2 = cnt((errs & 8u) != 0u);
+  if (lane == 0) {
+    auto add = [&](const int c, const uint32_t k) { if (k) atomicAdd(&lds_counts[c], k); };
+    add(DCRX_C_READ_COUNT, (uint32_t)__popcll(m_all));
+    add(DCRX_C_VJ_COUNT, n_ok);
+    if (forward) add(DCRX_C_FRAME_FORWARD, n_ok);
+    add(DCRX_C_FOUNDV1NOTV2, n_v1);
+    add(DCRX_C_FOUNDV2NOTV1, n_v2 + n_j2);            // the reference bumps the V key for the exhausted J half-2 list (:526)
+    add(DCRX_C_NO_VTAGS_FOUND, n_vn);
+    add(DCRX_C_MULTIPLE_J_MATCHES, n_jm);
+    add(DCRX_C_NO_J_ASSIGNED, n_jn);
+    add(DCRX_C_FOUNDJ1NOTJ2, n_j1);
+    add(DCRX_C_VJ_ASSIGNMENT_FAILED, n_jm + n_jn + n_j1 + n_j2);
+    add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG, n_tl);
+    add(DCRX_C_DCRFILTER_IMPOSS_DELETION, n_im);
+    add(DCRX_C_DCRFILTER_TAG_OVERLAP, n_ov);
+    add(DCRX_C_VERR1, e_v1); add(DCRX_C_VERR2, e_v2); add(DCRX_C_JERR1, e_j1); add(DCRX_C_JERR2, e_j2);
+  }
+}
+
+// The lean rescue kernel: the scan kernel's event entries in straight-line code (rescue2_fast), one wave per
+// region, entries read one batch ahead.  What that form does not settle is copied to the region's slow list and
+// takes the general form in the event kernel's launch behind the tail kernel.
 template <bool UNIFORM_LEN, int NW>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, int which, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   V2Ori V = T0.v2[0];
   if (o) V = T0.v2[1];
-  // which: 0 = the scan kernel's event entries, 1 = the tail kernel's slow entries
-  const uint4 *list = which ? Q.slow : Q.events;
-  const uint32_t lcap = which ? Q.scap : Q.ecap;
   uint32_t *lds_counts = smem;
   uint32_t *lds_side = smem + DCRX_N_COUNTERS;
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
@@ -364,28 +401,133 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
   stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
-  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes);
+  uint32_t kw_base[K_NCLASS];
+#pragma unroll
+  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
+  const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1, kw_base);
+  __syncthreads();
+  const int lane = tid & 63;
+  const bool tagged = B.n_reads < (1ull << 30);
+  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
+  for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
+    const uint32_t en = min(Q.counts[4 * region + 1], Q.ecap);
+    const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
+    uint4 *sq = Q.slow + (size_t)region * Q.scap * V2Rows<NW>::E;
+    constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
+    uint32_t x1[1 + 2 * NW];
+    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(eq, Q.ecap, lane, lane < en, x1);
+    for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
+      uint32_t x[1 + 2 * NW];
+      if constexpr (AHEAD) {
+#pragma unroll
+        for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
+        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);     // the next batch, in flight during this one
+      } else {
+        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + lane, first + lane < en, x);
+      }
+      uint32_t lg[NW], w[NW];
+#pragma unroll
+      for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
+      int status = -2;
+      uint32_t errs = 0;
+      const uint32_t r = x[0] & V2_R_MASK;
+      if (first + lane < en) {
+        status = RESCUE2_SLOW;
+        if (!(x[0] & V2_R_EXC)) {
+          const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+          dcrx_record_t rec;
+          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+          status = o ? rescue2_fast<true, NW>(rt, w, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, w, lg, n, cfg, rec, errs);
+          if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
+          else errs = 0;
+        }
+      }
+      v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
+      const unsigned long long ms = __ballot(status == RESCUE2_SLOW);
+      if (ms) {      // (the tail kernel appends to the same list later, with atomics: the count is kept the same way)
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 2], (uint32_t)__popcll(ms));
+        base = __shfl(base, 0);
+        const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+        if (status == RESCUE2_SLOW) {
+          if (at < Q.scap) v2_put_rows<1 + 2 * NW>(sq, Q.scap, at, x);
+          else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, (x[0] & V2_R_EXC) != 0u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+
+// The event kernel: the general form (dcr_frame3) on reads held in registers.  Reads with exception bytes
+// are resolved against their slice of the exception list.  A block takes `group` consecutive regions at a
+// time and its waves the batches of 64 of their entries taken together (lane -> region and slot through the
+// prefix sums of the regions' counts): the slow list holds a handful of entries per region, and the
+// general form costs a wave the same whether 5 or 64 of its lanes are at work.
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, int which, uint32_t group, uint32_t width, uint32_t ext, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  V2Ori V = T0.v2[ORI];
+  // which: 0 = the scan kernel's event entries, 1 = slow list 1 (the lean rescue's leftovers), 2 = slow list 2 (the tail kernel's)
+  const uint4 *list = which == 0 ? Q.events : (which == 1 ? Q.slow : Q.slow2);
+  const uint32_t lcap = which == 0 ? Q.ecap : (which == 1 ? Q.scap : Q.s2cap);
+  // ext: the packed germline regions are staged behind the side tables (the launcher found room for them)
+  const uint32_t side_bytes = (ext ? T0.lds_image2_bytes : T0.lds_image_bytes) - T0.dfa_bytes;
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_side = smem + DCRX_N_COUNTERS;
+  uint32_t *lds_bk = lds_side + side_bytes / 4;
+  const int tid = threadIdx.x;
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, side_bytes / 16, 0, 0, tid);
+  stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
+  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes, ext != 0u);
   V.bk = reinterpret_cast<const uint8_t *>(lds_bk);
   __syncthreads();
   const Counters C{lds_counts};
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
   uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
-  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
-  for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
-    const uint32_t en = min(Q.counts[4 * region + 1 + which], lcap);      // (the tail kernel's appends may have run past the region's end)
-    const uint4 *eq = list + (size_t)region * lcap * V2Rows<NW>::E;
+  __shared__ uint32_t pref[DCRX_V2_GROUP_MAX + 1];
+  for (uint32_t g0 = blockIdx.x * group; g0 < n_regions; g0 += gridDim.x * group) {
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (uint32_t k = 0; k < group; k++) {
+        pref[k] = acc;
+        if (g0 + k < n_regions) acc += min(Q.counts[4 * (g0 + k) + 1 + which], lcap);     // (appends may have run past a region's end)
+      }
+      pref[group] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = pref[group];
     // (no look-ahead here: this kernel needs its registers, and a spilled one would make every reload wait for
     // the loads in flight; the other waves of the CU cover the entry loads)
-    for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
+    // `width` lanes of a wave take entries (64, or fewer for the slow list: the general form costs a wave the longest
+    // of its lanes' loops, and a short list is better spread over many waves than packed into a few)
+    const uint32_t dbg_skip = width >> 8;
+    width &= 0xFFu;
+    for (uint32_t first = width * (uint32_t)(tid >> 6); first < total && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += width * (DCRX_V2_FBLOCK / 64)) {
+      const uint32_t i = first + lane;
+      const bool live = (uint32_t)lane < width && i < total;
+      const unsigned long long tp0 = clock64();
+      unsigned long long tp1 = tp0, tp2 = tp0, tp3 = tp0;
+      uint32_t g = 0;
+      for (uint32_t k = 1; k < group; k++) g += i >= pref[k] ? 1u : 0u;
+      const uint32_t slot = i - pref[g];
+      const uint4 *eq = list + (size_t)(g0 + g) * lcap * V2Rows<NW>::E;
       uint32_t x[1 + 2 * NW];
-      v2_get_rows<1 + 2 * NW>(eq, lcap, first + lane, first + lane < en, x);
+      v2_get_rows<1 + 2 * NW>(eq, lcap, slot, live, x);
       uint32_t lg[NW], w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
-      if (first + lane < en) {
+      if (live) {
         const uint32_t r = x[0] & V2_R_MASK;
         const bool exc = (x[0] & V2_R_EXC) != 0u;
+        if (((dbg_skip & 1u) && exc) || ((dbg_skip & 2u) && !exc)) continue;      // (debugging aid, DCRX_SLOW_SKIP: records are NOT results)
         const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
         // the read's event list, from its flag log (a read with exception bytes keeps every flag: none is certain)
         const Digest2 d = digest2<NW>(lg);
@@ -393,6 +535,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
         uint32_t ev[3];
         const bool fits = events2<NW>(lg, d, exc ? 0xFu : bnd, ev);
         const uint4 e = make_uint4(x[0], ev[0], ev[1], ev[2]);
+        tp1 = clock64() + (ev[0] & 1u);
         if (!fits) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc); continue; }   // more flagged pairs than a list holds: the three-launch form
         int x0 = 0, x1e = 0;
         if (exc) {                      // the read's slice of the (sorted) exception list
@@ -401,11 +544,18 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
           x0 = (int)lo;
           while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
           x1e = (int)lo;
+          if (x1e - x0 > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); continue; }   // more exception bytes than the register frame holds
         }
-        if (finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1e, C, records)) {
+        tp2 = clock64() + ((uint32_t)x0 & 1u);
+        if (finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1e, C, records)) {
           if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
         } else {
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
+        }
+        tp3 = clock64();
+        if (dbg_skip & 4u) {
+          atomicMax(&g_dbg_phase[0], tp1 - tp0); atomicMax(&g_dbg_phase[1], tp2 - tp1); atomicMax(&g_dbg_phase[2], tp3 - tp2);
+          atomicAdd(&g_dbg_phase[4], tp1 - tp0); atomicAdd(&g_dbg_phase[5], tp2 - tp1); atomicAdd(&g_dbg_phase[6], tp3 - tp2); atomicAdd(&g_dbg_phase[7], 1ull);
         }
       }
     }
@@ -433,7 +583,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                             unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
   auto kt = tail2_kernel<UNIFORM, NW>;
-  auto ke = events2_kernel<UNIFORM, NW>;
+  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
+  auto kr = rescue2_kernel<UNIFORM, NW>;
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
@@ -443,9 +595,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
   }
   if (B.n_reads == 0) return hipSuccess;       // the prologue has zeroed the counters
-  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
   const uint64_t tile = (uint64_t)DCRX_V2_BLOCK * RPL;
   const uint64_t n_tiles = (B.n_reads + tile - 1) / tile;
@@ -457,8 +610,12 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const uint32_t n_regions = grid * (DCRX_V2_BLOCK / 64);
   Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions);
   Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions);
-  Q.scap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_slow_rows / V2Rows<NW>::E / n_regions);
-  if (Q.tcap < 64 || Q.ecap < 64 || Q.scap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  // the slow allocation holds both slow lists: list 1 sized like the event list, list 2 in what is left
+  Q.scap = Q.ecap;
+  Q.slow2 = Q.slow + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
+  const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
+  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_wave, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) : 0u;
+  if (Q.tcap < 64 || Q.ecap < 64 || Q.s2cap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, queue, gqueue, qcap,
                      queue_count);
@@ -466,30 +623,78 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (e != hipSuccess) return e;
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
-    // Event kernel, tail kernel, then the slow entries the tail kernel made through the event kernel again.  (Running
-    // the first two side by side — the event kernel on the handle's side stream, DCRX_F_V2_FORK — was measured
-    // slower: 0.70 against 0.63 ms per step; kept for A/B.)
+    // Lean rescue kernel (event entries), lean tail kernel (tail entries), and the general form (event kernel) for what
+    // they do not settle: the rescue kernel's leftovers (slow list 1), then — behind the tail kernel — the tail kernel's
+    // own (slow list 2).  DCRX_F_V2_FORK puts the first of the two beside the tail kernel on the handle's side stream
+    // (A/B: measured no faster, 0.646 against 0.641 ms per step).
     const uint32_t fgrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    static const uint32_t DCRX_V2_SLOW_GROUP = getenv("DCRX_SLOW_GROUP") ? std::min<uint32_t>(DCRX_V2_GROUP_MAX, std::max(1, atoi(getenv("DCRX_SLOW_GROUP")))) : DCRX_V2_SLOW_GROUP_DEFAULT;
+    const uint32_t sgrid = (n_regions + DCRX_V2_SLOW_GROUP - 1) / DCRX_V2_SLOW_GROUP;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
+    const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
+    const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
+    const uint32_t elds = ext ? elds_ext : flds;
+    static const uint32_t slow_width = (getenv("DCRX_SLOW_WIDTH") ? (uint32_t)atoi(getenv("DCRX_SLOW_WIDTH")) : 16u) | (getenv("DCRX_SLOW_SKIP") ? (uint32_t)atoi(getenv("DCRX_SLOW_SKIP")) << 8 : 0u);
     const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
     hipStream_t se = fork ? P.v2_side : s;
+    // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
+    if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)
+      hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, ext, n_regions, queue,
+                         gqueue, qcap, queue_count);
+    else
+      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue, qcap,
+                         queue_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
     if (fork) {
       e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(se, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, se, T, B, cfg, rec, d_counters, Q, 0, n_regions, queue, gqueue, qcap,
-                       queue_count);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (!(cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)) {
+      static const int reps = getenv("DCRX_SLOW_REPS") ? atoi(getenv("DCRX_SLOW_REPS")) : 1;      // (debugging aid: counters are NOT results when > 1)
+      for (int rep = 1; rep < reps; rep++)
+        hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+                           gqueue, qcap, queue_count);
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+                         gqueue, qcap, queue_count);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
     if (fork) { e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kt, dim3(fgrid * DCRX_V2_TSPLIT), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue,
                        qcap, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (fork) { e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, 1, n_regions, queue, gqueue, qcap,
-                       queue_count);
+    hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue, gqueue,
+                       qcap, queue_count);
     e = hipGetLastError();
+    if (slow_width & (4u << 8)) {          // debugging aid: phase times of the event kernel (synchronises)
+      unsigned long long h[8];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_phase), sizeof h);
+      fprintf(stderr, "dcrx event-kernel phases (ticks): max load+digest %llu exc search %llu finish %llu | mean %llu %llu %llu over %llu lanes\n", h[0], h[1], h[2],
+              h[7] ? h[4] / h[7] : 0, h[7] ? h[5] / h[7] : 0, h[7] ? h[6] / h[7] : 0, h[7]);
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_phase), z, sizeof z);
+#ifdef DCRX_DEBUG_PHASES
+      unsigned long long h2[16], z2[16] = {0};
+      (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_dbg_phase2), sizeof h2);
+      fprintf(stderr, "dcr_frame3 phases mean (sweep V, sweep J, vanalysis, janalysis, filters): %llu %llu %llu %llu %llu | max %llu %llu %llu %llu %llu\n",
+              h[7] ? h2[0] / h[7] : 0, h[7] ? h2[1] / h[7] : 0, h[7] ? h2[2] / h[7] : 0, h[7] ? h2[3] / h[7] : 0, h[7] ? h2[4] / h[7] : 0, h2[8], h2[9], h2[10], h2[11], h2[12]);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_phase2), z2, sizeof z2);
+#endif
+    }
+    static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
+    if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
+      std::vector<uint32_t> h(4 * (size_t)n_regions);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
+      unsigned long long t = 0, ev = 0, sl = 0, smax = 0;
+      unsigned long long sl2 = 0;
+      for (uint32_t r = 0; r < n_regions; r++) { t += h[4 * r]; ev += h[4 * r + 1]; sl += h[4 * r + 2]; sl2 += h[4 * r + 3]; smax = std::max<unsigned long long>(smax, h[4 * r + 2]); }
+      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu events %llu slow1 %llu (max per region %llu) slow2 %llu\n", n_regions, t, ev, sl, smax, sl2);
+    }
   }
   return e;
 }
@@ -524,10 +729,13 @@ void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *
   *tail_rows = entries * rt;
   *event_rows = (entries / 2) * re;
 }
-// ... and for the tail kernel's slow list: an eighth of the reads, at least 256 entries per region
+// ... and for the slow list (what the lean rescue and the lean tail do not settle): as many entries as the event list
 uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu) {
+  uint64_t tr, er;
+  v2_list_rows(max_reads, stride, n_cu, &tr, &er);
+  // ... plus the tail kernel's slow list: an eighth of the reads, at least 256 entries per region
   const uint64_t re = stride <= 40 ? V2Rows<10>::E : V2Rows<DCRX_NWMAX>::E;
-  return (max_reads / 8 + (uint64_t)n_cu * 16 * 256) * re;
+  return er + (max_reads / 8 + (uint64_t)n_cu * 16 * 256) * re;
 }
 
 }  // namespace dcrx

@@ -362,16 +362,23 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
     P.reg_len = as_off<uint32_t>(B.put(A.reg_len));
   }
   R.lds_image_bytes = (uint32_t)((B.bytes.size() + 15) & ~(size_t)15);
+  // extended image: the packed germline regions behind the side tables — the event kernel stages them as well when
+  // they fit (its exact walks read a region word per step)
+  for (int g = 0; g < 2; g++) {
+    GeneArrays &A = GA[g];
+    GeneDevPtrs &P = R.g[g];
+    P.reg_pk_off = as_off<uint32_t>(B.put(A.reg_pk_off));
+    P.reg_clean = as_off<uint8_t>(B.put(A.reg_clean));
+    P.reg_pk = as_off<uint32_t>(B.put(A.reg_pk));
+    P.reg_pk_rc = as_off<uint32_t>(B.put(A.reg_pk_rc));
+  }
+  R.lds_image2_bytes = (uint32_t)((B.bytes.size() + 15) & ~(size_t)15);
   for (int g = 0; g < 2; g++) {
     GeneArrays &A = GA[g];
     GeneDevPtrs &P = R.g[g];
     P.tag_ascii = as_off<uint8_t>(B.put(A.tag_ascii));
     P.reg_off = as_off<uint32_t>(B.put(A.reg_off));
     P.reg_bytes = as_off<uint8_t>(B.put(A.reg_bytes));
-    P.reg_pk_off = as_off<uint32_t>(B.put(A.reg_pk_off));
-    P.reg_pk = as_off<uint32_t>(B.put(A.reg_pk));
-    P.reg_pk_rc = as_off<uint32_t>(B.put(A.reg_pk_rc));
-    P.reg_clean = as_off<uint8_t>(B.put(A.reg_clean));
   }
   // two-bases-per-step table for the fast kernel (new numbering throughout)
   R.trans16 = nullptr; R.dfa16_bytes = 0; R.row16_0 = 0;

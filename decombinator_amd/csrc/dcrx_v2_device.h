@@ -260,12 +260,22 @@ DCRX_DEV void tail2_events(const uint32_t t, uint32_t (&ev)[3], bool &jmulti) {
 // the NW registers.  The finishing code of the v2 kernel works on this: one round of loads per
 // read, then no load at all.
 // ------------------------------------------------------------------------------
+constexpr int V2_MAX_EXC = 4;        // exception bytes of a read the register frame holds (a read with more takes the three-launch form)
 template <bool REV_, int NW>
 struct FrameReg {
   static constexpr bool kRev = REV_;
+  static constexpr bool kWindowedWalks = true;
   const uint32_t (&w)[NW];
-  const ReadView &r;       // length and exception list (r.words is not used)
-  DCRX_DEVNI FrameReg(const uint32_t (&words)[NW], const ReadView &rv) : w(words), r(rv) {}
+  const ReadView &r;       // length and complement table (r.words and the exception list are not read after construction)
+  // the read's exception bytes, loaded once: stored position (16 bits each) and byte (8 bits each) of up to V2_MAX_EXC
+  uint64_t xpos; uint32_t xchr; int nx;
+  DCRX_DEVNI FrameReg(const uint32_t (&words)[NW], const ReadView &rv) : w(words), r(rv), xpos(0), xchr(0), nx(rv.e1 - rv.e0) {
+#pragma unroll
+    for (int k = 0; k < V2_MAX_EXC; k++)
+      if (k < nx) { xpos |= (uint64_t)rv.exc_pos[rv.e0 + k] << (16 * k); xchr |= (uint32_t)rv.exc_chr[rv.e0 + k] << (8 * k); }
+  }
+  DCRX_DEV int xp(int k) const { return (int)((xpos >> (16 * k)) & 0xFFFFu); }
+  DCRX_DEV uint8_t xc(int k) const { return (uint8_t)((xchr >> (8 * k)) & 0xFFu); }
   DCRX_DEV int n() const { return r.n; }
   DCRX_DEV int fpos(int i) const { return REV_ ? r.n - 1 - i : i; }
   DCRX_DEV uint32_t word(int idx) const {        // 0 beyond the registers
@@ -279,33 +289,43 @@ struct FrameReg {
     const int c = (int)((word(m >> 4) >> ((m & 15) * 2)) & 3u);
     return REV_ ? (c ^ 3) : c;
   }
-  DCRX_DEVNI int exc_index(int i) const {
+  DCRX_DEV int exc_index(int i) const {          // index into the held exceptions, or -1
     const int m = fpos(i);
-    for (int x = r.e0; x < r.e1; x++)
-      if ((int)r.exc_pos[x] == m) return x;
-    return -1;
+    int at = -1;
+    for (int k = 0; k < nx; k++)
+      if (xp(k) == m) at = k;
+    return at;
   }
-  DCRX_DEV bool has_exc() const { return r.e1 > r.e0; }
+  DCRX_DEV bool has_exc() const { return nx > 0; }
   DCRX_DEV bool clean(int a, int b) const {
-    for (int x = r.e0; x < r.e1; x++) {
-      const int i = REV_ ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
-      if (i >= a && i < b) return false;
+    bool ok = true;
+    for (int k = 0; k < nx; k++) {
+      const int i = REV_ ? r.n - 1 - xp(k) : xp(k);
+      if (i >= a && i < b) ok = false;
     }
-    return true;
+    return ok;
+  }
+  DCRX_DEV uint64_t exc_slots(int b) const {      // exception bytes among the stored bases [b, b + 32): bit 2s for base b + s
+    uint64_t m = 0;
+    for (int k = 0; k < nx; k++) {
+      const int d = xp(k) - b;
+      if (d >= 0 && d < 32) m |= 1ull << (2 * d);
+    }
+    return m;
   }
   DCRX_DEVNI bool has_N(int lo, int hi) const {
     bool hasN = false;
-    for (int x = r.e0; x < r.e1; x++) {
-      const int i = REV_ ? r.n - 1 - (int)r.exc_pos[x] : (int)r.exc_pos[x];
-      const uint8_t b = REV_ ? r.comp[r.exc_chr[x]] : r.exc_chr[x];
+    for (int k = 0; k < nx; k++) {
+      const int i = REV_ ? r.n - 1 - xp(k) : xp(k);
+      const uint8_t b = REV_ ? r.comp[xc(k)] : xc(k);
       if (i >= lo && i < hi && b == (uint8_t)'N') hasN = true;
     }
     return hasN;
   }
   DCRX_DEVNI uint8_t chr(int i) const {
     if (has_exc()) {
-      const int x = exc_index(i);
-      if (x >= 0) { const uint8_t b = r.exc_chr[x]; return REV_ ? r.comp[b] : b; }
+      const int k = exc_index(i);
+      if (k >= 0) { const uint8_t b = xc(k); return REV_ ? r.comp[b] : b; }
     }
     return (uint8_t)("ACGT"[code(i)]);
   }
@@ -377,6 +397,14 @@ DCRX_DEVNI int v2_lookup(const V2Ori &V, const int cls, const uint64_t val) {
 // (the caller hands the read to the three-launch form).
 // jmulti: several pairs hold a J tag (tail entries; their pairs are not listed).
 // ------------------------------------------------------------------------------
+#if defined(DCRX_DEBUG_PHASES) && !defined(DCRX_HOST_EMUL)
+extern __device__ unsigned long long g_dbg_phase2[16];
+#define DCRX_PHASE(k) do { const unsigned long long t_ = clock64(); atomicAdd(&g_dbg_phase2[k], t_ - tph_); atomicMax(&g_dbg_phase2[8 + (k)], t_ - tph_); tph_ = t_; } while (0)
+#define DCRX_PHASE_INIT unsigned long long tph_ = clock64()
+#else
+#define DCRX_PHASE(k) ((void)0)
+#define DCRX_PHASE_INIT ((void)0)
+#endif
 constexpr int V2_MAX_HITS = 8;
 struct Hits2 {            // hits of one class in findall order: 32 bits each, keyword (class-local) << 16 | stored end base
   uint64_t a, b, c, d;    // slots 0-1, 2-3, 4-5, 6-7
@@ -396,6 +424,7 @@ struct Hits2 {            // hits of one class in findall order: 32 bits each, k
 template <class FR>
 DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const int nwords, const uint32_t (&ev_in)[3],
                           const bool jmulti, const CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
+  DCRX_PHASE_INIT;
   const Events2 E{(uint64_t)ev_in[0] | ((uint64_t)ev_in[1] << 32), ev_in[2]};   // scalars: an array picked with a lane-varying index would live in scratch memory
   constexpr bool REV = FR::kRev;
   const int n = F.n();
@@ -465,7 +494,9 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
     }
   };
   sweep(V2_F_VF, V2_F_VH, K_VFULL, K_VH1, K_VH2, Lvf, Lv1, Lv2, hvf, hv1, hv2);
+  DCRX_PHASE(0);
   sweep(V2_F_JF, V2_F_JH, K_JFULL, K_JH1, K_JH2, Ljf, Lj1, Lj2, hjf, hj1, hj2);
+  DCRX_PHASE(1);
   if (cfg.flags & DCRX_F_PROFILE_RESCUE_HITS_ONLY) {   // profiling aid: price the sweep alone (records are NOT results)
     rec.v = (uint16_t)(hvf.n + hjf.n + hv1.n + hv2.n + hj1.n + hj2.n); rec.j = (uint16_t)(hvf.a ^ hjf.a ^ hv1.a ^ hv2.a ^ hj1.a ^ hj2.a);
     return 254;
@@ -504,6 +535,7 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
     }
   }
   const int end_of_v = vdat.pos + 1;                                               // :547
+  DCRX_PHASE(2);
 
   // ---- janalysis ----
   int jstatus = DCRX_S_OK;
@@ -535,13 +567,16 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
       }
     }
   }
+  DCRX_PHASE(3);
   if (jstatus != DCRX_S_OK) { C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); return jstatus; }  // :583-585
-  return dcr_filters(T, F, vdat, jdat, cfg, C, rec);
+  const int fst = dcr_filters(T, F, vdat, jdat, cfg, C, rec);
+  DCRX_PHASE(4);
+  return fst;
 }
 
 // One read from its events to its record, the read's words loaded into registers once (NW words;
 // typed global loads on the device).  false: the read goes to the three-launch form (see dcr_frame3).  [x0, x1): the read's slice of the exception list (x0 == x1: a clean read).
-template <bool UNIFORM_LEN, int NW>
+template <bool UNIFORM_LEN, int NW, int ORI = -1>
 DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
                             const uint32_t (&w)[NW], const uint32_t (&ev)[3], const bool jmulti, const int x0, const int x1,
                             const Counters &C, dcrx_record_t *records);
@@ -579,7 +614,9 @@ DCRX_DEV bool finish2_reg(const DevTables &T, const V2Ori &V, const BatchDev &B,
   return finish2_words<UNIFORM_LEN, NW>(T, V, B, cfg, r, w, ev, jmulti, x0, x1, C, records);
 }
 
-template <bool UNIFORM_LEN, int NW>
+// ORI: -1 the frame cfg.orientation names, picked at run time; 0 / 1 only the forward / reverse frame's code (the
+// event kernel is instantiated per frame: half the code, and it is the code's size that a short list pays for)
+template <bool UNIFORM_LEN, int NW, int ORI>
 DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
                             const uint32_t (&w)[NW], const uint32_t (&ev)[3], const bool jmulti, const int x0, const int x1,
                             const Counters &C, dcrx_record_t *records) {
@@ -594,7 +631,7 @@ DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
   int status, frame;
-  if (cfg.orientation == DCRX_ORIENT_FORWARD) {
+  if (ORI == 0 || (ORI < 0 && cfg.orientation == DCRX_ORIENT_FORWARD)) {
     status = dcr_frame3(T, V, FrameReg<false, NW>(w, rv), (int)nw, ev, jmulti, cfg, C, rec); frame = 1;
   } else {
     status = dcr_frame3(T, V, FrameReg<true, NW>(w, rv), (int)nw, ev, jmulti, cfg, C, rec); frame = 0;
@@ -766,6 +803,316 @@ DCRX_DEV void tail2_count(const Counters &C, const int status, const bool forwar
   else if (status == DCRX_S_F_TOOLONG) C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG);
   else if (status == DCRX_S_F_IMPOSS_DEL) C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION);
   else if (status == DCRX_S_F_OVERLAP) C.add(DCRX_C_DCRFILTER_TAG_OVERLAP);
+}
+
+// ------------------------------------------------------------------------------
+// The lean rescue: an event entry whose V and J sides are each one of
+//   - one pair that holds the full tag (as the lean tail resolves it),
+//   - no full tag and at most four pairs with a half-tag flag: the half-tag rescue of
+//     vanalysis :292-394 / janalysis :420-531 on the hits of those pairs, in findall order,
+//   - (J only) no J flag at all, or several J-tag pairs,
+// finished without the general form's hit lists: per flagged pair one window of the stored read,
+// per base of the pair the bucket look-ups of the two half-tag classes; a half-1 hit tries its
+// candidate tags at once (Hamming <= 1 of the whole tag window, then the 32-base walk), half-2
+// hits wait in four register slots and are tried only when no half-1 keyword occurred (:337-339).
+// Everything else — exception bytes, a window that leaves the read, a walk the 32-base form does
+// not settle, a candidate that passes the Hamming test but whose walk fails (the reference then
+// goes on with the next candidate) — returns RESCUE2_SLOW with nothing decided and no counter
+// touched; the caller sends the entry to the general form (dcr_frame3).
+// `errs`: bits 0-1 the V rescue that succeeded (1 = second half matched: verr1, 2 = first half
+// matched: verr2), bits 2-3 likewise for J (jerr1 / jerr2) — the counters :318/:370/:445/:504.
+// ------------------------------------------------------------------------------
+struct Rescue2Tabs {
+  Tail2Tabs t;
+  dcrx_ldsaddr h_start[2][2], h_kw[2][2], h_pk[2][2];   // [gene][half - 1]: buckets of the half-tag classes (starts, class-local keyword, packed keyword)
+  dcrx_ldsaddr kw_begin, kw_tags;                        // keyword -> its tags, ascending (uint32 CSR)
+  dcrx_ldsaddr tag_pk[2];                                // uint64 per tag: the tag as the stored read shows it in this frame
+  uint32_t kw_base[2][2];                                // first global keyword id of the class
+  uint32_t Lh[2][2];                                     // keyword length of the class
+  int32_t split[2];
+};
+
+DCRX_DEV Rescue2Tabs rescue2_tabs(const DevTables &T0, const V2Ori &V0, const uint8_t *side, const uint8_t *bk, const bool rev,
+                                  const uint32_t (&kw_base)[K_NCLASS]) {
+  Rescue2Tabs r;
+  r.t = tail2_tabs(T0, V0, side, bk, rev);
+  auto at_side = [&](const void *p) { return dcrx_ldsaddr_of(side + ((reinterpret_cast<const uint8_t *>(p) - T0.image) - T0.dfa_bytes)); };
+  for (int g = 0; g < 2; g++) {
+    for (int h = 0; h < 2; h++) {
+      const int cls = g == 0 ? (h == 0 ? K_VH1 : K_VH2) : (h == 0 ? K_JH1 : K_JH2);
+      r.h_start[g][h] = dcrx_ldsaddr_of(bk + V0.bk_start_off[cls]);
+      r.h_kw[g][h] = dcrx_ldsaddr_of(bk + V0.bk_kw_off[cls]);
+      r.h_pk[g][h] = dcrx_ldsaddr_of(bk + V0.bk_pk_off[cls]);
+      r.kw_base[g][h] = kw_base[cls];
+      r.Lh[g][h] = T0.kw_len[cls];
+    }
+    r.tag_pk[g] = at_side(rev ? T0.g[g].tag_pk_rc : T0.g[g].tag_pk_fwd);
+    r.split[g] = T0.g[g].split;
+  }
+  r.kw_begin = at_side(T0.kw_begin);
+  r.kw_tags = at_side(T0.kw_tags);
+  return r;
+}
+
+constexpr int RESCUE2_SLOW = -1;
+#ifdef DCRX_R2_REASONS
+extern unsigned long long g_r2_reasons[32];
+#define R2S(k) (g_r2_reasons[k]++, RESCUE2_SLOW)
+#else
+#define R2S(k) RESCUE2_SLOW
+#endif
+
+// class-local keyword whose packed form is `val`, or -1
+DCRX_DEV int rescue2_lookup(const dcrx_ldsaddr start, const dcrx_ldsaddr kws, const dcrx_ldsaddr pk, const uint64_t val) {
+  const uint32_t h = v2_hash(val);
+  const uint32_t a = dcrx_lds_at<uint16_t>(start, h), b = dcrx_lds_at<uint16_t>(start, h + 1);
+  int kw = -1;
+  for (uint32_t i = a; i < b; i++)
+    if (dcrx_lds_at<uint64_t>(pk, i) == val) kw = (int)dcrx_lds_at<uint16_t>(kws, i);
+  return kw;
+}
+
+// The candidate tags of one half-tag hit (keyword gk of half HALF of gene G, starting at frame
+// position p): the first whose whole tag window is within Hamming distance 1 — the `indices`
+// loops of :298-317 / :342-369 / :425-444 / :476-503.  1 with k / q (tag start in the frame),
+// 0 none.
+template <bool REV, int NW, int G>
+DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const int n, const int half, const uint32_t gk,
+                                const int p, int &k_out, int &q_out) {
+  const int L = (int)rt.t.L[G];
+  const int q = half == 1 ? p : p - rt.split[G];
+  // a window that leaves the read: the reference's slice read[q:q+L] then comes out shorter than the tag (empty when q < 0
+  // and q + L >= 0, as n > L) and the candidates are passed over (:302-307 and siblings); q + L < 0 would wrap around
+  if (q + L < 0) return R2S(1);
+  if (q < 0 || q + L > n) return 0;
+  const int b = REV ? n - q - L : q;                           // where the window starts in the stored read
+  const int ws = min(b, n - 32);
+  const uint64_t mask = (1ull << (2 * L)) - 1ull;
+  const uint64_t val = (reg_stored64<NW>(w, ws) >> (2 * (b - ws))) & mask;
+  const uint32_t x0 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk), x1 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk + 1);
+  int found = 0;
+  for (uint32_t x = x0; x < x1 && !found; x++) {
+    const int k = (int)dcrx_lds_at<uint32_t>(rt.kw_tags, x);
+    const uint64_t y = mismatch_slots(val, dcrx_lds_at<uint64_t>(rt.tag_pk[G], (uint32_t)k)) & mask;
+    if (dcrx_popc64(y) <= 1) { found = 1; k_out = k; q_out = q; }
+  }
+  return found;
+}
+
+// The other flagged pairs of a read that has three or four (`mask8`: the flag's bit in every nibble;
+// `first` / `last`: bit positions 4 * pair + bit as the digest found them): the second and the second
+// last as bit positions (equal when there are three).
+template <int NW>
+DCRX_DEV void rescue2_mid_pairs(const uint32_t (&lg)[NW], const uint32_t mask8, const uint32_t first, const uint32_t last, uint32_t &second,
+                                uint32_t &second_last) {
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    uint32_t m = lg[kk] & mask8;
+    if ((first >> 5) == (uint32_t)kk) m &= ~(1u << (first & 31u));
+    if ((last >> 5) == (uint32_t)kk) m &= ~(1u << (last & 31u));
+    const uint32_t kb = (uint32_t)kk << 5;
+    lo = min(lo, (m ? (uint32_t)dcrx_ctz32(m) : 0xFFFFFFFFu) | kb);
+    hi = max(hi, m ? ((31u - (uint32_t)dcrx_clz32(m)) | kb) : 0u);
+  }
+  second = lo; second_last = hi;
+}
+
+// The half-tag rescue of gene G over its flagged pairs (cnt = 1 .. 4 pairs pp0 <= pp1 <= pp2 <= pp3 in
+// stored order, the first cnt of them valid).
+// 1: a candidate passed the Hamming test (k, q, p = the keyword's frame start, half); 0: none did
+// (half = the list the reference walks: 1 when a half-1 keyword occurred, else 2, 0 when no half-tag
+// keyword occurred at all); RESCUE2_SLOW.
+// One sweep in findall order: a half-1 hit tries its candidates at once and a success ends the sweep;
+// half-2 hits wait in four register slots and are tried only when no half-1 keyword occurred — the
+// reference consults the half-2 list only then (:337-339 / :471-473).
+template <bool REV, int NW, int G>
+DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const int n, const int cnt, const int pp0, const int pp1,
+                          const int pp2, const int pp3, int &k_out, int &q_out, int &p_out, int &half_out) {
+  const int L1 = (int)rt.Lh[G][0], L2 = (int)rt.Lh[G][1];
+  const uint64_t m1 = (1ull << (2 * L1)) - 1ull, m2 = (1ull << (2 * L2)) - 1ull;
+  uint64_t h2lo = 0, h2hi = 0;           // half-2 hits in findall order: slot i = (keyword + 1) << 16 | stored end base
+  int h2n = 0;
+  bool any1 = false;
+  int res = 0;
+  for (int t = 0; t < cnt && res == 0; t++) {
+    const int u = REV ? cnt - 1 - t : t;
+    const int pair = u == 0 ? pp0 : (u == 1 ? pp1 : (u == 2 ? pp2 : pp3));
+    const int f1 = 2 * pair + 1;                                 // the pair's second stored base
+    const int xs = f1 >= 31 ? f1 - 31 : 0;                       // window: stored bases [xs, xs + 32)
+    const uint64_t X = reg_stored64<NW>(w, xs);
+    for (int y = 0; y < 2 && res == 0; y++) {
+      const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
+      if (f >= n) continue;
+      const int s1 = f - L1 + 1, s2 = f - L2 + 1;
+      const int kw1 = s1 >= 0 ? rescue2_lookup(rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> (2 * (s1 - xs))) & m1) : -1;
+      const int kw2 = s2 >= 0 ? rescue2_lookup(rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> (2 * (s2 - xs))) & m2) : -1;
+      if (kw2 >= 0) {
+        const uint64_t e = ((uint64_t)(uint32_t)(kw2 + 1) << 16) | (uint64_t)(uint32_t)f;
+        if (h2n < 2) h2lo |= e << (32 * h2n); else if (h2n < 4) h2hi |= e << (32 * (h2n - 2));
+        h2n++;
+      }
+      if (kw1 >= 0) {
+        any1 = true;
+        const int p = REV ? n - s1 - L1 : s1;
+        res = rescue2_candidates<REV, NW, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
+        p_out = p;
+      }
+    }
+  }
+  half_out = 1;
+  if (res != 0 || any1) return res;
+  if (h2n > 4) return R2S(13);
+  half_out = h2n ? 2 : 0;
+  for (int i = 0; i < h2n && res == 0; i++) {
+    const uint32_t e = (uint32_t)((i < 2 ? h2lo : h2hi) >> (32 * (i & 1)));
+    const int f = (int)(e & 0xFFFFu), kw2 = (int)(e >> 16) - 1;
+    const int s2 = f - L2 + 1;
+    const int p = REV ? n - s2 - L2 : s2;
+    res = rescue2_candidates<REV, NW, G>(rt, w, n, 2, rt.kw_base[G][1] + (uint32_t)kw2, p, k_out, q_out);
+    p_out = p;
+  }
+  return res;
+}
+
+template <bool REV, int NW>
+DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
+                          dcrx_record_t &rec, uint32_t &errs) {
+  const Tail2Tabs &tt = rt.t;
+  const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
+  errs = 0;
+  if (n < 32 || Lv > 31 || Lj > 31) return R2S(2);
+  // ---- what the flag log holds: per kind the number of pairs, the first and (half tags) the last ----
+  uint32_t vfn = 0, jfn = 0, vhn = 0, jhn = 0, vf1 = 0xFFFFFFFFu, jf1 = 0xFFFFFFFFu, vh1 = 0xFFFFFFFFu, jh1 = 0xFFFFFFFFu, vhl = 0, jhl = 0;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    const uint32_t l = lg[kk];
+    const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u, hv = l & 0x44444444u, hj = l & 0x88888888u;
+    vfn += (uint32_t)dcrx_popc64(tv); jfn += (uint32_t)dcrx_popc64(tj); vhn += (uint32_t)dcrx_popc64(hv); jhn += (uint32_t)dcrx_popc64(hj);
+    const uint32_t kb = (uint32_t)kk << 5;
+    vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
+    jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
+    vh1 = min(vh1, (hv ? (uint32_t)dcrx_ctz32(hv) : 0xFFFFFFFFu) | kb);
+    jh1 = min(jh1, (hj ? (uint32_t)dcrx_ctz32(hj) : 0xFFFFFFFFu) | kb);
+    vhl = max(vhl, hv ? ((31u - (uint32_t)dcrx_clz32(hv)) | kb) : 0u);
+    jhl = max(jhl, hj ? ((31u - (uint32_t)dcrx_clz32(hj)) | kb) : 0u);
+  }
+  if ((n & 1) && log_nibble<NW>(lg, n >> 1)) return R2S(3);       // a flag on the half pair at the end of an odd-length read may not stand
+  if (vfn > 1 || (vfn == 0 && (vhn == 0 || vhn > 4)) || (jfn == 0 && jhn > 4)) return R2S(4);
+  const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
+
+  // ---- vanalysis ----
+  int v = -1, vp = 0, te = 0;
+  if (vfn == 1) {
+    const int vpair = (int)(vf1 >> 2);
+    const int sva = 2 * vpair - Lv + 1;
+    const int wsv = min(max(sva, 0), n - 32);
+    const uint64_t Wv = reg_stored64<NW>(w, wsv);
+    const bool oka = sva >= 0, okb = sva + 1 + Lv <= n;
+    const int ta = oka ? tail2_lookup(tt, 0, (Wv >> (2 * (sva - wsv))) & mv) : -1;
+    const int tb = okb ? tail2_lookup(tt, 0, (Wv >> (2 * (sva + 1 - wsv))) & mv) : -1;
+    if ((ta >= 0) == (tb >= 0)) return R2S(5);
+    v = ta >= 0 ? ta : tb;
+    const int sv = ta >= 0 ? sva : sva + 1;
+    vp = REV ? n - sv - Lv : sv;
+    te = vp + dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v) - 1;                       // :283-285
+  } else {
+    int k = 0, q = 0, p = 0, half = 0;
+    uint32_t a = vh1, b = vhl, c = vhl, d = vhl;          // ascending: the first, (second,) (second last,) last flagged pair
+    if (vhn > 2) { rescue2_mid_pairs<NW>(lg, 0x44444444u, vh1, vhl, b, c); }
+    if (vhn == 3) { c = vhl; }
+    const int res = rescue2_half<REV, NW, 0>(rt, w, n, (int)vhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    if (res < 0) return R2S(6);
+    if (res == 0) return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_V_HALF2_EXHAUSTED : DCRX_S_V_NONE);   // :334 / :389 / :393
+    v = k; vp = q;
+    const int jump = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)k);
+    te = half == 1 ? p + jump - 1 : p + jump - rt.split[0] - 1;                       // :320-322 / :372-377
+    errs |= half == 1 ? 2u : 1u;
+  }
+  const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
+  const int fv = te + 1;
+  if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return R2S(7);
+  const uint64_t rwv = reg_stored64<NW>(w, REV ? n - fv : fv - 32);
+  const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
+  const int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  if (kv < 0) return R2S(8);
+  const int end_v = te - kv;
+  const int end_of_v = end_v + 1;                                                     // :547
+
+  // ---- janalysis ----
+  if (jfn >= 2) return DCRX_S_J_MULTI;                                                // :402-404
+  int j = -1, jend = 0, ts = 0;
+  if (jfn == 1) {
+    const int jpair = (int)(jf1 >> 2);
+    const int sja = 2 * jpair - Lj + 1;
+    const int wsj = min(max(sja, 0), n - 32);
+    const uint64_t Wj = reg_stored64<NW>(w, wsj);
+    const bool oka = sja >= 0, okb = sja + 1 + Lj <= n;
+    const int ta = oka ? tail2_lookup(tt, 1, (Wj >> (2 * (sja - wsj))) & mj) : -1;
+    const int tb = okb ? tail2_lookup(tt, 1, (Wj >> (2 * (sja + 1 - wsj))) & mj) : -1;
+    if ((ta >= 0) == (tb >= 0)) return R2S(9);
+    j = ta >= 0 ? ta : tb;
+    const int sj = ta >= 0 ? sja : sja + 1;
+    const int jp = REV ? n - sj - Lj : sj;
+    ts = jp - dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);                          // :407-409
+    jend = jp + Lj;
+  } else {
+    if (jhn == 0) return DCRX_S_J_NONE;                                               // :530-531
+    int k = 0, q = 0, p = 0, half = 0;
+    uint32_t a = jh1, b = jhl, c = jhl, d = jhl;
+    if (jhn > 2) { rescue2_mid_pairs<NW>(lg, 0x88888888u, jh1, jhl, b, c); }
+    if (jhn == 3) { c = jhl; }
+    const int res = rescue2_half<REV, NW, 1>(rt, w, n, (int)jhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    if (res < 0) return R2S(10);
+    if (res == 0) return half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_J_HALF2_EXHAUSTED : DCRX_S_J_NONE);   // :469 / :526 / :530
+    j = k;
+    const int jump = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)k);
+    ts = half == 1 ? p - jump : p - jump - rt.split[1];                               // :447-449 / :506-510
+    jend = half == 1 ? p + (int)rt.Lh[1][0] + rt.split[1] : p + (int)rt.Lh[1][1];     // :450-454 / :511
+    errs |= half == 1 ? 8u : 4u;
+  }
+  const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
+  if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return R2S(11);
+  const uint64_t rwj = reg_stored64<NW>(w, REV ? n - ts - 32 : ts);
+  const int k0 = end_of_v > ts ? end_of_v - ts : 0;
+  const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
+  const int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  if (kj < 0) return R2S(12);
+  const int start_j = ts + kj;
+  // ---- filters :553-569 (a clean read holds no N) ----
+  if ((vp - jend) >= cfg.lenthreshold) return DCRX_S_F_TOOLONG;
+  if (kv > jumpv - Lv || kj > jumpj) return DCRX_S_F_IMPOSS_DEL;
+  if (vp + Lv > jend + Lj) return DCRX_S_F_OVERLAP;
+  int lo, hi;
+  pyslice(n, end_v + 1, start_j, lo, hi);                                             // read[vdat[1]+1 : jdat[1]] :577
+  rec.v = (uint16_t)v; rec.j = (uint16_t)j;
+  rec.v_start = (uint16_t)vp; rec.j_end = (uint16_t)jend;
+  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
+  rec.vdel = (uint8_t)kv; rec.jdel = (uint8_t)kj;
+  return DCRX_S_OK;
+}
+
+// the counters a status of the lean rescue stands for (besides read_count); errs as rescue2_fast leaves them
+DCRX_DEV void rescue2_count(const Counters &C, const int status, const uint32_t errs, const bool forward) {
+  C.add(DCRX_C_READ_COUNT);
+  if (errs & 1u) C.add(DCRX_C_VERR1);
+  if (errs & 2u) C.add(DCRX_C_VERR2);
+  if (errs & 4u) C.add(DCRX_C_JERR1);
+  if (errs & 8u) C.add(DCRX_C_JERR2);
+  switch (status) {
+    case DCRX_S_OK: C.add(DCRX_C_VJ_COUNT); if (forward) C.add(DCRX_C_FRAME_FORWARD); break;
+    case DCRX_S_V_HALF1_EXHAUSTED: C.add(DCRX_C_FOUNDV1NOTV2); break;
+    case DCRX_S_V_HALF2_EXHAUSTED: C.add(DCRX_C_FOUNDV2NOTV1); break;
+    case DCRX_S_V_NONE: C.add(DCRX_C_NO_VTAGS_FOUND); break;
+    case DCRX_S_J_MULTI: C.add(DCRX_C_MULTIPLE_J_MATCHES); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;
+    case DCRX_S_J_NONE: C.add(DCRX_C_NO_J_ASSIGNED); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;
+    case DCRX_S_J_HALF1_EXHAUSTED: C.add(DCRX_C_FOUNDJ1NOTJ2); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;
+    case DCRX_S_J_HALF2_EXHAUSTED: C.add(DCRX_C_FOUNDV2NOTV1); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;   // the reference bumps the V key (:526)
+    case DCRX_S_F_TOOLONG: C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG); break;
+    case DCRX_S_F_IMPOSS_DEL: C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION); break;
+    case DCRX_S_F_OVERLAP: C.add(DCRX_C_DCRFILTER_TAG_OVERLAP); break;
+    default: break;
+  }
 }
 
 }  // namespace dcrx

@@ -126,7 +126,8 @@ typedef struct dcrx_cfg {
 #define DCRX_F_PROFILE_NO_FINISH 128u /* profiling: the v2 kernel scans and sorts reads onto its stacks but finishes none of them (records are NOT results) */
 #define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
 #define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
-#define DCRX_F_V2_FORK 4096u         /* the v2 event kernel on a side stream beside the tail kernel instead of before it (A/B: measured slower) */
+#define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
+#define DCRX_F_V2_FORK 4096u         /* A/B: the general-form pass over the lean rescue's leftovers beside the tail kernel on the handle's side stream (measured no faster) */
 #define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
 #define DCRX_F_V2_SHAPE(k) ((uint32_t)(k) << 8) /* v2 kernel launch shape, A/B: 0 default, 2 = two reads per lane, 3 = one read per lane (one 1024-thread block per CU either way) */
 #define DCRX_F_ONE_BASE_SCAN 4u      /* use the one-base-per-step fast kernel even when the two-base table fits LDS (A/B, tests) */

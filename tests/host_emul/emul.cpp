@@ -6,6 +6,7 @@
 // the kernel's launch geometry, LDS staging, counter reduction and the real
 // ISA are only exercised by `pytest -m gpu`.
 #define DCRX_HOST_EMUL 1
+#define DCRX_R2_REASONS 1
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +49,10 @@ static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B,
 
 static uint64_t g_v2_lean = 0;    // ... of them settled by the lean tail
 extern "C" uint64_t emul_v2_lean(void) { const uint64_t v = g_v2_lean; g_v2_lean = 0; return v; }
+namespace dcrx { unsigned long long g_r2_reasons[32]; unsigned long long g_walk_steps[2]; }
+static unsigned long long g_walk_hist[2][16];
+extern "C" void emul_walk_hist(uint64_t *out) { for (int i = 0; i < 32; i++) { out[i] = g_walk_hist[i / 16][i % 16]; g_walk_hist[i / 16][i % 16] = 0; } }
+extern "C" void emul_r2_reasons(uint64_t *out) { for (int i = 0; i < 32; i++) { out[i] = dcrx::g_r2_reasons[i]; dcrx::g_r2_reasons[i] = 0; } }
 static uint64_t g_v2_stats[64];  // [what] ; 8 + min(#events, 15) ; 24 + kind of event entry; 32 + status of event entries
 extern "C" void emul_v2_stats(uint64_t *out) { for (int i = 0; i < 64; i++) { out[i] = g_v2_stats[i]; g_v2_stats[i] = 0; } }
 static uint64_t g_v2_reads = 0;   // reads that took the v2 form since the last emul_v2_reads() call
@@ -79,6 +84,7 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
   int what = classify2(d, bnd);
   if (exc && what != V2_VNONE) what = V2_EVENTS;
   g_v2_stats[what]++;
+  if (what == V2_EVENTS && x1 - x0 > V2_MAX_EXC) return FAST_TO_GENERAL;      // more exception bytes than the register frame holds
   if (what == V2_VNONE || what == V2_VMULTI) {
     dcrx_record_t rec;
     std::memset(&rec, 0, sizeof rec);
@@ -107,12 +113,31 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     tail2_events(tail2_pack(d), ev, jmulti);
     return finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, jmulti, 0, 0, CC, records) ? FAST_DONE : FAST_TO_RESCUE;
   }
+  if (!exc && !(C.flags & DCRX_F_V2_NO_LEAN_RESCUE)) {
+    // the lean rescue first (the kernel's order): what it settles is final
+    uint32_t kwb[K_NCLASS];
+    for (int c = 0; c < K_NCLASS; c++) kwb[c] = T.kw_base[c];
+    const Rescue2Tabs rt = rescue2_tabs(T, V, T.image + T.dfa_bytes, V.bk, o == 1, kwb);
+    dcrx_record_t rec;
+    std::memset(&rec, 0, sizeof rec);
+    uint32_t errs = 0;
+    const int st = o ? rescue2_fast<true, NW>(rt, w[0], lg[0], n, C, rec, errs) : rescue2_fast<false, NW>(rt, w[0], lg[0], n, C, rec, errs);
+    if (st >= 0) {
+      rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
+      records[r] = rec;
+      rescue2_count(CC, st, errs, o == 0);
+      g_v2_stats[62]++;
+      return FAST_DONE;
+    }
+  }
   if (!events2<NW>(lg[0], d, exc ? 0xFu : bnd, ev)) return exc ? FAST_TO_GENERAL : FAST_TO_RESCUE;
   {
     const Events2 E{(uint64_t)ev[0] | ((uint64_t)ev[1] << 32), ev[2]};
     g_v2_stats[8 + E.count()]++;
     g_v2_stats[24 + (d.vf_n == 1 ? 0 : 1) + (d.jf_n == 1 ? 0 : (d.jf_n == 0 ? 2 : 4))]++;   // 24 V1 J1(bnd) ; 25 V0 J1 ; 26 V1 J0 ; 27 V0 J0 ; 28/29 J multi
+    dcrx::g_walk_steps[0] = dcrx::g_walk_steps[1] = 0;
     const bool ok = finish2_reg<UNIFORM, NW>(T, V, B, C, r, ev, false, x0, x1, CC, records);
+    for (int g = 0; g < 2; g++) { unsigned long long st = dcrx::g_walk_steps[g]; int b = 0; while (st) { b++; st >>= 1; } g_walk_hist[g][b]++; }
     if (ok) g_v2_stats[32 + (records[r].status < 30 ? records[r].status : 30)]++; else g_v2_stats[63]++;
     return ok ? FAST_DONE : (exc ? FAST_TO_GENERAL : FAST_TO_RESCUE);
   }

@@ -13,7 +13,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for p in glob.glob(sys.argv[1]+"/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         k=r["Kernel_Name"].split("(")[0].split("<")[0]
-        if ("decombine" in k or "finish2" in k or "scan2" in k): agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if any(t in k for t in ("decombine", "rescue2", "tail2", "events2", "scan2")): agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items(): print("PMC flags="+sys.argv[2], k, {c: round(sum(x)/len(x)) for c,x in sorted(v.items())})
 PY
 done
