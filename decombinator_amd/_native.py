@@ -42,6 +42,8 @@ F_FORCE_SLOW_READER = 1
 F_PROFILE_SCAN_ONLY = 2
 F_ONE_BASE_SCAN = 4
 F_V1_KERNELS = 64        # the three-launch form even where the v2 kernel applies
+F_V2_NO_LEAN_RESCUE = 8192   # A/B and tests: event entries go to the general form at once (no lean rescue kernel)
+F_V2_FORK = 4096             # A/B: first general-form pass beside the tail kernel on the handle's side stream
 
 
 def F_V2_SHAPE(k):

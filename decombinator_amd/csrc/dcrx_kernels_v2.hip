@@ -34,9 +34,6 @@
 #include "dcrx_launch.h"
 #include "dcrx_dcr_device.h"
 #include "dcrx_v2_device.h"
-#ifdef DCRX_DEBUG_PHASES
-namespace dcrx { __device__ unsigned long long g_dbg_phase2[16]; }
-#endif
 
 namespace dcrx {
 
@@ -47,9 +44,15 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #ifndef DCRX_V2_TSPLIT
 #define DCRX_V2_TSPLIT 2    /* waves of the tail kernel per region */
 #endif
-__device__ unsigned long long g_dbg_phase[8];   // debugging aid (DCRX_DEBUG_PHASES): longest time a wave of the event kernel spent per phase, in clock ticks
+#ifndef DCRX_V2_TBLOCK
+#define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
+#define DCRX_V2_TWAVES 5        /* ... and the waves per SIMD it is compiled for */
+#endif
+#ifndef DCRX_LEAN_LDS_WORDS
+#define DCRX_LEAN_LDS_WORDS 1   /* the lean kernels keep the read in hand in LDS strips (0: in registers, A/B) */
+#endif
 constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
-constexpr uint32_t DCRX_V2_SLOW_GROUP_DEFAULT = 4;  // ... and what it takes of the slow list
+constexpr uint32_t DCRX_V2_SLOW_GROUP = 4;  // ... and what it takes of the slow list
 
 // ---- the lists: per wave of the scan kernel one region of tail entries and one of event entries ----
 // An entry carries the read's packed words (the scan kernel has them in registers), so that the
@@ -277,9 +280,9 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
 // hand finds everything in registers.  What the lean form does not settle becomes an entry of the
 // region's slow list (full waves in a later event-kernel launch, not two lanes here).
 template <bool UNIFORM_LEN, int NW>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
+__global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, uint32_t to_slow2, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
@@ -290,19 +293,26 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
-  stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
+  stage_lds<DCRX_V2_TBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+  stage_lds<DCRX_V2_TBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
   const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1);
+  // each lane's strip of LDS for the read in hand (its two zero words are written once)
+  uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
+  strip[NW] = 0u; strip[NW + 1] = 0u;
+  const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
   // DCRX_V2_TSPLIT waves share a region: wave k of them takes the batches k, k + DCRX_V2_TSPLIT, ...
-  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
+  const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
   for (uint32_t job = gwave; job < n_regions * DCRX_V2_TSPLIT; job += n_gwaves) {
     const uint32_t region = job / DCRX_V2_TSPLIT, part = job % DCRX_V2_TSPLIT;
     const uint32_t tn = Q.counts[4 * region];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
-    uint4 *eq = Q.slow2 + (size_t)region * Q.s2cap * V2Rows<NW>::E;
+    // what the lean form does not settle: slow list 1 behind the rescue kernel's leftovers, or (the event kernel's first pass
+    // running beside this kernel) slow list 2
+    const uint32_t scap = to_slow2 ? Q.s2cap : Q.scap;
+    uint4 *eq = (to_slow2 ? Q.slow2 : Q.slow) + (size_t)region * scap * V2Rows<NW>::E;
     constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
@@ -320,18 +330,25 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
         const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
         dcrx_record_t rec;
         rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-        status = o ? tail2_fast<true, NW>(tt, w, n, dg, cfg, rec) : tail2_fast<false, NW>(tt, w, n, dg, cfg, rec);
+#if DCRX_LEAN_LDS_WORDS
+#pragma unroll
+        for (int k = 0; k < NW; k++) strip[k] = w[k];
+        status = o ? tail2_fast<true>(tt, lw, n, dg, cfg, rec) : tail2_fast<false>(tt, lw, n, dg, cfg, rec);
+#else
+        const RegWords<NW> rw{w};
+        status = o ? tail2_fast<true>(tt, rw, n, dg, cfg, rec) : tail2_fast<false>(tt, rw, n, dg, cfg, rec);
+#endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
       }
       v2_tally(lds_counts, lane, status, o == 0);
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
       if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 3], (uint32_t)__popcll(ms));
+        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + (to_slow2 ? 3 : 2)], (uint32_t)__popcll(ms));
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == TAIL2_SLOW) {
-          if (at < Q.s2cap) {
+          if (at < scap) {
             // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
             const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
             uint32_t y[1 + 2 * NW];
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 5) void tail2_kernel(
               if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
               y[1 + k] = l; y[1 + NW + k] = w[k];
             }
-            v2_put_rows<1 + 2 * NW>(eq, Q.s2cap, at, y);
+            v2_put_rows<1 + 2 * NW>(eq, scap, at, y);
           } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
         }
       }
@@ -405,6 +422,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
 #pragma unroll
   for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
   const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1, kw_base);
+  uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();      // as in the tail kernel
+  strip[NW] = 0u; strip[NW + 1] = 0u;
+  const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
@@ -437,7 +457,14 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
           const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
           dcrx_record_t rec;
           rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-          status = o ? rescue2_fast<true, NW>(rt, w, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, w, lg, n, cfg, rec, errs);
+#if DCRX_LEAN_LDS_WORDS
+#pragma unroll
+          for (int k = 0; k < NW; k++) strip[k] = w[k];
+          status = o ? rescue2_fast<true, NW>(rt, lw, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, lw, lg, n, cfg, rec, errs);
+#else
+          const RegWords<NW> rw{w};
+          status = o ? rescue2_fast<true, NW>(rt, rw, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, rw, lg, n, cfg, rec, errs);
+#endif
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
           else errs = 0;
         }
@@ -508,13 +535,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     // the loads in flight; the other waves of the CU cover the entry loads)
     // `width` lanes of a wave take entries (64, or fewer for the slow list: the general form costs a wave the longest
     // of its lanes' loops, and a short list is better spread over many waves than packed into a few)
-    const uint32_t dbg_skip = width >> 8;
-    width &= 0xFFu;
     for (uint32_t first = width * (uint32_t)(tid >> 6); first < total && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += width * (DCRX_V2_FBLOCK / 64)) {
       const uint32_t i = first + lane;
       const bool live = (uint32_t)lane < width && i < total;
-      const unsigned long long tp0 = clock64();
-      unsigned long long tp1 = tp0, tp2 = tp0, tp3 = tp0;
       uint32_t g = 0;
       for (uint32_t k = 1; k < group; k++) g += i >= pref[k] ? 1u : 0u;
       const uint32_t slot = i - pref[g];
@@ -527,7 +550,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
       if (live) {
         const uint32_t r = x[0] & V2_R_MASK;
         const bool exc = (x[0] & V2_R_EXC) != 0u;
-        if (((dbg_skip & 1u) && exc) || ((dbg_skip & 2u) && !exc)) continue;      // (debugging aid, DCRX_SLOW_SKIP: records are NOT results)
         const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
         // the read's event list, from its flag log (a read with exception bytes keeps every flag: none is certain)
         const Digest2 d = digest2<NW>(lg);
@@ -535,7 +557,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
         uint32_t ev[3];
         const bool fits = events2<NW>(lg, d, exc ? 0xFu : bnd, ev);
         const uint4 e = make_uint4(x[0], ev[0], ev[1], ev[2]);
-        tp1 = clock64() + (ev[0] & 1u);
         if (!fits) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc); continue; }   // more flagged pairs than a list holds: the three-launch form
         int x0 = 0, x1e = 0;
         if (exc) {                      // the read's slice of the (sorted) exception list
@@ -546,16 +567,10 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
           x1e = (int)lo;
           if (x1e - x0 > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); continue; }   // more exception bytes than the register frame holds
         }
-        tp2 = clock64() + ((uint32_t)x0 & 1u);
         if (finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1e, C, records)) {
           if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
         } else {
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
-        }
-        tp3 = clock64();
-        if (dbg_skip & 4u) {
-          atomicMax(&g_dbg_phase[0], tp1 - tp0); atomicMax(&g_dbg_phase[1], tp2 - tp1); atomicMax(&g_dbg_phase[2], tp3 - tp2);
-          atomicAdd(&g_dbg_phase[4], tp1 - tp0); atomicAdd(&g_dbg_phase[5], tp2 - tp1); atomicAdd(&g_dbg_phase[6], tp3 - tp2); atomicAdd(&g_dbg_phase[7], 1ull);
         }
       }
     }
@@ -574,7 +589,8 @@ bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
   if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
-  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) <= 64u * 1024u;
+  // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
+  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 <= 64u * 1024u;
 }
 
 template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
@@ -591,7 +607,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (first_use_on_device(seen)) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
@@ -623,18 +639,19 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (e != hipSuccess) return e;
   if (ev_stop) { e = hipEventRecord(ev_stop, s); if (e != hipSuccess) return e; }
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
-    // Lean rescue kernel (event entries), lean tail kernel (tail entries), and the general form (event kernel) for what
-    // they do not settle: the rescue kernel's leftovers (slow list 1), then — behind the tail kernel — the tail kernel's
-    // own (slow list 2).  DCRX_F_V2_FORK puts the first of the two beside the tail kernel on the handle's side stream
-    // (A/B: measured no faster, 0.646 against 0.641 ms per step).
+    // Lean rescue kernel (event entries), lean tail kernel (tail entries), then the general form (event kernel) over what
+    // the two did not settle (slow list 1).  DCRX_F_V2_FORK (A/B) runs the general form for the rescue kernel's leftovers
+    // beside the tail kernel on the handle's side stream and the tail kernel's own (slow list 2) behind it: measured no
+    // faster (0.592 against 0.603 ms per step with the best shape), the event kernel's waves wait for registers the tail
+    // kernel's waves hold.
     const uint32_t fgrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-    static const uint32_t DCRX_V2_SLOW_GROUP = getenv("DCRX_SLOW_GROUP") ? std::min<uint32_t>(DCRX_V2_GROUP_MAX, std::max(1, atoi(getenv("DCRX_SLOW_GROUP")))) : DCRX_V2_SLOW_GROUP_DEFAULT;
     const uint32_t sgrid = (n_regions + DCRX_V2_SLOW_GROUP - 1) / DCRX_V2_SLOW_GROUP;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
+    const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4;      // the lean kernels: + a strip per lane
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;
-    static const uint32_t slow_width = (getenv("DCRX_SLOW_WIDTH") ? (uint32_t)atoi(getenv("DCRX_SLOW_WIDTH")) : 16u) | (getenv("DCRX_SLOW_SKIP") ? (uint32_t)atoi(getenv("DCRX_SLOW_SKIP")) << 8 : 0u);
+    const uint32_t slow_width = 16u;       // lanes of a wave that take entries of a slow list
     const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
     hipStream_t se = fork ? P.v2_side : s;
     // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
@@ -642,48 +659,35 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
     else
-      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue, qcap,
+      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue, qcap,
                          queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (fork) {
+    const dim3 tgrid((n_regions * DCRX_V2_TSPLIT + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
+    const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
+    if (!fork) {
+      // the tail kernel, then one pass of the event kernel over slow list 1 (both lean kernels' leftovers)
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+                         gqueue, qcap, queue_count);
+      e = hipGetLastError();
+    } else {
       e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(se, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
-    }
-    if (!(cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)) {
-      static const int reps = getenv("DCRX_SLOW_REPS") ? atoi(getenv("DCRX_SLOW_REPS")) : 1;      // (debugging aid: counters are NOT results when > 1)
-      for (int rep = 1; rep < reps; rep++)
-        hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
-                           gqueue, qcap, queue_count);
       hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
-    }
-    if (fork) { e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(kt, dim3(fgrid * DCRX_V2_TSPLIT), dim3(DCRX_V2_FBLOCK), flds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue,
-                       qcap, queue_count);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (fork) { e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue, gqueue,
-                       qcap, queue_count);
-    e = hipGetLastError();
-    if (slow_width & (4u << 8)) {          // debugging aid: phase times of the event kernel (synchronises)
-      unsigned long long h[8];
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_phase), sizeof h);
-      fprintf(stderr, "dcrx event-kernel phases (ticks): max load+digest %llu exc search %llu finish %llu | mean %llu %llu %llu over %llu lanes\n", h[0], h[1], h[2],
-              h[7] ? h[4] / h[7] : 0, h[7] ? h[5] / h[7] : 0, h[7] ? h[6] / h[7] : 0, h[7]);
-      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_phase), z, sizeof z);
-#ifdef DCRX_DEBUG_PHASES
-      unsigned long long h2[16], z2[16] = {0};
-      (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_dbg_phase2), sizeof h2);
-      fprintf(stderr, "dcr_frame3 phases mean (sweep V, sweep J, vanalysis, janalysis, filters): %llu %llu %llu %llu %llu | max %llu %llu %llu %llu %llu\n",
-              h[7] ? h2[0] / h[7] : 0, h[7] ? h2[1] / h[7] : 0, h[7] ? h2[2] / h[7] : 0, h[7] ? h2[3] / h[7] : 0, h[7] ? h2[4] / h[7] : 0, h2[8], h2[9], h2[10], h2[11], h2[12]);
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_phase2), z2, sizeof z2);
-#endif
+      e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 1u, n_regions, queue, gqueue, qcap, queue_count);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+                         gqueue, qcap, queue_count);
+      e = hipGetLastError();
     }
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)

@@ -397,14 +397,6 @@ DCRX_DEVNI int v2_lookup(const V2Ori &V, const int cls, const uint64_t val) {
 // (the caller hands the read to the three-launch form).
 // jmulti: several pairs hold a J tag (tail entries; their pairs are not listed).
 // ------------------------------------------------------------------------------
-#if defined(DCRX_DEBUG_PHASES) && !defined(DCRX_HOST_EMUL)
-extern __device__ unsigned long long g_dbg_phase2[16];
-#define DCRX_PHASE(k) do { const unsigned long long t_ = clock64(); atomicAdd(&g_dbg_phase2[k], t_ - tph_); atomicMax(&g_dbg_phase2[8 + (k)], t_ - tph_); tph_ = t_; } while (0)
-#define DCRX_PHASE_INIT unsigned long long tph_ = clock64()
-#else
-#define DCRX_PHASE(k) ((void)0)
-#define DCRX_PHASE_INIT ((void)0)
-#endif
 constexpr int V2_MAX_HITS = 8;
 struct Hits2 {            // hits of one class in findall order: 32 bits each, keyword (class-local) << 16 | stored end base
   uint64_t a, b, c, d;    // slots 0-1, 2-3, 4-5, 6-7
@@ -424,7 +416,6 @@ struct Hits2 {            // hits of one class in findall order: 32 bits each, k
 template <class FR>
 DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const int nwords, const uint32_t (&ev_in)[3],
                           const bool jmulti, const CfgDev &cfg, const Counters &C, dcrx_record_t &rec) {
-  DCRX_PHASE_INIT;
   const Events2 E{(uint64_t)ev_in[0] | ((uint64_t)ev_in[1] << 32), ev_in[2]};   // scalars: an array picked with a lane-varying index would live in scratch memory
   constexpr bool REV = FR::kRev;
   const int n = F.n();
@@ -494,9 +485,7 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
     }
   };
   sweep(V2_F_VF, V2_F_VH, K_VFULL, K_VH1, K_VH2, Lvf, Lv1, Lv2, hvf, hv1, hv2);
-  DCRX_PHASE(0);
   sweep(V2_F_JF, V2_F_JH, K_JFULL, K_JH1, K_JH2, Ljf, Lj1, Lj2, hjf, hj1, hj2);
-  DCRX_PHASE(1);
   if (cfg.flags & DCRX_F_PROFILE_RESCUE_HITS_ONLY) {   // profiling aid: price the sweep alone (records are NOT results)
     rec.v = (uint16_t)(hvf.n + hjf.n + hv1.n + hv2.n + hj1.n + hj2.n); rec.j = (uint16_t)(hvf.a ^ hjf.a ^ hv1.a ^ hv2.a ^ hj1.a ^ hj2.a);
     return 254;
@@ -535,7 +524,6 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
     }
   }
   const int end_of_v = vdat.pos + 1;                                               // :547
-  DCRX_PHASE(2);
 
   // ---- janalysis ----
   int jstatus = DCRX_S_OK;
@@ -567,11 +555,8 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
       }
     }
   }
-  DCRX_PHASE(3);
   if (jstatus != DCRX_S_OK) { C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); return jstatus; }  // :583-585
-  const int fst = dcr_filters(T, F, vdat, jdat, cfg, C, rec);
-  DCRX_PHASE(4);
-  return fst;
+  return dcr_filters(T, F, vdat, jdat, cfg, C, rec);
 }
 
 // One read from its events to its record, the read's words loaded into registers once (NW words;
@@ -716,13 +701,34 @@ DCRX_DEV uint64_t reg_stored64(const uint32_t (&w)[NW], const int s) {
   return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
 }
 
+// Where a lean kernel keeps the read in hand: in registers (a 32-base window is a select chain over the
+// words, ~45 VALU instructions) or in a per-lane strip of LDS (three ds_read_b32 at lane-varying addresses;
+// the strip holds the NW words and two zero words, at an odd stride in words so that the lanes of a wave
+// spread over the banks).
+template <int NW>
+struct RegWords {
+  const uint32_t (&w)[NW];
+  DCRX_DEV uint64_t stored64(const int s) const { return reg_stored64<NW>(w, s); }
+};
+struct LdsWords {
+  dcrx_ldsaddr strip;      // this lane's first word
+  DCRX_DEV uint64_t stored64(const int s) const {
+    const uint32_t i = (uint32_t)s >> 4;
+    const int sh = (s & 15) * 2;
+    const uint32_t w0 = dcrx_lds_at<uint32_t>(strip, i), w1 = dcrx_lds_at<uint32_t>(strip, i + 1), w2 = dcrx_lds_at<uint32_t>(strip, i + 2);
+    return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+  }
+};
+template <int NW>
+constexpr int lds_words_stride() { return ((NW + 2) | 1); }      // words per lane: NW + 2 zero words, made odd
+
 // One tail entry (`digest`: tail2_pack) on a read whose words sit in registers (the finishing
 // kernel loads them one batch ahead: nothing here waits for global memory).  Returns the read's
 // status with `rec` filled (status and frame left to the caller), or TAIL2_SLOW with nothing
 // decided.  No counter is touched here: the caller tallies by status (each status of this form
 // implies its counters).
-template <bool REV, int NW>
-DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const uint32_t (&w)[NW], const int n, const uint32_t digest, const CfgDev &cfg,
+template <bool REV, class WS>
+DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uint32_t digest, const CfgDev &cfg,
                         dcrx_record_t &rec) {
   const int vpair = (int)(digest & 0xFFu), jpair = (int)((digest >> 8) & 0xFFu), jc = (int)((digest >> 16) & 3u);
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
@@ -730,10 +736,10 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const uint32_t (&w)[NW], const int 
   // ---- the windows that hold the tags (both candidate ends of a pair share one window) ----
   const int sva = 2 * vpair - Lv + 1;                      // the V tag starts here (ends at the pair's first base) or one base on
   const int wsv = min(max(sva, 0), n - 32);
-  const uint64_t Wv = reg_stored64<NW>(w, wsv);
+  const uint64_t Wv = w.stored64(wsv);
   const int sja = 2 * jpair - Lj + 1;
   const int wsj = min(max(sja, 0), n - 32);
-  const uint64_t Wj = reg_stored64<NW>(w, wsj);
+  const uint64_t Wj = w.stored64(wsj);
   const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
   int v = -1, sv = 0;
   {
@@ -757,7 +763,7 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const uint32_t (&w)[NW], const int 
   const int te = vp + jumpv - 1;                           // decombine.py:283-285
   const int fv = te + 1;
   if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return TAIL2_SLOW;
-  const uint64_t rwv = reg_stored64<NW>(w, REV ? n - fv : fv - 32);
+  const uint64_t rwv = w.stored64(REV ? n - fv : fv - 32);
   int jumpj = 0, jp = 0, ts = 0;
   uint64_t rwj = 0;
   if (jc == 1) {
@@ -765,7 +771,7 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const uint32_t (&w)[NW], const int 
     jp = REV ? n - sj - Lj : sj;
     ts = jp - jumpj;                                       // :407-409
     if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return TAIL2_SLOW;
-    rwj = reg_stored64<NW>(w, REV ? n - ts - 32 : ts);
+    rwj = w.stored64(REV ? n - ts - 32 : ts);
   }
   // get_v_deletions (:749-785), the 32-base form
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
@@ -876,8 +882,8 @@ DCRX_DEV int rescue2_lookup(const dcrx_ldsaddr start, const dcrx_ldsaddr kws, co
 // position p): the first whose whole tag window is within Hamming distance 1 — the `indices`
 // loops of :298-317 / :342-369 / :425-444 / :476-503.  1 with k / q (tag start in the frame),
 // 0 none.
-template <bool REV, int NW, int G>
-DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const int n, const int half, const uint32_t gk,
+template <bool REV, class WS, int G>
+DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const WS &w, const int n, const int half, const uint32_t gk,
                                 const int p, int &k_out, int &q_out) {
   const int L = (int)rt.t.L[G];
   const int q = half == 1 ? p : p - rt.split[G];
@@ -888,7 +894,7 @@ DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const uint32_t (&w)[NW], 
   const int b = REV ? n - q - L : q;                           // where the window starts in the stored read
   const int ws = min(b, n - 32);
   const uint64_t mask = (1ull << (2 * L)) - 1ull;
-  const uint64_t val = (reg_stored64<NW>(w, ws) >> (2 * (b - ws))) & mask;
+  const uint64_t val = (w.stored64(ws) >> (2 * (b - ws))) & mask;
   const uint32_t x0 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk), x1 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk + 1);
   int found = 0;
   for (uint32_t x = x0; x < x1 && !found; x++) {
@@ -926,8 +932,8 @@ DCRX_DEV void rescue2_mid_pairs(const uint32_t (&lg)[NW], const uint32_t mask8, 
 // One sweep in findall order: a half-1 hit tries its candidates at once and a success ends the sweep;
 // half-2 hits wait in four register slots and are tried only when no half-1 keyword occurred — the
 // reference consults the half-2 list only then (:337-339 / :471-473).
-template <bool REV, int NW, int G>
-DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const int n, const int cnt, const int pp0, const int pp1,
+template <bool REV, class WS, int G>
+DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const int n, const int cnt, const int pp0, const int pp1,
                           const int pp2, const int pp3, int &k_out, int &q_out, int &p_out, int &half_out) {
   const int L1 = (int)rt.Lh[G][0], L2 = (int)rt.Lh[G][1];
   const uint64_t m1 = (1ull << (2 * L1)) - 1ull, m2 = (1ull << (2 * L2)) - 1ull;
@@ -940,7 +946,7 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     const int pair = u == 0 ? pp0 : (u == 1 ? pp1 : (u == 2 ? pp2 : pp3));
     const int f1 = 2 * pair + 1;                                 // the pair's second stored base
     const int xs = f1 >= 31 ? f1 - 31 : 0;                       // window: stored bases [xs, xs + 32)
-    const uint64_t X = reg_stored64<NW>(w, xs);
+    const uint64_t X = w.stored64(xs);
     for (int y = 0; y < 2 && res == 0; y++) {
       const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
       if (f >= n) continue;
@@ -955,7 +961,7 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
       if (kw1 >= 0) {
         any1 = true;
         const int p = REV ? n - s1 - L1 : s1;
-        res = rescue2_candidates<REV, NW, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
+        res = rescue2_candidates<REV, WS, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
         p_out = p;
       }
     }
@@ -969,14 +975,14 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     const int f = (int)(e & 0xFFFFu), kw2 = (int)(e >> 16) - 1;
     const int s2 = f - L2 + 1;
     const int p = REV ? n - s2 - L2 : s2;
-    res = rescue2_candidates<REV, NW, G>(rt, w, n, 2, rt.kw_base[G][1] + (uint32_t)kw2, p, k_out, q_out);
+    res = rescue2_candidates<REV, WS, G>(rt, w, n, 2, rt.kw_base[G][1] + (uint32_t)kw2, p, k_out, q_out);
     p_out = p;
   }
   return res;
 }
 
-template <bool REV, int NW>
-DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
+template <bool REV, int NW, class WS>
+DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
                           dcrx_record_t &rec, uint32_t &errs) {
   const Tail2Tabs &tt = rt.t;
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
@@ -1007,7 +1013,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     const int vpair = (int)(vf1 >> 2);
     const int sva = 2 * vpair - Lv + 1;
     const int wsv = min(max(sva, 0), n - 32);
-    const uint64_t Wv = reg_stored64<NW>(w, wsv);
+    const uint64_t Wv = w.stored64(wsv);
     const bool oka = sva >= 0, okb = sva + 1 + Lv <= n;
     const int ta = oka ? tail2_lookup(tt, 0, (Wv >> (2 * (sva - wsv))) & mv) : -1;
     const int tb = okb ? tail2_lookup(tt, 0, (Wv >> (2 * (sva + 1 - wsv))) & mv) : -1;
@@ -1021,7 +1027,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     uint32_t a = vh1, b = vhl, c = vhl, d = vhl;          // ascending: the first, (second,) (second last,) last flagged pair
     if (vhn > 2) { rescue2_mid_pairs<NW>(lg, 0x44444444u, vh1, vhl, b, c); }
     if (vhn == 3) { c = vhl; }
-    const int res = rescue2_half<REV, NW, 0>(rt, w, n, (int)vhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    const int res = rescue2_half<REV, WS, 0>(rt, w, n, (int)vhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
     if (res < 0) return R2S(6);
     if (res == 0) return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_V_HALF2_EXHAUSTED : DCRX_S_V_NONE);   // :334 / :389 / :393
     v = k; vp = q;
@@ -1032,7 +1038,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
   const int fv = te + 1;
   if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return R2S(7);
-  const uint64_t rwv = reg_stored64<NW>(w, REV ? n - fv : fv - 32);
+  const uint64_t rwv = w.stored64(REV ? n - fv : fv - 32);
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
   const int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
   if (kv < 0) return R2S(8);
@@ -1046,7 +1052,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     const int jpair = (int)(jf1 >> 2);
     const int sja = 2 * jpair - Lj + 1;
     const int wsj = min(max(sja, 0), n - 32);
-    const uint64_t Wj = reg_stored64<NW>(w, wsj);
+    const uint64_t Wj = w.stored64(wsj);
     const bool oka = sja >= 0, okb = sja + 1 + Lj <= n;
     const int ta = oka ? tail2_lookup(tt, 1, (Wj >> (2 * (sja - wsj))) & mj) : -1;
     const int tb = okb ? tail2_lookup(tt, 1, (Wj >> (2 * (sja + 1 - wsj))) & mj) : -1;
@@ -1062,7 +1068,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
     uint32_t a = jh1, b = jhl, c = jhl, d = jhl;
     if (jhn > 2) { rescue2_mid_pairs<NW>(lg, 0x88888888u, jh1, jhl, b, c); }
     if (jhn == 3) { c = jhl; }
-    const int res = rescue2_half<REV, NW, 1>(rt, w, n, (int)jhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    const int res = rescue2_half<REV, WS, 1>(rt, w, n, (int)jhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
     if (res < 0) return R2S(10);
     if (res == 0) return half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_J_HALF2_EXHAUSTED : DCRX_S_J_NONE);   // :469 / :526 / :530
     j = k;
@@ -1073,7 +1079,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const uint32_t (&w)[NW], const 
   }
   const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
   if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return R2S(11);
-  const uint64_t rwj = reg_stored64<NW>(w, REV ? n - ts - 32 : ts);
+  const uint64_t rwj = w.stored64(REV ? n - ts - 32 : ts);
   const int k0 = end_of_v > ts ? end_of_v - ts : 0;
   const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
   const int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);

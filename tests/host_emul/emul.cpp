@@ -102,7 +102,12 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     const Tail2Tabs tt = tail2_tabs(T, V, T.image + T.dfa_bytes, V.bk, o == 1);
     dcrx_record_t rec;
     std::memset(&rec, 0, sizeof rec);
-    const int st = o ? tail2_fast<true, NW>(tt, w[0], n, tail2_pack(d), C, rec) : tail2_fast<false, NW>(tt, w[0], n, tail2_pack(d), C, rec);
+    // (the words in a strip of memory, as the kernel keeps them in LDS)
+    uint32_t strip[NW + 2];
+    for (int k = 0; k < NW; k++) strip[k] = w[0][k];
+    strip[NW] = strip[NW + 1] = 0u;
+    const LdsWords lw{dcrx_ldsaddr_of(strip)};
+    const int st = o ? tail2_fast<true>(tt, lw, n, tail2_pack(d), C, rec) : tail2_fast<false>(tt, lw, n, tail2_pack(d), C, rec);
     if (st != TAIL2_SLOW) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
       records[r] = rec;
@@ -121,7 +126,8 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     dcrx_record_t rec;
     std::memset(&rec, 0, sizeof rec);
     uint32_t errs = 0;
-    const int st = o ? rescue2_fast<true, NW>(rt, w[0], lg[0], n, C, rec, errs) : rescue2_fast<false, NW>(rt, w[0], lg[0], n, C, rec, errs);
+    const RegWords<NW> rw{w[0]};      // (and from registers here: both word sources are exercised)
+    const int st = o ? rescue2_fast<true, NW>(rt, rw, lg[0], n, C, rec, errs) : rescue2_fast<false, NW>(rt, rw, lg[0], n, C, rec, errs);
     if (st >= 0) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
       records[r] = rec;

@@ -9,8 +9,8 @@ from tests import parity_util as pu
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
-                         ids=["pairscan", "onebase", "slowreader", "listrescue"])
+@pytest.mark.parametrize("flags", [0, nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE, nat.F_V2_NO_LEAN_RESCUE],
+                         ids=["pairscan", "onebase", "slowreader", "listrescue", "general-form-only"])
 def test_emul_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("emul", path, flags) > 500
 
@@ -122,3 +122,48 @@ def _long_reads(kind, n):
 
 def test_emul_reads_of_321_to_511_nt():
     assert _long_reads("emul", 3000) == 3000
+
+
+def _synthetic_vs_oracle(kind, ts, n, orientation, flags, forward_strand=False, **synth_kw):
+    """`n` synthetic reads of tag set `ts` through backend `kind` against the oracle: records and counters.  The
+    generator writes the reverse strand; forward_strand hands the backend the reverse complements instead."""
+    from oracle import oracle as orc
+    vs, js = ts.half_splits
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=vs, j_half_split=js)
+    t = pu.native_tables(d)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], vs, js)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(**synth_kw), 0, n)
+    reads = nat.unpack_reads(hb)
+    if forward_strand:
+        reads = [orc.revcomp(r) for r in reads]
+        hb = nat.pack_reads(reads)
+    rec, cnt = pu.Backend(kind, d).run(hb, orientation, flags=flags)
+    orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+    pu.assert_records_equal(rec, orec, reads, orientation)
+    pu.assert_counters_equal(cnt, ocnt)
+    return int((orec["status"] == 0).sum())
+
+
+_LEAN_CASES = [  # (substitution rate, exception-byte rate, read length): rescue-heavy, exception-heavy, odd, short, long, hopeless
+    (0.03, 0.0005, 150), (0.10, 0.02, 150), (0.05, 0.05, 101), (0.04, 0.01, 75), (0.06, 0.01, 300), (0.15, 0.0, 60)]
+
+
+@pytest.mark.parametrize("flags", [0, nat.F_V2_NO_LEAN_RESCUE, nat.F_V1_KERNELS], ids=["lean-rescue", "general-form", "three-launch"])
+@pytest.mark.parametrize("chain", ["beta-original", "alpha-extended", "delta-original"])
+def test_emul_rescue_forms_on_both_strands(chain, flags):
+    """The lean rescue (straight-line half-tag rescue, up to four flagged pairs per gene), the general form and the
+    three-launch form on reads that need the rescue often, carry exception bytes, end in half pairs, are too short
+    for a 32-base window or long enough for several: each against the oracle, the reverse frame on the generator's
+    strand and the forward frame on its reverse complement.  The walks' window-by-window form (read edge, exception
+    bytes as mismatches) is what the general form runs here."""
+    from decombinator_amd import synth
+    ts = {"beta-original": synth.config_tagset(2), "alpha-extended": synth.config3_tagsets()[0],
+          "delta-original": synth.config5_tagsets()[1]}[chain]
+    n_ok = 0
+    for k, (sub, nrate, length) in enumerate(_LEAN_CASES):
+        n_ok += _synthetic_vs_oracle("emul", ts, 2500, "reverse", flags, seed=60 + k, sub_rate=sub, n_rate=nrate, read_len=length)
+        n_ok += _synthetic_vs_oracle("emul", ts, 2500, "forward", flags, forward_strand=True, seed=80 + k, sub_rate=sub,
+                                     n_rate=nrate, read_len=length)
+    assert n_ok > 2000

@@ -29,13 +29,15 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
-                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "onebase", "slowreader", "listrescue"])
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_FORK, nat.F_ONE_BASE_SCAN,
+                                   nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
+                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "v2-general-form-only", "v2-fork", "onebase", "slowreader",
+                              "listrescue"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
 
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS], ids=["v2", "v1"])
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_FORK], ids=["v2", "v1", "v2-general-form-only", "v2-fork"])
 @pytest.mark.parametrize("config,seed,sub,n", [(2, 2, 0.005, 1_000_000), (5, 5, 0.02, 300_000)])
 def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n, flags):
     ts = synth.config_tagset(config)
@@ -439,3 +441,20 @@ def test_table_sizes_around_the_lds_limits(n_v):
     pu.assert_records_equal(rec, orec, reads, f"n_v {n_v}")
     pu.assert_counters_equal(cnt, ocnt, f"n_v {n_v}")
     assert int(ocnt[nat.COUNTER_NAMES.index("verr1")]) + int(ocnt[nat.COUNTER_NAMES.index("verr2")]) > 1000
+
+
+@pytest.mark.parametrize("flags", [0, nat.F_V2_NO_LEAN_RESCUE, nat.F_V1_KERNELS], ids=["lean-rescue", "general-form", "three-launch"])
+@pytest.mark.parametrize("chain", ["beta-original", "alpha-extended", "delta-original"])
+def test_rescue_forms_on_both_strands(chain, flags):
+    """tests/test_emul_parity.py::test_emul_rescue_forms_on_both_strands on the device, with ten times the reads: the lean
+    rescue kernel, the general form alone and the three-launch form against the oracle — rescue-heavy, exception-heavy,
+    odd-length, short and long reads, reverse frame on the generator's strand and forward frame on its reverse complement."""
+    from tests import test_emul_parity as tep
+    ts = {"beta-original": synth.config_tagset(2), "alpha-extended": synth.config3_tagsets()[0],
+          "delta-original": synth.config5_tagsets()[1]}[chain]
+    n_ok = 0
+    for k, (sub, nrate, length) in enumerate(tep._LEAN_CASES):
+        n_ok += tep._synthetic_vs_oracle("hip", ts, 25_000, "reverse", flags, seed=60 + k, sub_rate=sub, n_rate=nrate, read_len=length)
+        n_ok += tep._synthetic_vs_oracle("hip", ts, 25_000, "forward", flags, forward_strand=True, seed=80 + k, sub_rate=sub,
+                                         n_rate=nrate, read_len=length)
+    assert n_ok > 20_000
