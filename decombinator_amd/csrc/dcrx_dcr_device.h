@@ -47,6 +47,17 @@ DCRX_DEV void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) {
   v.w = (uint32_t)rec.vdel | ((uint32_t)rec.jdel << 8) | ((uint32_t)rec.status << 16) | ((uint32_t)rec.frame << 24);
   __builtin_nontemporal_store(v, reinterpret_cast<dcrx_v4u *>(dst));
 }
+// ... and through the caches: for the kernels whose records fall between records other kernels write (a 64-byte
+// line of records gets its pieces from up to three kernels: merged in L2 / the Infinity Cache, not in memory)
+DCRX_DEV void dcrx_store_record_cached(dcrx_record_t *dst, const dcrx_record_t &rec) {
+  typedef uint32_t dcrx_v4u __attribute__((ext_vector_type(4)));
+  dcrx_v4u v;
+  v.x = (uint32_t)rec.v | ((uint32_t)rec.j << 16);
+  v.y = (uint32_t)rec.v_start | ((uint32_t)rec.j_end << 16);
+  v.z = (uint32_t)rec.ins_start | ((uint32_t)rec.ins_len << 16);
+  v.w = (uint32_t)rec.vdel | ((uint32_t)rec.jdel << 8) | ((uint32_t)rec.status << 16) | ((uint32_t)rec.frame << 24);
+  *reinterpret_cast<dcrx_v4u *>(dst) = v;
+}
 // pointer into LDS with its address space spelled out (ds_read/ds_write instead of flat_*)
 typedef __attribute__((address_space(3))) uint32_t dcrx_lds_u32;
 #define DCRX_TO_LDS(p) ((dcrx_lds_u32 *)(p))
@@ -80,6 +91,7 @@ inline uint32_t dcrx_brev32(uint32_t v) {
   return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24);
 }
 inline void dcrx_store_record(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
+inline void dcrx_store_record_cached(dcrx_record_t *dst, const dcrx_record_t &rec) { *dst = rec; }
 typedef uint32_t dcrx_lds_u32;
 #define DCRX_TO_LDS(p) (p)
 inline uint32_t dcrx_lds_address(const uint8_t *) { return 0; }

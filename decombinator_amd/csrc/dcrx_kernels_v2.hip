@@ -48,8 +48,30 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
 #define DCRX_V2_TWAVES 5        /* ... and the waves per SIMD it is compiled for */
 #endif
+#ifndef DCRX_V2_RECORD_STORES
+#define DCRX_V2_RECORD_STORES 1   /* 0: streamed record stores everywhere; 1: through the caches in the finishing kernels; 2: in the scan kernel as well */
+#endif
+#if DCRX_V2_RECORD_STORES >= 1
+#define DCRX_STORE_FINISH dcrx_store_record_cached
+#else
+#define DCRX_STORE_FINISH dcrx_store_record
+#endif
+#if DCRX_V2_RECORD_STORES >= 2
+#define DCRX_STORE_SCAN dcrx_store_record_cached
+#else
+#define DCRX_STORE_SCAN dcrx_store_record
+#endif
+#ifndef DCRX_V2_FULL_LINE_RECORDS
+#define DCRX_V2_FULL_LINE_RECORDS 1   /* the scan kernel writes a record for every read (a placeholder where a later kernel settles it): whole lines leave the wave; A/B: 0.545 against 0.554 ms per step */
+#endif
 #ifndef DCRX_LEAN_LDS_WORDS
 #define DCRX_LEAN_LDS_WORDS 1   /* the lean kernels keep the read in hand in LDS strips (0: in registers, A/B) */
+#endif
+#ifdef DCRX_DEBUG_TAIL
+__device__ unsigned long long g_dbg_tail[8];
+#define DCRX_TT(k) do { const unsigned long long t_ = clock64(); tacc_[k] += t_ - tt_; tt_ = t_; } while (0)
+#else
+#define DCRX_TT(k) ((void)0)
 #endif
 constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
 constexpr uint32_t DCRX_V2_SLOW_GROUP = 4;  // ... and what it takes of the slow list
@@ -73,20 +95,27 @@ template <int NW>
 struct V2Rows {
   static constexpr int T = (2 + NW + 3) / 4, E = (1 + 2 * NW + 3) / 4;
 };
-// dwords x[0 .. N) of slot `at` into the rows of a region (cap slots per row)
+// dwords x[0 .. N) of slot `at` of a region.  Layout: chunks of 64 slots, inside a chunk structure of arrays
+// (row k of slot i at rows[((i / 64) * R + k) * 64 + i % 64], R = rows per entry): a wave's batch of 64
+// entries is one contiguous piece of R KB, every load of it fully coalesced, and a region is one stream of
+// addresses, not R of them (the lists are hundreds of MB: fewer streams, fewer pages in flight).
 template <int N>
 __device__ __forceinline__ void v2_put_rows(uint4 *rows, const uint32_t cap, const uint32_t at, const uint32_t (&x)[N]) {
+  constexpr uint32_t R = (N + 3) / 4;
+  uint4 *p = rows + ((size_t)(at >> 6) * R) * 64 + (at & 63u);
 #pragma unroll
   for (int k = 0; k < (N + 3) / 4; k++)
-    rows[(size_t)k * cap + at] = make_uint4(x[4 * k], 4 * k + 1 < N ? x[4 * k + 1] : 0u, 4 * k + 2 < N ? x[4 * k + 2] : 0u,
-                                            4 * k + 3 < N ? x[4 * k + 3] : 0u);
+    p[(size_t)k * 64] = make_uint4(x[4 * k], 4 * k + 1 < N ? x[4 * k + 1] : 0u, 4 * k + 2 < N ? x[4 * k + 2] : 0u,
+                                   4 * k + 3 < N ? x[4 * k + 3] : 0u);
 }
 template <int N>
 __device__ __forceinline__ void v2_get_rows(const uint4 *rows, const uint32_t cap, const uint32_t at, const bool live, uint32_t (&x)[N]) {
+  constexpr uint32_t R = (N + 3) / 4;
+  const uint4 *p = rows + ((size_t)(at >> 6) * R) * 64 + (at & 63u);
 #pragma unroll
   for (int k = 0; k < (N + 3) / 4; k++) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (live) v = rows[(size_t)k * cap + at];
+    if (live) v = p[(size_t)k * 64];
     x[4 * k] = v.x;
     if (4 * k + 1 < N) x[4 * k + 1] = v.y;
     if (4 * k + 2 < N) x[4 * k + 2] = v.z;
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
           __align__(16) dcrx_record_t rec;
           rec.v = (uint16_t)d.any; rec.j = (uint16_t)d.vf_n; rec.v_start = (uint16_t)d.vf_pair; rec.j_end = (uint16_t)d.jf_n;
           rec.ins_start = (uint16_t)d.jf_pair; rec.ins_len = 0; rec.vdel = rec.jdel = 0; rec.status = 254; rec.frame = 0;
-          dcrx_store_record(records + r, rec);
+          DCRX_STORE_SCAN(records + r, rec);
         }
         continue;
       }
@@ -209,14 +238,18 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       int what = live ? classify2(d, bnd) : -1;
       if (exc && what != V2_VNONE) what = V2_EVENTS;
       const bool vnone = what == V2_VNONE, vmulti = what == V2_VMULTI;
+#if DCRX_V2_FULL_LINE_RECORDS
+      if (live) {     // every lane writes: whole lines of records leave the wave (reads that go on get a placeholder, rewritten by the kernel that settles them)
+#else
       if (vnone || vmulti) {
+#endif
         __align__(16) dcrx_record_t rec;
         rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
         rec.vdel = rec.jdel = 0;
-        rec.status = (uint8_t)(vnone ? DCRX_S_V_NONE : DCRX_S_V_MULTI);
+        rec.status = (uint8_t)(vnone ? DCRX_S_V_NONE : (vmulti ? DCRX_S_V_MULTI : DCRX_S_DEFER));
         rec.frame = (uint8_t)(o == 0 ? 1 : 0);
-        dcrx_store_record(records + r, rec);
-        if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));   // the flag has served: the bitmap is all zero again when the batch ends
+        DCRX_STORE_SCAN(records + r, rec);
+        if (exc && (vnone || vmulti)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));   // the flag has served: the bitmap is all zero again when the batch ends
       }
       const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
       if (lane == 0) {
@@ -302,6 +335,11 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
   const int lane = tid & 63;
+#ifdef DCRX_DEBUG_TAIL
+  unsigned long long tt_ = clock64();
+  unsigned long long tacc_[5] = {0, 0, 0, 0, 0};
+#endif
+  DCRX_TT(0);     // (staging is before this point; measured from kernel entry by the first call below)
   const bool tagged = B.n_reads < (1ull << 30);
   // DCRX_V2_TSPLIT waves share a region: wave k of them takes the batches k, k + DCRX_V2_TSPLIT, ...
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
@@ -316,10 +354,15 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
+    DCRX_TT(1);
     for (uint32_t first = 64 * part; first < tn && !(cfg.flags & DCRX_F_PROFILE_NO_TAIL); first += STEP) {
       uint32_t x[2 + NW];
 #pragma unroll
       for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
+#ifdef DCRX_DEBUG_TAIL
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      DCRX_TT(2);
       v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
       uint32_t w[NW];
 #pragma unroll
@@ -333,14 +376,18 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
 #if DCRX_LEAN_LDS_WORDS
 #pragma unroll
         for (int k = 0; k < NW; k++) strip[k] = w[k];
+        if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(w[0] ^ w[NW - 1]); }
+        else
         status = o ? tail2_fast<true>(tt, lw, n, dg, cfg, rec) : tail2_fast<false>(tt, lw, n, dg, cfg, rec);
 #else
         const RegWords<NW> rw{w};
         status = o ? tail2_fast<true>(tt, rw, n, dg, cfg, rec) : tail2_fast<false>(tt, rw, n, dg, cfg, rec);
 #endif
-        if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
+        if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
+      DCRX_TT(3);
       v2_tally(lds_counts, lane, status, o == 0);
+      DCRX_TT(4);
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
       if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
@@ -365,6 +412,9 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
       }
     }
   }
+#ifdef DCRX_DEBUG_TAIL
+  if (lane == 0) { for (int k = 0; k < 5; k++) atomicAdd(&g_dbg_tail[k], tacc_[k]); atomicAdd(&g_dbg_tail[7], 1ull); }
+#endif
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -465,7 +515,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
           const RegWords<NW> rw{w};
           status = o ? rescue2_fast<true, NW>(rt, rw, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, rw, lg, n, cfg, rec, errs);
 #endif
-          if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); dcrx_store_record(records + r, rec); }
+          if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
         }
       }
@@ -624,13 +674,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   V2Lists Q;
   Q.tail = P.v2_tail; Q.events = P.v2_events; Q.slow = P.v2_slow; Q.counts = P.v2_counts;
   const uint32_t n_regions = grid * (DCRX_V2_BLOCK / 64);
-  Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions);
-  Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions);
+  Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
+  Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~63u;
   // the slow allocation holds both slow lists: list 1 sized like the event list, list 2 in what is left
   Q.scap = Q.ecap;
   Q.slow2 = Q.slow + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
   const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
-  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_wave, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) : 0u;
+  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_wave, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
   if (Q.tcap < 64 || Q.ecap < 64 || Q.s2cap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
   if (ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, T, B, cfg, rec, d_counters, Q, queue, gqueue, qcap,
@@ -689,6 +739,16 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
     }
+#ifdef DCRX_DEBUG_TAIL
+    {
+      unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_tail), sizeof h);
+      fprintf(stderr, "tail kernel, ticks per wave: setup %llu counts+first load %llu wait for batch %llu compute+store %llu tally %llu (waves %llu)\n",
+              h[0] / (h[7] ? h[7] : 1), h[1] / (h[7] ? h[7] : 1), h[2] / (h[7] ? h[7] : 1), h[3] / (h[7] ? h[7] : 1), h[4] / (h[7] ? h[7] : 1), h[7]);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_tail), z, sizeof z);
+    }
+#endif
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
       std::vector<uint32_t> h(4 * (size_t)n_regions);

@@ -628,7 +628,7 @@ DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &
     if (frame) C.add(DCRX_C_FRAME_FORWARD);
   }
   rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
-  dcrx_store_record(records + r, rec);
+  dcrx_store_record_cached(records + r, rec);      // (its neighbours in the line come from other kernels: merged in the caches)
   return true;
 }
 
@@ -673,6 +673,45 @@ DCRX_DEV uint64_t tail2_load64(const dcrx_gwords words, const int s) {
   const uint32_t w0 = words[i], w1 = words[i + 1];
   const uint32_t w2 = sh ? words[i + 2] : 0u;
   return (uint64_t)dcrx_funnel_r(w0, w1, sh) | ((uint64_t)dcrx_funnel_r(w1, w2, sh) << 32);
+}
+
+// N bucket look-ups in lockstep: the bucket bounds of all of them are requested together, then per round
+// one slot of each (packed keyword and its id).  A look-up alone is a chain of dependent LDS reads (bounds,
+// slot, id, next slot ...); side by side the chains cost one wait per round for all of them.
+struct LookupQ {
+  dcrx_ldsaddr start, ids, pk;   // the class's bucket bounds (uint16[V2_NB + 1]), per slot an id (uint16) and the packed keyword (uint64)
+  uint64_t val;                  // the window to find
+  bool on;                       // false: no look-up (the result is -1)
+};
+template <int N>
+DCRX_DEV void lookup_lockstep(const LookupQ (&q)[N], int (&out)[N]) {
+  uint32_t a[N], b[N];
+  uint32_t longest = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const uint32_t h = v2_hash(q[k].val);
+    a[k] = dcrx_lds_at<uint16_t>(q[k].start, h);
+    b[k] = dcrx_lds_at<uint16_t>(q[k].start, h + 1);
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    if (!q[k].on) b[k] = a[k];
+    longest = max(longest, b[k] - a[k]);
+    out[k] = -1;
+  }
+  for (uint32_t i = 0; i < longest; i++) {
+    uint64_t pv[N];
+    uint32_t id[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const uint32_t slot = a[k] + i < b[k] ? a[k] + i : a[k];      // (a slot of the class in any case: the bucket table ends with one)
+      pv[k] = dcrx_lds_at<uint64_t>(q[k].pk, slot);
+      id[k] = dcrx_lds_at<uint16_t>(q[k].ids, slot);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      if (a[k] + i < b[k] && pv[k] == q[k].val) out[k] = (int)id[k];
+  }
 }
 
 // first tag holding the full-tag keyword whose packed form is `val`, or -1
@@ -741,21 +780,21 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
   const int wsj = min(max(sja, 0), n - 32);
   const uint64_t Wj = w.stored64(wsj);
   const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
-  int v = -1, sv = 0;
-  {
-    const bool oka = sva >= 0, okb = sva + 1 + Lv <= n;
-    const int ta = oka ? tail2_lookup(tt, 0, (Wv >> (2 * (sva - wsv))) & mv) : -1;
-    const int tb = okb ? tail2_lookup(tt, 0, (Wv >> (2 * (sva + 1 - wsv))) & mv) : -1;
-    if ((ta >= 0) == (tb >= 0)) return TAIL2_SLOW;        // none (cannot be) or two V tags inside the pair
-    v = ta >= 0 ? ta : tb; sv = ta >= 0 ? sva : sva + 1;
-  }
-  int j = -1, sj = 0;
-  if (jc == 1) {
-    const bool oka = sja >= 0, okb = sja + 1 + Lj <= n;
-    const int ta = oka ? tail2_lookup(tt, 1, (Wj >> (2 * (sja - wsj))) & mj) : -1;
-    const int tb = okb ? tail2_lookup(tt, 1, (Wj >> (2 * (sja + 1 - wsj))) & mj) : -1;
-    if ((ta >= 0) == (tb >= 0)) return TAIL2_SLOW;
-    j = ta >= 0 ? ta : tb; sj = ta >= 0 ? sja : sja + 1;
+  int v = -1, sv = 0, j = -1, sj = 0;
+  {   // both candidate ends of the V pair and of the J pair, side by side
+    const LookupQ q[4] = {
+        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva >= 0 ? sva - wsv : 0))) & mv, sva >= 0},
+        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva + 1 - wsv))) & mv, sva + 1 + Lv <= n},
+        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja >= 0 ? sja - wsj : 0))) & mj, jc == 1 && sja >= 0},
+        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja + 1 - wsj))) & mj, jc == 1 && sja + 1 + Lj <= n}};
+    int t[4];
+    lookup_lockstep<4>(q, t);
+    if ((t[0] >= 0) == (t[1] >= 0)) return TAIL2_SLOW;    // none (cannot be) or two V tags inside the pair
+    v = t[0] >= 0 ? t[0] : t[1]; sv = t[0] >= 0 ? sva : sva + 1;
+    if (jc == 1) {
+      if ((t[2] >= 0) == (t[3] >= 0)) return TAIL2_SLOW;
+      j = t[2] >= 0 ? t[2] : t[3]; sj = t[2] >= 0 ? sja : sja + 1;
+    }
   }
   // ---- the walk windows ----
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
@@ -951,8 +990,11 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const int n, const
       const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
       if (f >= n) continue;
       const int s1 = f - L1 + 1, s2 = f - L2 + 1;
-      const int kw1 = s1 >= 0 ? rescue2_lookup(rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> (2 * (s1 - xs))) & m1) : -1;
-      const int kw2 = s2 >= 0 ? rescue2_lookup(rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> (2 * (s2 - xs))) & m2) : -1;
+      const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> (2 * (s1 >= 0 ? s1 - xs : 0))) & m1, s1 >= 0},
+                            {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> (2 * (s2 >= 0 ? s2 - xs : 0))) & m2, s2 >= 0}};
+      int kw[2];
+      lookup_lockstep<2>(q, kw);
+      const int kw1 = kw[0], kw2 = kw[1];
       if (kw2 >= 0) {
         const uint64_t e = ((uint64_t)(uint32_t)(kw2 + 1) << 16) | (uint64_t)(uint32_t)f;
         if (h2n < 2) h2lo |= e << (32 * h2n); else if (h2n < 4) h2hi |= e << (32 * (h2n - 2));
@@ -1014,9 +1056,11 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int sva = 2 * vpair - Lv + 1;
     const int wsv = min(max(sva, 0), n - 32);
     const uint64_t Wv = w.stored64(wsv);
-    const bool oka = sva >= 0, okb = sva + 1 + Lv <= n;
-    const int ta = oka ? tail2_lookup(tt, 0, (Wv >> (2 * (sva - wsv))) & mv) : -1;
-    const int tb = okb ? tail2_lookup(tt, 0, (Wv >> (2 * (sva + 1 - wsv))) & mv) : -1;
+    const LookupQ q[2] = {{tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva >= 0 ? sva - wsv : 0))) & mv, sva >= 0},
+                          {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva + 1 - wsv))) & mv, sva + 1 + Lv <= n}};
+    int t[2];
+    lookup_lockstep<2>(q, t);
+    const int ta = t[0], tb = t[1];
     if ((ta >= 0) == (tb >= 0)) return R2S(5);
     v = ta >= 0 ? ta : tb;
     const int sv = ta >= 0 ? sva : sva + 1;
@@ -1053,9 +1097,11 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int sja = 2 * jpair - Lj + 1;
     const int wsj = min(max(sja, 0), n - 32);
     const uint64_t Wj = w.stored64(wsj);
-    const bool oka = sja >= 0, okb = sja + 1 + Lj <= n;
-    const int ta = oka ? tail2_lookup(tt, 1, (Wj >> (2 * (sja - wsj))) & mj) : -1;
-    const int tb = okb ? tail2_lookup(tt, 1, (Wj >> (2 * (sja + 1 - wsj))) & mj) : -1;
+    const LookupQ q[2] = {{tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja >= 0 ? sja - wsj : 0))) & mj, sja >= 0},
+                          {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja + 1 - wsj))) & mj, sja + 1 + Lj <= n}};
+    int t[2];
+    lookup_lockstep<2>(q, t);
+    const int ta = t[0], tb = t[1];
     if ((ta >= 0) == (tb >= 0)) return R2S(9);
     j = ta >= 0 ? ta : tb;
     const int sj = ta >= 0 ? sja : sja + 1;

@@ -126,6 +126,7 @@ typedef struct dcrx_cfg {
 #define DCRX_F_PROFILE_NO_FINISH 128u /* profiling: the v2 kernel scans and sorts reads onto its stacks but finishes none of them (records are NOT results) */
 #define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
 #define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
+#define DCRX_F_PROFILE_TAIL_STREAM_ONLY 16384u /* profiling: the tail kernel reads its entries and writes records but resolves nothing (records are NOT results) */
 #define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
 #define DCRX_F_V2_FORK 4096u         /* A/B: the general-form pass over the lean rescue's leftovers beside the tail kernel on the handle's side stream (measured no faster) */
 #define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
