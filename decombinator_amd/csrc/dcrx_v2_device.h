@@ -678,6 +678,8 @@ DCRX_DEV uint64_t tail2_load64(const dcrx_gwords words, const int s) {
 // N bucket look-ups in lockstep: the bucket bounds of all of them are requested together, then per round
 // one slot of each (packed keyword and its id).  A look-up alone is a chain of dependent LDS reads (bounds,
 // slot, id, next slot ...); side by side the chains cost one wait per round for all of them.
+// shift count for a window offset in bases (a look-up that is switched off may carry an offset outside the window)
+DCRX_DEV int v2_sh(const int bases) { return 2 * min(max(bases, 0), 31); }
 struct LookupQ {
   dcrx_ldsaddr start, ids, pk;   // the class's bucket bounds (uint16[V2_NB + 1]), per slot an id (uint16) and the packed keyword (uint64)
   uint64_t val;                  // the window to find
@@ -783,10 +785,10 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
   int v = -1, sv = 0, j = -1, sj = 0;
   {   // both candidate ends of the V pair and of the J pair, side by side
     const LookupQ q[4] = {
-        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva >= 0 ? sva - wsv : 0))) & mv, sva >= 0},
-        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva + 1 - wsv))) & mv, sva + 1 + Lv <= n},
-        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja >= 0 ? sja - wsj : 0))) & mj, jc == 1 && sja >= 0},
-        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja + 1 - wsj))) & mj, jc == 1 && sja + 1 + Lj <= n}};
+        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
+        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva + 1 - wsv)) & mv, sva + 1 + Lv <= n},
+        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, jc == 1 && sja >= 0},
+        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, jc == 1 && sja + 1 + Lj <= n}};
     int t[4];
     lookup_lockstep<4>(q, t);
     if ((t[0] >= 0) == (t[1] >= 0)) return TAIL2_SLOW;    // none (cannot be) or two V tags inside the pair
@@ -990,8 +992,8 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const int n, const
       const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
       if (f >= n) continue;
       const int s1 = f - L1 + 1, s2 = f - L2 + 1;
-      const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> (2 * (s1 >= 0 ? s1 - xs : 0))) & m1, s1 >= 0},
-                            {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> (2 * (s2 >= 0 ? s2 - xs : 0))) & m2, s2 >= 0}};
+      const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
+                            {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
       int kw[2];
       lookup_lockstep<2>(q, kw);
       const int kw1 = kw[0], kw2 = kw[1];
@@ -1056,8 +1058,8 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int sva = 2 * vpair - Lv + 1;
     const int wsv = min(max(sva, 0), n - 32);
     const uint64_t Wv = w.stored64(wsv);
-    const LookupQ q[2] = {{tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva >= 0 ? sva - wsv : 0))) & mv, sva >= 0},
-                          {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> (2 * (sva + 1 - wsv))) & mv, sva + 1 + Lv <= n}};
+    const LookupQ q[2] = {{tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
+                          {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva + 1 - wsv)) & mv, sva + 1 + Lv <= n}};
     int t[2];
     lookup_lockstep<2>(q, t);
     const int ta = t[0], tb = t[1];
@@ -1097,8 +1099,8 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int sja = 2 * jpair - Lj + 1;
     const int wsj = min(max(sja, 0), n - 32);
     const uint64_t Wj = w.stored64(wsj);
-    const LookupQ q[2] = {{tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja >= 0 ? sja - wsj : 0))) & mj, sja >= 0},
-                          {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> (2 * (sja + 1 - wsj))) & mj, sja + 1 + Lj <= n}};
+    const LookupQ q[2] = {{tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, sja >= 0},
+                          {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, sja + 1 + Lj <= n}};
     int t[2];
     lookup_lockstep<2>(q, t);
     const int ta = t[0], tb = t[1];
