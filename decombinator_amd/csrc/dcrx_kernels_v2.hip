@@ -3,7 +3,7 @@
 // orientation `both`, tag sets the v2 tables do not express, and the few reads these kernels
 // hand over (more flagged pairs than an entry holds).
 //
-// Two launches per batch:
+// Launches per batch:
 //
 //   scan2_kernel    persistent, one 1024-thread block per CU.  LDS holds the frame's 16-bit pair
 //                   table (at LDS address 0) and nothing else.  Per tile of 1024 * RPL reads: the
@@ -11,17 +11,19 @@
 //                   per lane, one ds_read_u16 + one v_alignbit per two bases), the flag log is
 //                   digested, and by ballot a read is
 //                     - finished at once (no V tag and no V half tag / several V tags),
-//                     - appended to the wave's TAIL list (read, V pair, J pair: 8 bytes), or
-//                     - appended to the wave's EVENT list (read, up to six flagged pairs: 16 bytes).
+//                     - appended to the wave's TAIL list (read, V pair, J pair, words), or
+//                     - appended to the wave's EVENT list (read, flag log, words).
 //                   Each wave owns a region of both lists (no atomics) and leaves its counts.
-//   finish2_kernel  one wave per region, 256-thread blocks, the side tables and keyword buckets in
-//                   LDS, four such blocks per CU.  Tail entries take the lean form (tail2_fast),
-//                   event entries and whatever the lean form does not settle the general form
-//                   (dcr_frame3) on a read held in registers.  Reads with exception bytes arrive
-//                   here as event entries and are resolved with their exception list.
+//   rescue2_kernel  event entries in straight-line code (rescue2_fast): full-tag pairs as the tail
+//                   kernel resolves them, half-tag rescue over up to four flagged pairs per gene.
+//   tail2_kernel    tail entries in straight-line code (tail2_fast).
+//                   Both lean kernels: 256-thread blocks, side tables and keyword buckets in LDS, the
+//                   read in hand in a per-lane LDS strip; what they do not settle goes to the slow list.
+//   events2_kernel  the slow list through the general form (dcr_frame3) on a read held in registers;
+//                   reads with exception bytes are resolved here against their exception list.
 //
-// The scan has its registers to itself (no finishing code in that kernel), and the finishing,
-// which waits on memory, runs at twice the scan kernel's wave count.
+// The scan has its registers to itself (no finishing code in that kernel); the lean kernels run at
+// 4-5 waves per SIMD; the general form sees a few thousand reads per batch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
