@@ -14,12 +14,28 @@
 //     newline for all but an unterminated last line — that one loses a real character.
 // Records come out in batches as offsets into one library-owned text buffer, so that the
 // Python host slices strings only for the reads that decombine.
+//
+// Fast path (plain four-line FASTQ, the common case): a block of the file holding the batch is
+// cut at record starts and its pieces are parsed by several threads with a strict grammar
+// ('@' header / one sequence line / '+' line / one quality line at least as long); the batch's
+// text buffer is the block itself (no per-line copies).  The pieces must chain — each piece's
+// parse has to end exactly where the next one was cut — and any line that does not fit the
+// grammar (wrapped records, FASTA, a truncated or unterminated tail, '>' headers) sends the
+// whole batch through the line-by-line generator below, which is the definition.
+// A plain file is mapped and, while everything so far was strict, parsed straight from the page cache (the
+// batch's text is a piece of the mapping); the first block that is not ends that for good and the buffered
+// paths go on from the first record not handed out.
+// DCRX_FASTQ_SERIAL=1 switches the fast paths off, DCRX_FASTQ_NO_MMAP=1 the mapping (tests compare them).
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <future>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dcrx.h"
@@ -43,9 +59,24 @@ struct dcrx_fastq {
     std::vector<char> text;
     std::vector<uint64_t> name_off, seq_off, qual_off;
     std::vector<uint32_t> name_len, seq_len, qual_len;
+    // the fast path's text buffer: a block of the file as it is (grown with realloc, never zero-filled, kept between batches)
+    char *raw = nullptr;
+    size_t raw_cap = 0, raw_len = 0;
+    bool use_raw = false;
+    const char *ext = nullptr;      // ... or a piece of the mapped file (not owned)
+    size_t ext_len = 0;
+    ~Store() { std::free(raw); }
+    bool raw_reserve(size_t cap) {
+      if (cap <= raw_cap) return true;
+      char *p = (char *)std::realloc(raw, cap);
+      if (!p) return false;
+      raw = p; raw_cap = cap;
+      return true;
+    }
     void clear() {
       text.clear(); name_off.clear(); seq_off.clear(); qual_off.clear();
       name_len.clear(); seq_len.clear(); qual_len.clear();
+      use_raw = false; ext = nullptr; ext_len = 0;
     }
     void emit(uint64_t no, uint32_t nl, uint64_t so, uint32_t sl, uint64_t qo, uint32_t ql) {
       name_off.push_back(no); name_len.push_back(nl);
@@ -62,6 +93,15 @@ struct dcrx_fastq {
   const char *err_msg = nullptr;
 
   int parse(Store &S, uint64_t max_records);
+  bool parse_fast(Store &S, uint64_t max_records);
+  size_t est_record_bytes = 0;     // running estimate for sizing the fast path's block (0: not known yet)
+  bool fast_ok = true;             // false: DCRX_FASTQ_SERIAL was set when the file was opened
+  // the plain file mapped: the fast path parses straight from the page cache while everything so far was strict records
+  const char *mm = nullptr;
+  size_t mm_size = 0, mm_off = 0;
+  bool mm_ok = false;
+  int strict_block(const char *b, size_t len, bool at_eof, uint64_t max_records, Store &S, size_t &used);
+  bool parse_mapped(Store &S, uint64_t max_records);
 
   long raw_read(char *dst, size_t cap) {
     if (gz) {
@@ -114,6 +154,40 @@ struct dcrx_fastq {
     return true;
   }
 
+  // Reads up to cap - 1 bytes of the file to dst, newline-normalised like refill(); n = bytes stored (0 at the end of
+  // the file, then eof is set).  False on a read error.
+  bool read_into(char *dst, size_t cap, size_t &n) {
+    n = 0;
+    if (eof || cap < 2) return true;
+    size_t w = 0;
+    if (pending_cr) { dst[0] = '\n'; w = 1; }
+    const long k = raw_read(dst + w, cap - w - 1);
+    if (k < 0) return false;
+    if (k == 0) {
+      eof = true;
+      if (pending_cr) { n = 1; pending_cr = false; }
+      return true;
+    }
+    char *chunk = dst + w;
+    size_t m = (size_t)k;
+    if (pending_cr) {
+      pending_cr = false;
+      if (chunk[0] == '\n') { std::memmove(dst, chunk, m); chunk = dst; w = 0; }
+    }
+    if (std::memchr(chunk, '\r', m)) {
+      size_t o = 0;
+      for (size_t i = 0; i < m; i++) {
+        const char c = chunk[i];
+        if (c != '\r') { chunk[o++] = c; continue; }
+        if (i + 1 == m) { pending_cr = true; break; }
+        if (chunk[i + 1] != '\n') chunk[o++] = '\n';
+      }
+      m = o;
+    }
+    n = w + m;
+    return true;
+  }
+
   // One line of the file: [p, p+len) INCLUDING its '\n' when it has one.  False at EOF.
   bool next_line(const char *&p, size_t &len, int &err) {
     for (;;) {
@@ -130,8 +204,224 @@ struct dcrx_fastq {
   }
 };
 
+
+namespace {
+
+struct Piece {          // records of one piece of a block, offsets relative to the block
+  std::vector<uint64_t> name_off, seq_off, qual_off;
+  std::vector<uint32_t> name_len, seq_len, qual_len;
+  size_t end = 0;       // where the piece's parse stopped (the next record's header, or the block's end)
+  bool ok = true;
+};
+
+// Strict four-line records from block[from ..): stops before the first record that starts at or after `to`
+// or is not complete inside the block (then P.end is that record's start).
+void parse_piece(const char *b, size_t from, size_t to, size_t block_end, Piece &P) {
+  size_t p = from;
+  while (p < to) {
+    if (b[p] != '@') { P.ok = false; break; }
+    const char *l1 = (const char *)std::memchr(b + p, '\n', block_end - p);
+    if (!l1) break;
+    const size_t s = (size_t)(l1 - b) + 1;
+    const char *l2 = s < block_end ? (const char *)std::memchr(b + s, '\n', block_end - s) : nullptr;
+    if (!l2) break;
+    const size_t t = (size_t)(l2 - b) + 1;
+    const char *l3 = t < block_end ? (const char *)std::memchr(b + t, '\n', block_end - t) : nullptr;
+    if (!l3) break;
+    const size_t q = (size_t)(l3 - b) + 1;
+    const char *l4 = q < block_end ? (const char *)std::memchr(b + q, '\n', block_end - q) : nullptr;
+    if (!l4) break;
+    const size_t nx = (size_t)(l4 - b) + 1;
+    const size_t seq_len = t - 1 - s, qual_len = nx - 1 - q;
+    // the generator's rules that a strict record satisfies: a sequence line that is not a header or '+' line, followed
+    // directly by the '+' line; one quality line that reaches the sequence's length (readfq :239-260)
+    if (seq_len == 0 || b[s] == '@' || b[s] == '+' || b[s] == '>' || b[t] != '+' || qual_len < seq_len || seq_len > 0xFFFFFFF0ull ||
+        qual_len > 0xFFFFFFF0ull) { P.ok = false; break; }
+    const char *h = b + p + 1;
+    const size_t hl = s - 1 - (p + 1);
+    const void *sp = std::memchr(h, ' ', hl);
+    P.name_off.push_back(p + 1); P.name_len.push_back((uint32_t)(sp ? (size_t)((const char *)sp - h) : hl));
+    P.seq_off.push_back(s); P.seq_len.push_back((uint32_t)seq_len);
+    P.qual_off.push_back(q); P.qual_len.push_back((uint32_t)qual_len);
+    p = nx;
+  }
+  P.end = p;
+}
+
+}  // namespace
+
+// Strict records of block b[0 .. len): cut at record starts, pieces parsed by several threads, chained.  0: the batch
+// (up to max_records records, S filled with offsets relative to b, `used` = bytes of b they take); 1: the block holds
+// fewer than max_records and the file goes on (est_record_bytes raised: come back with a bigger block); 2: not strict.
+int dcrx_fastq::strict_block(const char *b, size_t len, bool at_eof, uint64_t max_records, Store &S, size_t &used) {
+  unsigned nt = std::thread::hardware_concurrency() / 2;
+  if (nt > 16) nt = 16;
+  if (nt < 1) nt = 1;
+  // cut at record starts: "\n@" where the line after next starts with '+'
+  const unsigned np_want = len < (1u << 20) ? 1u : nt;
+  std::vector<size_t> cut{0};
+  for (unsigned k = 1; k < np_want; k++) {
+    size_t o = len / np_want * k;
+    if (o <= cut.back()) continue;
+    bool found = false;
+    for (int tries = 0; tries < 64 && !found; tries++) {
+      const char *nl = (const char *)std::memchr(b + o, '\n', len - o);
+      if (!nl || (size_t)(nl - b) + 1 >= len) break;
+      o = (size_t)(nl - b) + 1;
+      if (b[o] != '@') continue;
+      const char *l1 = (const char *)std::memchr(b + o, '\n', len - o);
+      const char *l2 = l1 && (size_t)(l1 - b) + 1 < len ? (const char *)std::memchr(l1 + 1, '\n', len - ((size_t)(l1 - b) + 1)) : nullptr;
+      if (l2 && (size_t)(l2 - b) + 1 < len && l2[1] == '+') found = true;
+    }
+    if (found) cut.push_back(o);
+  }
+  cut.push_back(len);
+  const size_t np = cut.size() - 1;
+  std::vector<Piece> pieces(np);
+  {
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < np; k++) th.emplace_back(parse_piece, b, cut[k], cut[k + 1], len, std::ref(pieces[k]));
+    parse_piece(b, cut[0], cut[1], len, pieces[0]);
+    for (auto &t : th) t.join();
+  }
+  // the pieces must chain, each ending where the next was cut (the last one wherever its last whole record ends)
+  uint64_t total = 0;
+  bool ok = true;
+  for (size_t k = 0; k < np && ok; k++) {
+    ok = pieces[k].ok && (k + 1 == np || pieces[k].end == cut[k + 1]);
+    total += pieces[k].name_off.size();
+  }
+  if (!ok) return 2;
+  const bool whole_tail = pieces[np - 1].end == len;
+  if (total < max_records && !(at_eof && whole_tail)) {
+    if (at_eof) return 2;                                       // a tail that is not whole strict records: the generator's business
+    if (total > 0) est_record_bytes = len / total + 16;         // records are longer than estimated: a bigger block
+    else est_record_bytes *= 4;
+    return 1;
+  }
+  // take max_records of them; the block up to the end of the last one is the batch's text
+  const uint64_t take = total < max_records ? total : max_records;
+  S.name_off.reserve(take); S.name_len.reserve(take); S.seq_off.reserve(take); S.seq_len.reserve(take);
+  S.qual_off.reserve(take); S.qual_len.reserve(take);
+  uint64_t left = take;
+  used = 0;
+  for (size_t k = 0; k < np && left; k++) {
+    const Piece &P = pieces[k];
+    const size_t m = P.name_off.size() < left ? P.name_off.size() : (size_t)left;
+    S.name_off.insert(S.name_off.end(), P.name_off.begin(), P.name_off.begin() + m);
+    S.name_len.insert(S.name_len.end(), P.name_len.begin(), P.name_len.begin() + m);
+    S.seq_off.insert(S.seq_off.end(), P.seq_off.begin(), P.seq_off.begin() + m);
+    S.seq_len.insert(S.seq_len.end(), P.seq_len.begin(), P.seq_len.begin() + m);
+    S.qual_off.insert(S.qual_off.end(), P.qual_off.begin(), P.qual_off.begin() + m);
+    S.qual_len.insert(S.qual_len.end(), P.qual_len.begin(), P.qual_len.begin() + m);
+    if (m) used = (size_t)(P.qual_off[m - 1] + P.qual_len[m - 1]) + 1;      // past the last record's newline
+    left -= m;
+  }
+  return 0;
+}
+
+// The next batch straight from the mapped file (no read, no copy): true when S holds it.  The first block that is not
+// strict records (or holds a '\r') ends the mapped mode for good: the stream is positioned at the first record not
+// handed out and the buffered paths take over.
+bool dcrx_fastq::parse_mapped(Store &S, uint64_t max_records) {
+  if (!mm_ok || !fast_ok || finished || max_records == 0) return false;
+  auto leave = [&]() {
+    mm_ok = false;
+    if (fseeko(fp, (off_t)mm_off, SEEK_SET) != 0) { finished = true; err_msg = "cannot seek in the FASTQ file"; }
+    pos = end = 0; eof = false; pending_cr = false; have_last = false; last.clear();
+    return false;
+  };
+  if (mm_off >= mm_size) { finished = true; S.clear(); return true; }
+  if (est_record_bytes == 0) {
+    const size_t n = mm_size - mm_off < (1u << 20) ? mm_size - mm_off : (1u << 20);
+    Piece probe;
+    parse_piece(mm + mm_off, 0, n, n, probe);
+    if (!probe.ok || probe.name_off.empty()) return leave();
+    est_record_bytes = probe.end / probe.name_off.size() + 8;
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    const size_t want = (size_t)max_records * est_record_bytes + (1u << 16);
+    const size_t len = mm_size - mm_off < want ? mm_size - mm_off : want;
+    const char *b = mm + mm_off;
+    if (std::memchr(b, '\r', len)) return leave();          // universal newlines: the buffered paths rewrite them
+    S.clear();
+    size_t used = 0;
+    const int st = strict_block(b, len, mm_off + len == mm_size, max_records, S, used);
+    if (st == 2) return leave();
+    if (st == 1) continue;
+    S.ext = b; S.ext_len = used;
+    mm_off += used;
+    if (!S.name_off.empty()) est_record_bytes = used / S.name_off.size() + 8;
+    if (mm_off == mm_size) finished = true;
+    return true;
+  }
+  return leave();
+}
+
+// The next batch by the fast path: true when S holds it (S.text = the block's bytes, file position advanced);
+// false with nothing consumed when the block does not fit the strict grammar (or the path does not apply).
+bool dcrx_fastq::parse_fast(Store &S, uint64_t max_records) {
+  if (!fast_ok || finished || (have_last && !last.empty()) || max_records == 0) return false;
+  have_last = false; last.clear();
+  // the block is assembled in the store's own buffer: first what the stream buffer still holds, then the file itself
+  S.clear();
+  S.raw_len = 0;
+  auto give_back = [&]() {            // the block returns to the stream buffer: the generator goes on from there
+    if (buf.size() < S.raw_len + (1u << 20)) buf.resize(S.raw_len + (4u << 20));
+    if (S.raw_len) std::memcpy(buf.data(), S.raw, S.raw_len);
+    pos = 0; end = S.raw_len;
+    S.raw_len = 0;
+    return false;
+  };
+  if (!S.raw_reserve((end - pos) + (1u << 20))) return false;
+  if (end > pos) { std::memcpy(S.raw, buf.data() + pos, end - pos); S.raw_len = end - pos; }
+  pos = end = 0;
+  if (est_record_bytes == 0) {        // a first look at the file: the size of its records from the first megabyte
+    while (!eof && S.raw_len < (1u << 20)) {
+      if (!S.raw_reserve((2u << 20))) return give_back();
+      size_t n = 0;
+      if (!read_into(S.raw + S.raw_len, (1u << 20) + 2 - S.raw_len, n)) return give_back();
+      S.raw_len += n;
+    }
+    Piece probe;
+    parse_piece(S.raw, 0, S.raw_len, S.raw_len, probe);
+    if (!probe.ok || probe.name_off.empty()) return give_back();
+    est_record_bytes = probe.end / probe.name_off.size() + 8;
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    // enough of the file for the batch (by the running estimate of a record's size), or all that is left
+    const size_t want = (size_t)max_records * est_record_bytes + (1u << 16);
+    while (!eof && S.raw_len < want) {
+      if (!S.raw_reserve(want + (1u << 20))) return give_back();
+      size_t n = 0;
+      if (!read_into(S.raw + S.raw_len, S.raw_cap - S.raw_len, n)) return give_back();      // the generator reports the read error
+      S.raw_len += n;
+    }
+    if (S.raw_len == 0) return give_back();        // end of file: the generator finishes
+    const char *b = S.raw;
+    const size_t len = S.raw_len;
+    size_t used = 0;
+    const int st = strict_block(b, len, eof, max_records, S, used);
+    if (st == 2) return give_back();
+    if (st == 1) continue;
+    // what lies behind the batch goes back to the stream buffer (little, once the estimate has settled)
+    const size_t rest = len - used;
+    if (buf.size() < rest + (1u << 20)) buf.resize(rest + (4u << 20));
+    if (rest) std::memcpy(buf.data(), b + used, rest);
+    pos = 0; end = rest;
+    S.raw_len = used;
+    S.use_raw = true;
+    if (!S.name_off.empty()) est_record_bytes = used / S.name_off.size() + 8;
+    if (eof && rest == 0) finished = true;      // the generator would find no further header
+    return true;
+  }
+  return give_back();
+}
+
 int dcrx_fastq::parse(Store &S, uint64_t max_records) {
   dcrx_fastq *f = this;
+  if (!gz && (parse_mapped(S, max_records) || parse_fast(S, max_records))) return DCRX_OK;
+  if (finished && err_msg) return DCRX_E_INVALID;
   S.clear();
   int err = 0;
   const char *p; size_t len;
@@ -213,6 +503,17 @@ int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out) {
     if (!f->fp) { delete f; return set_err(DCRX_E_INVALID, "cannot open FASTQ file"); }
   }
   f->buf.resize(4u << 20);
+  f->fast_ok = std::getenv("DCRX_FASTQ_SERIAL") == nullptr;
+  if (f->fp && f->fast_ok && !std::getenv("DCRX_FASTQ_NO_MMAP")) {
+    struct stat sb;
+    if (fstat(fileno(f->fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+      void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(f->fp), 0);
+      if (m != MAP_FAILED) {
+        f->mm = (const char *)m; f->mm_size = (size_t)sb.st_size; f->mm_ok = true;
+        (void)madvise(m, f->mm_size, MADV_SEQUENTIAL);
+      }
+    }
+  }
   *out = f;
   return DCRX_OK;
 }
@@ -221,6 +522,7 @@ void dcrx_fastq_close(dcrx_fastq_t *f) {
   if (!f) return;
   if (f->ahead_valid) { f->ahead.get(); f->ahead_valid = false; }
   if (f->gz) gzclose(f->gz);
+  if (f->mm) munmap(const_cast<char *>(f->mm), f->mm_size);
   if (f->fp) std::fclose(f->fp);
   delete f;
 }
@@ -257,8 +559,8 @@ int dcrx_fastq_next(dcrx_fastq_t *f, uint64_t max_records, dcrx_fastq_batch_t *o
   const size_t k = have < max_records ? have : (size_t)max_records;
   const size_t c = f->cursor;
   out->n_records = k;
-  out->text = S.text.data();
-  out->text_bytes = S.text.size();
+  out->text = S.ext ? S.ext : (S.use_raw ? S.raw : S.text.data());
+  out->text_bytes = S.ext ? S.ext_len : (S.use_raw ? S.raw_len : S.text.size());
   out->name_off = S.name_off.data() + c; out->name_len = S.name_len.data() + c;
   out->seq_off = S.seq_off.data() + c; out->seq_len = S.seq_len.data() + c;
   out->qual_off = S.qual_off.data() + c; out->qual_len = S.qual_len.data() + c;

@@ -190,3 +190,57 @@ def test_separator_inside_a_field_falls_back_to_the_per_row_path():
     out = host.N12Rows()
     host.assemble_rows_spans(rec, sp, into=out)
     assert out == rows and len(out) == 2 and out[1][5] == "id2"
+
+
+def test_parallel_fast_path_equals_the_generator(tmp_path, monkeypatch):
+    """Four-line FASTQ goes through the reader's parallel fast path (a block cut at record starts, pieces parsed by
+    several threads, the block itself as the text buffer); DCRX_FASTQ_SERIAL=1 keeps the line-by-line generator.  Same
+    records either way, for batch sizes that do and do not divide the file, with names that hold spaces, '@' and '+' at
+    the start of quality lines, long and short records — and files the strict grammar does not take (a wrapped record
+    in the middle, an unterminated last line, CRLF) fall back as a whole batch."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    def fastq(n, wrap_at=None, crlf=False, cut_tail=False):
+        out = []
+        for i in range(n):
+            L = int(rng.integers(1, 400))
+            seq = "".join(rng.choice(list("ACGTN"), size=L))
+            qual = "".join(rng.choice(list("@+>#IJK5"), size=L + (int(rng.integers(0, 3)) if i % 97 == 0 else 0)))
+            if wrap_at is not None and i == wrap_at:
+                out.append(f"@r{i} x y\n{seq[:L // 2]}\n{seq[L // 2:]}\n+\n{qual[:L // 2]}\n{qual[L // 2:]}\n")
+            else:
+                out.append(f"@r{i} lane:{i % 7} +@\n{seq}\n+{'r%d' % i if i % 5 == 0 else ''}\n{qual}\n")
+        text = "".join(out)
+        if cut_tail:
+            text = text[:-1]
+        return text.replace("\n", "\r\n") if crlf else text
+
+    def records(path, batch):
+        got = []
+        with nat.FastqReader(str(path)) as rd:
+            while True:
+                b = rd.next(batch)
+                if b.n == 0:
+                    break
+                t = bytes(b.text)
+                for k in range(b.n):
+                    q = None if b.qual_len[k] == nat.NO_QUAL else t[b.qual_off[k]:b.qual_off[k] + b.qual_len[k]]
+                    got.append((t[b.name_off[k]:b.name_off[k] + b.name_len[k]], t[b.seq_off[k]:b.seq_off[k] + b.seq_len[k]], q))
+                if b.n < batch:
+                    break
+        return got
+
+    cases = {"plain": fastq(30000), "wrapped": fastq(20000, wrap_at=11111), "crlf": fastq(8000, crlf=True),
+             "unterminated": fastq(9000, cut_tail=True)}
+    for name, text in cases.items():
+        p = tmp_path / f"{name}.fq"
+        p.write_bytes(text.encode())
+        monkeypatch.setenv("DCRX_FASTQ_SERIAL", "1")
+        want = records(p, 4096)
+        monkeypatch.delenv("DCRX_FASTQ_SERIAL")
+        assert len(want) >= 8000
+        for batch in (4096, 7001, 1 << 20):
+            assert records(p, batch) == want, (name, batch, "mapped")           # parsed from the mapped file while it is strict
+            monkeypatch.setenv("DCRX_FASTQ_NO_MMAP", "1")
+            assert records(p, batch) == want, (name, batch, "buffered")         # blocks read into the reader's own buffer
+            monkeypatch.delenv("DCRX_FASTQ_NO_MMAP")
