@@ -409,6 +409,8 @@ class N12Rows(coll.abc.Sequence):
 
     def __init__(self):
         self._chunks = []      # (bytes blob with _FIELD_SEP between fields and "\n" after each row | None, list | None)
+        self._tags = []        # per chunk: the value of _tag when it was added (the batch index in decombinator())
+        self._tag = 0
         self._len = 0
         self._lists = None
 
@@ -417,6 +419,16 @@ class N12Rows(coll.abc.Sequence):
             self._chunks.append([blob, None, n])
             self._len += n
             self._lists = None
+            self._tags.append(self._tag)
+
+    def _tagged_chunks(self):
+        """(tag, text, number of rows) per chunk — the tag is the batch the rows came from (sharded runs merge by it)."""
+        out = []
+        for (blob, rows, n), tag in zip(self._chunks, self._tags):
+            if blob is None:
+                blob = "".join(_FIELD_SEP.join(str(x) for x in r) + "\n" for r in rows).encode("utf-8")
+            out.append((tag, bytes(blob), n))
+        return out
 
     def extend(self, rows) -> None:
         rows = list(rows)
@@ -424,6 +436,7 @@ class N12Rows(coll.abc.Sequence):
             self._chunks.append([None, rows, len(rows)])
             self._len += len(rows)
             self._lists = None
+            self._tags.append(self._tag)
 
     def append(self, row) -> None:
         self.extend([row])
@@ -561,10 +574,17 @@ def _summary_text(inputargs, chain, samplenam, date, timetaken):
     return "\n".join(lines)
 
 
-def decombinator(inputargs: dict) -> list:
+def decombinator(inputargs: dict, shard=None, reduce_counts=None) -> list:
     """The decombine stage (reference decombinator(), :881-1202): returns the 10-field rows
     that write_out_intermediate() turns into the `.n12` file, as an N12Rows sequence (a lazy
-    list of lists)."""
+    list of lists).
+
+    shard = (rank, world): this process decombines the batches whose index is `rank` modulo `world` (it still reads
+    the whole file: the reader is two orders of magnitude faster than the rest) and tags its rows with their batch;
+    reduce_counts(counts), when given, is called once the loop is over and must leave the sums over all ranks in
+    `counts`; only rank 0 prints the totals and writes the summary log (decombinator_amd.sharded.decombinator_sharded
+    drives this)."""
+    rank, world = shard if shard is not None else (0, 1)
     print("Running Decombinator (MI355X / HIP build) version", __version__)
     opener = opener_check(inputargs)
     tcr = import_tcr_info(inputargs)
@@ -605,11 +625,18 @@ def decombinator(inputargs: dict) -> list:
         rd2 = nat.FastqReader(inputargs["infile"].replace("1.f", "2.f"), gz) if paired else None
         sampling = bool(inputargs.get("sampling_analysis"))
         try:
+            batch_index = -1
             while True:
                 t0 = time()
                 spans = _next_spans(rd1, rd2, bclength, sampling)
                 if spans is None:
                     break
+                batch_index += 1
+                if batch_index % world != rank:     # another rank's batch: read, not processed
+                    if spans.last:
+                        break
+                    continue
+                outdata._tag = batch_index
                 n = len(spans.v_start)
                 if inputargs["allowNs"] == False:  # noqa: E712    counted, never dropped (:985-989)
                     counts["dcrfilter_barcodeN"] += nat.count_prefix_byte(spans.bc_text, spans.bc_start, spans.bc_len,
@@ -646,8 +673,12 @@ def decombinator(inputargs: dict) -> list:
             print("Non-barcoding option selected, but default output file extension (n12) detected. "
                   "Automatically changing to 'nbc'.")
 
+    if reduce_counts is not None:
+        reduce_counts(counts)
     counts["end_time"] = time()
     timetaken = counts["end_time"] - counts["start_time"]
+    if rank != 0:
+        return outdata
     print("Analysed", "{:,}".format(counts["read_count"]), "reads, finding", "{:,}".format(counts["vj_count"]),
           chainnams[chain], "VJ rearrangements")
     print("Reading from", inputargs["infile"] + ", writing to variable")

@@ -4,7 +4,8 @@ sum of the counters (torch.distributed; backend "nccl" is RCCL over xGMI on
 ROCm, "gloo" in the CPU tests).
 
 The reference is single-process: nothing here mirrors reference
-code.  Each read's result depends only on that read and the replicated tables
+code.  decombinator_sharded() is the product entry (the whole stage over the ranks);
+TupleGather is what bench.py times (device-resident shards, tuples gathered per step).  Each read's result depends only on that read and the replicated tables
 (reference decombine.py:534-585 has no cross-read state but the additive
 Counter, :598), so the only exchange is the final one:
 
@@ -251,3 +252,54 @@ class _NullCtx:
 
     def __exit__(self, *a):
         return False
+
+
+def decombinator_sharded(inputargs: dict, device_index: int | None = None):
+    """The decombine stage over all ranks of the initialised process group (one process per GPU): the multi-GPU form
+    of decombinator_amd.decombine.decombinator().
+
+    Batches of the input (BATCH_READS records) are dealt to the ranks round-robin — every rank reads the whole FASTQ
+    (the reader is far faster than the rest of the stage) and decombines its own batches on its own GPU; the rows
+    travel to rank 0 as text, tagged with their batch, and are put back in input order there (the order contract of
+    the reference's outdata.append, decombine.py:1039); the counters are summed over the ranks before rank 0 prints
+    the totals and writes the summary log.  Returns the rows (an N12Rows, as decombinator() does) on rank 0 and None
+    on the other ranks.  No data-path collective: one gather of text at the end and one all-reduce of 64 integers."""
+    import numpy as np
+
+    from decombinator_amd import _native as nat
+    from decombinator_amd import decombine as dec
+
+    if not dist.is_initialized():
+        raise RuntimeError("decombinator_sharded needs an initialised torch.distributed process group")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if device_index is not None:
+        nat.check(nat.lib().dcrx_set_device(int(device_index)))
+
+    keys_holder = {}
+
+    def reduce_counts(counts):
+        # the Counter's keys differ between ranks (a key appears with its first increment): agree on the union first
+        mine = sorted(k for k in counts if k not in ("start_time", "end_time"))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        keys = sorted(set(k for ks in every for k in ks))
+        keys_holder["keys"] = keys
+        t = torch.tensor([int(counts.get(k, 0)) for k in keys], dtype=torch.int64)
+        if t.numel():
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            for k, v in zip(keys, t.cpu().tolist()):
+                counts[k] = int(v)
+
+    rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts)
+    chunks = rows._tagged_chunks()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(chunks, gathered, dst=0)
+    if rank != 0:
+        return None
+    merged = dec.N12Rows()
+    for tag, blob, n in sorted((c for part in gathered for c in part), key=lambda c: c[0]):
+        merged._tag = tag
+        merged._add_blob(blob, n)
+    return merged

@@ -458,3 +458,53 @@ def test_rescue_forms_on_both_strands(chain, flags):
         n_ok += tep._synthetic_vs_oracle("hip", ts, 25_000, "forward", flags, forward_strand=True, seed=80 + k, sub_rate=sub,
                                          n_rate=nrate, read_len=length)
     assert n_ok > 20_000
+
+
+SHARDED_STAGE_WORKER = '''
+import json, os, sys
+import torch                      # first: its bundled HIP runtime must be the one libdcrx binds to
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DCRX_ROOT"])
+from decombinator_amd import sharded, decombine as dec
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29547")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dec.BATCH_READS = 9
+args = json.load(open(os.path.join(os.environ["DCRX_WORK"], "args.json")))
+rows = sharded.decombinator_sharded(args, device_index=0)
+json.dump([list(r) for r in rows], open(os.path.join(os.environ["DCRX_WORK"], "rows.json"), "w"))
+print("SHARDED_STAGE_OK", len(rows))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_stage_entry_on_one_rank_over_rccl(tmp_path):
+    """decombinator_amd.sharded.decombinator_sharded (the multi-GPU form of the stage: batches dealt to the ranks, rows
+    gathered as text and put back in input order, counters all-reduced) on this GPU as the only rank of an RCCL group:
+    the reference-generated stage fixture's rows.  Two ranks run in tests/test_sharded_gloo.py with the oracle as device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from decombinator_amd import io as dio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stage = json.load(open(os.path.join(root, "tests", "golden", "stage_human_extended_b.json")))
+    run = stage["runs"][0]
+    ts = stage["tagset"]
+    synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
+                 v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
+                 j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(tmp_path / "tags"))
+    (tmp_path / "SYNTH_1.fq").write_text(stage["fastq_r1"])
+    (tmp_path / "SYNTH_2.fq").write_text(stage["fastq_r2"])
+    args = dio.create_args_dict(infile=str(tmp_path / "SYNTH_1.fq"), chain="b", bc_read=run["bc_read"], dontgzip=True, dontcount=True,
+                                orientation=run["orientation"], allowNs=run["allowNs"], tagfastadir=str(tmp_path / "tags"),
+                                outpath=str(tmp_path) + os.sep, command="decombine")
+    json.dump(args, open(tmp_path / "args.json", "w"))
+    script = tmp_path / "sharded_stage_worker.py"
+    script.write_text(SHARDED_STAGE_WORKER)
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, DCRX_ROOT=root, DCRX_WORK=str(tmp_path)),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "SHARDED_STAGE_OK" in out.stdout, out.stdout[-3000:]
+    assert json.load(open(tmp_path / "rows.json")) == run["rows"]

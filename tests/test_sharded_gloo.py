@@ -164,3 +164,90 @@ def test_shard_range_covers_everything():
             r = [sharded.shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+STAGE_WORKER = textwrap.dedent('''
+    import json, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["DCRX_ROOT"])
+    from decombinator_amd import sharded, decombine as dec, io as dio, _native as nat
+    from tests import golden_util as gu, parity_util as pu
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    work = os.environ["DCRX_WORK"]
+    stage = json.load(open(os.path.join(os.environ["DCRX_ROOT"], "tests", "golden", "stage_human_extended_b.json")))
+    ot = gu.oracle_tables(stage["tagset"])
+
+    def oracle_device(tables, batch, orientation="reverse", allow_ns=False, lenthreshold=130, flags=0):
+        return pu.oracle_records(ot, nat.unpack_reads(batch), orientation, allow_ns, lenthreshold)   # stands in for the GPU (CPU test)
+    nat.decombine = oracle_device
+    dec.BATCH_READS = 7                       # many small batches: every rank gets several, the last one is short
+    args = json.load(open(os.path.join(work, "args.json")))
+    rows = sharded.decombinator_sharded(args)
+    if rank == 0:
+        json.dump({"rows": [list(r) for r in rows], "counts": {k: int(v) for k, v in dec.counts.items() if k not in ("start_time", "end_time")}},
+                  open(os.path.join(work, "sharded.json"), "w"))
+    else:
+        assert rows is None
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_sharded_stage_equals_single_process(tmp_path, monkeypatch):
+    """decombinator_sharded() on two gloo ranks (the oracle standing in for the GPUs) against decombinator() in this
+    process on the same files: the same rows in the same order, the same counters, one summary log."""
+    import json
+    from decombinator_amd import decombine as dec, io as dio, _native as nat
+    from tests import golden_util as gu, parity_util as pu
+    from decombinator_amd import synth
+    from tests import test_host_stage as ths
+    stage = json.load(open(os.path.join(ROOT, "tests", "golden", "stage_human_extended_b.json")))
+    run = stage["runs"][0]
+    work = tmp_path / "w"
+    work.mkdir()
+    ts = stage["tagset"]
+    synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
+                 v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
+                 j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(work / "tags"))
+    (work / "SYNTH_1.fq").write_text(stage["fastq_r1"])
+    (work / "SYNTH_2.fq").write_text(stage["fastq_r2"])
+    (work / "single").mkdir()
+    (work / "sharded").mkdir()
+
+    def make_args(out):
+        return dio.create_args_dict(infile=str(work / "SYNTH_1.fq"), chain="b", bc_read=run["bc_read"], dontgzip=True, dontcount=True,
+                                    orientation=run["orientation"], allowNs=run["allowNs"], tagfastadir=str(work / "tags"),
+                                    outpath=str(work / out) + os.sep, command="decombine")
+    json.dump(make_args("sharded"), open(work / "args.json", "w"))
+    monkeypatch.setattr(nat, "decombine", ths._oracle_device(stage))
+    monkeypatch.setattr(dec, "BATCH_READS", 7)
+    dec.counts.clear()
+    want_rows = [list(r) for r in dec.decombinator(make_args("single"))]
+    assert want_rows == run["rows"]
+    want_counts = {k: int(v) for k, v in dec.counts.items() if k not in ("start_time", "end_time")}
+    script = tmp_path / "sworker.py"
+    script.write_text(STAGE_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCRX_ROOT=ROOT, DCRX_WORK=str(work), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = json.load(open(work / "sharded.json"))
+    assert len(want_rows) > 20
+    assert got["rows"] == want_rows
+    assert got["counts"] == want_counts
+    logs = list((work / "sharded" / "Logs").glob("*.csv"))          # written once, by rank 0, from the summed counters
+    assert len(logs) == 1
+    keep = [ln for ln in logs[0].read_text().split("\n") if not ln.startswith(("Directory,", "DateFinished,", "TimeFinished,", "TimeTaken"))]
+    assert keep == run["summary_lines"]
