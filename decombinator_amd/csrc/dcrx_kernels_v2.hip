@@ -69,12 +69,6 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #ifndef DCRX_LEAN_LDS_WORDS
 #define DCRX_LEAN_LDS_WORDS 1   /* the lean kernels keep the read in hand in LDS strips (0: in registers, A/B) */
 #endif
-#ifdef DCRX_DEBUG_TAIL
-__device__ unsigned long long g_dbg_tail[8];
-#define DCRX_TT(k) do { const unsigned long long t_ = clock64(); tacc_[k] += t_ - tt_; tt_ = t_; } while (0)
-#else
-#define DCRX_TT(k) ((void)0)
-#endif
 constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
 constexpr uint32_t DCRX_V2_SLOW_GROUP = 4;  // ... and what it takes of the slow list
 
@@ -337,11 +331,6 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
   const int lane = tid & 63;
-#ifdef DCRX_DEBUG_TAIL
-  unsigned long long tt_ = clock64();
-  unsigned long long tacc_[5] = {0, 0, 0, 0, 0};
-#endif
-  DCRX_TT(0);     // (staging is before this point; measured from kernel entry by the first call below)
   const bool tagged = B.n_reads < (1ull << 30);
   // DCRX_V2_TSPLIT waves share a region: wave k of them takes the batches k, k + DCRX_V2_TSPLIT, ...
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
@@ -356,15 +345,10 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
-    DCRX_TT(1);
     for (uint32_t first = 64 * part; first < tn && !(cfg.flags & DCRX_F_PROFILE_NO_TAIL); first += STEP) {
       uint32_t x[2 + NW];
 #pragma unroll
       for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
-#ifdef DCRX_DEBUG_TAIL
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-      DCRX_TT(2);
       v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
       uint32_t w[NW];
 #pragma unroll
@@ -387,9 +371,7 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
-      DCRX_TT(3);
       v2_tally(lds_counts, lane, status, o == 0);
-      DCRX_TT(4);
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
       if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
@@ -414,9 +396,6 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
       }
     }
   }
-#ifdef DCRX_DEBUG_TAIL
-  if (lane == 0) { for (int k = 0; k < 5; k++) atomicAdd(&g_dbg_tail[k], tacc_[k]); atomicAdd(&g_dbg_tail[7], 1ull); }
-#endif
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -741,16 +720,6 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
     }
-#ifdef DCRX_DEBUG_TAIL
-    {
-      unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_tail), sizeof h);
-      fprintf(stderr, "tail kernel, ticks per wave: setup %llu counts+first load %llu wait for batch %llu compute+store %llu tally %llu (waves %llu)\n",
-              h[0] / (h[7] ? h[7] : 1), h[1] / (h[7] ? h[7] : 1), h[2] / (h[7] ? h[7] : 1), h[3] / (h[7] ? h[7] : 1), h[4] / (h[7] ? h[7] : 1), h[7]);
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_tail), z, sizeof z);
-    }
-#endif
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
       std::vector<uint32_t> h(4 * (size_t)n_regions);

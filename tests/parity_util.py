@@ -36,6 +36,8 @@ def emul_lib(asan: bool = False):
         L.emul_decombine.restype = C.c_int
         L.emul_decombine.argtypes = [C.POINTER(nat.TagSetC), C.POINTER(nat.CfgC), C.POINTER(nat.BatchC),
                                      C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.emul_v2_lean.restype = C.c_uint64
+        L.emul_v2_reads.restype = C.c_uint64
         _emul = L
     return _emul
 

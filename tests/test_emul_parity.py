@@ -167,3 +167,25 @@ def test_emul_rescue_forms_on_both_strands(chain, flags):
         n_ok += _synthetic_vs_oracle("emul", ts, 2500, "forward", flags, forward_strand=True, seed=80 + k, sub_rate=sub,
                                      n_rate=nrate, read_len=length)
     assert n_ok > 2000
+
+
+def test_lean_forms_settle_nearly_all_reads_of_the_bench_workload():
+    """Guards the kernels' cost model, not their results: on BASELINE config 2's reads the lean tail settles its entries
+    but for a few in 10 000 and the lean rescue more than nine event entries in ten — the general form (the event
+    kernel) is priced for a handful of reads per thousand.  (Counted by the host emulation, which runs the same code.)"""
+    import ctypes as C
+    from decombinator_amd import synth
+    ts = synth.config_tagset(2)
+    n = 200_000
+    stats = (C.c_uint64 * 64)()
+    pu.emul_lib().emul_v2_stats(stats)          # (the tallies are cumulative: reading them clears them)
+    pu.emul_lib().emul_v2_lean()
+    assert _synthetic_vs_oracle("emul", ts, n, "reverse", 0, seed=2, sub_rate=0.005, n_rate=0.0005) > 0.3 * n
+    pu.emul_lib().emul_v2_stats(stats)
+    none, multi, tail, events = (int(stats[k]) for k in range(4))
+    assert none + multi + tail + events == n
+    assert 0.30 * n < tail < 0.40 * n and 0.08 * n < events < 0.14 * n
+    lean_tail = int(pu.emul_lib().emul_v2_lean())
+    lean_rescue = int(stats[62])
+    assert lean_tail > 0.999 * tail, (lean_tail, tail)
+    assert lean_rescue > 0.93 * events, (lean_rescue, events)
