@@ -1,0 +1,28 @@
+"""Throughput of the hot path on reads longer than the bench's 150 nt (device-resident, like bench.py): the 250 and
+300 nt of 2x250 / 2x300 libraries take the kernels' second register shape (20 words per read), 321-511 nt the
+three-launch form's general list kernel.  usage (GPU box): python tools/long_reads.py [read_len ...]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: F401  (first: one HIP runtime for the process)
+from decombinator_amd import _native as nat, synth
+
+ts = synth.config_tagset(2)
+t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
+for L in [int(x) for x in sys.argv[1:]] or [150, 250, 300, 400]:
+    n = 4_000_000 if L <= 320 else 1_000_000
+    db = nat.synth_reads_device(t, nat.synth_cfg(seed=2, read_len=L), 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    for _ in range(3):
+        nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    t0 = time.perf_counter()
+    k = 10
+    for _ in range(k):
+        nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    print(f"LONG read_len={L} reads={n} ms_per_step={dt * 1e3:.3f} Mreads/s={n / dt / 1e6:.0f} Gbases/s={n * L / dt / 1e9:.0f}")
