@@ -506,6 +506,18 @@ DCRX_DEVNI bool hamming_le1(const GeneDevPtrs &G, int k, const FR &F, int lo, in
   constexpr bool REV = FR::kRev;
   const int Lt = (int)G.tag_len[k];
   const int n = F.n();
+  // packed form for a frame that can say where its exception bytes lie: the slice is the whole tag-long window; a 32-base
+  // load placed inside the read covers it, and an exception byte is a mismatch (tags are pure ACGT) — no per-character
+  // loop at the read's ends or next to an N
+  if (FR::kWindowedWalks && hi - lo == Lt && n >= 32 && Lt <= 32) {
+    const int b = REV ? n - lo - Lt : lo;
+    const int bs = b < n - 32 ? b : n - 32;
+    const int sh = 2 * (b - bs);
+    const uint64_t mask = (Lt >= 32) ? ~0ull : ((1ull << (2 * Lt)) - 1ull);
+    const uint64_t xm = F.has_exc() ? (F.exc_slots(bs) >> sh) : 0ull;
+    const uint64_t y = (mismatch_slots(F.load64(bs) >> sh, REV ? G.tag_pk_rc[k] : G.tag_pk_fwd[k]) | xm) & mask;
+    return dcrx_popc64(y) <= 1;
+  }
   // packed form: the slice is the whole tag-long window, pure ACGT, and a 32-base load covers it
   if (hi - lo == Lt) {
     const int b = REV ? n - lo - Lt : lo;           // forward position of the window's first stored base
