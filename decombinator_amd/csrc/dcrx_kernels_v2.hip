@@ -685,6 +685,24 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t slow_width = 16u;       // lanes of a wave that take entries of a slow list
     const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
     hipStream_t se = fork ? P.v2_side : s;
+    const dim3 tgrid((n_regions * DCRX_V2_TSPLIT + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
+    const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
+    // The two lean kernels run beside each other, the tail kernel on the handle's side stream: different lists, one bound
+    // by VALU issue, the other by its record stores (0.531 against 0.546 ms per step; DCRX_F_V2_LEAN_SERIAL: one after the
+    // other on the caller's stream, A/B).  Both append to the slow list with atomics; the event kernel waits for both.
+    const bool lean2 = P.v2_side && P.v2_ev_fork && P.v2_ev_join && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL) && !fork &&
+                       !(cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE);
+    auto launch_tail_side = [&]() -> hipError_t {
+      hipError_t e2 = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e2 != hipSuccess) return e2;
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
+      e2 = hipGetLastError();
+      if (e2 != hipSuccess) return e2;
+      return hipEventRecord(P.v2_ev_join, P.v2_side);
+    };
+    if (lean2) {
+      e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
+      e = launch_tail_side(); if (e != hipSuccess) return e;
+    }
     // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
     if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)
       hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, ext, n_regions, queue,
@@ -694,13 +712,15 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                          queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const dim3 tgrid((n_regions * DCRX_V2_TSPLIT + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
-    const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
     if (!fork) {
       // the tail kernel, then one pass of the event kernel over slow list 1 (both lean kernels' leftovers)
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
+      if (lean2) {
+        e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
+      } else {
+        hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
       hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
       e = hipGetLastError();

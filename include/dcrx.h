@@ -19,7 +19,9 @@
  *   - nothing throws, aborts or prints;
  *   - a dcrx_tables_t is not thread-safe: serialise calls that share one, and launch the
  *     asynchronous entry points that share one on ONE stream (the handle owns a workspace
- *     that consecutive launches reuse);
+ *     that consecutive launches reuse).  A launch may fork part of its work onto a stream the
+ *     handle owns and joins it back before its last kernel: to the caller it is ordered on
+ *     the stream it was given, like any other work there;
  *   - "device" pointers are HIP device memory on the current device
  *     (dcrx_set_device), "host" pointers ordinary process memory.
  */
@@ -127,6 +129,7 @@ typedef struct dcrx_cfg {
 #define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
 #define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
 #define DCRX_F_PROFILE_TAIL_STREAM_ONLY 16384u /* profiling: the tail kernel reads its entries and writes records but resolves nothing (records are NOT results) */
+#define DCRX_F_V2_LEAN_SERIAL 32768u /* A/B: the two lean kernels one after the other on the caller's stream (default: the tail kernel beside the rescue kernel on the handle's side stream) */
 #define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
 #define DCRX_F_V2_FORK 4096u         /* A/B: the general-form pass over the lean rescue's leftovers beside the tail kernel on the handle's side stream (measured no faster) */
 #define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
