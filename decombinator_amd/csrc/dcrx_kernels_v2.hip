@@ -308,15 +308,14 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
 // the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
 // hand finds everything in registers.  What the lean form does not settle becomes an entry of the
 // region's slow list (full waves in a later event-kernel launch, not two lanes here).
-template <bool UNIFORM_LEN, int NW>
+template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t to_slow2, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
-  V2Ori V = T0.v2[0];
-  if (o) V = T0.v2[1];
+  constexpr int o = ORI;      // the frame is a template argument: one frame's code per kernel
+  const V2Ori V = T0.v2[ORI];
   uint32_t *lds_counts = smem;
   uint32_t *lds_side = smem + DCRX_N_COUNTERS;
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
@@ -364,10 +363,10 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         for (int k = 0; k < NW; k++) strip[k] = w[k];
         if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(w[0] ^ w[NW - 1]); }
         else
-        status = o ? tail2_fast<true>(tt, lw, n, dg, cfg, rec) : tail2_fast<false>(tt, lw, n, dg, cfg, rec);
+        status = tail2_fast<ORI == 1>(tt, lw, n, dg, cfg, rec);
 #else
         const RegWords<NW> rw{w};
-        status = o ? tail2_fast<true>(tt, rw, n, dg, cfg, rec) : tail2_fast<false>(tt, rw, n, dg, cfg, rec);
+        status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec);
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
@@ -433,15 +432,14 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
 // The lean rescue kernel: the scan kernel's event entries in straight-line code (rescue2_fast), one wave per
 // region, entries read one batch ahead.  What that form does not settle is copied to the region's slow list and
 // takes the general form in the event kernel's launch behind the tail kernel.
-template <bool UNIFORM_LEN, int NW>
+template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
-  V2Ori V = T0.v2[0];
-  if (o) V = T0.v2[1];
+  constexpr int o = ORI;
+  const V2Ori V = T0.v2[ORI];
   uint32_t *lds_counts = smem;
   uint32_t *lds_side = smem + DCRX_N_COUNTERS;
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
@@ -491,10 +489,10 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
 #if DCRX_LEAN_LDS_WORDS
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
-          status = o ? rescue2_fast<true, NW>(rt, lw, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, lw, lg, n, cfg, rec, errs);
+          status = rescue2_fast<ORI == 1, NW>(rt, lw, lg, n, cfg, rec, errs);
 #else
           const RegWords<NW> rw{w};
-          status = o ? rescue2_fast<true, NW>(rt, rw, lg, n, cfg, rec, errs) : rescue2_fast<false, NW>(rt, rw, lg, n, cfg, rec, errs);
+          status = rescue2_fast<ORI == 1, NW>(rt, rw, lg, n, cfg, rec, errs);
 #endif
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
@@ -629,10 +627,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                             uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
                             unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
-  auto kt = tail2_kernel<UNIFORM, NW>;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
-  auto kr = rescue2_kernel<UNIFORM, NW>;
+  auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
+  auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
