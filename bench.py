@@ -254,7 +254,7 @@ def main():
                                 f"2% substitutions (half-tag rescue path), both chains per step, {n} reads per step"}[args.config],
                 "reads_per_gpu_per_step": n, "read_len": READ_LEN, "seed": SEED,
                 "tagset": "synthetic " + " + ".join(x.file_stem("v")[:-1] for x in tagsets) + " (real tag files are not available offline)",
-                "kernels": "v2 (scan2 / tail2 / events2)" if v2 else "three-launch form",
+                "kernels": "v2 (scan2 / rescue2 + tail2 / events2)" if v2 else "three-launch form",
                 "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if v2 else info["dfa_bytes"],
                 "decombined_fraction": round(n_hits / n, 4),
                 "parallelism": f"reads sharded x{world}, RCCL gather of DCR tuples to rank 0" if world > 1 else "single GPU",
