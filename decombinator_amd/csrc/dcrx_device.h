@@ -59,8 +59,12 @@ inline
 __host__ __device__
 #endif
 uint32_t v2_hash(uint64_t v) {
+  // three 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 run at full rate, v_mul_lo_u32 at a quarter of it): the key's
+  // bits 0-23, 24-47 and 48-63 each times an odd 24-bit constant, summed; the bucket is bits 18-23 of the sum
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  return ((lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ (lo >> 15)) >> 26;
+  const uint32_t a = lo & 0xFFFFFFu, b = ((lo >> 24) | (hi << 8)) & 0xFFFFFFu, c = hi >> 16;
+  const uint32_t s = a * 0x9E3779u + b * 0x85EBCBu + c * 0xC2B2AFu;      // (24-bit operands: the device compiles these to the u24 forms)
+  return ((s >> 18) ^ (s >> 7)) & 63u;
 }
 
 struct V2Ori {
