@@ -680,7 +680,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;
-    const uint32_t slow_width = 16u;       // lanes of a wave that take entries of a slow list
+    const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a slow list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
     const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
     hipStream_t se = fork ? P.v2_side : s;
     const dim3 tgrid((n_regions * DCRX_V2_TSPLIT + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
