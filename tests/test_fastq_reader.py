@@ -244,3 +244,72 @@ def test_parallel_fast_path_equals_the_generator(tmp_path, monkeypatch):
             monkeypatch.setenv("DCRX_FASTQ_NO_MMAP", "1")
             assert records(p, batch) == want, (name, batch, "buffered")         # blocks read into the reader's own buffer
             monkeypatch.delenv("DCRX_FASTQ_NO_MMAP")
+
+
+def test_fast_paths_equal_the_generator_on_random_line_soup(tmp_path, monkeypatch):
+    """Differential test: files assembled at random from FASTQ-like fragments (records of one to three sequence lines,
+    FASTA records, blank lines, stray '+' and '@' lines, CR/LF and lone CR, a missing final newline, over- and
+    under-long qualities) — the mapped and the buffered fast path must give exactly the generator's records, whatever
+    they make of the file (mostly: hand it over at the first line that is not strict four-line FASTQ)."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    alphabet = list("ACGTN")
+
+    def seq(n):
+        return "".join(rng.choice(alphabet, size=n))
+
+    def fragment():
+        k = int(rng.integers(0, 12))
+        L = int(rng.integers(0, 60))
+        s = seq(L)
+        q = "".join(rng.choice(list("@+>!IJ#"), size=L))
+        if k <= 5:
+            return f"@r{int(rng.integers(0, 1000))} d\n{s}\n+\n{q}\n"                      # strict record (possibly empty sequence)
+        if k == 6:
+            h = L // 2
+            return f"@w\n{s[:h]}\n{s[h:]}\n+\n{q[:h]}\n{q[h:]}\n"                          # wrapped
+        if k == 7:
+            return f">fa x\n{s}\n"                                                          # FASTA
+        if k == 8:
+            return "\n"
+        if k == 9:
+            return f"@long\n{s}\n+\n{q}{q[:3]}\n"                                           # quality longer than the sequence
+        if k == 10:
+            return f"@short\n{s}\n+\n{q[:max(0, L - 2)]}\n"                                 # quality shorter: runs into the next lines
+        return "+stray\n" if rng.random() < 0.5 else "@stray\n"
+
+    def records(path, batch):
+        got = []
+        with nat.FastqReader(str(path)) as rd:
+            while True:
+                b = rd.next(batch)
+                if b.n == 0:
+                    break
+                t = bytes(b.text)
+                for k in range(b.n):
+                    q = None if b.qual_len[k] == nat.NO_QUAL else t[b.qual_off[k]:b.qual_off[k] + b.qual_len[k]]
+                    got.append((t[b.name_off[k]:b.name_off[k] + b.name_len[k]], t[b.seq_off[k]:b.seq_off[k] + b.seq_len[k]], q))
+                if b.n < batch:
+                    break
+        return got
+
+    for trial in range(120):
+        strict_prefix = "".join(f"@p{i}\n{seq(20)}\n+\n{'I' * 20}\n" for i in range(int(rng.integers(0, 40))))
+        text = strict_prefix + "".join(fragment() for _ in range(int(rng.integers(0, 40))))
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            text = text.replace("\n", "\r\n")
+        elif mode == 2:
+            text = text.replace("\n", "\r")
+        if rng.random() < 0.3 and text.endswith(("\n", "\r")):
+            text = text[:-1]
+        p = tmp_path / f"soup{trial}.fq"
+        p.write_bytes(text.encode())
+        batch = int(rng.choice([1, 3, 16, 1000]))
+        monkeypatch.setenv("DCRX_FASTQ_SERIAL", "1")
+        want = records(p, batch)
+        monkeypatch.delenv("DCRX_FASTQ_SERIAL")
+        assert records(p, batch) == want, (trial, "mapped", batch)
+        monkeypatch.setenv("DCRX_FASTQ_NO_MMAP", "1")
+        assert records(p, batch) == want, (trial, "buffered", batch)
+        monkeypatch.delenv("DCRX_FASTQ_NO_MMAP")
