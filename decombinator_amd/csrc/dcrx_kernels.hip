@@ -591,7 +591,10 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const bool rescue16 = !v2 && ARITY == 16 && T.pair_rescue && !(cfg.flags & DCRX_F_LIST_RESCUE) &&
                         P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA <= 160u * 1024u;
   if (!rescue16 || all_general) {
-    hipLaunchKernelGGL(klist, dim3(qgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
+    // (behind the v2 kernels a quarter of the grid: every block signs off with an atomic on one address, and that,
+    // not the handful of reads, is what the launch costs there)
+    const uint32_t lgrid = v2 ? std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4)) : qgrid;
+    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
                        queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

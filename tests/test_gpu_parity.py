@@ -509,3 +509,20 @@ def test_sharded_stage_entry_on_one_rank_over_rccl(tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and "SHARDED_STAGE_OK" in out.stdout, out.stdout[-3000:]
     assert json.load(open(tmp_path / "rows.json")) == run["rows"]
+
+
+def test_thousands_of_hand_overs_to_the_list_kernel():
+    """A third of the reads carry twelve tandem copies of a J half tag: more flagged pairs than an event entry's list (or a
+    half-tag hit list) holds, so the v2 kernels hand thousands of reads to the three-launch form's list kernel behind
+    them — records and counters against the oracle."""
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=3), 0, 200_000)
+    reads = nat.unpack_reads(hb)
+    from oracle import oracle as orc
+    h = orc.revcomp(ts.j_tags[0][:6])
+    reads = [r[:20] + (h + "AC") * 12 + r[116:] if i % 3 == 0 else r for i, r in enumerate(reads)]
+    rec, cnt = nat.decombine(t, nat.pack_reads(reads))
+    orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+    pu.assert_records_equal(rec, orec, reads, "hand-overs")
+    pu.assert_counters_equal(cnt, ocnt, "hand-overs")
