@@ -304,12 +304,11 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   B.n_reads = b->n_reads; B.n_exc = b->n_exc; B.exc_read = b->exc_read; B.exc_pos = b->exc_pos;
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
-  if (t->ev_step_start) HIP_TRY(hipEventRecord(t->ev_step_start, (hipStream_t)stream));
+  t->plan.ev_step_start = t->ev_step_start; t->plan.ev_step_stop = t->ev_step_stop;
   const hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
                                          t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
                                          (hipStream_t)stream, t->ev_start, t->ev_stop);
   if (le != hipSuccess) { t->ws_dirty = true; return hip_err(le, "launch_decombine"); }
-  if (t->ev_step_stop) HIP_TRY(hipEventRecord(t->ev_step_stop, (hipStream_t)stream));
   return DCRX_OK;
 }
 

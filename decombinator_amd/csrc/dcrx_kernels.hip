@@ -30,6 +30,7 @@
 // Integer/byte work only; no MFMA.  Bound: VALU issue and LDS look-ups of the scan;
 // HBM carries the packed reads (40 B) and the records (16 B).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -561,9 +562,10 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   // zeroed for the next batch.
   {
     const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));
-    hipLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc,
-                       all_general ? 1 : 0, v2 ? 0 : 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
-                       queue_count + 1, d_counters);
+    // (the call's start event, when one is set, rides on this dispatch)
+    hipExtLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, P.ev_step_start, nullptr, 0, B.exc_read, B.n_exc,
+                          all_general ? 1 : 0, v2 ? 0 : 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
+                          queue_count + 1, d_counters);
   }
   if (v2) {
     e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop);
@@ -594,8 +596,9 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     // (behind the v2 kernels a quarter of the grid: every block signs off with an atomic on one address, and that,
     // not the handful of reads, is what the launch costs there)
     const uint32_t lgrid = v2 ? std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4)) : qgrid;
-    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, cfg, rec, d_counters, queue, gqueue,
-                       queue_count);
+    const bool list_is_last = !(rescue16 && !all_general);
+    hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, list_is_last ? P.ev_step_stop : nullptr, 0, T, B, cfg, rec,
+                          d_counters, queue, gqueue, queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -607,8 +610,8 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
       if (e != hipSuccess) return e;
     }
     const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
-    hipLaunchKernelGGL(kresc, dim3(cus), dim3(DCRX_RBLOCK), lds_resc, s, T, B, cfg, rec, d_counters, queue, gqueue, queue_count,
-                       qcap);
+    hipExtLaunchKernelGGL(kresc, dim3(cus), dim3(DCRX_RBLOCK), lds_resc, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, queue, gqueue,
+                          queue_count, qcap);
     e = hipGetLastError();
   }
   return e;

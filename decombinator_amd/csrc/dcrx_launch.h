@@ -27,6 +27,9 @@ struct LaunchPlan {
   uint64_t v2_tail_rows = 0, v2_event_rows = 0, v2_slow_rows = 0;       // 16-byte rows allocated for each list
   hipStream_t v2_side = nullptr;                      // the event kernel runs here, beside the tail kernel
   hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr;
+  // optional, set per call (dcrx_set_step_events): start of the first and end of the last kernel of the call.  Attached to
+  // those kernels' own dispatches (hipExtLaunchKernelGGL): a separate event record costs the stream ~10 us of gap each
+  hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
