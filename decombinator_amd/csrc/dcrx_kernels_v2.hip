@@ -662,9 +662,15 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
   Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_wave, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
   if (Q.tcap < 64 || Q.ecap < 64 || Q.s2cap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
-  // (the timing events of the dominant kernel ride on its own dispatch: recorded separately they cost the stream a gap each)
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, ev_stop, 0, T, B, cfg, rec, d_counters, Q, queue,
-                        gqueue, qcap, queue_count);
+  // (the timing events of the dominant kernel ride on its own dispatch: recorded separately they cost the stream a gap each.
+  // So does the event that forks the tail kernel onto the side stream: when no timing event claims the place it is the scan
+  // dispatch's own stop event, and the rescue kernel follows the scan on the caller's queue without a marker in between)
+  const bool finish = !(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH));
+  const bool lean2_early = finish && P.v2_side && P.v2_ev_fork && P.v2_ev_join &&
+                           !(cfg.flags & (DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_FORK | DCRX_F_V2_NO_LEAN_RESCUE));
+  const bool fork_rides = lean2_early && !ev_stop;
+  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
+                        d_counters, Q, queue, gqueue, qcap, queue_count);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
@@ -692,13 +698,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
                        !(cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE);
     auto launch_tail_side = [&]() -> hipError_t {
       hipError_t e2 = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e2 != hipSuccess) return e2;
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
-      e2 = hipGetLastError();
-      if (e2 != hipSuccess) return e2;
-      return hipEventRecord(P.v2_ev_join, P.v2_side);
+      // (the join event is the tail dispatch's own stop event)
+      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue,
+                            gqueue, qcap, queue_count);
+      return hipGetLastError();
     };
     if (lean2) {
-      e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
+      if (!fork_rides) { e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e; }
       e = launch_tail_side(); if (e != hipSuccess) return e;
     }
     // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
