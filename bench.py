@@ -1,36 +1,51 @@
 #!/usr/bin/env python3
 """bench.py — Mreads/s decombined on synthetic 150 bp human-beta reads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): 10 M x 150 bp synthetic human-beta reads
 against the original-like synthetic tag set, generated ON the GPU from
 (seed, read index) so that the timed region starts with the packed reads
 resident in HBM.  A step is one pass of the hot path (dcrx_decombine_device:
-DFA scan + rescue + walks + filters -> 16-byte records + counters) over the
-rank's 10 M-read batch; with N > 1 every rank takes its own 10 M reads (weak
-scaling), compacts its DCR tuples and the tuples are gathered on rank 0 over
+automaton scan + half-tag rescue + walks + filters -> 16-byte records + counters)
+over the rank's 10 M-read batch; with N > 1 every rank takes its own 10 M reads
+(weak scaling), compacts its DCR tuples and the tuples are gathered on rank 0 over
 RCCL inside the same step.
+
+`--gpus N` without a launcher (WORLD_SIZE unset): this process — before it
+imports torch or touches HIP — starts N child processes of this same file, one
+per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
+their environment), waits for them, relays rank 0's JSON line and exits non-zero
+if any of them did.  Under torch.distributed.run the ranks are the launcher's.
 
 Rank 0 prints ONE JSON line with the whole-job rate, the HBM roofline of the
 hot path (algorithmic 54 B/read divided by the device time of ALL launches of a
 step, measured with HIP events around them on their stream; the dominant
 kernel's own launch time rides along) and a CPU baseline: the oracle (a C port
 of the reference's algorithm) timed on a bounded sample of the same reads on the
-host cores, one thread and all of them, threaded inside the C library.
+host cores, threaded inside the C library, at several thread counts.
 
 --config 3 / 5 run the other single-GPU workloads of BASELINE.json (human
 alpha+beta on extended-like tag sets, both chains per step; mouse gamma+delta);
-the default, and the line the driver records, is config 2.
+--config 4 is BASELINE configs[3]: a FIXED total of 1 B reads (--total-reads)
+sharded over the ranks (sharded.shard_range), every rank working through its
+shard in 10 M-read steps — the strong-scaling curve at 1/2/4/8 GPUs.  The
+default, and the line the driver records, is config 2.
+
+--dry-gloo (CPU, tests only): the same rank program over the gloo backend with
+tests/dry_device.py standing in for the GPU — it exercises the spawn path, the
+sharding and the tuple-gather protocol; its line says "dry_run": true and carries
+no rate.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,13 +57,96 @@ READ_LEN = 150
 SEED = 2
 ALGO_BYTES_PER_READ = 54      # 38 B packed 150-mer (rounded up) + 16 B record: SURVEY.md §8(d)
 HBM_PEAK_GBS = 8000.0         # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-TUPLE_BYTES = 16 + 8          # gathered per decombined read: record + global read index
+CONFIG_SEED = {2: SEED, 3: 3, 4: 4, 5: 5}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg-flags", type=int, default=0, help="profiling only: DCRX_F_* bits (results are then not checked)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                    help="BASELINE.json workload: 2 (default; the recorded metric), 3 = alpha+beta extended-like sets, "
+                         "4 = a fixed total of reads sharded over the ranks (strong scaling), 5 = mouse gamma+delta")
+    ap.add_argument("--total-reads", type=int, default=10**9, help="config 4: reads of the whole job")
+    ap.add_argument("--no-gather-ab", action="store_true", help="N > 1: skip the second loop that prices the exposed gather time")
+    ap.add_argument("--dry-gloo", action="store_true", help="tests only: CPU ranks over gloo, tests/dry_device.py as the device")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv) -> int:
+    """The parent of a plain `bench.py --gpus N`: N children of this file, one per GPU.  Nothing here imports torch or
+    initialises HIP (a process that has must not exec another program on this pool, and need not: the children are
+    fresh processes)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    out0 = ""
+    failed = None
+    # rank 0's stdout is read to its end (the JSON line), then every child is waited for; a child that fails takes the
+    # others down (exact PIDs), so that a half-started job cannot hang on a collective
+    import threading
+    buf = []
+    t = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and failed is None:
+                failed = (r, rc)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join(timeout=10)
+    out0 = buf[0] if buf else ""
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        return failed[1] if failed[1] > 0 else 1
+    return 0
+
+
+def host_cpu_report() -> dict:
+    """What the CPU baseline ran on: the cores this process may use, the cgroup's CPU quota, the box's count."""
+    rep = {"os_cpu_count": os.cpu_count()}
+    try:
+        rep["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        rep["sched_getaffinity"] = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            rep["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+        except Exception:
+            pass
+    try:
+        rep["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except Exception:
+        pass
+    return rep
 
 
 def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
-    """The oracle on `sample_reads` of the very same reads: one thread, then every host core
-    (POSIX threads inside the C library; each thread repeats its slice until it has about a
-    second of work, so that thread start-up does not show)."""
+    """The oracle on `sample_reads` of the very same reads (POSIX threads inside the C library; each thread owns a
+    contiguous slice and repeats it until it has about a second of work, so that thread start-up does not show):
+    one thread, then 8 / 32 / 128 / every core this process may use — `value` is the best of them."""
     from oracle import oracle as orc
 
     vs, js = ts.half_splits
@@ -64,40 +162,34 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     rate1 = n1 / t1
     # the cores this process may run on (a container's share of the host), not every core of the box
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    passes = max(1, int(round(rate1 * 1.0 / max(1, sample_reads // cores))))      # ~1 s of work per thread
-    passes = min(passes, 64)
-    t0 = time.perf_counter()
-    ot.decombine_batch_mt(buf, offsets, n_threads=cores, passes=passes)
-    tn = time.perf_counter() - t0
+    ladder = sorted(set(k for k in (8, 32, 128, cores) if k <= cores))
+    by_threads = {1: round(rate1 / 1e6, 4)}
+    best, best_k, best_t, best_passes = rate1, 1, t1, 1
+    for k in ladder:
+        passes = max(1, int(round(rate1 * 1.0 / max(1, sample_reads // k))))          # ~1 s of work per thread
+        passes = min(passes, 64)
+        t0 = time.perf_counter()
+        ot.decombine_batch_mt(buf, offsets, n_threads=k, passes=passes)
+        tn = time.perf_counter() - t0
+        rate = sample_reads * passes / tn
+        by_threads[k] = round(rate / 1e6, 4)
+        if rate > best:
+            best, best_k, best_t, best_passes = rate, k, tn, passes
     return {
-        "value": round(sample_reads * passes / tn / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-        "sample": f"first {sample_reads} reads of the same synthetic workload x {passes} passes, oracle/dcr_oracle.c "
-                  f"(C port of the reference's Python path), {cores} POSIX threads (cores this process may use; the box reports "
-                  f"{os.cpu_count()}), {tn:.2f} s",
+        "value": round(best / 1e6, 4), "unit": "Mreads/s", "cores": best_k, "kind": "port",
+        "sample": f"first {sample_reads} reads of the same synthetic workload x {best_passes} passes, oracle/dcr_oracle.c "
+                  f"(C port of the reference's Python path), {best_k} POSIX threads (the fastest of the thread counts tried), {best_t:.2f} s",
         "value_1thread": round(rate1 / 1e6, 4), "sample_1thread": f"first {n1} reads, 1 thread, {t1:.2f} s",
+        "mreads_per_s_by_threads": by_threads, "host": host_cpu_report(),
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cfg-flags", type=int, default=0, help="profiling only: DCRX_F_* bits (results are then not checked)")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
-                    help="BASELINE.json workload: 2 (default; the recorded metric), 3 = alpha+beta extended-like sets, 5 = mouse gamma+delta")
-    args = ap.parse_args()
-
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
+    dry = args.dry_gloo
 
     # torch first: its bundled HIP runtime (same soname as /opt/rocm's) must be the one
     # libdcrx binds to, so that torch/RCCL and the kernels share one runtime.
@@ -109,22 +201,27 @@ def main():
     from decombinator_amd import synth
     from decombinator_amd import sharded
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the decombine hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    nat.check(nat.lib().dcrx_set_device(local_rank))
-    # DCRX_BENCH_FORCE_GATHER=1 under torchrun with one rank exercises the RCCL path on one GPU
+    if dry:
+        from tests import dry_device          # CPU stand-in for the device (tests only; its line is marked dry_run)
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the decombine hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        nat.check(nat.lib().dcrx_set_device(local_rank))
+        dev = torch.device("cuda", local_rank)
+    # DCRX_BENCH_FORCE_GATHER=1 with one rank exercises the gather path on one GPU
     use_dist = world > 1 or (os.environ.get("DCRX_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream()
-    sptr = stream.cuda_stream
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sptr = 0 if dry else torch.cuda.current_stream().cuda_stream
 
     # the chains a step resolves: one table set each (the reference resolves one chain per call, decombine.py:593-661)
-    if args.config == 2:
+    if args.config in (2, 4):
         tagsets = [synth.config_tagset(2)]
     elif args.config == 3:
         tagsets = list(synth.config3_tagsets())
@@ -136,119 +233,99 @@ def main():
     algo_bytes = 38 + 16 * len(all_tables)           # 54 B/read one chain, 70 B/read two
     n = args.reads
     stride = nat.stride_for(READ_LEN)
-    cfg_synth = nat.synth_cfg(seed={2: SEED, 3: 3, 5: 5}[args.config], read_len=READ_LEN, sub_rate=0.02 if args.config == 5 else 0.005)
-    if os.environ.get("DCRX_BENCH_N_RATE"):          # experiments only: share of reads with an N (default 0.0005)
-        cfg_synth = nat.synth_cfg(seed={2: SEED, 3: 3, 5: 5}[args.config], read_len=READ_LEN, sub_rate=0.02 if args.config == 5 else 0.005,
-                                  n_rate=float(os.environ["DCRX_BENCH_N_RATE"]))
-    first = rank * n
+    seed = CONFIG_SEED[args.config]
+    n_rate = float(os.environ["DCRX_BENCH_N_RATE"]) if os.environ.get("DCRX_BENCH_N_RATE") else 0.0005     # experiments only
+    cfg_synth = nat.synth_cfg(seed=seed, read_len=READ_LEN, sub_rate=0.02 if args.config == 5 else 0.005, n_rate=n_rate)
 
-    # inputs resident in HBM before the timed region
-    # (several chains: the batch is drawn in equal parts from each chain's germlines, part k from chain k)
-    d_packed = torch.empty(n * stride + 16, dtype=torch.uint8, device=dev)
-    ers, eps, ecs = [], [], []
-    for k, tb in enumerate(all_tables):
-        lo, hi = n * k // len(all_tables), n * (k + 1) // len(all_tables)
-        nat.check(nat.lib().dcrx_synth_reads_device(tb.handle, nat.C.byref(cfg_synth), first + lo, hi - lo, stride,
-                                                    d_packed.data_ptr() + lo * stride, sptr))
-        e_r, e_p, e_c = nat.synth_exceptions_host(tb, cfg_synth, first + lo, hi - lo)
-        ers.append(e_r.astype(np.int64) + lo); eps.append(e_p); ecs.append(e_c)
-    er, ep, ec = np.concatenate(ers), np.concatenate(eps), np.concatenate(ecs)
-    d_er = torch.from_numpy(er.astype(np.int64)).to(dev).to(torch.int32)  # same bits as uint32
-    d_ep = torch.from_numpy(ep.astype(np.int32)).to(dev).to(torch.int16)
-    d_ec = torch.from_numpy(ec).to(dev)
-    d_recs = [torch.empty(n * 16, dtype=torch.uint8, device=dev) for _ in all_tables]      # one record plane per chain
-    d_cnts = [torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev) for _ in all_tables]
-    d_rec, d_cnt = d_recs[-1], d_cnts[-1]
-    batch = nat.BatchC()
-    batch.n_reads, batch.packed, batch.stride, batch.read_len, batch.lens = n, d_packed.data_ptr(), stride, READ_LEN, None
-    batch.n_exc = len(er)
-    batch.exc_read, batch.exc_pos, batch.exc_chr = (d_er.data_ptr(), d_ep.data_ptr(), d_ec.data_ptr()) if len(er) else (None, None, None)
-    cfg = nat.make_cfg("reverse", False, 130, args.cfg_flags)
-    for tb in all_tables:
-        nat.check(nat.lib().dcrx_reserve_device(tb.handle, n))
-    gather = sharded.TupleGather(n, world, rank, dev) if use_dist else None
-    if world > 1:
+    # ---- what a rank works through: `batches` = [(first read index, reads)], one per step of a pass ----
+    if args.config == 4:
+        lo, hi = sharded.shard_range(args.total_reads, world, rank)
+        batches = [(a, min(n, hi - a)) for a in range(lo, hi, n)] or [(lo, 0)]
+        glo = [sharded.shard_range(args.total_reads, world, r) for r in range(world)]
+        n_steps = max((b - a + n - 1) // n for a, b in glo)          # every rank runs the same number of steps (short shards: empty steps)
+        while len(batches) < n_steps:
+            batches.append((hi, 0))
+        args.steps = n_steps
+        job_reads_per_pass = args.total_reads
+    else:
+        batches = [(rank * n, n)]
+        job_reads_per_pass = None
+    if dry:
+        device = dry_device.DryDevice(nat, all_tables, tagsets, cfg_synth, batches, n)
+    else:
+        device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
+    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact) if use_dist else None
+    if world > 1 and not dry:
         # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the
         # tuples of step k really move beside the scan of step k+1 (on one GPU, where the "gather" is a
         # local copy, reserving units only costs: 0.85 ms/step with none, 0.89 with 16)
-        nat.check(nat.lib().dcrx_set_reserved_cus(tables.handle, int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))))
+        for tb in all_tables:
+            nat.check(nat.lib().dcrx_set_reserved_cus(tb.handle, int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))))
 
-    def step(ev=None):
-        rec = d_rec
-        if gather is not None:           # alternating record buffers: the previous step's tuples are still being compacted
-            gather.before_scan()
-            rec = gather.records()
-        for k, tb in enumerate(all_tables):
-            last = k == len(all_tables) - 1
-            if ev is not None:           # events: (step start, step stop, kernel start, kernel stop) per chain
-                nat.check(nat.lib().dcrx_set_step_events(tb.handle, ev[k][0].ptr, ev[k][1].ptr))
-                nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[k][2].ptr, ev[k][3].ptr))
-            nat.check(nat.lib().dcrx_decombine_device(tb.handle, nat.C.byref(cfg), nat.C.byref(batch),
-                                                      (rec if last else d_recs[k]).data_ptr(), d_cnts[k].data_ptr(), sptr))
-            if ev is not None:
-                nat.check(nat.lib().dcrx_set_step_events(tb.handle, None, None))
-                nat.check(nat.lib().dcrx_set_timing_events(tb.handle, None, None))
-        if gather is not None:
-            gather.step(n)
-
-    def fence():
-        if gather is not None:
-            gather.finish()
+    def fence(g):
+        if g is not None:
+            g.finish()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    events = [[tuple(nat.Event() for _ in range(4)) for _ in all_tables] for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    # HIP events around the kernels are not free (a step that carries its four costs ~20 us more: 0.508 against 0.485 ms,
-    # whether recorded separately or riding on the dispatches): every EVENT_EVERY-th step of the timed region carries
-    # them, and the device-side averages below are over those steps
+    def timed_loop(g, steps, events=None, timed=()):
+        fence(g)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            device.step(k, g, events[k] if events is not None and k in timed else None)
+        fence(g)
+        return time.perf_counter() - t0
+
+    for k in range(args.warmup):
+        device.step(k, gather, None)
+    fence(gather)
+    # HIP events around the kernels are not free (a step that carries its four costs ~20 us more): every
+    # EVENT_EVERY-th step of the timed region carries them, and the device-side averages below are over those steps
     every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
     timed = [k for k in range(args.steps) if k % every == every - 1 or args.steps < every]
-    for k in range(args.steps):
-        step(events[k] if k in timed else None)
-    fence()
-    elapsed = time.perf_counter() - t0
-    events = [events[k] for k in timed]
+    events = device.make_events(args.steps, timed)
+    elapsed = timed_loop(gather, args.steps, events, set(timed))
+    elapsed_nogather = None
+    if gather is not None and world > 1 and not args.no_gather_ab:
+        # the same steps without the gather: the difference is the gather time the steps do not hide
+        elapsed_nogather = timed_loop(None, args.steps)
 
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    step_ms = [sum(e[0].elapsed_ms(e[1]) for e in evs) for evs in events]         # all launches of a step, on the device
-    kern_ms = [sum(e[2].elapsed_ms(e[3]) for e in evs) for evs in events]         # the dominant kernel(s) alone
-    step_avg_ms, kern_avg_ms = sum(step_ms) / len(step_ms), sum(kern_ms) / len(kern_ms)
-    counters = d_cnt.cpu().numpy().astype(np.uint64)
-    n_hits = sum(int(c.cpu().numpy().astype(np.uint64)[nat.COUNTER_NAMES.index("vj_count")]) for c in d_cnts)
-    assert args.cfg_flags or all(int(c.cpu().numpy().astype(np.uint64)[nat.COUNTER_NAMES.index("read_count")]) == n for c in d_cnts)
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
+    if elapsed_nogather is not None:
+        elapsed_nogather = max_over_ranks(elapsed_nogather)
+    step_ms, kern_ms = device.event_times(events, timed)
+    n_hits, n_read = device.totals()
+    assert args.cfg_flags or n_read == device.expected_read_count(), (n_read, device.expected_read_count())
     if gather is not None:
-        gather.check(int(counters[nat.COUNTER_NAMES.index("vj_count")]))
+        gather.check(device.last_step_hits())
+    names = [None] * world
+    if use_dist:
+        dist.all_gather_object(names, device.name())
+    else:
+        names = [device.name()]
+    hits_all = n_hits
+    if use_dist:
+        t = torch.tensor([n_hits], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        hits_all = int(t.item())
 
     if rank == 0:
-        total_reads = n * world * args.steps
+        total_reads = args.total_reads if args.config == 4 else n * world * args.steps
         value = total_reads / elapsed / 1e6
-        achieved = algo_bytes * n / (step_avg_ms * 1e-3) / 1e9
-        v2 = bool(info.get("v2_tables")) and not (args.cfg_flags & 64)
-        dominant = "dcrx::scan2_kernel" if v2 else "dcrx::decombine_kernel"
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.config == 2:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == ("v2" if v2 else "v1"):
-                    traffic = tj.get("hbm_bytes_per_step")
-                    traffic_source = "profiles/traffic.json: rocprofv3 --pmc passes of this command on an earlier run (" + tj.get("profile", "?") + "), not measured by this run"
-            except Exception:
-                traffic = None
         line = {
-            "metric": "Mreads/s decombined (150 bp human-beta)" if args.config == 2 else f"Mreads/s decombined (150 bp, BASELINE config {args.config})",
-            "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Mreads/s decombined (150 bp human-beta)" if args.config in (2, 4) else f"Mreads/s decombined (150 bp, BASELINE config {args.config})",
+            "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {
                 "workload": {2: "BASELINE configs[1]: synthetic 10M x 150bp human-beta reads, original-like synthetic "
@@ -256,29 +333,62 @@ def main():
                              3: "BASELINE configs[2]: synthetic 150bp reads, human alpha + beta on extended-like synthetic tag sets "
                                 "(104 V / 61 J and 88 V / 14 J), both chains resolved per step (two passes over the resident reads), "
                                 f"{n} reads per step",
+                             4: f"BASELINE configs[3]: {args.total_reads} synthetic 150bp human-beta reads in all (fixed), sharded over "
+                                f"{world} rank(s) in contiguous ranges (sharded.shard_range), {n} reads per rank and step, the whole shard "
+                                "resident in HBM before the timed region, DCR tuples gathered on rank 0",
                              5: "BASELINE configs[4]: synthetic 150bp reads, mouse gamma + delta original-like synthetic tag sets, "
                                 f"2% substitutions (half-tag rescue path), both chains per step, {n} reads per step"}[args.config],
-                "reads_per_gpu_per_step": n, "read_len": READ_LEN, "seed": SEED,
+                "reads_per_gpu_per_step": n, "read_len": READ_LEN, "seed": seed,
                 "tagset": "synthetic " + " + ".join(x.file_stem("v")[:-1] for x in tagsets) + " (real tag files are not available offline)",
-                "kernels": "v2 (scan2 / rescue2 + tail2 / events2)" if v2 else "three-launch form",
-                "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if v2 else info["dfa_bytes"],
-                "decombined_fraction": round(n_hits / n, 4),
-                "parallelism": f"reads sharded x{world}, RCCL gather of DCR tuples to rank 0" if world > 1 else "single GPU",
+                "kernels": device.kernels(info),
+                "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if info.get("v2_tables") else info["dfa_bytes"],
+                "decombined_fraction": round(hits_all / max(1, device.expected_read_count() * world if args.config != 4 else args.total_reads), 4),
+                "parallelism": f"reads sharded x{world}, gather of DCR tuples to rank 0 ({'gloo' if dry else 'RCCL'})" if world > 1 else "single GPU",
+                "world_size": dist.get_world_size() if use_dist else 1, "devices": names,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "all launches of a step (dcrx_decombine_device: prologue, scan, finishing kernels)",
+        }
+        if dry:
+            line["dry_run"] = True
+            line["note"] = "CPU ranks over gloo with tests/dry_device.py in place of the GPU: a test of the launch, sharding and gather protocol, not a measurement"
+        else:
+            step_avg_ms, kern_avg_ms = sum(step_ms) / len(step_ms), sum(kern_ms) / len(kern_ms)
+            # (the timed steps that carry events: for config 4 the last, shorter step of a shard may be among them; the reads of
+            # an average step are what the device time is set against)
+            achieved = algo_bytes * (total_reads / world / args.steps) / (step_avg_ms * 1e-3) / 1e9
+            traffic, traffic_source = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            v2 = bool(info.get("v2_tables")) and not (args.cfg_flags & 64)
+            if os.path.exists(tpath) and args.config == 2:
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == device.kernels_tag(info):
+                        traffic = tj.get("hbm_bytes_per_step")
+                        traffic_source = ("profiles/traffic.json: rocprofv3 --pmc passes of this command on an earlier run (" +
+                                          tj.get("profile", "?") + "), not measured by this run")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "all launches of a step (dcrx_decombine_device)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_read": algo_bytes,
                 "step_device_ms_avg": round(step_avg_ms, 5), "step_device_ms_min": round(min(step_ms), 5),
-                "dominant_kernel": dominant, "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
+                "dominant_kernel": "dcrx::scan2_kernel" if v2 else "dcrx::decombine_kernel", "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
                 "dominant_kernel_ms_min": round(min(kern_ms), 5),
-                "events": f"HIP events on {len(events)} of the {args.steps} timed steps (every {every}th: a step that carries them runs ~4 % "
+                "events": f"HIP events on {len(timed)} of the {args.steps} timed steps (every {every}th: a step that carries them runs a few % "
                           "longer, so the device-side averages can exceed ms_per_step)",
-            },
+            }
             # the same algorithmic bytes over the host-side time of a step (launch gaps included)
-            "step_frac": round(algo_bytes * n * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 5),
-        }
-        if world == 1 and not args.no_cpu_baseline:
+            line["step_frac"] = round(algo_bytes * total_reads / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5)
+        if gather is not None:
+            hits_per_step = hits_all / (args.steps if args.config == 4 else 1)       # config 4: the counters are those of a whole pass
+            tuple_mb = hits_per_step * sharded.TupleGather.TUPLE_BYTES / 1e6
+            line["gather"] = {
+                "tuple_bytes": sharded.TupleGather.TUPLE_BYTES,
+                "mb_per_step_all_ranks": round(tuple_mb + world * ((n + 63) // 64) * 8 / 1e6, 3),
+                "ms_per_step_without_gather": None if elapsed_nogather is None else round(elapsed_nogather / args.steps * 1e3, 4),
+                "exposed_ms_per_step": None if elapsed_nogather is None else round((elapsed - elapsed_nogather) / args.steps * 1e3, 4),
+            }
+        if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(nat, tables, ts, cfg_synth, min(args.cpu_sample, n))
         else:
             line["cpu_baseline"] = None
@@ -286,6 +396,116 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class HipDevice:
+    """The rank's GPU: resident reads of every batch, the record planes and one dcrx_decombine_device per chain and step."""
+
+    def __init__(self, nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, cfg_flags):
+        self.nat, self.torch, self.np, self.dev, self.sptr = nat, torch, np, dev, sptr
+        self.all_tables, self.batches, self.n, self.stride = all_tables, batches, n, stride
+        self.cfg_flags = cfg_flags
+        total = sum(b[1] for b in batches)
+        # inputs resident in HBM before the timed region
+        # (several chains: a batch is drawn in equal parts from each chain's germlines, part k from chain k)
+        self.d_packed = torch.empty(max(1, total) * stride + 16, dtype=torch.uint8, device=dev)
+        self.bc = []
+        self._keep = []
+        at = 0
+        for first, cnt in batches:
+            ers, eps, ecs = [], [], []
+            for k, tb in enumerate(all_tables):
+                lo, hi = cnt * k // len(all_tables), cnt * (k + 1) // len(all_tables)
+                if hi > lo:
+                    nat.check(nat.lib().dcrx_synth_reads_device(tb.handle, nat.C.byref(cfg_synth), first + lo, hi - lo, stride,
+                                                                self.d_packed.data_ptr() + (at + lo) * stride, sptr))
+                e_r, e_p, e_c = nat.synth_exceptions_host(tb, cfg_synth, first + lo, hi - lo)
+                ers.append(e_r.astype(np.int64) + lo); eps.append(e_p); ecs.append(e_c)
+            er, ep, ec = np.concatenate(ers), np.concatenate(eps), np.concatenate(ecs)
+            d_er = torch.from_numpy(er.astype(np.int64)).to(dev).to(torch.int32)  # same bits as uint32
+            d_ep = torch.from_numpy(ep.astype(np.int32)).to(dev).to(torch.int16)
+            d_ec = torch.from_numpy(ec).to(dev)
+            self._keep.append((d_er, d_ep, d_ec))
+            b = nat.BatchC()
+            b.n_reads, b.packed, b.stride, b.read_len, b.lens = cnt, self.d_packed.data_ptr() + at * stride, stride, READ_LEN, None
+            b.n_exc = len(er)
+            b.exc_read, b.exc_pos, b.exc_chr = (d_er.data_ptr(), d_ep.data_ptr(), d_ec.data_ptr()) if len(er) else (None, None, None)
+            self.bc.append(b)
+            at += cnt
+        self.d_recs = [torch.empty(n * 16, dtype=torch.uint8, device=dev) for _ in all_tables]      # one record plane per chain
+        self.d_cnts = [torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev) for _ in all_tables]
+        self.d_sum = [torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev) for _ in all_tables]   # config 4: over the steps of a pass
+        self.cfg = nat.make_cfg("reverse", False, 130, cfg_flags)
+        for tb in all_tables:
+            nat.check(nat.lib().dcrx_reserve_device(tb.handle, n))
+        self.accumulate = len(batches) > 1
+        self.compact = None            # TupleGather then compacts with dcrx_compact_hits_packed_device
+
+    def name(self):
+        return self.nat.device_name()
+
+    def kernels_tag(self, info):
+        return "v2" if bool(info.get("v2_tables")) and not (self.cfg_flags & 64) else "v1"
+
+    def kernels(self, info):
+        return "v2 (scan2 / rescue2 + tail2 / events2)" if self.kernels_tag(info) == "v2" else "three-launch form"
+
+    def make_events(self, steps, timed):
+        nat = self.nat
+        return {k: [tuple(nat.Event() for _ in range(4)) for _ in self.all_tables] for k in timed}
+
+    def step(self, k, gather, ev):
+        nat = self.nat
+        b = self.bc[k % len(self.bc)]
+        rec = self.d_recs[-1]
+        if gather is not None:           # alternating record buffers: the previous step's tuples are still being compacted
+            gather.before_scan()
+            rec = gather.records()
+        for c, tb in enumerate(self.all_tables):
+            last = c == len(self.all_tables) - 1
+            if ev is not None:           # events: (step start, step stop, kernel start, kernel stop) per chain
+                nat.check(nat.lib().dcrx_set_step_events(tb.handle, ev[c][0].ptr, ev[c][1].ptr))
+                nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[c][2].ptr, ev[c][3].ptr))
+            nat.check(nat.lib().dcrx_decombine_device(tb.handle, nat.C.byref(self.cfg), nat.C.byref(b),
+                                                      (rec if last else self.d_recs[c]).data_ptr(), self.d_cnts[c].data_ptr(), self.sptr))
+            if ev is not None:
+                nat.check(nat.lib().dcrx_set_step_events(tb.handle, None, None))
+                nat.check(nat.lib().dcrx_set_timing_events(tb.handle, None, None))
+            if self.accumulate:          # a pass over several batches: the pass's counters (every call zeroes its own block)
+                if k % len(self.bc) == 0:
+                    self.d_sum[c].zero_()
+                self.d_sum[c] += self.d_cnts[c]
+        if gather is not None:
+            gather.step(b.n_reads)
+
+    def event_times(self, events, timed):
+        step_ms = [sum(e[0].elapsed_ms(e[1]) for e in events[k]) for k in timed]         # all launches of a step, on the device
+        kern_ms = [sum(e[2].elapsed_ms(e[3]) for e in events[k]) for k in timed]         # the dominant kernel(s) alone
+        return step_ms, kern_ms
+
+    def _counter(self, name):
+        np, nat = self.np, self.nat
+        src = self.d_sum if self.accumulate else self.d_cnts
+        i = nat.COUNTER_NAMES.index(name)
+        return [int(c.cpu().numpy().astype(np.uint64)[i]) for c in src]
+
+    def totals(self):
+        return sum(self._counter("vj_count")), min(self._counter("read_count"))
+
+    def expected_read_count(self):
+        return sum(b[1] for b in self.batches) if self.accumulate else self.n
+
+    def last_step_hits(self):
+        np, nat = self.np, self.nat
+        return int(self.d_cnts[-1].cpu().numpy().astype(np.uint64)[nat.COUNTER_NAMES.index("vj_count")])
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -246,6 +246,9 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     // on the stream the kernels will run on (a non-blocking stream does not order against the null stream)
     HIP_TRY(hipMemsetAsync(t->d_exc_flag, 0, ((t->exc_flag_reads + 31) / 32) * 4 + 16, stream));
     HIP_TRY(hipMemsetAsync(t->d_queue, 0, DCRX_QUEUE_HEADER * 4, stream));
+    // dcrx_reserve_device and the host-buffer entry come here with the null stream: the fills must have landed before a
+    // later call's kernels start on a non-blocking stream of the caller's, which nothing orders against the null stream
+    if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
     t->ws_dirty = false;
   }
   if (max_reads > t->compact_reads) {

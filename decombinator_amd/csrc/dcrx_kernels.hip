@@ -514,12 +514,16 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
 // per-device "attribute already set" marks (one process may drive several devices)
+// (the mark is set by attributes_set_on_device once every hipFuncSetAttribute of the launcher has succeeded: a failure
+// in between must not leave later launches without the LDS attribute)
 bool first_use_on_device(bool (&seen)[64]) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-  const bool first = !seen[dev];
-  seen[dev] = true;
-  return first;
+  return !seen[dev];
+}
+void attributes_set_on_device(bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) seen[dev] = true;
 }
 
 template <bool TABLE_LDS, bool UNIFORM, int NW, int ARITY>
@@ -540,6 +544,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(klist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    attributes_set_on_device(attr_seen);
   }
   int occ_fast = 0, occ_list = 0;
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, kfast, FBLOCK, lds_fast);
@@ -608,6 +613,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     if (first_use_on_device(rattr_seen)) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(kresc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
+      attributes_set_on_device(rattr_seen);
     }
     const uint32_t lds_resc = P.lds16_bytes + DCRX_RESCUE_LDS_EXTRA;
     hipExtLaunchKernelGGL(kresc, dim3(cus), dim3(DCRX_RBLOCK), lds_resc, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, queue, gqueue,

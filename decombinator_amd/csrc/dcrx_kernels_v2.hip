@@ -41,6 +41,7 @@
 namespace dcrx {
 
 bool first_use_on_device(bool (&seen)[64]);
+void attributes_set_on_device(bool (&seen)[64]);
 
 constexpr int DCRX_V2_BLOCK = 1024;
 constexpr int DCRX_V2_FBLOCK = 256;
@@ -175,7 +176,8 @@ __device__ __forceinline__ void v2_load_tile(const BatchDev &B, const uint32_t n
 template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count) {
+    V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
+    uint32_t stagger) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   V2Ori V0 = T0.v2[0];
@@ -188,6 +190,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   stage_lds<DCRX_V2_BLOCK>(reinterpret_cast<const uint8_t *>(V0.trans), lds_trans, V0.trans_bytes / 16, 0, 0, tid);
   const V2Tab tab{};
   __syncthreads();
+  // The waves of a block would run their tiles in lockstep for the whole launch: all of them in the scan (the LDS array
+  // busy, the vector units half idle), then all of them in the digest and the pushes (the other way round).  The four waves
+  // that share a SIMD start `stagger` x 1024 clocks apart, so that one wave's look-ups run under another's arithmetic.
+  for (uint32_t k = 0; k < (uint32_t)(tid >> 8) * (stagger & 0xFFFFu); k++) __builtin_amdgcn_s_sleep(16);
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -202,15 +208,44 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   constexpr uint64_t TILE = (uint64_t)DCRX_V2_BLOCK * RPL;
   const int npairs = UNIFORM_LEN ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   uint32_t w[RPL][NW];
+#ifdef DCRX_SCAN_STAMPS
+  unsigned long long stamp_scan = 0, stamp_rest = 0, stamp_prev = 0;      // clocks inside scan2() / between two scan2() calls, per wave
+  const unsigned long long stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   uint64_t tile = blockIdx.x;
   if (PREFETCH && tile * TILE < B.n_reads) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
-  for (; tile * TILE < B.n_reads; tile += gridDim.x) {
+  uint32_t tileno = 0;
+  for (; tile * TILE < B.n_reads; tile += gridDim.x, tileno++) {
+    // The four waves that share a SIMD are served oldest first: with equal work the first would end a quarter earlier than
+    // the last (148 against 193 us) and idle until the launch ends.  Their issue priorities rotate tile by tile instead.
+    if (stagger & 0x10000u) {
+      switch (((uint32_t)(tid >> 8) + tileno) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     uint32_t wn[RPL][NW];
     const bool more = PREFETCH && (tile + gridDim.x) * TILE < B.n_reads;
     if (!PREFETCH) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
     if (PREFETCH) { if (more) v2_load_tile<NW, RPL>(B, nw, (tile + gridDim.x) * TILE, tid, wn); }     // in flight while this tile is scanned
     uint32_t lg[RPL][NW];
+#ifdef DCRX_SCAN_STAMPS
+    const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
     scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
+#ifdef DCRX_SCAN_STAMPS
+    {
+      uint32_t keep = 0;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) keep ^= lg[q][NW - 1];
+      asm volatile("" :: "v"(keep));
+    }
+    const unsigned long long st1 = __builtin_readcyclecounter();
+    stamp_scan += st1 - st0;
+    if (stamp_prev) stamp_rest += st0 - stamp_prev;
+#endif
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const uint64_t r = tile * TILE + (uint64_t)q * DCRX_V2_BLOCK + tid;
@@ -293,8 +328,20 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #pragma unroll
         for (int k = 0; k < NW; k++) w[q][k] = wn[q][k];
     }
+#ifdef DCRX_SCAN_STAMPS
+    stamp_prev = st1;
+#endif
   }
+#ifdef DCRX_SCAN_STAMPS
+  if (lane == 0) {
+    // tail / event counts are not needed by this build's runs (DCRX_F_PROFILE_NO_FINISH): wave lifetime in shader clocks and in the 100 MHz real-time counter
+    (void)stamp_c0;
+    Q.counts[4 * region] = (uint32_t)stamp_r0; Q.counts[4 * region + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    Q.counts[4 * region + 2] = (uint32_t)(stamp_scan >> 6); Q.counts[4 * region + 3] = (uint32_t)(stamp_rest >> 6);
+  }
+#else
   if (lane == 0) { Q.counts[4 * region] = tn; Q.counts[4 * region + 1] = en; Q.counts[4 * region + 2] = 0u; Q.counts[4 * region + 3] = 0u; }
+#endif
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -643,6 +690,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    attributes_set_on_device(seen);
   }
   if (B.n_reads == 0) return hipSuccess;       // the prologue has zeroed the counters
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
@@ -669,8 +717,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const bool lean2_early = finish && P.v2_side && P.v2_ev_fork && P.v2_ev_join &&
                            !(cfg.flags & (DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_FORK | DCRX_F_V2_NO_LEAN_RESCUE));
   const bool fork_rides = lean2_early && !ev_stop;
+  static const uint32_t stagger = getenv("DCRX_SCAN_STAGGER") ? (uint32_t)atoi(getenv("DCRX_SCAN_STAGGER")) : 0u;
   hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count);
+                        d_counters, Q, queue, gqueue, qcap, queue_count, stagger);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
@@ -753,8 +802,28 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       unsigned long long sl2 = 0;
       for (uint32_t r = 0; r < n_regions; r++) { t += h[4 * r]; ev += h[4 * r + 1]; sl += h[4 * r + 2]; sl2 += h[4 * r + 3]; smax = std::max<unsigned long long>(smax, h[4 * r + 2]); }
       fprintf(stderr, "dcrx v2 lists: regions %u tail %llu events %llu slow1 %llu (max per region %llu) slow2 %llu\n", n_regions, t, ev, sl, smax, sl2);
+
     }
   }
+#ifdef DCRX_SCAN_STAMPS
+  if ((cfg.flags & DCRX_F_PROFILE_NO_FINISH) && e == hipSuccess) {      // instrumented build (tools/): where a scan wave's clocks go
+    std::vector<uint32_t> h(4 * (size_t)n_regions);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
+    if (const char *dump = getenv("DCRX_STAMPS_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); } }
+    double a = 0, b = 0, life = 0;
+    uint32_t t_first = 0xFFFFFFFFu;
+    for (uint32_t r = 0; r < n_regions; r++) t_first = std::min(t_first, h[4 * r]);
+    std::vector<uint32_t> starts, ends;
+    for (uint32_t r = 0; r < n_regions; r++) { a += h[4 * r + 2]; b += h[4 * r + 3]; life += h[4 * r + 1] - h[4 * r]; starts.push_back(h[4 * r] - t_first); ends.push_back(h[4 * r + 1] - t_first); }
+    std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+    auto pc = [&](const std::vector<uint32_t> &v, double q) { return v[(size_t)(q * (v.size() - 1))] / 100.0; };
+    fprintf(stderr, "dcrx scan stamps: per wave, mean ticks inside scan2() %.0f, between scans %.0f; mean wave lifetime %.1f us; wave starts (us after the first) p50 %.1f p90 %.1f max %.1f; "
+            "wave ends min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
+            64.0 * a / n_regions, 64.0 * b / n_regions, life / n_regions / 100.0, pc(starts, 0.5), pc(starts, 0.9), pc(starts, 1.0),
+            pc(ends, 0.0), pc(ends, 0.1), pc(ends, 0.5), pc(ends, 0.9), pc(ends, 0.99), pc(ends, 1.0));
+  }
+#endif
   return e;
 }
 

@@ -574,17 +574,9 @@ def _summary_text(inputargs, chain, samplenam, date, timetaken):
     return "\n".join(lines)
 
 
-def decombinator(inputargs: dict, shard=None, reduce_counts=None) -> list:
-    """The decombine stage (reference decombinator(), :881-1202): returns the 10-field rows
-    that write_out_intermediate() turns into the `.n12` file, as an N12Rows sequence (a lazy
-    list of lists).
-
-    shard = (rank, world): this process decombines the batches whose index is `rank` modulo `world` (it still reads
-    the whole file: the reader is two orders of magnitude faster than the rest) and tags its rows with their batch;
-    reduce_counts(counts), when given, is called once the loop is over and must leave the sums over all ranks in
-    `counts`; only rank 0 prints the totals and writes the summary log (decombinator_amd.sharded.decombinator_sharded
-    drives this)."""
-    rank, world = shard if shard is not None else (0, 1)
+def _decombinator_part(inputargs: dict, rank: int, world: int, state: dict) -> None:
+    """This rank's part of the stage up to the first collective: tables, (rank 0) log directory and FASTQ check, the read
+    loop.  Leaves its results in `state`."""
     print("Running Decombinator (MI355X / HIP build) version", __version__)
     opener = opener_check(inputargs)
     tcr = import_tcr_info(inputargs)
@@ -597,13 +589,13 @@ def decombinator(inputargs: dict, shard=None, reduce_counts=None) -> list:
     date = strftime("%Y_%m_%d")
     if inputargs["suppresssummary"] == False:  # noqa: E712
         logpath = inputargs["outpath"] + f"Logs{os.sep}"
-        if not os.path.exists(logpath):
-            os.makedirs(logpath)
+        if rank == 0:
+            os.makedirs(logpath, exist_ok=True)
         summaryname = logpath + date + "_"
         if inputargs["chain"]:
             summaryname += chainnams[chain] + "_"
         summaryname += samplenam + "_Decombinator_Summary.csv"
-    if inputargs["dontcheck"] == False:  # noqa: E712
+    if inputargs["dontcheck"] == False and rank == 0:  # noqa: E712
         # (the reference crashes here with suppresssummary=True; this build checks anyway)
         fastq_check(inputargs, opener, samplenam, summaryname, logpath, chain)
 
@@ -673,6 +665,33 @@ def decombinator(inputargs: dict, shard=None, reduce_counts=None) -> list:
             print("Non-barcoding option selected, but default output file extension (n12) detected. "
                   "Automatically changing to 'nbc'.")
 
+    state.update(outdata=outdata, chain=chain, samplenam=samplenam, summaryname=summaryname, logpath=logpath, date=date)
+
+
+def decombinator(inputargs: dict, shard=None, reduce_counts=None, exchange_error=None) -> list:
+    """The decombine stage (reference decombinator(), :881-1202): returns the 10-field rows
+    that write_out_intermediate() turns into the `.n12` file, as an N12Rows sequence (a lazy
+    list of lists).
+
+    shard = (rank, world): this process decombines the batches whose index is `rank` modulo `world` (it still reads
+    the whole file: the reader is two orders of magnitude faster than the rest) and tags its rows with their batch;
+    reduce_counts(counts), when given, is called once the loop is over and must leave the sums over all ranks in
+    `counts`; only rank 0 creates the log directory, checks the FASTQ, prints the totals and writes the summary log.
+    exchange_error(exc_or_None), when given, is called by every rank before the first collective with whatever this
+    rank's part raised: it must raise on every rank when any rank failed (a rank that died alone would leave the
+    others waiting in reduce_counts for ever).  decombinator_amd.sharded.decombinator_sharded drives this."""
+    rank, world = shard if shard is not None else (0, 1)
+    state = {}
+    err = None
+    try:
+        _decombinator_part(inputargs, rank, world, state)
+    except BaseException as e:      # (SystemExit too: the reference leaves through sys.exit() for bad chains and tag sets)
+        if exchange_error is None:
+            raise
+        err = e
+    if exchange_error is not None:
+        exchange_error(err)
+    outdata, chain, samplenam, summaryname, logpath, date = (state[k] for k in ("outdata", "chain", "samplenam", "summaryname", "logpath", "date"))
     if reduce_counts is not None:
         reduce_counts(counts)
     counts["end_time"] = time()

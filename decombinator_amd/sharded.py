@@ -184,6 +184,8 @@ class TupleGather:
             for w in s["work"]:          # ... and are done
                 w.wait()
             s["work"] = []
+            if n_reads < self.n_reads:
+                s["bitmap"].zero_()      # a short batch (the end of a shard): no stale bits beyond its reads
             if self.compact is not None:
                 self.compact(s, n_reads)
             else:
@@ -292,7 +294,21 @@ def decombinator_sharded(inputargs: dict, device_index: int | None = None):
             for k, v in zip(keys, t.cpu().tolist()):
                 counts[k] = int(v)
 
-    rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts)
+    def exchange_error(err):
+        # every rank reports whether its part raised; if any did, every rank raises here, before the first collective of
+        # the results (a rank that stopped alone would leave the others waiting in all_gather_object for ever)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        if int(flag.item()) == 0:
+            return
+        said = [None] * world
+        dist.all_gather_object(said, None if err is None else f"{type(err).__name__}: {err}")
+        if err is not None:
+            raise err
+        raise RuntimeError("decombinator_sharded: " + "; ".join(f"rank {r}: {m}" for r, m in enumerate(said) if m))
+
+    rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts, exchange_error=exchange_error)
     chunks = rows._tagged_chunks()
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(chunks, gathered, dst=0)

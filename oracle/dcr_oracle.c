@@ -573,15 +573,17 @@ void dcro_decombine_batch(const dcro_tables *t, const char *ascii, const uint64_
 typedef struct {
   const dcro_tables *t; const char *ascii; const uint64_t *offsets; uint64_t lo, hi;
   int orientation, allow_ns, lenthreshold, passes; dcro_result *res; uint64_t counts[DCRX_N_COUNTERS];
-} dcro_job;
+} __attribute__((aligned(128))) dcro_job;      /* a job per thread on cache lines of its own */
 static void *dcro_worker(void *arg) {
   dcro_job *j = (dcro_job *)arg;
+  uint64_t local[DCRX_N_COUNTERS];             /* tallied on the thread's stack, handed back once */
   for (int p = 0; p < j->passes; p++) {
-    memset(j->counts, 0, sizeof j->counts);
+    memset(local, 0, sizeof local);
     for (uint64_t r = j->lo; r < j->hi; r++)
       dcro_decombine_read(j->t, j->ascii + j->offsets[r], (int)(j->offsets[r + 1] - j->offsets[r]), j->orientation,
-                          j->allow_ns, j->lenthreshold, &j->res[r], j->counts);
+                          j->allow_ns, j->lenthreshold, &j->res[r], local);
   }
+  memcpy(j->counts, local, sizeof local);
   return NULL;
 }
 int dcro_decombine_batch_mt(const dcro_tables *t, const char *ascii, const uint64_t *offsets,
@@ -589,7 +591,9 @@ int dcro_decombine_batch_mt(const dcro_tables *t, const char *ascii, const uint6
                             dcro_result *res, uint64_t *counts, int n_threads, int passes) {
   if (n_threads < 1) n_threads = 1;
   if (passes < 1) passes = 1;
-  dcro_job *jobs = (dcro_job *)calloc((size_t)n_threads, sizeof *jobs);
+  dcro_job *jobs = NULL;
+  if (posix_memalign((void **)&jobs, 128, (size_t)n_threads * sizeof *jobs) != 0) jobs = NULL;
+  else memset(jobs, 0, (size_t)n_threads * sizeof *jobs);
   pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof *th);
   if (!jobs || !th) { free(jobs); free(th); return -1; }
   int started = 0;

@@ -251,3 +251,78 @@ def test_two_rank_sharded_stage_equals_single_process(tmp_path, monkeypatch):
     assert len(logs) == 1
     keep = [ln for ln in logs[0].read_text().split("\n") if not ln.startswith(("Directory,", "DateFinished,", "TimeFinished,", "TimeTaken"))]
     assert keep == run["summary_lines"]
+
+
+FAIL_WORKER = textwrap.dedent('''
+    import json, os, sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["DCRX_ROOT"])
+    from decombinator_amd import sharded, decombine as dec, _native as nat
+    from tests import golden_util as gu, parity_util as pu
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    work = os.environ["DCRX_WORK"]
+    stage = json.load(open(os.path.join(os.environ["DCRX_ROOT"], "tests", "golden", "stage_human_extended_b.json")))
+    ot = gu.oracle_tables(stage["tagset"])
+    calls = [0]
+
+    def oracle_device(tables, batch, orientation="reverse", allow_ns=False, lenthreshold=130, flags=0):
+        calls[0] += 1
+        if rank == 1 and calls[0] == 2:
+            raise ValueError("rank 1 stops at its second batch")       # one rank alone fails in the middle of its loop
+        return pu.oracle_records(ot, nat.unpack_reads(batch), orientation, allow_ns, lenthreshold)
+    nat.decombine = oracle_device
+    dec.BATCH_READS = 7
+    args = json.load(open(os.path.join(work, "args.json")))
+    try:
+        sharded.decombinator_sharded(args)
+    except ValueError as e:
+        assert rank == 1, e
+        print("RAISED_OWN", e)
+    except RuntimeError as e:
+        assert rank == 0 and "rank 1" in str(e), e
+        print("RAISED_PEER", e)
+    else:
+        raise SystemExit("no error surfaced on rank %d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_a_rank_that_fails_alone_fails_every_rank_without_a_hang(tmp_path):
+    """ADVICE r2: an exception on one rank (here in the middle of its read loop) used to leave the other ranks blocked in
+    the first collective.  Every rank now exchanges an error flag first; the failing rank re-raises its own exception and
+    the others raise a RuntimeError naming it.  Both ranks start on an output directory that does not exist yet (the
+    makedirs race of the same finding: only rank 0 creates it, with exist_ok)."""
+    import json
+    from decombinator_amd import io as dio, synth
+    stage = json.load(open(os.path.join(ROOT, "tests", "golden", "stage_human_extended_b.json")))
+    run = stage["runs"][0]
+    work = tmp_path / "w"
+    work.mkdir()
+    ts = stage["tagset"]
+    synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
+                 v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
+                 j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(work / "tags"))
+    (work / "SYNTH_1.fq").write_text(stage["fastq_r1"])
+    (work / "SYNTH_2.fq").write_text(stage["fastq_r2"])
+    args = dio.create_args_dict(infile=str(work / "SYNTH_1.fq"), chain="b", bc_read=run["bc_read"], dontgzip=True, dontcount=True,
+                                orientation=run["orientation"], allowNs=run["allowNs"], tagfastadir=str(work / "tags"),
+                                outpath=str(work / "fresh") + os.sep, command="decombine")
+    json.dump(args, open(work / "args.json", "w"))
+    script = tmp_path / "fworker.py"
+    script.write_text(FAIL_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCRX_ROOT=ROOT, DCRX_WORK=str(work), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RAISED_PEER" in outs[0] and "RAISED_OWN" in outs[1], outs
