@@ -45,9 +45,6 @@ void attributes_set_on_device(bool (&seen)[64]);
 
 constexpr int DCRX_V2_BLOCK = 1024;
 constexpr int DCRX_V2_FBLOCK = 256;
-#ifndef DCRX_V2_TSPLIT
-#define DCRX_V2_TSPLIT 2    /* waves of the tail kernel per region */
-#endif
 #ifndef DCRX_V2_TBLOCK
 #define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
 #define DCRX_V2_TWAVES 5        /* ... and the waves per SIMD it is compiled for */
@@ -72,7 +69,6 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #define DCRX_LEAN_LDS_WORDS 1   /* the lean kernels keep the read in hand in LDS strips (0: in registers, A/B) */
 #endif
 constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
-constexpr uint32_t DCRX_V2_SLOW_GROUP = 4;  // ... and what it takes of the slow list
 
 // ---- the lists: per wave of the scan kernel one region of tail entries and one of event entries ----
 // An entry carries the read's packed words (the scan kernel has them in registers), so that the
@@ -157,79 +153,90 @@ __device__ __forceinline__ void v2_tally(uint32_t *lds_counts, const int lane, c
   }
 }
 
+// One wave's item: 64 * RPL consecutive reads from `first`, lane l holding reads first + 64 q + l (q < RPL) while they
+// lie below `hi` (the end of the block's range).  With the words comes the wave's slice of the exception bitmap
+// (64-read groups start on multiples of 64: two words per group, the same for every lane).
 template <int NW, int RPL>
-__device__ __forceinline__ void v2_load_tile(const BatchDev &B, const uint32_t nw, const uint64_t first_read, const int tid,
-                                             uint32_t (&w)[RPL][NW]) {
+__device__ __forceinline__ void v2_load_item(const BatchDev &B, const uint32_t nw, const uint64_t first, const uint64_t hi, const int lane,
+                                             uint32_t (&w)[RPL][NW], unsigned long long (&xm)[RPL]) {
 #pragma unroll
   for (int q = 0; q < RPL; q++) {
-    const uint64_t r = first_read + (uint64_t)q * DCRX_V2_BLOCK + tid;
-    const uint2 *wp2 = reinterpret_cast<const uint2 *>(B.packed + (r < B.n_reads ? r : 0) * B.stride);
+    const uint64_t r = first + (uint64_t)q * 64 + lane;
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(B.packed + (r < hi ? r : 0) * B.stride);
 #pragma unroll
     for (int k = 0; k < NW / 2; k++) {
       uint2 t = make_uint2(0u, 0u);
-      if ((uint32_t)(2 * k) < nw && r < B.n_reads) t = wp2[k];
+      if ((uint32_t)(2 * k) < nw && r < hi) t = wp2[k];
       w[q][2 * k] = t.x; w[q][2 * k + 1] = t.y;
+    }
+    xm[q] = 0ull;
+    if (B.n_exc) {
+      const uint64_t g = (first + (uint64_t)q * 64) >> 5;       // (wave-uniform: the compiler may fetch it through the scalar cache)
+      xm[q] = (unsigned long long)B.exc_flag[g] | ((unsigned long long)B.exc_flag[g + 1] << 32);
     }
   }
 }
+
+// LDS of the scan kernel behind the pair table and the counters: the block's work counters
+enum { V2_WK_NEXT = 0, V2_WK_TAIL = 1, V2_WK_EVENTS = 2, V2_WK_WORDS = 4 };
 
 template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint32_t stagger) {
+    uint64_t per_block) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   V2Ori V0 = T0.v2[0];
   if (o) V0 = T0.v2[1];
   uint32_t *lds_trans = smem;                                         // the pair table, at LDS address 0
   uint32_t *lds_counts = smem + V0.trans_bytes / 4;
+  uint32_t *lds_work = lds_counts + DCRX_N_COUNTERS;
   const int tid = threadIdx.x;
   if (dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans)) != 0u) __builtin_trap();   // v2_entry reads the table at absolute LDS addresses
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  if (tid < V2_WK_WORDS) lds_work[tid] = 0;
   stage_lds<DCRX_V2_BLOCK>(reinterpret_cast<const uint8_t *>(V0.trans), lds_trans, V0.trans_bytes / 16, 0, 0, tid);
   const V2Tab tab{};
   __syncthreads();
-  // The waves of a block would run their tiles in lockstep for the whole launch: all of them in the scan (the LDS array
-  // busy, the vector units half idle), then all of them in the digest and the pushes (the other way round).  The four waves
-  // that share a SIMD start `stagger` x 1024 clocks apart, so that one wave's look-ups run under another's arithmetic.
-  for (uint32_t k = 0; k < (uint32_t)(tid >> 8) * (stagger & 0xFFFFu); k++) __builtin_amdgcn_s_sleep(16);
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const bool tagged = B.n_reads < (1ull << 30);
   uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
 
-  const size_t region = (size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6);
+  // The block owns the reads [blk_lo, blk_hi) and one region of each list; its waves draw items of 64 * RPL reads
+  // from a counter in LDS.  (The four waves that share a SIMD are served oldest first: with the same reads for each, the
+  // first ended a quarter earlier than the last — 148 against 193 us — and idled until the launch was over.)
+  const uint64_t blk_lo = (uint64_t)blockIdx.x * per_block;
+  const uint64_t blk_hi = blk_lo + per_block < B.n_reads ? blk_lo + per_block : B.n_reads;
+  constexpr uint32_t WT = 64u * RPL;
+  const uint32_t n_items = blk_lo < blk_hi ? (uint32_t)((blk_hi - blk_lo + WT - 1) / WT) : 0u;
+  const size_t region = blockIdx.x;
   uint4 *tq = Q.tail + region * Q.tcap * V2Rows<NW>::T;
   uint4 *eq = Q.events + region * Q.ecap * V2Rows<NW>::E;
-  uint32_t tn = 0, en = 0;
+  auto draw = [&]() -> uint32_t {
+    uint32_t i = 0;
+    if (lane == 0) i = atomicAdd(&lds_work[V2_WK_NEXT], 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+  };
 
-  constexpr uint64_t TILE = (uint64_t)DCRX_V2_BLOCK * RPL;
   const int npairs = UNIFORM_LEN ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   uint32_t w[RPL][NW];
+  unsigned long long xm[RPL];
 #ifdef DCRX_SCAN_STAMPS
   unsigned long long stamp_scan = 0, stamp_rest = 0, stamp_prev = 0;      // clocks inside scan2() / between two scan2() calls, per wave
-  const unsigned long long stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  uint64_t tile = blockIdx.x;
-  if (PREFETCH && tile * TILE < B.n_reads) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
-  uint32_t tileno = 0;
-  for (; tile * TILE < B.n_reads; tile += gridDim.x, tileno++) {
-    // The four waves that share a SIMD are served oldest first: with equal work the first would end a quarter earlier than
-    // the last (148 against 193 us) and idle until the launch ends.  Their issue priorities rotate tile by tile instead.
-    if (stagger & 0x10000u) {
-      switch (((uint32_t)(tid >> 8) + tileno) & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-      }
-    }
+  uint32_t item = draw();
+  if (PREFETCH && item < n_items) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)item * WT, blk_hi, lane, w, xm);
+  while (item < n_items) {
     uint32_t wn[RPL][NW];
-    const bool more = PREFETCH && (tile + gridDim.x) * TILE < B.n_reads;
-    if (!PREFETCH) v2_load_tile<NW, RPL>(B, nw, tile * TILE, tid, w);
-    if (PREFETCH) { if (more) v2_load_tile<NW, RPL>(B, nw, (tile + gridDim.x) * TILE, tid, wn); }     // in flight while this tile is scanned
+    unsigned long long xn[RPL];
+    const uint32_t next = draw();
+    const bool more = next < n_items;
+    if (!PREFETCH) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)item * WT, blk_hi, lane, w, xm);
+    if (PREFETCH) { if (more) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)next * WT, blk_hi, lane, wn, xn); }     // in flight while this item is scanned
     uint32_t lg[RPL][NW];
 #ifdef DCRX_SCAN_STAMPS
     const unsigned long long st0 = __builtin_readcyclecounter();
@@ -245,12 +252,13 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     const unsigned long long st1 = __builtin_readcyclecounter();
     stamp_scan += st1 - st0;
     if (stamp_prev) stamp_rest += st0 - stamp_prev;
+    stamp_prev = st1;
 #endif
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
-      const uint64_t r = tile * TILE + (uint64_t)q * DCRX_V2_BLOCK + tid;
-      const bool live = r < B.n_reads;
-      const bool exc = live && B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u);
+      const uint64_t r = blk_lo + (uint64_t)item * WT + (uint64_t)q * 64 + lane;
+      const bool live = r < blk_hi;
+      const bool exc = live && ((xm[q] >> lane) & 1ull);
       const int n = UNIFORM_LEN ? (int)B.read_len : (live ? (int)B.lens[r] : 0);
       if (!UNIFORM_LEN) mask_log2<NW>(lg[q], n);
       const Digest2 d = digest2<NW>(lg[q]);
@@ -292,8 +300,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       if (cfg.flags & DCRX_F_PROFILE_NO_FINISH) continue;
       bool to_tail = what == V2_TAIL;
       const unsigned long long mt0 = __ballot(to_tail);
-      if (mt0) {
-        const uint32_t at = tn + (uint32_t)__popcll(mt0 & lt_mask);
+      if (mt0) {           // the block's tail list: one LDS atomic per wave and group of 64 reads
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_TAIL], (uint32_t)__popcll(mt0));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t at = base + (uint32_t)__popcll(mt0 & lt_mask);
         if (to_tail && at >= Q.tcap) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, false); to_tail = false; }
         if (to_tail) {
           uint32_t x[2 + NW];
@@ -302,12 +313,14 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
           for (int k = 0; k < NW; k++) x[2 + k] = w[q][k];
           v2_put_rows<2 + NW>(tq, Q.tcap, at, x);
         }
-        tn = min(tn + (uint32_t)__popcll(mt0), Q.tcap);
       }
       bool to_ev = what == V2_EVENTS;
       const unsigned long long me0 = __ballot(to_ev);
       if (me0) {
-        const uint32_t at = en + (uint32_t)__popcll(me0 & lt_mask);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_EVENTS], (uint32_t)__popcll(me0));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t at = base + (uint32_t)__popcll(me0 & lt_mask);
         if (to_ev && at >= Q.ecap) {                 // a full region (its last lanes): the three-launch form
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
           to_ev = false;
@@ -319,30 +332,30 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
           for (int k = 0; k < NW; k++) { x[1 + k] = lg[q][k]; x[1 + NW + k] = w[q][k]; }
           v2_put_rows<1 + 2 * NW>(eq, Q.ecap, at, x);
         }
-        en = min(en + (uint32_t)__popcll(me0), Q.ecap);
       }
     }
     if (PREFETCH && more) {
 #pragma unroll
-      for (int q = 0; q < RPL; q++)
+      for (int q = 0; q < RPL; q++) {
 #pragma unroll
         for (int k = 0; k < NW; k++) w[q][k] = wn[q][k];
+        xm[q] = xn[q];
+      }
     }
-#ifdef DCRX_SCAN_STAMPS
-    stamp_prev = st1;
-#endif
+    item = next;
   }
+  __syncthreads();
 #ifdef DCRX_SCAN_STAMPS
-  if (lane == 0) {
-    // tail / event counts are not needed by this build's runs (DCRX_F_PROFILE_NO_FINISH): wave lifetime in shader clocks and in the 100 MHz real-time counter
-    (void)stamp_c0;
-    Q.counts[4 * region] = (uint32_t)stamp_r0; Q.counts[4 * region + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    Q.counts[4 * region + 2] = (uint32_t)(stamp_scan >> 6); Q.counts[4 * region + 3] = (uint32_t)(stamp_rest >> 6);
+  if (lane == 0) {      // instrumented build (tools/): per wave (not per region; its runs finish nothing) start and end in the 100 MHz counter, clocks inside / between scans
+    uint32_t *c = Q.counts + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));
+    c[0] = (uint32_t)stamp_r0; c[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); c[2] = (uint32_t)(stamp_scan >> 6); c[3] = (uint32_t)(stamp_rest >> 6);
   }
 #else
-  if (lane == 0) { Q.counts[4 * region] = tn; Q.counts[4 * region + 1] = en; Q.counts[4 * region + 2] = 0u; Q.counts[4 * region + 3] = 0u; }
+  if (tid == 0) {
+    Q.counts[4 * region] = min(lds_work[V2_WK_TAIL], Q.tcap); Q.counts[4 * region + 1] = min(lds_work[V2_WK_EVENTS], Q.ecap);
+    Q.counts[4 * region + 2] = 0u; Q.counts[4 * region + 3] = 0u;
+  }
 #endif
-  __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
@@ -351,7 +364,7 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
   return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
 }
 
-// The tail kernel: DCRX_V2_TSPLIT waves per region, 256-thread blocks, no register spills (a spill
+// The tail kernel: `split` waves per region, 256-thread blocks, no register spills (a spill
 // reload would wait for the loads in flight).  Software pipeline over the batches of 64:
 // the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
 // hand finds everything in registers.  What the lean form does not settle becomes an entry of the
@@ -359,7 +372,7 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
 template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t to_slow2, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, uint32_t to_slow2, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   constexpr int o = ORI;      // the frame is a template argument: one frame's code per kernel
@@ -379,17 +392,17 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   __syncthreads();
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
-  // DCRX_V2_TSPLIT waves share a region: wave k of them takes the batches k, k + DCRX_V2_TSPLIT, ...
+  // `split` waves share a region (a scan block's list): wave k of them takes the batches k, k + split, ...
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
-  for (uint32_t job = gwave; job < n_regions * DCRX_V2_TSPLIT; job += n_gwaves) {
-    const uint32_t region = job / DCRX_V2_TSPLIT, part = job % DCRX_V2_TSPLIT;
+  for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {
+    const uint32_t region = job / split, part = job % split;
     const uint32_t tn = Q.counts[4 * region];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
     // what the lean form does not settle: slow list 1 behind the rescue kernel's leftovers, or (the event kernel's first pass
     // running beside this kernel) slow list 2
     const uint32_t scap = to_slow2 ? Q.s2cap : Q.scap;
     uint4 *eq = (to_slow2 ? Q.slow2 : Q.slow) + (size_t)region * scap * V2Rows<NW>::E;
-    constexpr uint32_t STEP = 64 * DCRX_V2_TSPLIT;
+    const uint32_t STEP = 64 * split;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
     for (uint32_t first = 64 * part; first < tn && !(cfg.flags & DCRX_F_PROFILE_NO_TAIL); first += STEP) {
@@ -483,7 +496,7 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
 template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   constexpr int o = ORI;
@@ -506,19 +519,21 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
-  for (uint32_t region = gwave; region < n_regions; region += n_gwaves) {
+  for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {       // `split` waves per region, as in the tail kernel
+    const uint32_t region = job / split, part = job % split;
+    const uint32_t STEP = 64 * split;
     const uint32_t en = min(Q.counts[4 * region + 1], Q.ecap);
     const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
     uint4 *sq = Q.slow + (size_t)region * Q.scap * V2Rows<NW>::E;
     constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
     uint32_t x1[1 + 2 * NW];
-    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(eq, Q.ecap, lane, lane < en, x1);
-    for (uint32_t first = 0; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += 64) {
+    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(eq, Q.ecap, 64 * part + lane, 64 * part + lane < en, x1);
+    for (uint32_t first = 64 * part; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += STEP) {
       uint32_t x[1 + 2 * NW];
       if constexpr (AHEAD) {
 #pragma unroll
         for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
-        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + 64 + lane, first + 64 + lane < en, x1);     // the next batch, in flight during this one
+        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
       } else {
         v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + lane, first + lane < en, x);
       }
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
 template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, int which, uint32_t group, uint32_t width, uint32_t ext, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, int which, uint32_t group, uint32_t width, uint32_t bsplit, uint32_t ext, uint32_t n_regions, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   V2Ori V = T0.v2[ORI];
@@ -596,7 +611,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   const bool tagged = B.n_reads < (1ull << 30);
   uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
   __shared__ uint32_t pref[DCRX_V2_GROUP_MAX + 1];
-  for (uint32_t g0 = blockIdx.x * group; g0 < n_regions; g0 += gridDim.x * group) {
+  // `bsplit` blocks share a group of regions (a short list spread over many waves): block b of them takes the rounds b, b + bsplit, ...
+  const uint32_t bpart = blockIdx.x % bsplit, bsteps = width * (DCRX_V2_FBLOCK / 64) * bsplit;
+  for (uint32_t g0 = (blockIdx.x / bsplit) * group; g0 < n_regions; g0 += (gridDim.x / bsplit) * group) {
     __syncthreads();
     if (tid == 0) {
       uint32_t acc = 0;
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     // the loads in flight; the other waves of the CU cover the entry loads)
     // `width` lanes of a wave take entries (64, or fewer for the slow list: the general form costs a wave the longest
     // of its lanes' loops, and a short list is better spread over many waves than packed into a few)
-    for (uint32_t first = width * (uint32_t)(tid >> 6); first < total && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += width * (DCRX_V2_FBLOCK / 64)) {
+    for (uint32_t first = width * ((uint32_t)(tid >> 6) + (DCRX_V2_FBLOCK / 64) * bpart); first < total && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += bsteps) {
       const uint32_t i = first + lane;
       const bool live = (uint32_t)lane < width && i < total;
       uint32_t g = 0;
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
 
 // ---- launcher ------------------------------------------------------------------------------------
 // LDS the scan kernel needs for frame o: the pair table and the block's counters
-static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].trans_bytes + DCRX_N_COUNTERS * 4; }
+static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].trans_bytes + DCRX_N_COUNTERS * 4 + V2_WK_WORDS * 4; }
 
 // The v2 kernels serve one frame; the A/B switches of the three-launch form, the forced slow
 // reader and orientation `both` keep that form.
@@ -694,21 +711,22 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   }
   if (B.n_reads == 0) return hipSuccess;       // the prologue has zeroed the counters
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
-  const uint64_t tile = (uint64_t)DCRX_V2_BLOCK * RPL;
-  const uint64_t n_tiles = (B.n_reads + tile - 1) / tile;
-  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, n_tiles));
-  // each wave of the scan kernel owns a region of the two lists sized for the reads it can meet
-  const uint64_t per_wave = ((n_tiles + grid - 1) / grid) * 64ull * RPL;
+  // One scan block per compute unit, each with a contiguous range of the reads (a multiple of its waves' item size) and one
+  // region of every list, sized for the reads the block can meet; a small batch takes fewer blocks, 16 items each at least.
+  const uint64_t wt = 64ull * RPL;
+  const uint64_t n_items = (B.n_reads + wt - 1) / wt;
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, (n_items + 15) / 16));
+  const uint64_t per_block = (((B.n_reads + grid - 1) / grid + wt - 1) / wt) * wt;
   V2Lists Q;
   Q.tail = P.v2_tail; Q.events = P.v2_events; Q.slow = P.v2_slow; Q.counts = P.v2_counts;
-  const uint32_t n_regions = grid * (DCRX_V2_BLOCK / 64);
-  Q.tcap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
-  Q.ecap = (uint32_t)std::min<uint64_t>(per_wave, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~63u;
+  const uint32_t n_regions = grid;
+  Q.tcap = (uint32_t)std::min<uint64_t>(per_block, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
+  Q.ecap = (uint32_t)std::min<uint64_t>(per_block, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~63u;
   // the slow allocation holds both slow lists: list 1 sized like the event list, list 2 in what is left
   Q.scap = Q.ecap;
   Q.slow2 = Q.slow + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
   const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
-  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_wave, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
+  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_block, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
   if (Q.tcap < 64 || Q.ecap < 64 || Q.s2cap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
   // (the timing events of the dominant kernel ride on its own dispatch: recorded separately they cost the stream a gap each.
   // So does the event that forks the tail kernel onto the side stream: when no timing event claims the place it is the scan
@@ -717,9 +735,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const bool lean2_early = finish && P.v2_side && P.v2_ev_fork && P.v2_ev_join &&
                            !(cfg.flags & (DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_FORK | DCRX_F_V2_NO_LEAN_RESCUE));
   const bool fork_rides = lean2_early && !ev_stop;
-  static const uint32_t stagger = getenv("DCRX_SCAN_STAGGER") ? (uint32_t)atoi(getenv("DCRX_SCAN_STAGGER")) : 0u;
   hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, stagger);
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
@@ -728,8 +745,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // beside the tail kernel on the handle's side stream and the tail kernel's own (slow list 2) behind it: measured no
     // faster (0.592 against 0.603 ms per step with the best shape), the event kernel's waves wait for registers the tail
     // kernel's waves hold.
-    const uint32_t fgrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-    const uint32_t sgrid = (n_regions + DCRX_V2_SLOW_GROUP - 1) / DCRX_V2_SLOW_GROUP;
+    // waves of the finishing kernels that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
+    // 4096 on the event list of a full-size launch
+    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
+    const uint32_t fgrid = (n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over the event list (A/B): a block takes four regions
+    const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of the slow-list pass that share a region
+    const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
     const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4;      // the lean kernels: + a strip per lane
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
@@ -738,7 +760,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a slow list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
     const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
     hipStream_t se = fork ? P.v2_side : s;
-    const dim3 tgrid((n_regions * DCRX_V2_TSPLIT + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
+    const dim3 tgrid((n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
     const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
     // The two lean kernels run beside each other, the tail kernel on the handle's side stream: different lists, one bound
     // by VALU issue, the other by its record stores (0.531 against 0.546 ms per step; DCRX_F_V2_LEAN_SERIAL: one after the
@@ -748,7 +770,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     auto launch_tail_side = [&]() -> hipError_t {
       hipError_t e2 = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e2 != hipSuccess) return e2;
       // (the join event is the tail dispatch's own stop event)
-      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue,
+      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, 0u, n_regions, tsplit, queue,
                             gqueue, qcap, queue_count);
       return hipGetLastError();
     };
@@ -758,10 +780,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
     // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
     if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)
-      hipLaunchKernelGGL(ke, dim3(fgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, ext, n_regions, queue,
+      hipLaunchKernelGGL(ke, dim3(egrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, 1u, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
     else
-      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, queue, gqueue, qcap,
+      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
                          queue_count);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -770,26 +792,26 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       if (lean2) {
         e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
       } else {
-        hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, queue, gqueue, qcap, queue_count);
+        hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, tsplit, queue, gqueue, qcap, queue_count);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 1, 1u, slow_width, bsplit, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
     } else {
       e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(se, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, 1u, slow_width, bsplit, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 1u, n_regions, queue, gqueue, qcap, queue_count);
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 1u, n_regions, tsplit, queue, gqueue, qcap, queue_count);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, DCRX_V2_SLOW_GROUP, slow_width, ext, n_regions, queue,
+      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, 1u, slow_width, bsplit, ext, n_regions, queue,
                          gqueue, qcap, queue_count);
       e = hipGetLastError();
     }
