@@ -137,11 +137,13 @@ __device__ __forceinline__ void v2_hand_over(const BatchDev &B, uint32_t *queue,
 __device__ __forceinline__ void v2_tally(uint32_t *lds_counts, const int lane, const int status, const bool forward) {
   const unsigned long long m_ok = __ballot(status == DCRX_S_OK), m_jn = __ballot(status == DCRX_S_J_NONE),
                            m_jm = __ballot(status == DCRX_S_J_MULTI), m_tl = __ballot(status == DCRX_S_F_TOOLONG),
-                           m_im = __ballot(status == DCRX_S_F_IMPOSS_DEL), m_ov = __ballot(status == DCRX_S_F_OVERLAP);
+                           m_im = __ballot(status == DCRX_S_F_IMPOSS_DEL), m_ov = __ballot(status == DCRX_S_F_OVERLAP),
+                           m_jw = __ballot(status == DCRX_S_J_WALK_FAIL), m_all = __ballot(status >= 0);
   if (lane == 0) {
     const uint32_t n_ok = (uint32_t)__popcll(m_ok), n_jn = (uint32_t)__popcll(m_jn), n_jm = (uint32_t)__popcll(m_jm),
                    n_tl = (uint32_t)__popcll(m_tl), n_im = (uint32_t)__popcll(m_im), n_ov = (uint32_t)__popcll(m_ov);
-    const uint32_t all = n_ok + n_jn + n_jm + n_tl + n_im + n_ov;
+    const uint32_t all = (uint32_t)__popcll(m_all);      // (a walk that failed has counted its own counter: V_WALK_FAIL adds nothing else)
+    if (m_jw) atomicAdd(&lds_counts[DCRX_C_VJ_ASSIGNMENT_FAILED], (uint32_t)__popcll(m_jw));
     if (all) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], all);
     if (n_ok) { atomicAdd(&lds_counts[DCRX_C_VJ_COUNT], n_ok); if (forward) atomicAdd(&lds_counts[DCRX_C_FRAME_FORWARD], n_ok); }
     if (n_jn) atomicAdd(&lds_counts[DCRX_C_NO_J_ASSIGNED], n_jn);
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   stage_lds<DCRX_V2_TBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
   stage_lds<DCRX_V2_TBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
   const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1);
+  const Counters C{lds_counts};
   // each lane's strip of LDS for the read in hand (its two zero words are written once)
   uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
   strip[NW] = 0u; strip[NW + 1] = 0u;
@@ -424,10 +427,10 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         for (int k = 0; k < NW; k++) strip[k] = w[k];
         if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(w[0] ^ w[NW - 1]); }
         else
-        status = tail2_fast<ORI == 1>(tt, lw, n, dg, cfg, rec);
+        status = tail2_fast<ORI == 1>(tt, lw, n, dg, cfg, rec, T0, C);
 #else
         const RegWords<NW> rw{w};
-        status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec);
+        status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec, T0, C);
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
@@ -470,6 +473,7 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
                  n_vn = cnt(status == DCRX_S_V_NONE), n_jm = cnt(status == DCRX_S_J_MULTI), n_jn = cnt(status == DCRX_S_J_NONE),
                  n_j1 = cnt(status == DCRX_S_J_HALF1_EXHAUSTED), n_j2 = cnt(status == DCRX_S_J_HALF2_EXHAUSTED),
                  n_tl = cnt(status == DCRX_S_F_TOOLONG), n_im = cnt(status == DCRX_S_F_IMPOSS_DEL), n_ov = cnt(status == DCRX_S_F_OVERLAP),
+                 n_jw = cnt(status == DCRX_S_J_WALK_FAIL),       // (a full-tag walk that failed has counted its own counter)
                  e_v1 = cnt((errs & 1u) != 0u), e_v2 = cnt((errs & 2u) != 0u), e_j1 = cnt((errs & 4u) != 0u), e_j2 = cnt((errs & 8u) != 0u);
   if (lane == 0) {
     auto add = [&](const int c, const uint32_t k) { if (k) atomicAdd(&lds_counts[c], k); };
@@ -482,7 +486,7 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
     add(DCRX_C_MULTIPLE_J_MATCHES, n_jm);
     add(DCRX_C_NO_J_ASSIGNED, n_jn);
     add(DCRX_C_FOUNDJ1NOTJ2, n_j1);
-    add(DCRX_C_VJ_ASSIGNMENT_FAILED, n_jm + n_jn + n_j1 + n_j2);
+    add(DCRX_C_VJ_ASSIGNMENT_FAILED, n_jm + n_jn + n_j1 + n_j2 + n_jw);
     add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG, n_tl);
     add(DCRX_C_DCRFILTER_IMPOSS_DELETION, n_im);
     add(DCRX_C_DCRFILTER_TAG_OVERLAP, n_ov);
@@ -515,6 +519,8 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
   uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();      // as in the tail kernel
   strip[NW] = 0u; strip[NW + 1] = 0u;
   const LdsWords lw{dcrx_ldsaddr_of(strip)};
+  // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
+  const Counters C{lds_counts}, Cdry{lds_bk + V.bk_bytes / 4 + (uint32_t)DCRX_V2_FBLOCK * lds_words_stride<NW>()};
   __syncthreads();
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
@@ -552,10 +558,10 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
 #if DCRX_LEAN_LDS_WORDS
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
-          status = rescue2_fast<ORI == 1, NW>(rt, lw, lg, n, cfg, rec, errs);
+          status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ANY>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
 #else
           const RegWords<NW> rw{w};
-          status = rescue2_fast<ORI == 1, NW>(rt, rw, lg, n, cfg, rec, errs);
+          status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ANY>(rt, rw, lg, n, cfg, rec, errs, T0, C, Cdry);
 #endif
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
@@ -684,7 +690,7 @@ bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
-  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 <= 64u * 1024u;
+  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u;
 }
 
 template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
@@ -753,7 +759,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of the slow-list pass that share a region
     const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
-    const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4;      // the lean kernels: + a strip per lane
+    const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4;      // the lean kernels: + a strip per lane (+ the rescue kernel's scratch counters)
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;

@@ -763,6 +763,34 @@ struct LdsWords {
 template <int NW>
 constexpr int lds_words_stride() { return ((NW + 2) | 1); }      // words per lane: NW + 2 zero words, made odd
 
+// A clean read (no exception bytes) behind a word source WS (RegWords / LdsWords), seen in one frame: what the
+// walks and comparisons of dcrx_dcr_device.h ask of a frame.  The lean forms hand a walk that leaves its first
+// 32-base window to get_v_deletions / get_j_deletions through this (a rare branch: 0.02 % of their entries).
+template <bool REV_, class WS>
+struct FrameWS {
+  static constexpr bool kRev = REV_;
+  static constexpr bool kWindowedWalks = true;
+  const WS &w;
+  int len;
+  DCRX_DEV int n() const { return len; }
+  DCRX_DEV bool has_exc() const { return false; }
+  DCRX_DEV bool clean(int, int) const { return true; }
+  DCRX_DEV uint64_t exc_slots(int) const { return 0ull; }
+  DCRX_DEV bool has_N(int, int) const { return false; }
+  DCRX_DEV uint64_t load64(int b) const { return w.stored64(b); }
+  DCRX_DEV uint32_t window(int a, int l) const {
+    const int lo = REV_ ? len - a - l : a;
+    const uint32_t v = (uint32_t)w.stored64(lo);
+    return v & ((l >= 16) ? 0xFFFFFFFFu : ((1u << (2 * l)) - 1u));
+  }
+  DCRX_DEV int code(int i) const {
+    const int m = REV_ ? len - 1 - i : i;
+    const int c = (int)(w.stored64(m) & 3ull);
+    return REV_ ? (c ^ 3) : c;
+  }
+  DCRX_DEV uint8_t chr(int i) const { return (uint8_t)("ACGT"[code(i)]); }
+};
+
 // One tail entry (`digest`: tail2_pack) on a read whose words sit in registers (the finishing
 // kernel loads them one batch ahead: nothing here waits for global memory).  Returns the read's
 // status with `rec` filled (status and frame left to the caller), or TAIL2_SLOW with nothing
@@ -770,7 +798,7 @@ constexpr int lds_words_stride() { return ((NW + 2) | 1); }      // words per la
 // implies its counters).
 template <bool REV, class WS>
 DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uint32_t digest, const CfgDev &cfg,
-                        dcrx_record_t &rec) {
+                        dcrx_record_t &rec, const DevTables &T, const Counters &C) {
   const int vpair = (int)(digest & 0xFFu), jpair = (int)((digest >> 8) & 0xFFu), jc = (int)((digest >> 16) & 3u);
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
   if (n < 32 || Lv > 31 || Lj > 31) return TAIL2_SLOW;
@@ -814,20 +842,28 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
     if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return TAIL2_SLOW;
     rwj = w.stored64(REV ? n - ts - 32 : ts);
   }
-  // get_v_deletions (:749-785), the 32-base form
+  // (nothing has been counted up to here, and from here on no path returns TAIL2_SLOW)
+  // get_v_deletions (:749-785), the 32-base form; a walk that leaves that window goes on in the general function
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
-  const int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
-  if (kv < 0) return TAIL2_SLOW;
-  const int end_v = te - kv;
+  int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  int end_v = te - kv;
+  if (kv < 0) {
+    const FrameWS<REV, WS> F{w, n};
+    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, C)) return DCRX_S_V_WALK_FAIL;     // :288-290 (te < n here: v_del_failed, counted inside)
+  }
   if (jc == 0) return DCRX_S_J_NONE;                       // :530-531 (no J tag, no J half tag)
   if (jc == 2) return DCRX_S_J_MULTI;                      // :402-404
   // get_j_deletions (:788-817), the 32-base form
   const int end_of_v = end_v + 1;                          // :547
   const int k0 = end_of_v > ts ? end_of_v - ts : 0;
   const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
-  const int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
-  if (kj < 0) return TAIL2_SLOW;
-  const int start_j = ts + kj, jend = jp + Lj;
+  int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  int start_j = ts + kj;
+  if (kj < 0) {
+    const FrameWS<REV, WS> F{w, n};
+    if (!get_j_deletions(T.g[1], F, j, ts, end_of_v, start_j, kj, C)) return DCRX_S_J_WALK_FAIL;   // :413-418 (j_del_failed counted inside)
+  }
+  const int jend = jp + Lj;
   // filters :553-569 (a clean read holds no N)
   if ((vp - jend) >= cfg.lenthreshold) return DCRX_S_F_TOOLONG;
   if (kv > jumpv - Lv || kj > jumpj) return DCRX_S_F_IMPOSS_DEL;
@@ -847,6 +883,7 @@ DCRX_DEV void tail2_count(const Counters &C, const int status, const bool forwar
   if (status == DCRX_S_OK) { C.add(DCRX_C_VJ_COUNT); if (forward) C.add(DCRX_C_FRAME_FORWARD); return; }
   if (status == DCRX_S_J_NONE) { C.add(DCRX_C_NO_J_ASSIGNED); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); }
   else if (status == DCRX_S_J_MULTI) { C.add(DCRX_C_MULTIPLE_J_MATCHES); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); }
+  else if (status == DCRX_S_J_WALK_FAIL) C.add(DCRX_C_VJ_ASSIGNMENT_FAILED);        // (j_del_failed / v_del_failed were counted by the walk itself)
   else if (status == DCRX_S_F_TOOLONG) C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG);
   else if (status == DCRX_S_F_IMPOSS_DEL) C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION);
   else if (status == DCRX_S_F_OVERLAP) C.add(DCRX_C_DCRFILTER_TAG_OVERLAP);
@@ -946,67 +983,68 @@ DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const WS &w, const int n,
   return found;
 }
 
-// The other flagged pairs of a read that has three or four (`mask8`: the flag's bit in every nibble;
-// `first` / `last`: bit positions 4 * pair + bit as the digest found them): the second and the second
-// last as bit positions (equal when there are three).
+// word kk of a flag log held in registers (a lane-varying index: a select chain over the words)
 template <int NW>
-DCRX_DEV void rescue2_mid_pairs(const uint32_t (&lg)[NW], const uint32_t mask8, const uint32_t first, const uint32_t last, uint32_t &second,
-                                uint32_t &second_last) {
-  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+DCRX_DEV uint32_t log_word(const uint32_t (&lg)[NW], const int kk) {
+  uint32_t l = 0;
 #pragma unroll
-  for (int kk = 0; kk < NW; kk++) {
-    uint32_t m = lg[kk] & mask8;
-    if ((first >> 5) == (uint32_t)kk) m &= ~(1u << (first & 31u));
-    if ((last >> 5) == (uint32_t)kk) m &= ~(1u << (last & 31u));
-    const uint32_t kb = (uint32_t)kk << 5;
-    lo = min(lo, (m ? (uint32_t)dcrx_ctz32(m) : 0xFFFFFFFFu) | kb);
-    hi = max(hi, m ? ((31u - (uint32_t)dcrx_clz32(m)) | kb) : 0u);
-  }
-  second = lo; second_last = hi;
+  for (int k = 0; k < NW; k++) l = (kk == k) ? lg[k] : l;
+  return l;
 }
 
-// The half-tag rescue of gene G over its flagged pairs (cnt = 1 .. 4 pairs pp0 <= pp1 <= pp2 <= pp3 in
-// stored order, the first cnt of them valid).
+// The half-tag rescue of gene G over the pairs whose nibble of the flag log has bit `fbit` (V2_F_VH / V2_F_JH), however
+// many there are.
 // 1: a candidate passed the Hamming test (k, q, p = the keyword's frame start, half); 0: none did
 // (half = the list the reference walks: 1 when a half-1 keyword occurred, else 2, 0 when no half-tag
 // keyword occurred at all); RESCUE2_SLOW.
-// One sweep in findall order: a half-1 hit tries its candidates at once and a success ends the sweep;
-// half-2 hits wait in four register slots and are tried only when no half-1 keyword occurred — the
-// reference consults the half-2 list only then (:337-339 / :471-473).
-template <bool REV, class WS, int G>
-DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const int n, const int cnt, const int pp0, const int pp1,
-                          const int pp2, const int pp3, int &k_out, int &q_out, int &p_out, int &half_out) {
+// One sweep in findall order (ascending end position in the frame: the words of the log, and the pairs inside a word,
+// downwards in the reverse frame): a half-1 hit tries its candidates at once and a success ends the sweep; half-2 hits wait in
+// four register slots and are tried only when no half-1 keyword occurred — the reference consults the half-2 list only
+// then (:337-339 / :471-473).
+template <bool REV, int NW, class WS, int G>
+DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const uint32_t fbit,
+                          int &k_out, int &q_out, int &p_out, int &half_out) {
   const int L1 = (int)rt.Lh[G][0], L2 = (int)rt.Lh[G][1];
   const uint64_t m1 = (1ull << (2 * L1)) - 1ull, m2 = (1ull << (2 * L2)) - 1ull;
+  const uint32_t mask8 = fbit * 0x11111111u;
+  uint32_t nz = 0;                       // the words of the log that hold such a pair
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) nz |= (lg[kk] & mask8) ? (1u << kk) : 0u;
   uint64_t h2lo = 0, h2hi = 0;           // half-2 hits in findall order: slot i = (keyword + 1) << 16 | stored end base
   int h2n = 0;
   bool any1 = false;
   int res = 0;
-  for (int t = 0; t < cnt && res == 0; t++) {
-    const int u = REV ? cnt - 1 - t : t;
-    const int pair = u == 0 ? pp0 : (u == 1 ? pp1 : (u == 2 ? pp2 : pp3));
-    const int f1 = 2 * pair + 1;                                 // the pair's second stored base
-    const int xs = f1 >= 31 ? f1 - 31 : 0;                       // window: stored bases [xs, xs + 32)
-    const uint64_t X = w.stored64(xs);
-    for (int y = 0; y < 2 && res == 0; y++) {
-      const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
-      if (f >= n) continue;
-      const int s1 = f - L1 + 1, s2 = f - L2 + 1;
-      const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
-                            {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
-      int kw[2];
-      lookup_lockstep<2>(q, kw);
-      const int kw1 = kw[0], kw2 = kw[1];
-      if (kw2 >= 0) {
-        const uint64_t e = ((uint64_t)(uint32_t)(kw2 + 1) << 16) | (uint64_t)(uint32_t)f;
-        if (h2n < 2) h2lo |= e << (32 * h2n); else if (h2n < 4) h2hi |= e << (32 * (h2n - 2));
-        h2n++;
-      }
-      if (kw1 >= 0) {
-        any1 = true;
-        const int p = REV ? n - s1 - L1 : s1;
-        res = rescue2_candidates<REV, WS, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
-        p_out = p;
+  while (nz && res == 0) {
+    const int kk = REV ? 31 - dcrx_clz32(nz) : dcrx_ctz32(nz);
+    nz &= ~(1u << kk);
+    uint32_t m = log_word<NW>(lg, kk) & mask8;
+    while (m && res == 0) {
+      const int bit = REV ? 31 - dcrx_clz32(m) : dcrx_ctz32(m);
+      m &= ~(1u << bit);
+      const int pair = 8 * kk + (bit >> 2);
+      const int f1 = 2 * pair + 1;                                 // the pair's second stored base
+      const int xs = f1 >= 31 ? f1 - 31 : 0;                       // window: stored bases [xs, xs + 32)
+      const uint64_t X = w.stored64(xs);
+      for (int y = 0; y < 2 && res == 0; y++) {
+        const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
+        if (f >= n) continue;
+        const int s1 = f - L1 + 1, s2 = f - L2 + 1;
+        const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
+                              {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
+        int kw[2];
+        lookup_lockstep<2>(q, kw);
+        const int kw1 = kw[0], kw2 = kw[1];
+        if (kw2 >= 0) {
+          const uint64_t e = ((uint64_t)(uint32_t)(kw2 + 1) << 16) | (uint64_t)(uint32_t)f;
+          if (h2n < 2) h2lo |= e << (32 * h2n); else if (h2n < 4) h2hi |= e << (32 * (h2n - 2));
+          h2n++;
+        }
+        if (kw1 >= 0) {
+          any1 = true;
+          const int p = REV ? n - s1 - L1 : s1;
+          res = rescue2_candidates<REV, WS, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
+          p_out = p;
+        }
       }
     }
   }
@@ -1025,35 +1063,55 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const int n, const
   return res;
 }
 
-template <bool REV, int NW, class WS>
+// The shapes of an event entry, as the scan kernel sorts them (one list each, so that a wave runs one kind of sweep):
+//   V2_SHAPE_VF_JH  one pair holds the V tag, no pair a J tag, J half-tag flags: V as the lean tail, J by half-tag rescue
+//   V2_SHAPE_VH_JF  no V tag (V half-tag flags); the J side is a J tag (one pair or several) or nothing at all: V by rescue
+//   V2_SHAPE_VH_JH  no V tag, no J tag, half-tag flags of both genes
+//   V2_SHAPE_ANY    (the test build, A/B) decided per read
+enum { V2_SHAPE_ANY = -1, V2_SHAPE_VF_JH = 0, V2_SHAPE_VH_JF = 1, V2_SHAPE_VH_JH = 2 };
+DCRX_DEV int shape2(const uint32_t vf_n, const uint32_t jf_n, const uint32_t any) {
+  if (vf_n == 1u) return V2_SHAPE_VF_JH;
+  return (jf_n >= 1u || !(any & V2_F_JH)) ? V2_SHAPE_VH_JF : V2_SHAPE_VH_JH;
+}
+
+// T: the tables in global memory (a walk that leaves its first window reads the packed regions there);
+// C: the block's counters (a full-tag walk that fails is final and counts inside the walk); Cdry: a scratch block of
+// counters nobody reads (a half-tag candidate's walk that fails is not final: the read then takes the general form, and
+// nothing may have been counted).
+template <bool REV, int NW, int SHAPE, class WS>
 DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
-                          dcrx_record_t &rec, uint32_t &errs) {
+                          dcrx_record_t &rec, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry) {
   const Tail2Tabs &tt = rt.t;
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
   errs = 0;
   if (n < 32 || Lv > 31 || Lj > 31) return R2S(2);
-  // ---- what the flag log holds: per kind the number of pairs, the first and (half tags) the last ----
-  uint32_t vfn = 0, jfn = 0, vhn = 0, jhn = 0, vf1 = 0xFFFFFFFFu, jf1 = 0xFFFFFFFFu, vh1 = 0xFFFFFFFFu, jh1 = 0xFFFFFFFFu, vhl = 0, jhl = 0;
+  // ---- what the flag log holds: pairs with a V tag / a J tag (number and the first), any half-tag flag ----
+  uint32_t vfn = 0, jfn = 0, any = 0, vf1 = 0xFFFFFFFFu, jf1 = 0xFFFFFFFFu;
 #pragma unroll
   for (int kk = 0; kk < NW; kk++) {
     const uint32_t l = lg[kk];
-    const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u, hv = l & 0x44444444u, hj = l & 0x88888888u;
-    vfn += (uint32_t)dcrx_popc64(tv); jfn += (uint32_t)dcrx_popc64(tj); vhn += (uint32_t)dcrx_popc64(hv); jhn += (uint32_t)dcrx_popc64(hj);
+    any |= l;
+    const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
     const uint32_t kb = (uint32_t)kk << 5;
-    vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
-    jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
-    vh1 = min(vh1, (hv ? (uint32_t)dcrx_ctz32(hv) : 0xFFFFFFFFu) | kb);
-    jh1 = min(jh1, (hj ? (uint32_t)dcrx_ctz32(hj) : 0xFFFFFFFFu) | kb);
-    vhl = max(vhl, hv ? ((31u - (uint32_t)dcrx_clz32(hv)) | kb) : 0u);
-    jhl = max(jhl, hj ? ((31u - (uint32_t)dcrx_clz32(hj)) | kb) : 0u);
+    if (SHAPE != V2_SHAPE_VH_JF && SHAPE != V2_SHAPE_VH_JH) {
+      vfn += (uint32_t)dcrx_popc64(tv);
+      vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
+    }
+    if (SHAPE != V2_SHAPE_VF_JH && SHAPE != V2_SHAPE_VH_JH) {
+      jfn += (uint32_t)dcrx_popc64(tj);
+      jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
+    }
   }
+  any |= any >> 16; any |= any >> 8; any |= any >> 4; any &= 0xFu;
   if ((n & 1) && log_nibble<NW>(lg, n >> 1)) return R2S(3);       // a flag on the half pair at the end of an odd-length read may not stand
-  if (vfn > 1 || (vfn == 0 && (vhn == 0 || vhn > 4)) || (jfn == 0 && jhn > 4)) return R2S(4);
+  if (vfn > 1 || (vfn == 0 && !(any & V2_F_VH))) return R2S(4);   // (entries of the scan kernel never look like this)
+  if (SHAPE == V2_SHAPE_VF_JH && vfn != 1) return R2S(4);
   const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
 
   // ---- vanalysis ----
   int v = -1, vp = 0, te = 0;
-  if (vfn == 1) {
+  bool vhalf = false;
+  if (SHAPE == V2_SHAPE_VF_JH || (SHAPE == V2_SHAPE_ANY && vfn == 1)) {
     const int vpair = (int)(vf1 >> 2);
     const int sva = 2 * vpair - Lv + 1;
     const int wsv = min(max(sva, 0), n - 32);
@@ -1070,33 +1128,39 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     te = vp + dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v) - 1;                       // :283-285
   } else {
     int k = 0, q = 0, p = 0, half = 0;
-    uint32_t a = vh1, b = vhl, c = vhl, d = vhl;          // ascending: the first, (second,) (second last,) last flagged pair
-    if (vhn > 2) { rescue2_mid_pairs<NW>(lg, 0x44444444u, vh1, vhl, b, c); }
-    if (vhn == 3) { c = vhl; }
-    const int res = rescue2_half<REV, WS, 0>(rt, w, n, (int)vhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    const int res = rescue2_half<REV, NW, WS, 0>(rt, w, lg, n, V2_F_VH, k, q, p, half);
     if (res < 0) return R2S(6);
     if (res == 0) return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_V_HALF2_EXHAUSTED : DCRX_S_V_NONE);   // :334 / :389 / :393
     v = k; vp = q;
     const int jump = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)k);
     te = half == 1 ? p + jump - 1 : p + jump - rt.split[0] - 1;                       // :320-322 / :372-377
     errs |= half == 1 ? 2u : 1u;
+    vhalf = true;
   }
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
   const int fv = te + 1;
   if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return R2S(7);
   const uint64_t rwv = w.stored64(REV ? n - fv : fv - 32);
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
-  const int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
-  if (kv < 0) return R2S(8);
-  const int end_v = te - kv;
+  int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  int end_v = te - kv;
+  const int jpair_a = (int)(jf1 >> 2);
+  if (kv < 0) {      // the walk leaves its first window: the general function (rare)
+    const FrameWS<REV, WS> F{w, n};
+    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, vhalf ? Cdry : C)) {
+      if (vhalf) return R2S(8);                        // the reference goes on with the next candidate: the general form
+      return DCRX_S_V_WALK_FAIL;                       // :288-290
+    }
+  }
   const int end_of_v = end_v + 1;                                                     // :547
 
   // ---- janalysis ----
-  if (jfn >= 2) return DCRX_S_J_MULTI;                                                // :402-404
+  if (SHAPE != V2_SHAPE_VF_JH && SHAPE != V2_SHAPE_VH_JH && jfn >= 2) return DCRX_S_J_MULTI;      // :402-404
   int j = -1, jend = 0, ts = 0;
-  if (jfn == 1) {
-    const int jpair = (int)(jf1 >> 2);
-    const int sja = 2 * jpair - Lj + 1;
+  bool jhalf = false;
+  if (SHAPE == V2_SHAPE_VH_JF || (SHAPE == V2_SHAPE_ANY && jfn == 1)) {
+    if (jfn == 0) return DCRX_S_J_NONE;                                               // :530-531 (no J flag of any kind: V2_SHAPE_VH_JF)
+    const int sja = 2 * jpair_a - Lj + 1;
     const int wsj = min(max(sja, 0), n - 32);
     const uint64_t Wj = w.stored64(wsj);
     const LookupQ q[2] = {{tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, sja >= 0},
@@ -1111,12 +1175,9 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     ts = jp - dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);                          // :407-409
     jend = jp + Lj;
   } else {
-    if (jhn == 0) return DCRX_S_J_NONE;                                               // :530-531
+    if (!(any & V2_F_JH)) return DCRX_S_J_NONE;                                       // :530-531
     int k = 0, q = 0, p = 0, half = 0;
-    uint32_t a = jh1, b = jhl, c = jhl, d = jhl;
-    if (jhn > 2) { rescue2_mid_pairs<NW>(lg, 0x88888888u, jh1, jhl, b, c); }
-    if (jhn == 3) { c = jhl; }
-    const int res = rescue2_half<REV, WS, 1>(rt, w, n, (int)jhn, (int)(a >> 2), (int)(b >> 2), (int)(c >> 2), (int)(d >> 2), k, q, p, half);
+    const int res = rescue2_half<REV, NW, WS, 1>(rt, w, lg, n, V2_F_JH, k, q, p, half);
     if (res < 0) return R2S(10);
     if (res == 0) return half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_J_HALF2_EXHAUSTED : DCRX_S_J_NONE);   // :469 / :526 / :530
     j = k;
@@ -1124,15 +1185,22 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     ts = half == 1 ? p - jump : p - jump - rt.split[1];                               // :447-449 / :506-510
     jend = half == 1 ? p + (int)rt.Lh[1][0] + rt.split[1] : p + (int)rt.Lh[1][1];     // :450-454 / :511
     errs |= half == 1 ? 8u : 4u;
+    jhalf = true;
   }
   const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
   if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return R2S(11);
   const uint64_t rwj = w.stored64(REV ? n - ts - 32 : ts);
   const int k0 = end_of_v > ts ? end_of_v - ts : 0;
   const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
-  const int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
-  if (kj < 0) return R2S(12);
-  const int start_j = ts + kj;
+  int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  int start_j = ts + kj;
+  if (kj < 0) {
+    const FrameWS<REV, WS> F{w, n};
+    if (!get_j_deletions(T.g[1], F, j, ts, end_of_v, start_j, kj, jhalf ? Cdry : C)) {
+      if (jhalf) return R2S(12);
+      return DCRX_S_J_WALK_FAIL;                       // :413-418
+    }
+  }
   // ---- filters :553-569 (a clean read holds no N) ----
   if ((vp - jend) >= cfg.lenthreshold) return DCRX_S_F_TOOLONG;
   if (kv > jumpv - Lv || kj > jumpj) return DCRX_S_F_IMPOSS_DEL;
@@ -1162,6 +1230,7 @@ DCRX_DEV void rescue2_count(const Counters &C, const int status, const uint32_t 
     case DCRX_S_J_NONE: C.add(DCRX_C_NO_J_ASSIGNED); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;
     case DCRX_S_J_HALF1_EXHAUSTED: C.add(DCRX_C_FOUNDJ1NOTJ2); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;
     case DCRX_S_J_HALF2_EXHAUSTED: C.add(DCRX_C_FOUNDV2NOTV1); C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;   // the reference bumps the V key (:526)
+    case DCRX_S_J_WALK_FAIL: C.add(DCRX_C_VJ_ASSIGNMENT_FAILED); break;     // (j_del_failed / v_del_failed were counted by the walk itself)
     case DCRX_S_F_TOOLONG: C.add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG); break;
     case DCRX_S_F_IMPOSS_DEL: C.add(DCRX_C_DCRFILTER_IMPOSS_DELETION); break;
     case DCRX_S_F_OVERLAP: C.add(DCRX_C_DCRFILTER_TAG_OVERLAP); break;

@@ -107,7 +107,7 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     for (int k = 0; k < NW; k++) strip[k] = w[0][k];
     strip[NW] = strip[NW + 1] = 0u;
     const LdsWords lw{dcrx_ldsaddr_of(strip)};
-    const int st = o ? tail2_fast<true>(tt, lw, n, tail2_pack(d), C, rec) : tail2_fast<false>(tt, lw, n, tail2_pack(d), C, rec);
+    const int st = o ? tail2_fast<true>(tt, lw, n, tail2_pack(d), C, rec, T, CC) : tail2_fast<false>(tt, lw, n, tail2_pack(d), C, rec, T, CC);
     if (st != TAIL2_SLOW) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
       records[r] = rec;
@@ -127,7 +127,18 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     std::memset(&rec, 0, sizeof rec);
     uint32_t errs = 0;
     const RegWords<NW> rw{w[0]};      // (and from registers here: both word sources are exercised)
-    const int st = o ? rescue2_fast<true, NW>(rt, rw, lg[0], n, C, rec, errs) : rescue2_fast<false, NW>(rt, rw, lg[0], n, C, rec, errs);
+    uint32_t dry[DCRX_N_COUNTERS] = {0};
+    const Counters Cdry{dry};
+    // (the kernel sorts event entries by shape and runs the form compiled for the shape; here every other read takes that
+    // form and the rest the form that decides per read: both must agree with the oracle)
+    const int shp = shape2(d.vf_n, d.jf_n, d.any);
+    int st;
+#define DCRX_EMUL_R2(SH) (o ? rescue2_fast<true, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry) : rescue2_fast<false, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry))
+    if ((r & 1) || bnd) st = DCRX_EMUL_R2(V2_SHAPE_ANY);
+    else if (shp == V2_SHAPE_VF_JH) st = DCRX_EMUL_R2(V2_SHAPE_VF_JH);
+    else if (shp == V2_SHAPE_VH_JF) st = DCRX_EMUL_R2(V2_SHAPE_VH_JF);
+    else st = DCRX_EMUL_R2(V2_SHAPE_VH_JH);
+#undef DCRX_EMUL_R2
     if (st >= 0) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
       records[r] = rec;
