@@ -503,6 +503,8 @@ class HipDevice:
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    if args.cfg_flags:
+        os.environ.setdefault("DCRX_DEBUG_FLAGS", "1")      # profiling switches are refused by the library without this
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
     run_rank(args)

@@ -44,7 +44,6 @@ F_ONE_BASE_SCAN = 4
 F_V1_KERNELS = 64        # the three-launch form even where the v2 kernel applies
 F_V2_NO_LEAN_RESCUE = 8192   # A/B and tests: event entries go to the general form at once (no lean rescue kernel)
 F_V2_LEAN_SERIAL = 32768     # A/B: lean kernels one after the other instead of side by side
-F_V2_FORK = 4096             # A/B: first general-form pass beside the tail kernel on the handle's side stream
 
 
 def F_V2_SHAPE(k):

@@ -56,7 +56,7 @@ struct dcrx_tables {
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
   void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
-  hipStream_t v2_side = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr;
+  hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
   uint32_t *d_v2_counts = nullptr;
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
@@ -74,9 +74,11 @@ static void free_device_state(dcrx_tables *t) {
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
   if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
+  if (t->v2_side2) (void)hipStreamDestroy(t->v2_side2);
   if (t->v2_ev_fork) (void)hipEventDestroy(t->v2_ev_fork);
   if (t->v2_ev_join) (void)hipEventDestroy(t->v2_ev_join);
-  t->v2_side = nullptr; t->v2_ev_fork = t->v2_ev_join = nullptr;
+  if (t->v2_ev_join2) (void)hipEventDestroy(t->v2_ev_join2);
+  t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
   t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
@@ -230,14 +232,18 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
       t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
       t->plan.v2_slow = reinterpret_cast<uint4 *>(t->d_v2_slow);
       t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;
-      if (!t->v2_side) {     // the event kernel's stream and the two events that fork it off the caller's stream and join it back
+      if (!t->v2_side) {     // the two side streams (tail kernel; general form over list X) and the events that fork them off the caller's stream and join them back
         if (hipStreamCreateWithFlags(&t->v2_side, hipStreamNonBlocking) != hipSuccess) t->v2_side = nullptr;
-        if (t->v2_side && (hipEventCreateWithFlags(&t->v2_ev_fork, hipEventDisableTiming) != hipSuccess ||
-                           hipEventCreateWithFlags(&t->v2_ev_join, hipEventDisableTiming) != hipSuccess)) {
+        if (t->v2_side && hipStreamCreateWithFlags(&t->v2_side2, hipStreamNonBlocking) != hipSuccess) t->v2_side2 = nullptr;
+        if (t->v2_side && (!t->v2_side2 || hipEventCreateWithFlags(&t->v2_ev_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&t->v2_ev_join, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&t->v2_ev_join2, hipEventDisableTiming) != hipSuccess)) {
           (void)hipStreamDestroy(t->v2_side); t->v2_side = nullptr;
+          if (t->v2_side2) { (void)hipStreamDestroy(t->v2_side2); t->v2_side2 = nullptr; }
         }
       }
-      t->plan.v2_side = t->v2_side; t->plan.v2_ev_fork = t->v2_ev_fork; t->plan.v2_ev_join = t->v2_ev_join;
+      t->plan.v2_side = t->v2_side; t->plan.v2_side2 = t->v2_side2;
+      t->plan.v2_ev_fork = t->v2_ev_fork; t->plan.v2_ev_join = t->v2_ev_join; t->plan.v2_ev_join2 = t->v2_ev_join2;
     }
   }
   if (t->ws_dirty) {
@@ -300,6 +306,10 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   if (rc) return rc;
   if (b->n_reads && !d_records) return set_err(DCRX_E_INVALID, "d_records is null");
   if (cfg->orientation < 0 || cfg->orientation > 2) return set_err(DCRX_E_INVALID, "orientation must be 0, 1 or 2");
+  if (cfg->flags & DCRX_F_PROFILE_MASK) {       // profiling switches: the records are then not results
+    static const bool debug_flags = getenv("DCRX_DEBUG_FLAGS") && getenv("DCRX_DEBUG_FLAGS")[0] == '1';
+    if (!debug_flags) return set_err(DCRX_E_INVALID, "cfg.flags holds a profiling switch (records would not be results): set DCRX_DEBUG_FLAGS=1 to allow it");
+  }
   rc = ensure_device(t, b->n_reads, b->stride, (hipStream_t)stream);
   if (rc) return rc;
   BatchDev B;

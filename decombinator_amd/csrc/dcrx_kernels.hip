@@ -554,9 +554,10 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   // (reads beyond the register-resident scans' 320 nt: every read through the list kernel, like orientation `both`)
   const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
-  const bool v2 = B.stride <= 4 * DCRX_NWMAX && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);   // (the v2 entries keep two flags above a 30-bit read index)
   // reserved_cus: compute units left to other streams (an RCCL gather running beside the scan)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
+  // (the v2 entries keep two flags above a 30-bit read index, and a scan block counts its lists' entries in 21 bits)
+  const bool v2 = B.stride <= 4 * DCRX_NWMAX && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30) && B.n_reads / cus + 256 < (1ull << 21);
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, cus * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, cus * (uint32_t)occ_list);
   const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue, of the general

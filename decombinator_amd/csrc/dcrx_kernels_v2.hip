@@ -70,25 +70,38 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #endif
 constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block can take together
 
-// ---- the lists: per wave of the scan kernel one region of tail entries and one of event entries ----
+// ---- the lists: per block of the scan kernel one region of each ----
 // An entry carries the read's packed words (the scan kernel has them in registers), so that the
-// finishing kernels never gather from the read array: their loads are the entries, structure of
-// arrays inside a region (row k of slot i at rows[k * cap + i], 16 bytes each), one lane one slot,
+// finishing kernels never gather from the read array: their loads are the entries, one lane one slot,
 // fully coalesced.  Tail entry: read, digest (tail2_pack), words; event entry: read | flags, the
-// read's flag log, words (the event list is drawn from the log by the event kernel, where every
-// lane has one to draw).
+// read's flag log, words.  Event entries by what they need (rescue2_fast):
+//   region `ev`:  E = one gene has its full tag, the other needs the half-tag rescue (V2_SHAPE_ONE): one sweep per wave
+//   region `sx`:  C = half-tag rescue of both genes (V2_SHAPE_BOTH)  |  X = reads with exception bytes, flags on an odd read's
+//                     last half pair: the general form            (half of the region each)
+//   region `lo`:  L = what the lean kernels hand on (appended with atomics)
+// (a list that outgrows its room hands the rest to the three-launch form)
+enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_LEFT = 4, V2_L_COUNTS = 8 };
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
-  uint4 *events;      // [regions][rows_e][ecap]
-  uint4 *slow;        // [regions][rows_e][scap]: slow list 1, the event entries the lean rescue does not settle
-  uint4 *slow2;       // [regions][rows_e][s2cap]: slow list 2, event entries the tail kernel makes of what its lean form does not settle
-  uint32_t *counts;   // [regions][4]: tail entries, event entries, entries of slow list 1, of slow list 2
-  uint32_t tcap, ecap, scap, s2cap;
+  uint4 *ev;          // [regions][rows_e][ecap]
+  uint4 *sx;          // [regions][rows_e][scap]
+  uint4 *lo;          // [regions][rows_e][lcap]
+  uint32_t *counts;   // [regions][V2_L_COUNTS]: entries of each list (V2_L_*)
+  uint32_t tcap, ecap, scap, lcap;      // scap: a multiple of 128 (two lists of whole chunks)
 };
 template <int NW>
 struct V2Rows {
   static constexpr int T = (2 + NW + 3) / 4, E = (1 + 2 * NW + 3) / 4;
 };
+// an event list of a region: its rows (entry i in slot i) and its capacity
+struct V2ListRef { uint4 *rows; uint32_t cap; };
+template <int NW>
+__device__ __forceinline__ V2ListRef v2_list(const V2Lists &Q, const int which, const size_t region) {
+  constexpr size_t E = V2Rows<NW>::E;
+  if (which == V2_L_E) return V2ListRef{Q.ev + region * Q.ecap * E, Q.ecap};
+  if (which == V2_L_C || which == V2_L_X) return V2ListRef{Q.sx + (region * Q.scap + (which == V2_L_X ? Q.scap / 2 : 0u)) * E, Q.scap / 2};
+  return V2ListRef{Q.lo + region * Q.lcap * E, Q.lcap};
+}
 // dwords x[0 .. N) of slot `at` of a region.  Layout: chunks of 64 slots, inside a chunk structure of arrays
 // (row k of slot i at rows[((i / 64) * R + k) * 64 + i % 64], R = rows per entry): a wave's batch of 64
 // entries is one contiguous piece of R KB, every load of it fully coalesced, and a region is one stream of
@@ -180,7 +193,8 @@ __device__ __forceinline__ void v2_load_item(const BatchDev &B, const uint32_t n
 }
 
 // LDS of the scan kernel behind the pair table and the counters: the block's work counters
-enum { V2_WK_NEXT = 0, V2_WK_TAIL = 1, V2_WK_EVENTS = 2, V2_WK_WORDS = 4 };
+// next item; entries of each list (V2_WK_LIST + V2_L_*)
+enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_WORDS = 8 };
 
 template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
@@ -198,7 +212,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   if (dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans)) != 0u) __builtin_trap();   // v2_entry reads the table at absolute LDS addresses
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   if (tid < V2_WK_WORDS) lds_work[tid] = 0;
-  stage_lds<DCRX_V2_BLOCK>(reinterpret_cast<const uint8_t *>(V0.trans), lds_trans, V0.trans_bytes / 16, 0, 0, tid);
+  {      // (the block may be launched with fewer threads than it is compiled for: the stride is the block's own size)
+    const uint4 *src = reinterpret_cast<const uint4 *>(V0.trans);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_trans);
+    for (uint32_t i = tid; i < V0.trans_bytes / 16; i += blockDim.x) dst[i] = src[i];
+  }
   const V2Tab tab{};
   __syncthreads();
   const uint32_t nw = B.stride >> 2;
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   const uint32_t n_items = blk_lo < blk_hi ? (uint32_t)((blk_hi - blk_lo + WT - 1) / WT) : 0u;
   const size_t region = blockIdx.x;
   uint4 *tq = Q.tail + region * Q.tcap * V2Rows<NW>::T;
-  uint4 *eq = Q.events + region * Q.ecap * V2Rows<NW>::E;
+  uint4 *eq = Q.ev + region * Q.ecap * V2Rows<NW>::E;
   auto draw = [&]() -> uint32_t {
     uint32_t i = 0;
     if (lane == 0) i = atomicAdd(&lds_work[V2_WK_NEXT], 1u);
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       const unsigned long long mt0 = __ballot(to_tail);
       if (mt0) {           // the block's tail list: one LDS atomic per wave and group of 64 reads
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_TAIL], (uint32_t)__popcll(mt0));
+        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + V2_L_TAIL], (uint32_t)__popcll(mt0));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t at = base + (uint32_t)__popcll(mt0 & lt_mask);
         if (to_tail && at >= Q.tcap) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, false); to_tail = false; }
@@ -316,23 +334,45 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
           v2_put_rows<2 + NW>(tq, Q.tcap, at, x);
         }
       }
-      bool to_ev = what == V2_EVENTS;
+      // event entries: list E (one gene to rescue: nine in ten), or one of the rare lists C (both genes) and X (exception
+      // bytes, a flag on the last half pair of an odd read: the general form)
+      int lst = 0;
+      if (what == V2_EVENTS) lst = (exc || bnd) ? V2_L_X : (shape2(d.vf_n, d.jf_n, d.any) == V2_SHAPE_BOTH ? V2_L_C : V2_L_E);
+      auto put_event = [&](uint4 *rows, const uint32_t at) {
+        uint32_t x[1 + 2 * NW];
+        x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
+#pragma unroll
+        for (int k = 0; k < NW; k++) { x[1 + k] = lg[q][k]; x[1 + NW + k] = w[q][k]; }
+        v2_put_rows<1 + 2 * NW>(rows, 0u, at, x);
+      };
+      bool to_ev = lst == V2_L_E;
       const unsigned long long me0 = __ballot(to_ev);
       if (me0) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_EVENTS], (uint32_t)__popcll(me0));
+        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + V2_L_E], (uint32_t)__popcll(me0));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t at = base + (uint32_t)__popcll(me0 & lt_mask);
         if (to_ev && at >= Q.ecap) {                 // a full region (its last lanes): the three-launch form
           v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
           to_ev = false;
         }
-        if (to_ev) {
-          uint32_t x[1 + 2 * NW];
-          x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
-#pragma unroll
-          for (int k = 0; k < NW; k++) { x[1 + k] = lg[q][k]; x[1 + NW + k] = w[q][k]; }
-          v2_put_rows<1 + 2 * NW>(eq, Q.ecap, at, x);
+        if (to_ev) put_event(eq, at);
+      }
+      if (__ballot(lst > V2_L_E)) {
+#pragma unroll 1
+        for (int which = V2_L_C; which <= V2_L_X; which++) {
+          const bool mine = lst == which;
+          const unsigned long long mr = __ballot(mine);
+          if (!mr) continue;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + which], (uint32_t)__popcll(mr));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (mine) {
+            const V2ListRef l = v2_list<NW>(Q, which, region);
+            const uint32_t at = base + (uint32_t)__popcll(mr & lt_mask);
+            if (at >= l.cap) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
+            else put_event(l.rows, at);
+          }
         }
       }
     }
@@ -349,13 +389,14 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   __syncthreads();
 #ifdef DCRX_SCAN_STAMPS
   if (lane == 0) {      // instrumented build (tools/): per wave (not per region; its runs finish nothing) start and end in the 100 MHz counter, clocks inside / between scans
-    uint32_t *c = Q.counts + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));
+    uint32_t *c = Q.counts + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));      // (the counts array holds 8 words per compute unit's 16 waves: room for these)
     c[0] = (uint32_t)stamp_r0; c[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); c[2] = (uint32_t)(stamp_scan >> 6); c[3] = (uint32_t)(stamp_rest >> 6);
   }
 #else
-  if (tid == 0) {
-    Q.counts[4 * region] = min(lds_work[V2_WK_TAIL], Q.tcap); Q.counts[4 * region + 1] = min(lds_work[V2_WK_EVENTS], Q.ecap);
-    Q.counts[4 * region + 2] = 0u; Q.counts[4 * region + 3] = 0u;
+  if (tid < V2_L_COUNTS) {      // (entries beyond a list's capacity were handed over, not stored; L starts empty)
+    uint32_t c = tid <= V2_L_X ? lds_work[V2_WK_LIST + tid] : 0u;
+    c = min(c, tid == V2_L_TAIL ? Q.tcap : (tid == V2_L_E ? Q.ecap : Q.scap / 2));
+    Q.counts[V2_L_COUNTS * region + tid] = c;
   }
 #endif
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
@@ -374,7 +415,7 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
 template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t to_slow2, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   constexpr int o = ORI;      // the frame is a template argument: one frame's code per kernel
@@ -399,12 +440,11 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
   for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {
     const uint32_t region = job / split, part = job % split;
-    const uint32_t tn = Q.counts[4 * region];
+    const uint32_t tn = Q.counts[V2_L_COUNTS * region + V2_L_TAIL];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
-    // what the lean form does not settle: slow list 1 behind the rescue kernel's leftovers, or (the event kernel's first pass
-    // running beside this kernel) slow list 2
-    const uint32_t scap = to_slow2 ? Q.s2cap : Q.scap;
-    uint4 *eq = (to_slow2 ? Q.slow2 : Q.slow) + (size_t)region * scap * V2Rows<NW>::E;
+    // what the lean form does not settle: list L, as an event entry for the general form
+    const uint32_t scap = Q.lcap;
+    uint4 *eq = Q.lo + (size_t)region * scap * V2Rows<NW>::E;
     const uint32_t STEP = 64 * split;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
       const unsigned long long ms = __ballot(status == TAIL2_SLOW);
       if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + (to_slow2 ? 3 : 2)], (uint32_t)__popcll(ms));
+        if (lane == 0) base = atomicAdd(&Q.counts[V2_L_COUNTS * region + V2_L_LEFT], (uint32_t)__popcll(ms));
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == TAIL2_SLOW) {
@@ -494,9 +534,9 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
   }
 }
 
-// The lean rescue kernel: the scan kernel's event entries in straight-line code (rescue2_fast), one wave per
-// region, entries read one batch ahead.  What that form does not settle is copied to the region's slow list and
-// takes the general form in the event kernel's launch behind the tail kernel.
+// The lean rescue kernel: the scan kernel's event lists E and C in straight-line code (rescue2_fast compiled for the
+// list's shape), `split` waves per region and list, entries read one batch ahead.  What that form does not settle is
+// copied to the region's list L and takes the general form in the event kernel's last pass.
 template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
@@ -525,23 +565,25 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
-  for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {       // `split` waves per region, as in the tail kernel
-    const uint32_t region = job / split, part = job % split;
+  // jobs: (list, region, part); the lists one after the other, so that the waves in flight at one time run the same code
+  for (uint32_t job = gwave; job < 2u * n_regions * split && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
+    const int which = job < n_regions * split ? V2_L_E : V2_L_C;
+    const uint32_t region = (job / split) % n_regions, part = job % split;
     const uint32_t STEP = 64 * split;
-    const uint32_t en = min(Q.counts[4 * region + 1], Q.ecap);
-    const uint4 *eq = Q.events + (size_t)region * Q.ecap * V2Rows<NW>::E;
-    uint4 *sq = Q.slow + (size_t)region * Q.scap * V2Rows<NW>::E;
+    const V2ListRef l = v2_list<NW>(Q, which, region);
+    const uint32_t en = min(Q.counts[V2_L_COUNTS * region + which], l.cap);
+    uint4 *sq = Q.lo + (size_t)region * Q.lcap * V2Rows<NW>::E;
     constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
     uint32_t x1[1 + 2 * NW];
-    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(eq, Q.ecap, 64 * part + lane, 64 * part + lane < en, x1);
-    for (uint32_t first = 64 * part; first < en && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); first += STEP) {
+    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(l.rows, l.cap, 64 * part + lane, 64 * part + lane < en, x1);
+    for (uint32_t first = 64 * part; first < en; first += STEP) {
       uint32_t x[1 + 2 * NW];
       if constexpr (AHEAD) {
 #pragma unroll
         for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
-        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
+        v2_get_rows<1 + 2 * NW>(l.rows, l.cap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
       } else {
-        v2_get_rows<1 + 2 * NW>(eq, Q.ecap, first + lane, first + lane < en, x);
+        v2_get_rows<1 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x);
       }
       uint32_t lg[NW], w[NW];
 #pragma unroll
@@ -555,27 +597,23 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
           const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
           dcrx_record_t rec;
           rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-#if DCRX_LEAN_LDS_WORDS
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
-          status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ANY>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
-#else
-          const RegWords<NW> rw{w};
-          status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ANY>(rt, rw, lg, n, cfg, rec, errs, T0, C, Cdry);
-#endif
+          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
+          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
       const unsigned long long ms = __ballot(status == RESCUE2_SLOW);
-      if (ms) {      // (the tail kernel appends to the same list later, with atomics: the count is kept the same way)
+      if (ms) {      // (the tail kernel appends to the same list, with atomics as well)
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[4 * region + 2], (uint32_t)__popcll(ms));
+        if (lane == 0) base = atomicAdd(&Q.counts[V2_L_COUNTS * region + V2_L_LEFT], (uint32_t)__popcll(ms));
         base = __shfl(base, 0);
         const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
         if (status == RESCUE2_SLOW) {
-          if (at < Q.scap) v2_put_rows<1 + 2 * NW>(sq, Q.scap, at, x);
+          if (at < Q.lcap) v2_put_rows<1 + 2 * NW>(sq, Q.lcap, at, x);
           else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, (x[0] & V2_R_EXC) != 0u);
         }
       }
@@ -597,15 +635,20 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   V2Ori V = T0.v2[ORI];
-  // which: 0 = the scan kernel's event entries, 1 = slow list 1 (the lean rescue's leftovers), 2 = slow list 2 (the tail kernel's)
-  const uint4 *list = which == 0 ? Q.events : (which == 1 ? Q.slow : Q.slow2);
-  const uint32_t lcap = which == 0 ? Q.ecap : (which == 1 ? Q.scap : Q.s2cap);
+  // which: the list (V2_L_E .. V2_L_LEFT)
+  const uint32_t lcap = v2_list<NW>(Q, which, 0).cap;
   // ext: the packed germline regions are staged behind the side tables (the launcher found room for them)
   const uint32_t side_bytes = (ext ? T0.lds_image2_bytes : T0.lds_image_bytes) - T0.dfa_bytes;
   uint32_t *lds_counts = smem;
   uint32_t *lds_side = smem + DCRX_N_COUNTERS;
   uint32_t *lds_bk = lds_side + side_bytes / 4;
   const int tid = threadIdx.x;
+  // a short list's pass (one region to a group, the grid covers every region): a block whose share of its region's list
+  // is empty leaves before it stages anything — most blocks of such a pass
+  if (group == 1u && gridDim.x / bsplit >= n_regions) {
+    const uint32_t g = blockIdx.x / bsplit;
+    if (g >= n_regions || width * (DCRX_V2_FBLOCK / 64) * (blockIdx.x % bsplit) >= min(Q.counts[V2_L_COUNTS * g + which], lcap)) return;
+  }
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, side_bytes / 16, 0, 0, tid);
   stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
@@ -625,7 +668,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
       uint32_t acc = 0;
       for (uint32_t k = 0; k < group; k++) {
         pref[k] = acc;
-        if (g0 + k < n_regions) acc += min(Q.counts[4 * (g0 + k) + 1 + which], lcap);     // (appends may have run past a region's end)
+        if (g0 + k < n_regions) acc += min(Q.counts[V2_L_COUNTS * (g0 + k) + which], lcap);     // (appends may have run past a region's end)
       }
       pref[group] = acc;
     }
@@ -641,9 +684,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
       uint32_t g = 0;
       for (uint32_t k = 1; k < group; k++) g += i >= pref[k] ? 1u : 0u;
       const uint32_t slot = i - pref[g];
-      const uint4 *eq = list + (size_t)(g0 + g) * lcap * V2Rows<NW>::E;
+      const V2ListRef l = v2_list<NW>(Q, which, (size_t)(g0 + g));
       uint32_t x[1 + 2 * NW];
-      v2_get_rows<1 + 2 * NW>(eq, lcap, slot, live, x);
+      v2_get_rows<1 + 2 * NW>(l.rows, l.cap, slot, live, x);
       uint32_t lg[NW], w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
@@ -724,113 +767,97 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, (n_items + 15) / 16));
   const uint64_t per_block = (((B.n_reads + grid - 1) / grid + wt - 1) / wt) * wt;
   V2Lists Q;
-  Q.tail = P.v2_tail; Q.events = P.v2_events; Q.slow = P.v2_slow; Q.counts = P.v2_counts;
+  Q.tail = P.v2_tail; Q.ev = P.v2_events; Q.sx = P.v2_slow; Q.counts = P.v2_counts;
   const uint32_t n_regions = grid;
-  Q.tcap = (uint32_t)std::min<uint64_t>(per_block, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
-  Q.ecap = (uint32_t)std::min<uint64_t>(per_block, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~63u;
-  // the slow allocation holds both slow lists: list 1 sized like the event list, list 2 in what is left
+  const uint64_t pb128 = (per_block + 255) & ~127ull;           // (a block's reads, rounded up to whole chunks)
+  Q.tcap = (uint32_t)std::min<uint64_t>(pb128, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
+  Q.ecap = (uint32_t)std::min<uint64_t>(pb128, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~127u;    // (region `sx`, of the same size, holds two lists of whole chunks)
+  // the second allocation holds region `sx` (sized like `ev`) and, in what is left, region `lo`
   Q.scap = Q.ecap;
-  Q.slow2 = Q.slow + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
+  Q.lo = Q.sx + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
   const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
-  Q.s2cap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(per_block, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
-  if (Q.tcap < 64 || Q.ecap < 64 || Q.s2cap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
-  // (the timing events of the dominant kernel ride on its own dispatch: recorded separately they cost the stream a gap each.
-  // So does the event that forks the tail kernel onto the side stream: when no timing event claims the place it is the scan
-  // dispatch's own stop event, and the rescue kernel follows the scan on the caller's queue without a marker in between)
+  Q.lcap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(pb128, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
+  if (Q.tcap < 64 || Q.ecap < 128 || Q.lcap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  // Launch order.  Caller's stream: scan -> rescue (lists E, C) -> [join] -> general form over list L (what the lean
+  // kernels handed on) -> (dcrx_kernels.hip) the list kernel.  Side stream 1: the tail kernel; side stream 2: the general
+  // form over list X (reads with exception bytes: known when the scan ends, their long single-read latencies run under
+  // the lean kernels).  The fork event is the scan dispatch's own stop event when no timing event claims that place, the
+  // join events are the side kernels' own stop events: no marker packets on the queues.  DCRX_F_V2_LEAN_SERIAL (A/B, tests):
+  // everything on the caller's stream.
   const bool finish = !(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH));
-  const bool lean2_early = finish && P.v2_side && P.v2_ev_fork && P.v2_ev_join &&
-                           !(cfg.flags & (DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_FORK | DCRX_F_V2_NO_LEAN_RESCUE));
-  const bool fork_rides = lean2_early && !ev_stop;
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
+  const bool side = finish && P.v2_side && P.v2_side2 && P.v2_ev_fork && P.v2_ev_join && P.v2_ev_join2 && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL);
+  const bool fork_rides = side && !ev_stop;
+  static const uint32_t scan_threads = getenv("DCRX_SCAN_THREADS") ? (uint32_t)atoi(getenv("DCRX_SCAN_THREADS")) : (uint32_t)DCRX_V2_BLOCK;      // experiments
+  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(scan_threads), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
                         d_counters, Q, queue, gqueue, qcap, queue_count, per_block);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (!(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH))) {
-    // Lean rescue kernel (event entries), lean tail kernel (tail entries), then the general form (event kernel) over what
-    // the two did not settle (slow list 1).  DCRX_F_V2_FORK (A/B) runs the general form for the rescue kernel's leftovers
-    // beside the tail kernel on the handle's side stream and the tail kernel's own (slow list 2) behind it: measured no
-    // faster (0.592 against 0.603 ms per step with the best shape), the event kernel's waves wait for registers the tail
-    // kernel's waves hold.
+  if (finish) {
     // waves of the finishing kernels that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
-    // 4096 on the event list of a full-size launch
+    // 4096 on each rescue list of a full-size launch
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
-    const uint32_t fgrid = (n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-    const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over the event list (A/B): a block takes four regions
-    const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of the slow-list pass that share a region
+    uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    if (getenv("DCRX_RESC_BPC")) fgrid = std::min<uint32_t>(fgrid, cus * (uint32_t)atoi(getenv("DCRX_RESC_BPC")));
+    const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
+    const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of a short list's pass that share a region
     const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
     const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4;      // the lean kernels: + a strip per lane (+ the rescue kernel's scratch counters)
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;
-    const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a slow list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
-    const bool fork = P.v2_side && P.v2_ev_fork && P.v2_ev_join && (cfg.flags & DCRX_F_V2_FORK);
-    hipStream_t se = fork ? P.v2_side : s;
-    const dim3 tgrid((n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
+    const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a short list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
+    static const uint32_t tail_bpc = getenv("DCRX_TAIL_BPC") ? (uint32_t)atoi(getenv("DCRX_TAIL_BPC")) : 0u, resc_bpc = getenv("DCRX_RESC_BPC") ? (uint32_t)atoi(getenv("DCRX_RESC_BPC")) : 0u;      // experiments: blocks per CU
+    uint32_t tg = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
+    if (tail_bpc) tg = std::min<uint32_t>(tg, cus * tail_bpc);
+    const dim3 tgrid(tg);
     const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
-    // The two lean kernels run beside each other, the tail kernel on the handle's side stream: different lists, one bound
-    // by VALU issue, the other by its record stores (0.531 against 0.546 ms per step; DCRX_F_V2_LEAN_SERIAL: one after the
-    // other on the caller's stream, A/B).  Both append to the slow list with atomics; the event kernel waits for both.
-    const bool lean2 = P.v2_side && P.v2_ev_fork && P.v2_ev_join && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL) && !fork &&
-                       !(cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE);
-    auto launch_tail_side = [&]() -> hipError_t {
-      hipError_t e2 = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e2 != hipSuccess) return e2;
-      // (the join event is the tail dispatch's own stop event)
-      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, 0u, n_regions, tsplit, queue,
-                            gqueue, qcap, queue_count);
+    auto general = [&](hipStream_t st, const int which, const bool whole_list, hipEvent_t stop) -> hipError_t {
+      if (whole_list)
+        hipExtLaunchKernelGGL(ke, dim3(egrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, 1u, ext,
+                              n_regions, queue, gqueue, qcap, queue_count);
+      else
+        hipExtLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, 1u, slow_width, bsplit, ext, n_regions, queue,
+                              gqueue, qcap, queue_count);
       return hipGetLastError();
     };
-    if (lean2) {
+    if (side) {
       if (!fork_rides) { e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e; }
-      e = launch_tail_side(); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
+      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue,
+                            gqueue, qcap, queue_count);
+      e = hipGetLastError(); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(P.v2_side2, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
+      e = general(P.v2_side2, V2_L_X, false, P.v2_ev_join2); if (e != hipSuccess) return e;
     }
-    // the scan kernel's event entries: the lean rescue (what it does not settle joins slow list 1), or — A/B — the general form at once
-    if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE)
-      hipLaunchKernelGGL(ke, dim3(egrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 0, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, 1u, ext, n_regions, queue,
-                         gqueue, qcap, queue_count);
-    else
+    // the scan kernel's event lists E and C: the lean rescue, or — A/B — the general form at once
+    if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE) {
+      for (int which = V2_L_E; which <= V2_L_C; which++) { e = general(s, which, true, nullptr); if (e != hipSuccess) return e; }
+    } else {
       hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
                          queue_count);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (!fork) {
-      // the tail kernel, then one pass of the event kernel over slow list 1 (both lean kernels' leftovers)
-      if (lean2) {
-        e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
-      } else {
-        hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 0u, n_regions, tsplit, queue, gqueue, qcap, queue_count);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-      }
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 1, 1u, slow_width, bsplit, ext, n_regions, queue,
-                         gqueue, qcap, queue_count);
-      e = hipGetLastError();
-    } else {
-      e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e;
-      e = hipStreamWaitEvent(se, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, se, T, B, cfg, rec, d_counters, Q, 1, 1u, slow_width, bsplit, ext, n_regions, queue,
-                         gqueue, qcap, queue_count);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
-      e = hipEventRecord(P.v2_ev_join, se); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, 1u, n_regions, tsplit, queue, gqueue, qcap, queue_count);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
-      e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, s, T, B, cfg, rec, d_counters, Q, 2, 1u, slow_width, bsplit, ext, n_regions, queue,
-                         gqueue, qcap, queue_count);
-      e = hipGetLastError();
     }
+    if (side) {
+      e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(s, P.v2_ev_join2, 0); if (e != hipSuccess) return e;
+    } else {
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue, gqueue, qcap, queue_count);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;
+    }
+    e = general(s, V2_L_LEFT, false, nullptr);       // what the lean kernels handed on
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
-      std::vector<uint32_t> h(4 * (size_t)n_regions);
+      std::vector<uint32_t> h((size_t)V2_L_COUNTS * n_regions);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
-      unsigned long long t = 0, ev = 0, sl = 0, smax = 0;
-      unsigned long long sl2 = 0;
-      for (uint32_t r = 0; r < n_regions; r++) { t += h[4 * r]; ev += h[4 * r + 1]; sl += h[4 * r + 2]; sl2 += h[4 * r + 3]; smax = std::max<unsigned long long>(smax, h[4 * r + 2]); }
-      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu events %llu slow1 %llu (max per region %llu) slow2 %llu\n", n_regions, t, ev, sl, smax, sl2);
-
+      unsigned long long t[V2_L_COUNTS] = {0}, lmax = 0;
+      for (uint32_t r = 0; r < n_regions; r++) { for (int k = 0; k < V2_L_COUNTS; k++) t[k] += h[(size_t)V2_L_COUNTS * r + k]; lmax = std::max<unsigned long long>(lmax, h[(size_t)V2_L_COUNTS * r + V2_L_LEFT]); }
+      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu E %llu C %llu X %llu left %llu (max per region %llu)\n", n_regions, t[V2_L_TAIL], t[V2_L_E],
+              t[V2_L_C], t[V2_L_X], t[V2_L_LEFT], lmax);
     }
   }
 #ifdef DCRX_SCAN_STAMPS

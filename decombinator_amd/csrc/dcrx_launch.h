@@ -25,8 +25,8 @@ struct LaunchPlan {
   uint4 *v2_tail = nullptr; uint4 *v2_events = nullptr; uint32_t *v2_counts = nullptr;
   uint4 *v2_slow = nullptr;
   uint64_t v2_tail_rows = 0, v2_event_rows = 0, v2_slow_rows = 0;       // 16-byte rows allocated for each list
-  hipStream_t v2_side = nullptr;                      // the event kernel runs here, beside the tail kernel
-  hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr;
+  hipStream_t v2_side = nullptr, v2_side2 = nullptr;  // the tail kernel / the general form over the reads with exception bytes run here, beside the rescue kernel
+  hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
   // optional, set per call (dcrx_set_step_events): start of the first and end of the last kernel of the call.  Attached to
   // those kernels' own dispatches (hipExtLaunchKernelGGL): a separate event record costs the stream ~10 us of gap each
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;

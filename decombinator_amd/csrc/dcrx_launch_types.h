@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "dcrx_debug_flags.h"
+
 // words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
 #define DCRX_NWMAX 20
 #define DCRX_FAST_READ_LEN (16 * DCRX_NWMAX)

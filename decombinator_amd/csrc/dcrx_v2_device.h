@@ -956,15 +956,35 @@ DCRX_DEV int rescue2_lookup(const dcrx_ldsaddr start, const dcrx_ldsaddr kws, co
   return kw;
 }
 
-// The candidate tags of one half-tag hit (keyword gk of half HALF of gene G, starting at frame
+// Which gene a half-tag sweep serves: gene G (0 = V, 1 = J) for the whole wave, or (G = -1) picked lane by lane — for an
+// entry whose two genes differ in kind (one has its full tag, the other needs the rescue) one sweep then serves the V
+// rescues and the J rescues of a wave side by side, the same instructions on per-lane tables, instead of one sweep after
+// the other.  The tables' places are picked where they are used (two scalars and the lane's bit), not held per lane.
+template <int G>
+struct GeneOf {
+  const Rescue2Tabs &rt;
+  bool j;                                       // G = -1: this lane's gene
+  DCRX_DEV dcrx_ldsaddr h_start(int h) const { return G >= 0 ? rt.h_start[G < 0 ? 0 : G][h] : (j ? rt.h_start[1][h] : rt.h_start[0][h]); }
+  DCRX_DEV dcrx_ldsaddr h_kw(int h) const { return G >= 0 ? rt.h_kw[G < 0 ? 0 : G][h] : (j ? rt.h_kw[1][h] : rt.h_kw[0][h]); }
+  DCRX_DEV dcrx_ldsaddr h_pk(int h) const { return G >= 0 ? rt.h_pk[G < 0 ? 0 : G][h] : (j ? rt.h_pk[1][h] : rt.h_pk[0][h]); }
+  DCRX_DEV uint32_t kw_base(int h) const { return G >= 0 ? rt.kw_base[G < 0 ? 0 : G][h] : (j ? rt.kw_base[1][h] : rt.kw_base[0][h]); }
+  DCRX_DEV int Lh(int h) const { return (int)(G >= 0 ? rt.Lh[G < 0 ? 0 : G][h] : (j ? rt.Lh[1][h] : rt.Lh[0][h])); }
+  DCRX_DEV dcrx_ldsaddr tag_pk() const { return G >= 0 ? rt.tag_pk[G < 0 ? 0 : G] : (j ? rt.tag_pk[1] : rt.tag_pk[0]); }
+  DCRX_DEV int Lt() const { return (int)(G >= 0 ? rt.t.L[G < 0 ? 0 : G] : (j ? rt.t.L[1] : rt.t.L[0])); }
+  DCRX_DEV int split() const { return G >= 0 ? rt.split[G < 0 ? 0 : G] : (j ? rt.split[1] : rt.split[0]); }
+  DCRX_DEV uint32_t fbit() const { return G >= 0 ? (G == 0 ? V2_F_VH : V2_F_JH) : (j ? V2_F_JH : V2_F_VH); }   // the gene's half-tag flag in a nibble of the log
+};
+
+// The candidate tags of one half-tag hit (keyword gk of half `half` of the gene, starting at frame
 // position p): the first whose whole tag window is within Hamming distance 1 — the `indices`
 // loops of :298-317 / :342-369 / :425-444 / :476-503.  1 with k / q (tag start in the frame),
 // 0 none.
 template <bool REV, class WS, int G>
-DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const WS &w, const int n, const int half, const uint32_t gk,
+DCRX_DEV int rescue2_candidates(const GeneOf<G> &g, const WS &w, const int n, const int half, const uint32_t gk,
                                 const int p, int &k_out, int &q_out) {
-  const int L = (int)rt.t.L[G];
-  const int q = half == 1 ? p : p - rt.split[G];
+  const Rescue2Tabs &rt = g.rt;
+  const int L = g.Lt();
+  const int q = half == 1 ? p : p - g.split();
   // a window that leaves the read: the reference's slice read[q:q+L] then comes out shorter than the tag (empty when q < 0
   // and q + L >= 0, as n > L) and the candidates are passed over (:302-307 and siblings); q + L < 0 would wrap around
   if (q + L < 0) return R2S(1);
@@ -974,10 +994,11 @@ DCRX_DEV int rescue2_candidates(const Rescue2Tabs &rt, const WS &w, const int n,
   const uint64_t mask = (1ull << (2 * L)) - 1ull;
   const uint64_t val = (w.stored64(ws) >> (2 * (b - ws))) & mask;
   const uint32_t x0 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk), x1 = dcrx_lds_at<uint32_t>(rt.kw_begin, gk + 1);
+  const dcrx_ldsaddr tpk = g.tag_pk();
   int found = 0;
   for (uint32_t x = x0; x < x1 && !found; x++) {
     const int k = (int)dcrx_lds_at<uint32_t>(rt.kw_tags, x);
-    const uint64_t y = mismatch_slots(val, dcrx_lds_at<uint64_t>(rt.tag_pk[G], (uint32_t)k)) & mask;
+    const uint64_t y = mismatch_slots(val, dcrx_lds_at<uint64_t>(tpk, (uint32_t)k)) & mask;
     if (dcrx_popc64(y) <= 1) { found = 1; k_out = k; q_out = q; }
   }
   return found;
@@ -992,8 +1013,8 @@ DCRX_DEV uint32_t log_word(const uint32_t (&lg)[NW], const int kk) {
   return l;
 }
 
-// The half-tag rescue of gene G over the pairs whose nibble of the flag log has bit `fbit` (V2_F_VH / V2_F_JH), however
-// many there are.
+// The half-tag rescue of a gene over the pairs whose nibble of the flag log has the gene's half-tag bit, however many
+// there are.
 // 1: a candidate passed the Hamming test (k, q, p = the keyword's frame start, half); 0: none did
 // (half = the list the reference walks: 1 when a half-1 keyword occurred, else 2, 0 when no half-tag
 // keyword occurred at all); RESCUE2_SLOW.
@@ -1002,11 +1023,11 @@ DCRX_DEV uint32_t log_word(const uint32_t (&lg)[NW], const int kk) {
 // four register slots and are tried only when no half-1 keyword occurred — the reference consults the half-2 list only
 // then (:337-339 / :471-473).
 template <bool REV, int NW, class WS, int G>
-DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const uint32_t fbit,
+DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[NW], const int n,
                           int &k_out, int &q_out, int &p_out, int &half_out) {
-  const int L1 = (int)rt.Lh[G][0], L2 = (int)rt.Lh[G][1];
+  const int L1 = g.Lh(0), L2 = g.Lh(1);
   const uint64_t m1 = (1ull << (2 * L1)) - 1ull, m2 = (1ull << (2 * L2)) - 1ull;
-  const uint32_t mask8 = fbit * 0x11111111u;
+  const uint32_t mask8 = g.fbit() * 0x11111111u;
   uint32_t nz = 0;                       // the words of the log that hold such a pair
 #pragma unroll
   for (int kk = 0; kk < NW; kk++) nz |= (lg[kk] & mask8) ? (1u << kk) : 0u;
@@ -1029,8 +1050,8 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
         const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
         if (f >= n) continue;
         const int s1 = f - L1 + 1, s2 = f - L2 + 1;
-        const LookupQ q[2] = {{rt.h_start[G][0], rt.h_kw[G][0], rt.h_pk[G][0], (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
-                              {rt.h_start[G][1], rt.h_kw[G][1], rt.h_pk[G][1], (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
+        const LookupQ q[2] = {{g.h_start(0), g.h_kw(0), g.h_pk(0), (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
+                              {g.h_start(1), g.h_kw(1), g.h_pk(1), (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
         int kw[2];
         lookup_lockstep<2>(q, kw);
         const int kw1 = kw[0], kw2 = kw[1];
@@ -1042,7 +1063,7 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
         if (kw1 >= 0) {
           any1 = true;
           const int p = REV ? n - s1 - L1 : s1;
-          res = rescue2_candidates<REV, WS, G>(rt, w, n, 1, rt.kw_base[G][0] + (uint32_t)kw1, p, k_out, q_out);
+          res = rescue2_candidates<REV, WS, G>(g, w, n, 1, g.kw_base(0) + (uint32_t)kw1, p, k_out, q_out);
           p_out = p;
         }
       }
@@ -1057,21 +1078,20 @@ DCRX_DEV int rescue2_half(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int f = (int)(e & 0xFFFFu), kw2 = (int)(e >> 16) - 1;
     const int s2 = f - L2 + 1;
     const int p = REV ? n - s2 - L2 : s2;
-    res = rescue2_candidates<REV, WS, G>(rt, w, n, 2, rt.kw_base[G][1] + (uint32_t)kw2, p, k_out, q_out);
+    res = rescue2_candidates<REV, WS, G>(g, w, n, 2, g.kw_base(1) + (uint32_t)kw2, p, k_out, q_out);
     p_out = p;
   }
   return res;
 }
 
-// The shapes of an event entry, as the scan kernel sorts them (one list each, so that a wave runs one kind of sweep):
-//   V2_SHAPE_VF_JH  one pair holds the V tag, no pair a J tag, J half-tag flags: V as the lean tail, J by half-tag rescue
-//   V2_SHAPE_VH_JF  no V tag (V half-tag flags); the J side is a J tag (one pair or several) or nothing at all: V by rescue
-//   V2_SHAPE_VH_JH  no V tag, no J tag, half-tag flags of both genes
-//   V2_SHAPE_ANY    (the test build, A/B) decided per read
-enum { V2_SHAPE_ANY = -1, V2_SHAPE_VF_JH = 0, V2_SHAPE_VH_JF = 1, V2_SHAPE_VH_JH = 2 };
+// The shapes of an event entry, as the scan kernel sorts them:
+//   V2_SHAPE_ONE   one gene has its full tag (or, J: several, or no flag at all) and the other needs the half-tag rescue:
+//                  the full tag by look-up as in the lean tail, ONE sweep for the other gene, the gene picked lane by lane
+//   V2_SHAPE_BOTH  no V tag, no J tag, half-tag flags of both genes: two sweeps
+//   V2_SHAPE_ANY   (the test build) decided per read
+enum { V2_SHAPE_ANY = -1, V2_SHAPE_ONE = 0, V2_SHAPE_BOTH = 1 };
 DCRX_DEV int shape2(const uint32_t vf_n, const uint32_t jf_n, const uint32_t any) {
-  if (vf_n == 1u) return V2_SHAPE_VF_JH;
-  return (jf_n >= 1u || !(any & V2_F_JH)) ? V2_SHAPE_VH_JF : V2_SHAPE_VH_JH;
+  return (vf_n == 0u && jf_n == 0u && (any & V2_F_JH)) ? V2_SHAPE_BOTH : V2_SHAPE_ONE;
 }
 
 // T: the tables in global memory (a walk that leaves its first window reads the packed regions there);
@@ -1091,13 +1111,11 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   for (int kk = 0; kk < NW; kk++) {
     const uint32_t l = lg[kk];
     any |= l;
-    const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
-    const uint32_t kb = (uint32_t)kk << 5;
-    if (SHAPE != V2_SHAPE_VH_JF && SHAPE != V2_SHAPE_VH_JH) {
+    if (SHAPE != V2_SHAPE_BOTH) {
+      const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
+      const uint32_t kb = (uint32_t)kk << 5;
       vfn += (uint32_t)dcrx_popc64(tv);
       vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
-    }
-    if (SHAPE != V2_SHAPE_VF_JH && SHAPE != V2_SHAPE_VH_JH) {
       jfn += (uint32_t)dcrx_popc64(tj);
       jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
     }
@@ -1105,37 +1123,56 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   any |= any >> 16; any |= any >> 8; any |= any >> 4; any &= 0xFu;
   if ((n & 1) && log_nibble<NW>(lg, n >> 1)) return R2S(3);       // a flag on the half pair at the end of an odd-length read may not stand
   if (vfn > 1 || (vfn == 0 && !(any & V2_F_VH))) return R2S(4);   // (entries of the scan kernel never look like this)
-  if (SHAPE == V2_SHAPE_VF_JH && vfn != 1) return R2S(4);
+  const bool vfull = vfn == 1;
+  const bool jsweep = jfn == 0 && (any & V2_F_JH) != 0u;          // J by half-tag rescue (else: one J tag, several, or no J flag at all)
+  if (SHAPE == V2_SHAPE_ONE && vfull != jsweep) return R2S(4);    // (exactly one gene is swept in this shape: V unless it has its tag, then J)
+  if (SHAPE == V2_SHAPE_BOTH && (vfull || !jsweep)) return R2S(4);
   const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
+
+  // ---- the full tag of the gene that has one (its pair: both candidate ends) ----
+  int ftag = -1, fs = 0;                 // tag and where it starts in the stored read
+  const bool jfull = !vfull && jfn == 1;
+  if (SHAPE != V2_SHAPE_BOTH && (vfull || jfull)) {
+    const int Lf = vfull ? Lv : Lj;
+    const uint64_t mf = vfull ? mv : mj;
+    const int pair = (int)((vfull ? vf1 : jf1) >> 2);
+    const int sa = 2 * pair - Lf + 1;
+    const int ws = min(max(sa, 0), n - 32);
+    const uint64_t W = w.stored64(ws);
+    const dcrx_ldsaddr bs = vfull ? tt.bk_start[0] : tt.bk_start[1], bt = vfull ? tt.bk_tag[0] : tt.bk_tag[1], bp = vfull ? tt.bk_pk[0] : tt.bk_pk[1];
+    const LookupQ q[2] = {{bs, bt, bp, (W >> v2_sh(sa - ws)) & mf, sa >= 0}, {bs, bt, bp, (W >> v2_sh(sa + 1 - ws)) & mf, sa + 1 + Lf <= n}};
+    int t[2];
+    lookup_lockstep<2>(q, t);
+    if ((t[0] >= 0) == (t[1] >= 0)) return vfull ? R2S(5) : R2S(9);
+    ftag = t[0] >= 0 ? t[0] : t[1];
+    fs = t[0] >= 0 ? sa : sa + 1;
+  }
+  // ---- the sweeps (nothing is counted here: what they find is used below in the reference's order, V before J) ----
+  int vres = 0, vk = 0, vq = 0, vpp = 0, vhalf = 0, jres = 0, jk = 0, jq = 0, jpp = 0, jhalf = 0;
+  if (SHAPE == V2_SHAPE_ONE) {
+    const GeneOf<-1> g{rt, vfull};                     // the J rescue where V has its tag, else the V rescue
+    int k = 0, q = 0, p = 0, half = 0;
+    const int res = rescue2_half<REV, NW, WS, -1>(g, w, lg, n, k, q, p, half);
+    if (vfull) { jres = res; jk = k; jq = q; jpp = p; jhalf = half; } else { vres = res; vk = k; vq = q; vpp = p; vhalf = half; }
+  } else {
+    if (!vfull) vres = rescue2_half<REV, NW, WS, 0>(GeneOf<0>{rt, false}, w, lg, n, vk, vq, vpp, vhalf);
+    if (vres < 0) return R2S(6);
+    if (jsweep && (vfull || vres > 0)) jres = rescue2_half<REV, NW, WS, 1>(GeneOf<1>{rt, true}, w, lg, n, jk, jq, jpp, jhalf);
+  }
 
   // ---- vanalysis ----
   int v = -1, vp = 0, te = 0;
-  bool vhalf = false;
-  if (SHAPE == V2_SHAPE_VF_JH || (SHAPE == V2_SHAPE_ANY && vfn == 1)) {
-    const int vpair = (int)(vf1 >> 2);
-    const int sva = 2 * vpair - Lv + 1;
-    const int wsv = min(max(sva, 0), n - 32);
-    const uint64_t Wv = w.stored64(wsv);
-    const LookupQ q[2] = {{tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
-                          {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva + 1 - wsv)) & mv, sva + 1 + Lv <= n}};
-    int t[2];
-    lookup_lockstep<2>(q, t);
-    const int ta = t[0], tb = t[1];
-    if ((ta >= 0) == (tb >= 0)) return R2S(5);
-    v = ta >= 0 ? ta : tb;
-    const int sv = ta >= 0 ? sva : sva + 1;
-    vp = REV ? n - sv - Lv : sv;
+  if (vfull) {
+    v = ftag;
+    vp = REV ? n - fs - Lv : fs;
     te = vp + dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v) - 1;                       // :283-285
   } else {
-    int k = 0, q = 0, p = 0, half = 0;
-    const int res = rescue2_half<REV, NW, WS, 0>(rt, w, lg, n, V2_F_VH, k, q, p, half);
-    if (res < 0) return R2S(6);
-    if (res == 0) return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_V_HALF2_EXHAUSTED : DCRX_S_V_NONE);   // :334 / :389 / :393
-    v = k; vp = q;
-    const int jump = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)k);
-    te = half == 1 ? p + jump - 1 : p + jump - rt.split[0] - 1;                       // :320-322 / :372-377
-    errs |= half == 1 ? 2u : 1u;
-    vhalf = true;
+    if (vres < 0) return R2S(6);
+    if (vres == 0) return vhalf == 1 ? DCRX_S_V_HALF1_EXHAUSTED : (vhalf == 2 ? DCRX_S_V_HALF2_EXHAUSTED : DCRX_S_V_NONE);   // :334 / :389 / :393
+    v = vk; vp = vq;
+    const int jump = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)vk);
+    te = vhalf == 1 ? vpp + jump - 1 : vpp + jump - rt.split[0] - 1;                  // :320-322 / :372-377
+    errs |= vhalf == 1 ? 2u : 1u;
   }
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
   const int fv = te + 1;
@@ -1144,48 +1181,34 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
   int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
   int end_v = te - kv;
-  const int jpair_a = (int)(jf1 >> 2);
+  // (a full-tag walk that fails is final and counts inside the walk: whatever may still send the read to the general form
+  // because of the sweep has to be looked at before; the J side's own checks below come before anything they could count)
+  if (jsweep && jres < 0) return R2S(10);
   if (kv < 0) {      // the walk leaves its first window: the general function (rare)
     const FrameWS<REV, WS> F{w, n};
-    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, vhalf ? Cdry : C)) {
-      if (vhalf) return R2S(8);                        // the reference goes on with the next candidate: the general form
+    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, vfull ? C : Cdry)) {
+      if (!vfull) return R2S(8);                       // the reference goes on with the next candidate: the general form
       return DCRX_S_V_WALK_FAIL;                       // :288-290
     }
   }
   const int end_of_v = end_v + 1;                                                     // :547
 
   // ---- janalysis ----
-  if (SHAPE != V2_SHAPE_VF_JH && SHAPE != V2_SHAPE_VH_JH && jfn >= 2) return DCRX_S_J_MULTI;      // :402-404
   int j = -1, jend = 0, ts = 0;
-  bool jhalf = false;
-  if (SHAPE == V2_SHAPE_VH_JF || (SHAPE == V2_SHAPE_ANY && jfn == 1)) {
-    if (jfn == 0) return DCRX_S_J_NONE;                                               // :530-531 (no J flag of any kind: V2_SHAPE_VH_JF)
-    const int sja = 2 * jpair_a - Lj + 1;
-    const int wsj = min(max(sja, 0), n - 32);
-    const uint64_t Wj = w.stored64(wsj);
-    const LookupQ q[2] = {{tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, sja >= 0},
-                          {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, sja + 1 + Lj <= n}};
-    int t[2];
-    lookup_lockstep<2>(q, t);
-    const int ta = t[0], tb = t[1];
-    if ((ta >= 0) == (tb >= 0)) return R2S(9);
-    j = ta >= 0 ? ta : tb;
-    const int sj = ta >= 0 ? sja : sja + 1;
-    const int jp = REV ? n - sj - Lj : sj;
+  if (!jsweep) {
+    if (jfn >= 2) return DCRX_S_J_MULTI;                                              // :402-404
+    if (jfn == 0) return DCRX_S_J_NONE;                                               // :530-531 (no J flag of any kind)
+    j = ftag;
+    const int jp = REV ? n - fs - Lj : fs;
     ts = jp - dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);                          // :407-409
     jend = jp + Lj;
   } else {
-    if (!(any & V2_F_JH)) return DCRX_S_J_NONE;                                       // :530-531
-    int k = 0, q = 0, p = 0, half = 0;
-    const int res = rescue2_half<REV, NW, WS, 1>(rt, w, lg, n, V2_F_JH, k, q, p, half);
-    if (res < 0) return R2S(10);
-    if (res == 0) return half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : (half == 2 ? DCRX_S_J_HALF2_EXHAUSTED : DCRX_S_J_NONE);   // :469 / :526 / :530
-    j = k;
-    const int jump = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)k);
-    ts = half == 1 ? p - jump : p - jump - rt.split[1];                               // :447-449 / :506-510
-    jend = half == 1 ? p + (int)rt.Lh[1][0] + rt.split[1] : p + (int)rt.Lh[1][1];     // :450-454 / :511
-    errs |= half == 1 ? 8u : 4u;
-    jhalf = true;
+    if (jres == 0) return jhalf == 1 ? DCRX_S_J_HALF1_EXHAUSTED : (jhalf == 2 ? DCRX_S_J_HALF2_EXHAUSTED : DCRX_S_J_NONE);   // :469 / :526 / :530
+    j = jk;
+    const int jump = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)jk);
+    ts = jhalf == 1 ? jpp - jump : jpp - jump - rt.split[1];                          // :447-449 / :506-510
+    jend = jhalf == 1 ? jpp + (int)rt.Lh[1][0] + rt.split[1] : jpp + (int)rt.Lh[1][1];   // :450-454 / :511
+    errs |= jhalf == 1 ? 8u : 4u;
   }
   const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
   if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return R2S(11);
@@ -1196,8 +1219,8 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   int start_j = ts + kj;
   if (kj < 0) {
     const FrameWS<REV, WS> F{w, n};
-    if (!get_j_deletions(T.g[1], F, j, ts, end_of_v, start_j, kj, jhalf ? Cdry : C)) {
-      if (jhalf) return R2S(12);
+    if (!get_j_deletions(T.g[1], F, j, ts, end_of_v, start_j, kj, jsweep ? Cdry : C)) {
+      if (jsweep) return R2S(12);
       return DCRX_S_J_WALK_FAIL;                       // :413-418
     }
   }

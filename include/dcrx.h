@@ -120,21 +120,10 @@ typedef struct dcrx_cfg {
 } dcrx_cfg_t;
 
 #define DCRX_F_NONE 0u
-#define DCRX_F_FORCE_SLOW_READER 1u /* tests: route every read through the exception-aware reader */
-#define DCRX_F_PROFILE_SCAN_ONLY 2u  /* profiling: fast kernel stops after the DFA scan (records are NOT results) */
-#define DCRX_F_PROFILE_LIST_SCAN_ONLY 8u /* profiling: list kernel stops after its collecting scan (records are NOT results) */
-#define DCRX_F_PROFILE_RESCUE_HITS_ONLY 32u /* profiling: rescue kernel stops after resolving the half-tag hit lists (records are NOT results) */
-#define DCRX_F_LIST_RESCUE 16u       /* rescue queue through the list kernel (one-base collecting scan) even when the pair form applies (A/B, tests) */
-#define DCRX_F_PROFILE_NO_FINISH 128u /* profiling: the v2 kernel scans and sorts reads onto its stacks but finishes none of them (records are NOT results) */
-#define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
-#define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
-#define DCRX_F_PROFILE_TAIL_STREAM_ONLY 16384u /* profiling: the tail kernel reads its entries and writes records but resolves nothing (records are NOT results) */
-#define DCRX_F_V2_LEAN_SERIAL 32768u /* A/B: the two lean kernels one after the other on the caller's stream (default: the tail kernel beside the rescue kernel on the handle's side stream) */
-#define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
-#define DCRX_F_V2_FORK 4096u         /* A/B: the general-form pass over the lean rescue's leftovers beside the tail kernel on the handle's side stream (measured no faster) */
-#define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
-#define DCRX_F_V2_SHAPE(k) ((uint32_t)(k) << 8) /* v2 kernel launch shape, A/B: 0 default, 2 = two reads per lane, 3 = one read per lane (one 1024-thread block per CU either way) */
-#define DCRX_F_ONE_BASE_SCAN 4u      /* use the one-base-per-step fast kernel even when the two-base table fits LDS (A/B, tests) */
+/* Every other bit of `flags` is a test or profiling switch of the library's own build (declared in the private header
+ * decombinator_amd/csrc/dcrx_debug_flags.h, used by this repository's tests and tools).  The switches that leave the
+ * records unchanged (A/B launch shapes) are honoured; those that make a kernel stop half-way (records are then NOT
+ * results) are refused with DCRX_E_INVALID unless the environment holds DCRX_DEBUG_FLAGS=1.  A caller passes 0. */
 
 /* A batch of reads, 2-bit packed: base i of read r is bits [2(i%4), 2(i%4)+1] of
  * byte packed[r*stride + i/4]; A=0 C=1 G=2 T=3.  Bytes of the FASTQ sequence that

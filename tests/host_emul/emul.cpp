@@ -135,9 +135,8 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     int st;
 #define DCRX_EMUL_R2(SH) (o ? rescue2_fast<true, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry) : rescue2_fast<false, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry))
     if ((r & 1) || bnd) st = DCRX_EMUL_R2(V2_SHAPE_ANY);
-    else if (shp == V2_SHAPE_VF_JH) st = DCRX_EMUL_R2(V2_SHAPE_VF_JH);
-    else if (shp == V2_SHAPE_VH_JF) st = DCRX_EMUL_R2(V2_SHAPE_VH_JF);
-    else st = DCRX_EMUL_R2(V2_SHAPE_VH_JH);
+    else if (shp == V2_SHAPE_ONE) st = DCRX_EMUL_R2(V2_SHAPE_ONE);
+    else st = DCRX_EMUL_R2(V2_SHAPE_BOTH);
 #undef DCRX_EMUL_R2
     if (st >= 0) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
