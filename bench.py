@@ -254,7 +254,7 @@ def run_rank(args):
         device = dry_device.DryDevice(nat, all_tables, tagsets, cfg_synth, batches, n)
     else:
         device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
-    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact) if use_dist else None
+    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps) if use_dist else None
     if world > 1 and not dry:
         # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the
         # tuples of step k really move beside the scan of step k+1 (on one GPU, where the "gather" is a
@@ -381,9 +381,9 @@ def run_rank(args):
             line["step_frac"] = round(algo_bytes * total_reads / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5)
         if gather is not None:
             hits_per_step = hits_all / (args.steps if args.config == 4 else 1)       # config 4: the counters are those of a whole pass
-            tuple_mb = hits_per_step * sharded.TupleGather.TUPLE_BYTES / 1e6
+            tuple_mb = hits_per_step * gather.TUPLE_BYTES / 1e6
             line["gather"] = {
-                "tuple_bytes": sharded.TupleGather.TUPLE_BYTES,
+                "tuple_bytes": gather.TUPLE_BYTES,
                 "mb_per_step_all_ranks": round(tuple_mb + world * ((n + 63) // 64) * 8 / 1e6, 3),
                 "ms_per_step_without_gather": None if elapsed_nogather is None else round(elapsed_nogather / args.steps * 1e3, 4),
                 "exposed_ms_per_step": None if elapsed_nogather is None else round((elapsed - elapsed_nogather) / args.steps * 1e3, 4),

@@ -125,7 +125,7 @@ EXPORTS = [
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
-    "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_compact_hits_packed8_device", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
 
 _lib = None
@@ -165,6 +165,7 @@ def lib():
         "dcrx_compact_hits_device": (i32, [vp, u64, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_bitmap_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed_device": (i32, [vp, u64, vp, vp, vp, vp]),
+        "dcrx_compact_hits_packed8_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
         "dcrx_device_count": (i32, []),
         "dcrx_set_device": (i32, [i32]),
@@ -682,6 +683,35 @@ def compact_hits_bitmap_device(d_records: DeviceBuffer, n_reads: int, d_hits: De
                                d_n_hits: DeviceBuffer, stream=None):
     """Decombined records in input order + a bitmap of which reads they belong to ((n_reads+63)//64 uint64)."""
     check(lib().dcrx_compact_hits_bitmap_device(d_records.ptr, n_reads, d_hits.ptr, d_ok_bitmap.ptr, d_n_hits.ptr, stream))
+
+
+def pack_tuples8(rec) -> np.ndarray:
+    """Host-side twin of dcrx_compact_hits_packed8_device: the status-OK records of `rec` as (k, 2) uint32 tuples in read order."""
+    r = rec[rec["status"] == 0]
+    w = np.zeros((len(r), 2), dtype=np.uint32)
+    jd = r["jdel"].astype(np.uint32)
+    w[:, 0] = (r["v"].astype(np.uint32) & 0x7FF) | ((r["j"].astype(np.uint32) & 0x1FF) << 11) | (r["vdel"].astype(np.uint32) << 20) | ((jd & 0xF) << 28)
+    w[:, 1] = (jd >> 4) | ((r["v_start"].astype(np.uint32) & 0x1FF) << 4) | ((r["j_end"].astype(np.uint32) & 0x1FF) << 13) | \
+              ((r["ins_len"].astype(np.uint32) & 0x1FF) << 22) | ((r["frame"].astype(np.uint32) & 1) << 31)
+    return w
+
+
+def unpack_tuples8(words: np.ndarray, v_jumps) -> np.ndarray:
+    """(k, 2) uint32 tuples of dcrx_compact_hits_packed8_device -> RECORD_DTYPE records (status OK).  ins_start, which the
+    tuple leaves out, is the base after the end of V: v_start + jump_to_end_v[v] - vdel (decombine.py:283-285, :547, :577)."""
+    w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 2)
+    rec = np.zeros(len(w), dtype=RECORD_DTYPE)
+    rec["v"] = w[:, 0] & 0x7FF
+    rec["j"] = (w[:, 0] >> 11) & 0x1FF
+    rec["vdel"] = (w[:, 0] >> 20) & 0xFF
+    rec["jdel"] = ((w[:, 0] >> 28) & 0xF) | ((w[:, 1] & 0xF) << 4)
+    rec["v_start"] = (w[:, 1] >> 4) & 0x1FF
+    rec["j_end"] = (w[:, 1] >> 13) & 0x1FF
+    rec["ins_len"] = (w[:, 1] >> 22) & 0x1FF
+    rec["frame"] = (w[:, 1] >> 31) & 1
+    jumps = np.asarray(v_jumps, dtype=np.int64)
+    rec["ins_start"] = rec["v_start"].astype(np.int64) + jumps[rec["v"].astype(np.int64)] - rec["vdel"].astype(np.int64)
+    return rec
 
 
 def unpack_tuples12(words: np.ndarray) -> np.ndarray:

@@ -423,6 +423,12 @@ int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_r
   return compact_hits(d_records, n_reads, 0, reinterpret_cast<dcrx_record_t *>(d_tuples12), nullptr, d_ok_bitmap, 1, d_n_hits, stream);
 }
 
+int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples8,
+                                     uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
+  if (n_reads && !d_ok_bitmap) return set_err(DCRX_E_INVALID, "null argument");
+  return compact_hits(d_records, n_reads, 0, reinterpret_cast<dcrx_record_t *>(d_tuples8), nullptr, d_ok_bitmap, 2, d_n_hits, stream);
+}
+
 int dcrx_set_reserved_cus(dcrx_tables_t *t, uint32_t n_cus) {
   if (!t) return set_err(DCRX_E_INVALID, "tables is null");
   t->reserved_cus = n_cus;

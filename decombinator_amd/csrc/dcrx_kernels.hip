@@ -496,12 +496,19 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
     if (ok[k]) {
       const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
       const uint64_t dst = off + before + rank[k];
-      if (packed12) {      // the 12-byte tuple of include/dcrx.h (dcrx_compact_hits_packed_device)
+      if (packed12 == 1) {      // the 12-byte tuple of include/dcrx.h (dcrx_compact_hits_packed_device)
         const dcrx_record_t r = rec[i];
         uint32_t *o = reinterpret_cast<uint32_t *>(hits) + dst * 3;
         o[0] = (uint32_t)r.v | ((uint32_t)r.j << 12) | ((uint32_t)r.vdel << 24);
         o[1] = (uint32_t)r.v_start | ((uint32_t)r.j_end << 9) | ((uint32_t)r.ins_start << 18);
         o[2] = (uint32_t)r.ins_len | ((uint32_t)r.jdel << 9) | ((uint32_t)r.frame << 17);
+      } else if (packed12 == 2) {   // the 8-byte tuple (dcrx_compact_hits_packed8_device): ins_start is left out, the receiver re-derives it
+        const dcrx_record_t r = rec[i];
+        uint2 o;
+        o.x = ((uint32_t)r.v & 0x7FFu) | (((uint32_t)r.j & 0x1FFu) << 11) | ((uint32_t)r.vdel << 20) | (((uint32_t)r.jdel & 0xFu) << 28);
+        o.y = ((uint32_t)r.jdel >> 4) | (((uint32_t)r.v_start & 0x1FFu) << 4) | (((uint32_t)r.j_end & 0x1FFu) << 13) | (((uint32_t)r.ins_len & 0x1FFu) << 22) |
+              (((uint32_t)r.frame & 1u) << 31);
+        reinterpret_cast<uint2 *>(hits)[dst] = o;
       } else {
         reinterpret_cast<uint4 *>(hits)[dst] = reinterpret_cast<const uint4 *>(rec)[i];
       }

@@ -49,6 +49,9 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
 #define DCRX_V2_TWAVES 5        /* ... and the waves per SIMD it is compiled for */
 #endif
+#ifndef DCRX_V2_RWAVES
+#define DCRX_V2_RWAVES 4        /* waves per SIMD the rescue kernel is compiled for */
+#endif
 #ifndef DCRX_V2_RECORD_STORES
 #define DCRX_V2_RECORD_STORES 1   /* 0: streamed record stores everywhere; 1: through the caches in the finishing kernels; 2: in the scan kernel as well */
 #endif
@@ -538,7 +541,7 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
 // list's shape), `split` waves per region and list, entries read one batch ahead.  What that form does not settle is
 // copied to the region's list L and takes the general form in the event kernel's last pass.
 template <bool UNIFORM_LEN, int NW, int ORI>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void rescue2_kernel(
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count) {
@@ -787,8 +790,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const bool finish = !(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH));
   const bool side = finish && P.v2_side && P.v2_side2 && P.v2_ev_fork && P.v2_ev_join && P.v2_ev_join2 && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL);
   const bool fork_rides = side && !ev_stop;
-  static const uint32_t scan_threads = getenv("DCRX_SCAN_THREADS") ? (uint32_t)atoi(getenv("DCRX_SCAN_THREADS")) : (uint32_t)DCRX_V2_BLOCK;      // experiments
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(scan_threads), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
+  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
                         d_counters, Q, queue, gqueue, qcap, queue_count, per_block);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -796,8 +798,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // waves of the finishing kernels that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
     // 4096 on each rescue list of a full-size launch
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
-    uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-    if (getenv("DCRX_RESC_BPC")) fgrid = std::min<uint32_t>(fgrid, cus * (uint32_t)atoi(getenv("DCRX_RESC_BPC")));
+    const uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
     const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of a short list's pass that share a region
     const uint32_t sgrid = n_regions * bsplit;
@@ -807,10 +808,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;
     const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a short list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
-    static const uint32_t tail_bpc = getenv("DCRX_TAIL_BPC") ? (uint32_t)atoi(getenv("DCRX_TAIL_BPC")) : 0u, resc_bpc = getenv("DCRX_RESC_BPC") ? (uint32_t)atoi(getenv("DCRX_RESC_BPC")) : 0u;      // experiments: blocks per CU
-    uint32_t tg = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
-    if (tail_bpc) tg = std::min<uint32_t>(tg, cus * tail_bpc);
-    const dim3 tgrid(tg);
+    const dim3 tgrid((n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
     const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
     auto general = [&](hipStream_t st, const int which, const bool whole_list, hipEvent_t stop) -> hipError_t {
       if (whole_list)

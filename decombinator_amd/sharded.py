@@ -88,12 +88,21 @@ def bitmap_indices(bitmap, n_reads: int):
     return np.nonzero(bits)[0]
 
 
+def pack_tuples8(rec):
+    """Host-side twin of dcrx_compact_hits_packed8_device: (k, 2) uint32 tuples in read order and the bitmap."""
+    from . import _native as nat
+    _, bitmap = pack_tuples12(rec)
+    return nat.pack_tuples8(rec), bitmap
+
+
 class TupleGather:
     """Per-step gather of the DCR tuples on rank 0, exact sizes, nothing truncated.
 
-    A tuple travels as 12 bytes (dcrx_compact_hits_packed_device: the record's fields in three uint32,
-    in read order) plus one bit per read saying which reads decombined.  Per step, on a side stream
-    beside the scan of the following step:
+    A tuple travels as 8 bytes when the V tags' jumps are given (`v_jumps`; dcrx_compact_hits_packed8_device: every field of
+    the record but ins_start, which rank 0 re-derives from the tag file's jump — tag sets of < 2048 V and < 512 J tags) and
+    as 12 bytes otherwise (dcrx_compact_hits_packed_device), in read order, plus one bit per read saying which reads
+    decombined: at eight ranks and 20 G reads/s per rank the tuples are what the xGMI links into rank 0 carry.  Per step, on a
+    side stream beside the scan of the following step:
 
       1. compaction of the step's records -> tuples, bitmap, count (on the device);
       2. count exchange: all_gather of the ranks' counts, copied to pinned host memory;
@@ -105,11 +114,13 @@ class TupleGather:
     `compact` replaces step 1 (tests feed tuples made on the host); device None or CPU runs without streams
     (gloo), else on a CUDA side stream (RCCL)."""
 
-    TUPLE_BYTES = 12
+    TUPLE_BYTES = 12      # (the class default; an instance with v_jumps carries 8)
 
-    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None):
+    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None, v_jumps=None):
         from . import _native as nat
         self.nat = nat
+        self.v_jumps = None if v_jumps is None else list(v_jumps)
+        self.TUPLE_BYTES = 8 if self.v_jumps is not None else 12
         self.world, self.rank, self.n_reads = world, rank, n_reads
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.device = device if self.cuda else torch.device("cpu")
@@ -189,9 +200,9 @@ class TupleGather:
             if self.compact is not None:
                 self.compact(s, n_reads)
             else:
-                nat.check(nat.lib().dcrx_compact_hits_packed_device(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(),
-                                                                    s["bitmap"].data_ptr(), s["n"].data_ptr(),
-                                                                    self.side.cuda_stream))
+                fn = nat.lib().dcrx_compact_hits_packed8_device if self.TUPLE_BYTES == 8 else nat.lib().dcrx_compact_hits_packed_device
+                nat.check(fn(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(), s["bitmap"].data_ptr(), s["n"].data_ptr(),
+                             self.side.cuda_stream))
             if self.cuda:
                 s["compacted"] = self.side.record_event()
             if self.world > 1:
@@ -228,9 +239,10 @@ class TupleGather:
         counts = [int(x) for x in s["counts_host"].tolist()]
         out = []
         for r in range(self.world):
-            w = s["g_hits"][r][:counts[r] * self.TUPLE_BYTES].cpu().numpy().view(np.uint32).reshape(-1, 3)
+            w = s["g_hits"][r][:counts[r] * self.TUPLE_BYTES].cpu().numpy().view(np.uint32).reshape(-1, self.TUPLE_BYTES // 4)
             idx = bitmap_indices(s["g_bitmap"][r].cpu().numpy().view(np.uint64), self.n_reads)
-            out.append((self.nat.unpack_tuples12(w), idx, r))
+            rec = self.nat.unpack_tuples8(w, self.v_jumps) if self.TUPLE_BYTES == 8 else self.nat.unpack_tuples12(w)
+            out.append((rec, idx, r))
         return out
 
     def check(self, n_hits_local: int) -> None:

@@ -278,6 +278,15 @@ int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_r
 int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples12,
                                     uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
 
+/* The same in 8 bytes per decombined record (two little-endian uint32), what a sharded run gathers on rank 0:
+ *   word 0: v (bits 0-10) | j (11-19) | vdel (20-27) | jdel low 4 bits (28-31)
+ *   word 1: jdel high 4 bits (0-3) | v_start (4-12) | j_end (13-21) | ins_len (22-30) | frame (31)
+ * ins_start is not sent: it is the base after the end of V (decombine.py:547, :577), v_start + jump_to_end_v[v] - vdel, which
+ * the receiver has from the tag file.  Requires < 2048 V tags and < 512 J tags (any real tag set; dcrx_tables_info gives
+ * the counts); positions are < 512 by the read-length limit. */
+int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples8,
+                                     uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
+
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */
 int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);

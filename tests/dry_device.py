@@ -39,7 +39,7 @@ class DryDevice:
     def compact(self, slot, n_reads):          # stands in for dcrx_compact_hits_packed_device (same layout, made on the host)
         nat = self.nat
         rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
-        w, bm = sharded.pack_tuples12(rec)
+        w, bm = sharded.pack_tuples8(rec)      # (the bench gathers 8-byte tuples: TupleGather(v_jumps=...))
         slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
         slot["bitmap"].zero_()
         slot["bitmap"][:len(bm)] = torch.from_numpy(bm.view(np.int64).copy())

@@ -27,7 +27,7 @@ def test_two_ranks_started_by_the_bench_itself_dry():
     d = _line(_run(["--gpus", "2", "--dry-gloo", "--reads", "3000", "--steps", "3", "--warmup", "1"]))
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and len(d["config"]["devices"]) == 2
     assert d["dry_run"] is True and d["value"] is None            # a dry run never carries a rate
-    assert d["scaling"] == "weak" and d["gather"]["tuple_bytes"] == 12
+    assert d["scaling"] == "weak" and d["gather"]["tuple_bytes"] == 8
     assert d["gather"]["ms_per_step_without_gather"] is not None
 
 

@@ -316,7 +316,8 @@ n = 400_000
 ts = synth.config_tagset(2)
 t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
 dev = torch.device("cuda", 0)
-g = sharded.TupleGather(n, 1, 0, dev)
+g = sharded.TupleGather(n, 1, 0, dev, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None)
+assert g.TUPLE_BYTES == (8 if os.environ.get("DCRX_TUPLE8") == "1" else 12)
 stream = torch.cuda.current_stream()
 d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
 cfg = nat.make_cfg("reverse", False, 130, 0)
@@ -349,7 +350,8 @@ dist.destroy_process_group()
 '''
 
 
-def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path):
+@pytest.mark.parametrize("tuple8", ["0", "1"], ids=["12-byte-tuples", "8-byte-tuples"])
+def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path, tuple8):
     """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
     transfers) with one rank on this GPU, five steps with different reads: what rank 0 holds for every step equals the
     decombined records of that step, tuple for tuple and bit for bit of the bitmap.  In a child process: torch has to
@@ -360,7 +362,7 @@ def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_GATHER_WORKER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, DCRX_ROOT=root), stdout=subprocess.PIPE,
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, DCRX_ROOT=root, DCRX_TUPLE8=tuple8), stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_GATHER_OK" in out.stdout, out.stdout[-3000:]
 
@@ -401,6 +403,14 @@ def test_compact_hits_matches_numpy():
     assert int(d_n.to_host(np.uint64, 1)[0]) == k
     back = nat.unpack_tuples12(d_t12.to_host(np.uint32, 3 * k))
     assert back.tobytes() == rec[ok].tobytes()
+    # 8-byte tuples (what a sharded run gathers): ins_start comes back from the V tags' jumps
+    d_t8 = nat.DeviceBuffer(n * 8)
+    nat.check(nat.lib().dcrx_compact_hits_packed8_device(d_rec.ptr, n, d_t8.ptr, d_bm.ptr, d_n.ptr, None))
+    nat.synchronize()
+    assert int(d_n.to_host(np.uint64, 1)[0]) == k
+    w8 = d_t8.to_host(np.uint32, 2 * k)
+    assert nat.unpack_tuples8(w8, ts.v_jumps).tobytes() == rec[ok].tobytes()
+    assert (nat.pack_tuples8(rec).reshape(-1) == w8).all()          # the host-side twin the CPU tests use
 
 
 @pytest.mark.parametrize("tag_len", [21, 22], ids=["half15-pair-rescue", "half16-list-rescue"])

@@ -100,12 +100,12 @@ GATHER_WORKER = textwrap.dedent('''
 
     def compact(slot, n_reads):       # stands in for dcrx_compact_hits_packed_device: same layout, made on the host
         rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)
-        w, bm = sharded.pack_tuples12(rec)
+        w, bm = (sharded.pack_tuples8 if os.environ.get("DCRX_TUPLE8") == "1" else sharded.pack_tuples12)(rec)
         slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
         slot["bitmap"][:] = torch.from_numpy(bm.view(np.int64).copy())
         slot["n"][0] = len(w)
 
-    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact)
+    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None)
     checked = 0
     for step in range(STEPS):
         g.before_scan()
@@ -136,8 +136,12 @@ GATHER_WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path):
-    """The gather bench.py runs between ranks (count exchange, exact-size transfers of 12-byte tuples + bitmap,
+import pytest
+
+
+@pytest.mark.parametrize("tuple8", ["0", "1"], ids=["12-byte-tuples", "8-byte-tuples"])
+def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path, tuple8):
+    """The gather bench.py runs between ranks (count exchange, exact-size transfers of 12- or 8-byte tuples + bitmap,
     alternating slots), over gloo with two ranks and five steps whose decombined fractions range from 0 to 95 %:
     rank 0 re-expands every rank's tuples and they equal that rank's records."""
     script = tmp_path / "gworker.py"
@@ -149,7 +153,7 @@ def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DCRX_ROOT=ROOT, OMP_NUM_THREADS="1")
+                   DCRX_ROOT=ROOT, OMP_NUM_THREADS="1", DCRX_TUPLE8=tuple8)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
