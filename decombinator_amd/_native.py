@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -111,6 +112,50 @@ class SpansC(C.Structure):
     _fields_ = [("text", C.c_void_p), ("start", C.c_void_p), ("len", C.c_void_p)]
 
 
+_collapse_buf = None
+
+
+class CollapseCfgC(C.Structure):
+    _fields_ = [("oligo", C.c_int32), ("allow_ns", C.c_int32), ("lenthreshold", C.c_int32), ("min_bc_q", C.c_double),
+                ("bc_q_below_min", C.c_double), ("avg_q_threshold", C.c_double), ("field_sep", C.c_char * 8)]
+
+
+COLLAPSE_ROW_DTYPE = np.dtype([("b1start", "<i2"), ("b1end", "<i2"), ("b2start", "<i2"), ("b2end", "<i2"), ("status", "u1"),
+                               ("barcode_len", "u1"), ("barcode_qual_len", "u1"), ("pad", "u1"), ("barcode", "S24"), ("barcode_qual", "S24")])
+assert COLLAPSE_ROW_DTYPE.itemsize == 60
+COLLAPSE_OLIGOS = {"m13": 0, "i8": 1, "i8_single": 2, "nebio": 3, "takara": 4}
+COLLAPSE_COUNTERS = [
+    "readdata_input_dcrs", "getbarcode_fail_N", "getbarcode_fail_nospacerfound", "getbarcode_fail_not2spacersfound",
+    "getbarcode_fail_n1tooshort", "getbarcode_fail_n1toolong", "getbarcode_fail_n2pastend", "getbarcode_pass_exactmatch",
+    "getbarcode_pass_regexmatch", "getbarcode_pass_fuzzymatch_rightlen", "getbarcode_pass_fuzzymatch_short",
+    "getbarcode_pass_fuzzymatch_long", "getbarcode_pass_other", "readdata_fail_no_bclocs", "readdata_short_barcode",
+    "readdata_long_barcode", "readdata_fail_low_barcode_quality", "readdata_fail_overlong_intertag_seq", "readdata_success",
+]
+CF_OK, CF_NO_BCLOCS, CF_LOW_QUALITY, CF_OVERLONG, CF_DEFER = 0, 1, 2, 3, 255
+
+
+def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, quality_parameters, field_sep: str = ", ", n_threads: int = 0):
+    """dcrx_collapse_front over `.n12` text: (rows as COLLAPSE_ROW_DTYPE, row offsets (n + 1), counters uint64[len(COLLAPSE_COUNTERS)])."""
+    cfg = CollapseCfgC()
+    cfg.oligo = COLLAPSE_OLIGOS[oligo.lower()]
+    cfg.allow_ns, cfg.lenthreshold = int(bool(allow_ns)), int(lenthreshold)
+    cfg.min_bc_q, cfg.bc_q_below_min, cfg.avg_q_threshold = (float(x) for x in quality_parameters)
+    cfg.field_sep = field_sep.encode("ascii")
+    buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, dtype=np.uint8)
+    scratch = np.zeros(len(COLLAPSE_COUNTERS), dtype=np.uint64)
+    n = check(lib().dcrx_collapse_front(buf.ctypes.data, len(text), C.byref(cfg), None, 0, None, scratch.ctypes.data, 0))      # sizing call
+    # (the per-row records of a call are written once and the pages behind a fresh allocation cost more than the rows themselves:
+    # the buffer of the last call is kept and handed out again when the caller has let go of it)
+    global _collapse_buf
+    if _collapse_buf is None or len(_collapse_buf) < n or sys.getrefcount(_collapse_buf) > 2:
+        _collapse_buf = np.empty(max(n, 1), dtype=COLLAPSE_ROW_DTYPE)
+    rows = _collapse_buf
+    offs = np.empty(n + 1, dtype=np.uint64)
+    cnt = np.zeros(len(COLLAPSE_COUNTERS), dtype=np.uint64)
+    check(lib().dcrx_collapse_front(buf.ctypes.data, len(text), C.byref(cfg), rows.ctypes.data, n, offs.ctypes.data, cnt.ctypes.data, int(n_threads)))
+    return rows[:n], offs, cnt
+
+
 class SynthCfgC(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_rearranged", C.c_float),
                 ("sub_rate", C.c_float), ("n_rate", C.c_float)]
@@ -125,7 +170,7 @@ EXPORTS = [
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
-    "dcrx_compact_hits_packed8_device", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
 
 _lib = None
@@ -166,6 +211,7 @@ def lib():
         "dcrx_compact_hits_bitmap_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed8_device": (i32, [vp, u64, vp, vp, vp, vp]),
+        "dcrx_collapse_front": (C.c_int64, [vp, u64, C.POINTER(CollapseCfgC), vp, u64, vp, vp, i32]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
         "dcrx_device_count": (i32, []),
         "dcrx_set_device": (i32, [i32]),

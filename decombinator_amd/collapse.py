@@ -5,13 +5,14 @@ src/decombinator/collapse.py:482-565, with get_barcode_positions :367-479, set_b
 check_umi_quality :343-353 and the spacer searches :192-236).  Grouping and clustering (the
 stateful rest of the stage) are outside this build.
 
-Host code by design: BASELINE.json keeps the UMI collapse on the host, and a row costs one exact
-substring search in the common case.  The fuzzy searches are the reference's own `regex` patterns
-(`{1s<=2}`, `{2i+2d+1s<=2}`; regex is a pinned dependency of the reference, pyproject.toml) and
-run only for rows whose spacers do not occur verbatim — which is what makes this faster than the
-reference (three regex calls per row there) while returning the same values row for row.
-
-Same names, arguments and counter keys as the reference, so that its tests read the same here.
+read_in_rows() / read_in_data() run the batch entry of the library (dcrx_collapse_front,
+csrc/dcrx_collapse.cpp: threaded C++ over the row text libdcrx assembled): spacers verbatim or with up
+to two substitutions are decided there, with the reference's counters.  A row that reaches the
+reference's indel search (`{2i+2d+1s<=2}`, :198-201 — about one row in a thousand of real data)
+comes back undecided and goes through the per-row functions below, which are the reference's own
+`regex` patterns (regex is a pinned dependency of the reference, pyproject.toml): same values row for
+row.  The per-row functions keep the reference's names, arguments and counter keys, so that its tests
+read the same here.
 """
 from __future__ import annotations
 
@@ -209,62 +210,112 @@ def check_umi_quality(qualstring, parameters):
     return number_below_min > parameters[1] or average_quality < parameters[2]
 
 
-def read_in_rows(data, inputargs, barcode_quality_parameters):
-    """What read_in_data (collapse.py:482-565) does to each row before grouping.  `data`: rows as lists of
-    fields (the list decombinator() returns) or `.n12` lines.  Returns one entry per input row:
-    None for a dropped row, else (barcode, barcode_qualstring, dcr, seq, seq_qualstring, seq_id);
-    the module's `counts` receives the reference's keys."""
+def _row_front(line, inputargs, barcode_quality_parameters):
+    """One row through the per-row functions (the reference's loop body, :540-563)."""
+    counts["readdata_input_dcrs"] += 1
+    bc_locs = get_barcode_positions(line[8], inputargs, counts)
+    if not bc_locs:
+        counts["readdata_fail_no_bclocs"] += 1
+        return None
+    barcode, qual = set_barcode(line, bc_locs, inputargs)
+    if check_umi_quality(qual, barcode_quality_parameters):
+        counts["readdata_fail_low_barcode_quality"] += 1
+        return None
+    if len(line[6]) > inputargs["lenthreshold"]:
+        counts["readdata_fail_overlong_intertag_seq"] += 1
+        return None
+    counts["readdata_success"] += 1
+    return (barcode, qual, line[:5], line[6], line[7], line[5])
+
+
+def _rows_text(data) -> bytes:
+    """The rows as `.n12` text (fields joined by ", ", one row per line): what libdcrx's batch entry reads."""
+    chunks = getattr(data, "_tagged_chunks", None)
+    if chunks is not None:                                   # the rows decombinator() returned: already text
+        return b"".join(blob for _, blob, _ in chunks())
     out = []
-    allow_fast = True
-    name = str.lower(inputargs["oligo"])
-    oligo = OLIGOS.get(name)
     for line in data:
-        if isinstance(line, str):
-            line = line.rstrip("\n").split(", ")
-        counts["readdata_input_dcrs"] += 1
-        bc_locs = _positions_fast(line[8], name, oligo, inputargs) if allow_fast else None
-        if bc_locs is None:
-            bc_locs = get_barcode_positions(line[8], inputargs, counts)
-        if not bc_locs:
-            counts["readdata_fail_no_bclocs"] += 1
-            out.append(None)
-            continue
-        barcode, qual = set_barcode(line, bc_locs, inputargs)
-        if check_umi_quality(qual, barcode_quality_parameters):
-            counts["readdata_fail_low_barcode_quality"] += 1
-            out.append(None)
-            continue
-        dcr = line[:5]
-        seq = line[6]
-        if len(seq) > inputargs["lenthreshold"]:
-            counts["readdata_fail_overlong_intertag_seq"] += 1
-            out.append(None)
-            continue
-        counts["readdata_success"] += 1
-        out.append((barcode, qual, dcr, seq, line[7], line[5]))
-    return out
+        if isinstance(line, (bytes, bytearray)):
+            line = line.decode("utf-8", "replace")
+        out.append(line.rstrip("\n") if isinstance(line, str) else ", ".join(str(x) for x in line))
+    return ("\n".join(out) + ("\n" if out else "")).encode("utf-8")
 
 
-def _positions_fast(bcseq, name, oligo, inputargs):
-    """The verbatim case of get_barcode_positions for the two-spacer oligos (m13, i8): both spacers occur
-    exactly once where the reference looks for them, N1 has six bases, N2 fits.  Returns the positions
-    with the same counters bumped, or None (nothing counted) to let the general code decide."""
-    if name not in ("m13", "i8") or ("N" in bcseq and inputargs["allowNs"] == False):  # noqa: E712
-        return None
-    s1, s2 = oligo["spcr1"], oligo["spcr2"]
-    win = bcseq[:10 + len(s1)]
-    a = win.find(s1)
-    if a < 0 or win.find(s1, a + len(s1)) >= 0:
-        return None
-    rest = bcseq[len(s1):]
-    b = rest.find(s2)
-    if b < 0 or rest.find(s2, b + len(s2)) >= 0:
-        return None
-    p0 = bcseq.find(s1, 0)
-    p1 = bcseq.find(s2, len(s1))
-    b1start, b1end, b2start = p0 + len(s1), p1, p1 + len(s2)
-    if b1end - b1start != 6 or b2start + 6 > len(bcseq):
-        return None
-    counts["getbarcode_pass_exactmatch"] += 1
-    counts["getbarcode_pass_other"] += 1
-    return [b1start, b1end, b2start, b2start + 6]
+class FrontRows(coll.abc.Sequence):
+    """What the front half leaves of each input row, in input order: None for a dropped row, else
+    (barcode, barcode_qualstring, dcr, seq, seq_qualstring, seq_id) — built from the library's per-row records and the row
+    text only when asked for (a run has millions of rows; `status`, `barcode` and `kept()` give the columns at once)."""
+
+    def __init__(self, text, rows, offsets, decided):
+        self._text, self._rows, self._off, self._decided = text, rows, offsets, decided       # decided: {row index: entry} of the rows the regex path settled
+        self.status = rows["status"]
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __eq__(self, other):
+        if isinstance(other, (list, FrontRows)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def kept(self):
+        """Indices of the rows that passed."""
+        import numpy as np
+        ok = self._rows["status"] == 0
+        for k, v in self._decided.items():
+            ok[k] = v is not None
+        return np.nonzero(ok)[0]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if k in self._decided:
+            return self._decided[k]
+        r = self._rows[k]
+        if r["status"] != 0:
+            return None
+        line = self._text[int(self._off[k]):int(self._off[k + 1])].decode("utf-8", "replace").rstrip("\n").split(", ")
+        return (r["barcode"][:r["barcode_len"]].decode("ascii"), r["barcode_qual"][:r["barcode_qual_len"]].decode("ascii"),
+                line[:5], line[6], line[7], line[5])
+
+
+def read_in_rows(data, inputargs, barcode_quality_parameters, n_threads: int = 0):
+    """What read_in_data (collapse.py:482-565) does to each row before grouping, over a whole batch.  `data`: the rows
+    decombinator() returned (N12Rows), lists of fields, or `.n12` lines.  Returns a FrontRows (one entry per input row:
+    None for a dropped row, else (barcode, barcode_qualstring, dcr, seq, seq_qualstring, seq_id)); the module's `counts`
+    receives the reference's keys."""
+    from . import _native as nat
+    name = str.lower(inputargs["oligo"])
+    if name not in nat.COLLAPSE_OLIGOS:
+        raise ValueError("The flag for the -ol input must be one of M13, I8, I8_single, NEBIO, or TAKARA.")
+    text = _rows_text(data)
+    rows, offs, cnt = nat.collapse_front(text, name, inputargs["allowNs"], inputargs["lenthreshold"], barcode_quality_parameters,
+                                         n_threads=n_threads)
+    for key, v in zip(nat.COLLAPSE_COUNTERS, cnt.tolist()):
+        if v:
+            counts[key] += int(v)
+    decided = {}
+    import numpy as np
+    for k in np.nonzero(rows["status"] == nat.CF_DEFER)[0].tolist():      # the indel search (and malformed rows): the per-row functions
+        line = text[int(offs[k]):int(offs[k + 1])].decode("utf-8", "replace").rstrip("\n").split(", ")
+        decided[k] = _row_front(line, inputargs, barcode_quality_parameters)
+    return FrontRows(text, rows, offs, decided)
+
+
+def read_in_data(data, inputargs, barcode_quality_parameters, lev_threshold_fraction=None, dont_count=True, opener=None):
+    """The reference's entry (collapse.py:482-565) as far as this build goes: the rows' front half.  With
+    inputargs["command"] == "collapse", `data` is the path of an `.n12` file (opened with `opener`, as the reference does);
+    otherwise the rows decombinator() returned.  lev_threshold_fraction and the grouping it steers are outside this build."""
+    if inputargs.get("command") == "collapse":
+        fh = (opener or open)(data, "rt")
+        try:
+            data = fh.read().splitlines()
+        finally:
+            fh.close()
+    if not data:
+        raise ValueError("No reads found in input file. Check .n12 and log files for errors.")       # :508-511
+    if not dont_count:
+        print("Reading data in...")
+    return read_in_rows(data, inputargs, barcode_quality_parameters)

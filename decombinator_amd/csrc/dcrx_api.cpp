@@ -336,7 +336,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
   if (hb->lens)
     for (uint64_t r = 0; r < n; r++)
       if (hb->lens[r] > 4 * hb->stride) return set_err(DCRX_E_INVALID, "a read is longer than 4*stride");
-      else if (hb->lens[r] > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt");
+      else if (hb->lens[r] > DCRX_MAX_READ_LEN) { return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt"); }
   for (uint64_t i = 0; i < hb->n_exc; i++) {
     const uint8_t c = hb->exc_chr[i];
     if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return set_err(DCRX_E_INVALID, "exception byte is one of ACGT");

@@ -68,7 +68,7 @@ def _decombine(p: argparse.ArgumentParser):
 
 
 def _later_stage_flags(p: argparse.ArgumentParser):
-    # collapse / translate flags of the reference (io.py:230-383): parsed and carried, not acted on
+    # collapse / translate flags of the reference (io.py:230-383): -ol, -mq, -bm, -aq steer the front half of collapse; the rest are parsed and carried
     p.add_argument("-mq", "--minbcQ", type=int, default=20)
     p.add_argument("-bm", "--bcQbelowmin", type=int, default=1)
     p.add_argument("-aq", "--avgQthreshold", type=int, default=30)
@@ -86,15 +86,20 @@ def _later_stage_flags(p: argparse.ArgumentParser):
 def create_parser() -> argparse.ArgumentParser:
     parser = argparse.ArgumentParser(
         prog="decombinator",
-        description="Decombinator `decombine` stage on MI355X (HIP).  Sub-commands as in the reference; "
-                    "`collapse` and `translate` are not part of this build.")
+        description="Decombinator `decombine` stage on MI355X (HIP) and the per-row front half of `collapse`.  Sub-commands as in "
+                    "the reference; the grouping half of `collapse` and `translate` are not part of this build.")
     parser.add_argument("-v", "--version", action="version", version=__version__)
     sub = parser.add_subparsers(dest="command", help="Available commands")
     sub.required = False
-    pipe = sub.add_parser("pipeline", help="decombine, then (not in this build) collapse and translate")
+    pipe = sub.add_parser("pipeline", help="decombine, then the front half of collapse (grouping and translate: not in this build)")
     _common(pipe); _decombine(pipe); _later_stage_flags(pipe)
     dec = sub.add_parser("decombine", help="Decombine TCR reads")
     _common(dec); _decombine(dec)
+    col = sub.add_parser("collapse", help="front half of collapse over an .n12 file: barcode extraction and the row filters")
+    _common(col); _later_stage_flags(col)
+    col.add_argument("-in", "--infile", type=str, required=True, help=".n12 file of the decombine stage (optionally gzipped)")
+    col.add_argument("-N", "--allowNs", action="store_true", help="Allow barcodes containing N")
+    col.add_argument("-ln", "--lenthreshold", type=int, default=130, help="Inter-tag length threshold")
     return parser
 
 

@@ -287,6 +287,55 @@ int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_r
 int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples8,
                                      uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
 
+/* ---- the first consumer of the rows: the front half of `collapse` (host, threaded) -------------------------------
+ * What read_in_data (src/decombinator/collapse.py:482-565) does to every `.n12` row before it starts grouping rows:
+ * get_barcode_positions :367-479 (spacer searches :192-236), set_barcode :278-326, check_umi_quality :343-353 and the
+ * inter-tag length filter :553-556, with the reference's counter keys.  `text`: rows as dcrx_assemble_rows writes them
+ * (fields separated by cfg->field_sep, one row per line).  Per row a dcrx_collapse_row_t; counters are ADDED to
+ * counters[DCRX_CF_N_COUNTERS].  A row whose spacers occur neither verbatim nor with up to two substitutions reaches the
+ * reference's indel search ("{2i+2d+1s<=2}", :198-201): it is returned as DCRX_CF_DEFER with nothing counted, for the
+ * caller to decide with the same regex (decombinator_amd/collapse.py does).  rows == NULL: returns the number of rows.
+ * row_offsets (optional, n + 1 entries): where each row starts in `text`.  Returns the number of rows or an error. */
+enum dcrx_collapse_status { DCRX_CF_OK = 0, DCRX_CF_NO_BCLOCS = 1, DCRX_CF_LOW_QUALITY = 2, DCRX_CF_OVERLONG = 3, DCRX_CF_DEFER = 255 };
+enum dcrx_collapse_counter {
+  DCRX_CF_C_INPUT_DCRS = 0,        /* readdata_input_dcrs */
+  DCRX_CF_C_FAIL_N = 1,            /* getbarcode_fail_N */
+  DCRX_CF_C_FAIL_NOSPACER = 2,     /* getbarcode_fail_nospacerfound */
+  DCRX_CF_C_FAIL_NOT2SPACERS = 3,  /* getbarcode_fail_not2spacersfound */
+  DCRX_CF_C_FAIL_N1SHORT = 4,      /* getbarcode_fail_n1tooshort */
+  DCRX_CF_C_FAIL_N1LONG = 5,       /* getbarcode_fail_n1toolong */
+  DCRX_CF_C_FAIL_N2PASTEND = 6,    /* getbarcode_fail_n2pastend */
+  DCRX_CF_C_PASS_EXACT = 7,        /* getbarcode_pass_exactmatch */
+  DCRX_CF_C_PASS_REGEX = 8,        /* getbarcode_pass_regexmatch */
+  DCRX_CF_C_PASS_FUZZY_RIGHTLEN = 9, /* getbarcode_pass_fuzzymatch_rightlen */
+  DCRX_CF_C_PASS_FUZZY_SHORT = 10, /* getbarcode_pass_fuzzymatch_short */
+  DCRX_CF_C_PASS_FUZZY_LONG = 11,  /* getbarcode_pass_fuzzymatch_long */
+  DCRX_CF_C_PASS_OTHER = 12,       /* getbarcode_pass_other */
+  DCRX_CF_C_FAIL_NO_BCLOCS = 13,   /* readdata_fail_no_bclocs */
+  DCRX_CF_C_SHORT_BARCODE = 14,    /* readdata_short_barcode */
+  DCRX_CF_C_LONG_BARCODE = 15,     /* readdata_long_barcode */
+  DCRX_CF_C_FAIL_LOW_QUALITY = 16, /* readdata_fail_low_barcode_quality */
+  DCRX_CF_C_FAIL_OVERLONG = 17,    /* readdata_fail_overlong_intertag_seq */
+  DCRX_CF_C_SUCCESS = 18,          /* readdata_success */
+  DCRX_CF_N_COUNTERS = 19
+};
+typedef struct dcrx_collapse_cfg {
+  int32_t oligo;            /* 0 m13, 1 i8, 2 i8_single, 3 nebio, 4 takara (collapse.py:174-189) */
+  int32_t allow_ns;         /* inputargs["allowNs"] (:390) */
+  int32_t lenthreshold;     /* inputargs["lenthreshold"] (:553) */
+  double min_bc_q, bc_q_below_min, avg_q_threshold; /* barcode_quality_parameters (:343-353) */
+  char field_sep[8];        /* NUL-terminated; ", " for `.n12` text */
+} dcrx_collapse_cfg_t;
+typedef struct dcrx_collapse_row {
+  int16_t b1start, b1end, b2start, b2end; /* bc_locs (b2start = b2end = -1 for nebio / takara), -1 when none */
+  uint8_t status;                          /* enum dcrx_collapse_status */
+  uint8_t barcode_len, barcode_qual_len;
+  uint8_t pad;
+  char barcode[24], barcode_qual[24];      /* set_barcode's two strings */
+} dcrx_collapse_row_t;
+int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
+                            uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads);
+
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */
 int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);

@@ -102,6 +102,50 @@ def main():
     path = os.path.join(HERE, "..", "tests", "golden", "collapse_front.json")
     json.dump(out, open(path, "w"), separators=(",", ":"))
     print(len(out["cases"]), "cases ->", os.path.normpath(path), os.path.getsize(path) // 1024, "KiB")
+    stage_fixture(rng, params)
+
+
+def stage_fixture(rng, params):
+    """End-to-end fixture for FASTQ -> decombine -> rows -> collapse front half: the reads of the stage fixture
+    (tests/golden/stage_human_extended_b.json, whose rows the reference's decombinator() produced) with a NEW second file
+    whose records start with M13 barcode regions (spacers verbatim, substituted, with indels; N1 of 4-8 bases), and what the
+    reference's read_in_data loop makes of the rows that result (their fields 8 and 9 are the first 42 bytes of the second
+    file's sequence and quality, decombine.py:1021-1034)."""
+    stage = json.load(open(os.path.join(HERE, "..", "tests", "golden", "stage_human_extended_b.json")))
+    run = stage["runs"][0]
+    assert run["bc_read"] == "R2"
+    r1 = stage["fastq_r1"].split("\n")
+    ids = [r1[i][1:].partition(" ")[0] for i in range(0, len(r1) - 1, 4)]
+    bc_of = {}
+    r2 = []
+    for rid in ids:
+        seq, qual = region(rng, "m13")
+        seq = (seq + "".join(rng.choice("ACGT") for _ in range(60)))[:60]
+        qual = (qual + "I" * 60)[:60]
+        bc_of[rid] = (seq[:42], qual[:42])
+        r2 += ["@" + rid, seq, "+", qual]
+    rows = [r[:8] + list(bc_of[r[5]]) for r in run["rows"]]
+    args = {"oligo": "M13", "allowNs": False, "lenthreshold": 130}
+    ref.counts = coll.Counter()
+    res = []
+    for line in rows:
+        ref.counts["readdata_input_dcrs"] += 1
+        locs = ref.get_barcode_positions(line[8], args, ref.counts)
+        if not locs:
+            ref.counts["readdata_fail_no_bclocs"] += 1; res.append(None); continue
+        bc, bq = ref.set_barcode(line, locs, args)
+        if ref.check_umi_quality(bq, params):
+            ref.counts["readdata_fail_low_barcode_quality"] += 1; res.append(None); continue
+        if len(line[6]) > args["lenthreshold"]:
+            ref.counts["readdata_fail_overlong_intertag_seq"] += 1; res.append(None); continue
+        ref.counts["readdata_success"] += 1
+        res.append([bc, bq, line[:5], line[6], line[7], line[5]])
+    out = {"generator": "oracle/gen_collapse_golden.py: reference collapse.py functions on the stage fixture's rows with M13 barcode regions",
+           "stage": "stage_human_extended_b.json", "oligo": "M13", "params": params, "fastq_r2": "\n".join(r2) + "\n", "rows": rows,
+           "expect": res, "counts": dict(ref.counts)}
+    path = os.path.join(HERE, "..", "tests", "golden", "collapse_stage.json")
+    json.dump(out, open(path, "w"), separators=(",", ":"))
+    print(len(rows), "rows,", sum(1 for x in res if x), "kept ->", os.path.normpath(path), os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -91,3 +91,137 @@ def test_lines_and_lists_are_the_same_rows():
     collapse.counts = coll.Counter()
     b = collapse.read_in_rows([", ".join(r) + "\n" for r in rows], args, fx["params"])
     assert a == b
+
+
+def _random_rows(rng, oligo, n):
+    """Rows whose barcode regions carry the oligo's spacers verbatim, substituted, with indels, truncated, doubled or
+    absent, random N1 lengths, Ns, qualities around the thresholds, inter-tag lengths around the length threshold."""
+    o = collapse.getOligo(oligo)
+    rnd = lambda k: "".join(rng.choice("ACGT") for _ in range(k))
+
+    def mutate(s):
+        s = list(s)
+        kind = rng.random()
+        if kind < 0.45:
+            return "".join(s)
+        for _ in range(rng.choice([1, 1, 2, 2, 3])):
+            op = rng.random()
+            if op < 0.7 and s:
+                i = rng.randrange(len(s)); s[i] = rng.choice([c for c in "ACGT" if c != s[i]])
+            elif op < 0.85:
+                s.insert(rng.randrange(len(s) + 1), rng.choice("ACGT"))
+            elif s:
+                del s[rng.randrange(len(s))]
+        return "".join(s)
+
+    rows = []
+    for k in range(n):
+        s1 = mutate(o["spcr1"])
+        n1 = rnd(rng.choice([6, 6, 6, 6, 5, 7, 4, 3, 8, 9, 2, 10]))
+        if oligo in ("m13", "i8"):
+            s2 = mutate(o["spcr2"])
+            if rng.random() < 0.03:
+                s2 = s2 + rnd(2) + s2
+            seq = rnd(rng.choice([0, 0, 0, 1, 2, 5, 11])) + s1 + n1 + s2 + rnd(rng.choice([6, 6, 6, 7, 10, 4, 2, 0]))
+        elif oligo == "i8_single":
+            seq = n1 + s1 + rnd(rng.choice([6, 6, 8, 3, 0]))
+        elif oligo == "nebio":
+            seq = rnd(rng.choice([17, 17, 18, 16, 21, 5])) + s1 + rnd(rng.choice([0, 3, 5]))
+        else:
+            seq = rnd(rng.choice([12, 12, 11, 13, 3])) + s1 + rnd(rng.choice([0, 4, 7]))
+        if rng.random() < 0.04:
+            i = rng.randrange(len(seq)); seq = seq[:i] + "N" + seq[i + 1:]
+        if rng.random() < 0.02:
+            seq = rnd(rng.randrange(0, 40))
+        qual = "".join(chr(33 + rng.choice([40, 40, 38, 37, 35, 30, 25, 20, 19, 12, 2])) for _ in seq)
+        if rng.random() < 0.02:
+            qual = qual[:rng.randrange(0, len(qual) + 1)]
+        inter = rnd(rng.choice([40, 60, 90, 129, 130, 131, 150]))
+        rows.append([str(rng.randrange(50)), str(rng.randrange(13)), str(rng.randrange(9)), str(rng.randrange(9)), rnd(rng.randrange(0, 12)),
+                     f"read{k}", inter, "I" * len(inter), seq, qual])
+    return rows
+
+
+@pytest.mark.parametrize("oligo", ["m13", "i8", "i8_single", "nebio", "takara"])
+def test_library_batch_equals_the_regex_functions_row_for_row(oligo):
+    """dcrx_collapse_front (threaded C++: verbatim spacers and the {1s<=2} search decided natively, the indel search deferred)
+    against the per-row functions — the reference's own regex patterns — on 6 000 random rows per oligo: the same entry for
+    every row and the same counters, with allowNs off and on."""
+    import random
+    rng = random.Random(77 + len(oligo))
+    rows = _random_rows(rng, oligo, 6000)
+    params = [20, 1, 30]
+    for allow in (False, True):
+        args = {"oligo": oligo, "allowNs": allow, "lenthreshold": 130}
+        collapse.counts = coll.Counter()
+        want = []
+        for r in rows:
+            try:
+                want.append(collapse._row_front(r, args, params))
+            except ZeroDivisionError:              # (an empty barcode quality string: the reference's own crash)
+                want.append("CRASH")
+        want_counts = dict(collapse.counts)
+        keep = [i for i, w in enumerate(want) if w != "CRASH"]
+        collapse.counts = coll.Counter()
+        for r in (rows[i] for i in range(len(rows)) if want[i] == "CRASH"):     # what the crash rows had counted before they crashed
+            try:
+                collapse._row_front(r, args, params)
+            except ZeroDivisionError:
+                pass
+        crash_counts = collapse.counts
+        collapse.counts = coll.Counter()
+        got = collapse.read_in_rows([rows[i] for i in keep], args, params)
+        assert list(got) == [want[i] for i in keep]
+        diff = coll.Counter(want_counts); diff.subtract(crash_counts)
+        assert {k: v for k, v in collapse.counts.items() if v} == {k: v for k, v in diff.items() if v}
+        n_defer = int((got.status == 255).sum())
+        assert n_defer < len(keep) // 4          # (only rows where the spacer could occur with one base inserted or deleted; the mutated spacers above make that far more common than real data do)
+
+
+STAGE_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collapse_stage.json")
+
+
+def _stage_to_front(tmp_path, capsys=None):
+    """FASTQ files -> decombinator() -> rows -> the front half of collapse, against what the reference's read_in_data loop made of
+    the same rows (tests/golden/collapse_stage.json, oracle/gen_collapse_golden.py)."""
+    from decombinator_amd import decombine as dec, io as dio, synth, pipeline
+    fx = json.load(open(STAGE_FIXTURE))
+    stage = json.load(open(os.path.join(os.path.dirname(STAGE_FIXTURE), fx["stage"])))
+    ts = stage["tagset"]
+    synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
+                 v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
+                 j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(tmp_path / "tags"))
+    (tmp_path / "SYNTH_1.fq").write_text(stage["fastq_r1"])
+    (tmp_path / "SYNTH_2.fq").write_text(fx["fastq_r2"])
+    (tmp_path / "out").mkdir()
+    args = dio.create_args_dict(infile=str(tmp_path / "SYNTH_1.fq"), chain="b", bc_read="R2", dontgzip=True, dontcount=True,
+                                orientation="reverse", allowNs=False, tagfastadir=str(tmp_path / "tags"), oligo=fx["oligo"],
+                                outpath=str(tmp_path / "out") + os.sep, command="pipeline")
+    rows = pipeline.run(args)                       # decombine (+ .n12) and the front half with the stage's own flags
+    assert rows == fx["rows"]
+    assert {k: v for k, v in collapse.counts.items() if v} == fx["counts"]
+    collapse.counts.clear()
+    front = collapse.read_in_rows(rows, {"oligo": fx["oligo"], "allowNs": False, "lenthreshold": 130}, fx["params"])
+    assert [None if g is None else list(g) for g in front] == fx["expect"]
+    assert {k: v for k, v in collapse.counts.items() if v} == fx["counts"]
+    assert sum(1 for e in fx["expect"] if e) >= 20 and len(front.kept()) == sum(1 for e in fx["expect"] if e)
+    # the `collapse` sub-command over the .n12 the pipeline wrote: the same rows pass
+    n12 = str(tmp_path / "out" / "dcr_SYNTH_1_beta.n12")
+    pipeline.main(["collapse", "-in", n12, "-ol", fx["oligo"], "-dz", "-op", str(tmp_path / "out") + os.sep])
+    got = [ln.split(", ") for ln in open(str(tmp_path / "out" / "dcr_SYNTH_1_beta.n12u")).read().splitlines()]
+    want = [e[2] + [e[5], e[3], e[4], e[0], e[1]] for e in fx["expect"] if e]
+    assert got == want
+
+
+def test_fastq_to_front_half_with_oracle_as_device(tmp_path, monkeypatch):
+    from decombinator_amd import _native as nat
+    from tests import test_host_stage as ths
+    fx = json.load(open(STAGE_FIXTURE))
+    stage = json.load(open(os.path.join(os.path.dirname(STAGE_FIXTURE), fx["stage"])))
+    monkeypatch.setattr(nat, "decombine", ths._oracle_device(stage))
+    _stage_to_front(tmp_path)
+
+
+@pytest.mark.gpu
+def test_fastq_to_front_half_through_hip_path(tmp_path):
+    _stage_to_front(tmp_path)

@@ -13,7 +13,7 @@ _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)
 import numpy as np
 
 import torch  # noqa: F401  (first: one HIP runtime for the process, see _native.py)
-from decombinator_amd import _native as nat, decombine as dec, io as dio, synth
+from decombinator_amd import _native as nat, decombine as dec, io as dio, synth, collapse
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=4_000_000)
@@ -31,7 +31,8 @@ with tempfile.TemporaryDirectory() as td:
     op = (lambda p: gzip.open(p, "wt", compresslevel=1)) if args.gz else (lambda p: open(p, "w"))
     q1, q2 = "I" * 150, "I" * 50
     rng = np.random.default_rng(0)
-    bcs = ["".join(rng.choice(list("ACGT"), size=50)) for _ in range(1024)]
+    # barcode regions of the M13 oligo (spacer, N6, spacer, N6) so that the front half of collapse has UMIs to extract
+    bcs = ["GTCGTGACTGGGAAAACCCTGG" + "".join(rng.choice(list("ACGT"), size=6)) + "GTCGTGAT" + "".join(rng.choice(list("ACGT"), size=14)) for _ in range(1024)]
     with op(os.path.join(td, "S_1" + ext)) as f1, op(os.path.join(td, "S_2" + ext)) as f2:
         for i, r in enumerate(reads):
             f1.write(f"@SYN:{i}:1101:{i % 9973}:{i % 7919} 1:N:0:ACGT\n{r}\n+\n{q1}\n")
@@ -49,5 +50,10 @@ with tempfile.TemporaryDirectory() as td:
         out = dio.write_out_intermediate(rows, a, ".n12")
         dw = time.perf_counter() - t1
         ph = ", ".join(f"{k} {v:.2f}s" for k, v in dec.stage_seconds.items())
+        collapse.counts.clear()
+        t2 = time.perf_counter()
+        front = collapse.read_in_rows(rows, {"oligo": "m13", "allowNs": False, "lenthreshold": 130}, [20, 1, 30])
+        df = time.perf_counter() - t2
         print(f"STAGE reads={n} gz={args.gz} input_MB={size / 1e6:.0f} rows={len(rows)} decombinator={dt:.2f}s "
-              f"({n / dt / 1e6:.2f} Mreads/s; {ph}) write_n12={dw:.2f}s")
+              f"({n / dt / 1e6:.2f} Mreads/s; {ph}) write_n12={dw:.2f}s collapse_front={df:.2f}s "
+              f"({len(rows) / max(df, 1e-9) / 1e6:.2f} Mrows/s, {len(front.kept())} rows kept, {int((front.status == 255).sum())} deferred to the regex)")
