@@ -43,6 +43,26 @@ static int hip_err(hipError_t e, const char *what) {
     if (e_ != hipSuccess) return hip_err(e_, #call);    \
   } while (0)
 
+// reads per chunk of the host-buffer entry (dcrx_decombine): 80 MB in, 32 MB out at 150 nt
+#ifndef DCRX_HOST_CHUNK
+#define DCRX_HOST_CHUNK (2u << 20)
+#endif
+
+// memcpy over a few threads (a pinned staging buffer has to be filled faster than the link drains it)
+static void par_memcpy(void *dst, const void *src, size_t n) {
+  static const unsigned want = [] { const char *e = std::getenv("DCRX_HOST_THREADS"); unsigned k = e ? (unsigned)std::atoi(e) : std::min(12u, std::max(1u, std::thread::hardware_concurrency() / 2)); return std::max(1u, std::min(k, 16u)); }();
+  const unsigned nt = n < (8u << 20) ? 1u : want;
+  if (nt == 1) { std::memcpy(dst, src, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((n / nt) + 4095) & ~(size_t)4095;
+  for (unsigned k = 1; k < nt; k++) {
+    const size_t a = std::min(n, per * k), b = std::min(n, per * (k + 1));
+    if (b > a) th.emplace_back([=] { std::memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); });
+  }
+  std::memcpy(dst, src, std::min(n, per));
+  for (auto &x : th) x.join();
+}
+
 struct dcrx_tables {
   HostTables host;
   // state on the device the tables were last used on
@@ -61,9 +81,14 @@ struct dcrx_tables {
   uint32_t *d_tile_count = nullptr;
   uint64_t *d_tile_off = nullptr;
   uint64_t compact_reads = 0;
-  // staging for the host-buffer entry point
+  // staging for the host-buffer entry point: two sets of device buffers and pinned host buffers, three streams
+  // (copies in, kernels, copies out) and the events that order them
   uint8_t *d_stage = nullptr;
   size_t stage_bytes = 0;
+  uint8_t *h_stage = nullptr;       // pinned
+  size_t h_stage_bytes = 0;
+  hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
+  hipEvent_t hev_in[2] = {nullptr, nullptr}, hev_run[2] = {nullptr, nullptr}, hev_out[2] = {nullptr, nullptr};
   bool constants_ready = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // around the dominant kernel
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;  // around every launch of a call
@@ -81,6 +106,18 @@ static void free_device_state(dcrx_tables *t) {
   t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
   (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
+  if (t->h_stage) (void)hipHostFree(t->h_stage);
+  t->h_stage = nullptr; t->h_stage_bytes = 0;
+  if (t->hs_in) (void)hipStreamDestroy(t->hs_in);
+  if (t->hs_run) (void)hipStreamDestroy(t->hs_run);
+  if (t->hs_out) (void)hipStreamDestroy(t->hs_out);
+  t->hs_in = t->hs_run = t->hs_out = nullptr;
+  for (int k = 0; k < 2; k++) {
+    if (t->hev_in[k]) (void)hipEventDestroy(t->hev_in[k]);
+    if (t->hev_run[k]) (void)hipEventDestroy(t->hev_run[k]);
+    if (t->hev_out[k]) (void)hipEventDestroy(t->hev_out[k]);
+    t->hev_in[k] = t->hev_run[k] = t->hev_out[k] = nullptr;
+  }
   t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
   t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
   t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
@@ -347,43 +384,112 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     const uint32_t len = hb->lens ? hb->lens[hb->exc_read[i]] : hb->read_len;
     if (hb->exc_pos[i] >= len) return set_err(DCRX_E_INVALID, "exception position beyond the read");
   }
-  rc = ensure_device(t, n);
+  // The batch goes through in chunks of DCRX_HOST_CHUNK reads, three streams deep: while the kernels of chunk k run, chunk
+  // k + 1 is copied in and the records of chunk k - 1 are copied out (PCIe is full duplex: 40 bytes per read one way, 16 the
+  // other), through pinned staging buffers (a copy from pageable memory would not overlap anything).  The loop it stands
+  // for is the reference's read loop (decombine.py:963-1050).
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), DCRX_HOST_CHUNK);
+  rc = ensure_device(t, chunk, hb->stride);
   if (rc) return rc;
-  // one staging allocation: packed | lens | exc_read | exc_pos | exc_chr | records | counters
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // one chunk's staging: packed | lens | exc_read | exc_pos | exc_chr || records | counters    (x 2 sets)
+  uint64_t max_exc = 0;       // the most exception entries any chunk holds
+  {
+    uint64_t e = 0;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+      const uint64_t e0 = e;
+      while (e < hb->n_exc && hb->exc_read[e] < c0 + chunk) e++;
+      max_exc = std::max(max_exc, e - e0);
+    }
+  }
   const size_t o_packed = 0;
-  const size_t o_lens = o_packed + al(n * hb->stride + 16);
-  const size_t o_er = o_lens + al(hb->lens ? n * 2 : 0);
-  const size_t o_ep = o_er + al(hb->n_exc * 4);
-  const size_t o_ec = o_ep + al(hb->n_exc * 2);
-  const size_t o_rec = o_ec + al(hb->n_exc);
-  const size_t o_cnt = o_rec + al(n * sizeof(dcrx_record_t));
-  const size_t total = o_cnt + al(DCRX_N_COUNTERS * 8);
-  if (total > t->stage_bytes) {
+  const size_t o_lens = o_packed + al(chunk * hb->stride + 16);
+  const size_t o_er = o_lens + al(hb->lens ? chunk * 2 : 0);
+  const size_t o_ep = o_er + al(max_exc * 4);
+  const size_t o_ec = o_ep + al(max_exc * 2);
+  const size_t in_bytes = o_ec + al(max_exc);
+  const size_t o_rec = in_bytes;
+  const size_t o_cnt = o_rec + al(chunk * sizeof(dcrx_record_t));
+  const size_t set_bytes = o_cnt + al(DCRX_N_COUNTERS * 8);
+  if (2 * set_bytes > t->stage_bytes) {
     (void)hipFree(t->d_stage); t->d_stage = nullptr; t->stage_bytes = 0;
-    HIP_TRY(hipMalloc(&t->d_stage, total));
-    t->stage_bytes = total;
+    HIP_TRY(hipMalloc(&t->d_stage, 2 * set_bytes));
+    t->stage_bytes = 2 * set_bytes;
   }
-  uint8_t *d = t->d_stage;
-  if (n) HIP_TRY(hipMemcpy(d + o_packed, hb->packed, n * hb->stride, hipMemcpyHostToDevice));
-  if (hb->lens && n) HIP_TRY(hipMemcpy(d + o_lens, hb->lens, n * 2, hipMemcpyHostToDevice));
-  if (hb->n_exc) {
-    HIP_TRY(hipMemcpy(d + o_er, hb->exc_read, hb->n_exc * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d + o_ep, hb->exc_pos, hb->n_exc * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d + o_ec, hb->exc_chr, hb->n_exc, hipMemcpyHostToDevice));
+  if (2 * set_bytes > t->h_stage_bytes) {
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    t->h_stage = nullptr; t->h_stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&t->h_stage, 2 * set_bytes, hipHostMallocDefault));
+    t->h_stage_bytes = 2 * set_bytes;
   }
-  dcrx_batch_t db = *hb;
-  db.packed = d + o_packed;
-  db.lens = hb->lens ? reinterpret_cast<const uint16_t *>(d + o_lens) : nullptr;
-  db.exc_read = reinterpret_cast<const uint32_t *>(d + o_er);
-  db.exc_pos = reinterpret_cast<const uint16_t *>(d + o_ep);
-  db.exc_chr = d + o_ec;
-  rc = dcrx_decombine_device(t, cfg, &db, reinterpret_cast<dcrx_record_t *>(d + o_rec),
-                             reinterpret_cast<uint64_t *>(d + o_cnt), nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  if (n) HIP_TRY(hipMemcpy(records, d + o_rec, n * sizeof(dcrx_record_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(counters, d + o_cnt, DCRX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
+  if (!t->hs_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&t->hs_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&t->hs_run, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&t->hs_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipEventCreateWithFlags(&t->hev_in[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->hev_run[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->hev_out[k], hipEventDisableTiming));
+    }
+  }
+  for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
+  const uint64_t n_chunks = n ? (n + chunk - 1) / chunk : 1;
+  uint64_t exc_at = 0;
+  auto drain = [&](uint64_t k) -> int {       // chunk k's records and counters: from the pinned buffer to the caller's
+    const int set = (int)(k & 1);
+    HIP_TRY(hipEventSynchronize(t->hev_out[set]));
+    const uint8_t *h = t->h_stage + (size_t)set * set_bytes;
+    const uint64_t c0 = k * chunk, cn = std::min<uint64_t>(chunk, n - c0);
+    if (cn) par_memcpy(records + c0, h + o_rec, cn * sizeof(dcrx_record_t));
+    const uint64_t *hc = reinterpret_cast<const uint64_t *>(h + o_cnt);
+    for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] += hc[c];
+    return DCRX_OK;
+  };
+  for (uint64_t k = 0; k < n_chunks; k++) {
+    const int set = (int)(k & 1);
+    const uint64_t c0 = k * chunk, cn = n ? std::min<uint64_t>(chunk, n - c0) : 0;
+    uint8_t *h = t->h_stage + (size_t)set * set_bytes, *d = t->d_stage + (size_t)set * set_bytes;
+    // the records of chunk k - 2 leave the set's pinned buffer on a helper thread while this thread fills its input half
+    // (the halves do not overlap; the copy out of chunk k - 2 has landed before the helper touches anything)
+    int drc = DCRX_OK;
+    std::thread helper;
+    if (k >= 2) helper = std::thread([&, k] { drc = drain(k - 2); });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_helper{helper};
+    // the chunk into the pinned buffer (several threads: one memcpy does not keep up with the link) — once the copy in of
+    // chunk k - 2, which read the same bytes, is over
+    if (k >= 2) HIP_TRY(hipEventSynchronize(t->hev_in[set]));
+    uint64_t e0 = exc_at;
+    while (exc_at < hb->n_exc && hb->exc_read[exc_at] < c0 + cn) exc_at++;
+    const uint64_t ne = exc_at - e0;
+    if (cn) par_memcpy(h + o_packed, hb->packed + c0 * hb->stride, cn * hb->stride);
+    if (hb->lens && cn) std::memcpy(h + o_lens, hb->lens + c0, cn * 2);
+    uint32_t *her = reinterpret_cast<uint32_t *>(h + o_er);
+    for (uint64_t i = 0; i < ne; i++) her[i] = hb->exc_read[e0 + i] - (uint32_t)c0;      // read indices inside the chunk
+    if (ne) { std::memcpy(h + o_ep, hb->exc_pos + e0, ne * 2); std::memcpy(h + o_ec, hb->exc_chr + e0, ne); }
+    if (helper.joinable()) helper.join();
+    if (drc) return drc;
+    // copy in (after the kernels that last read this set's device buffers), kernels, copy out
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(t->hs_in, t->hev_run[set], 0));
+    HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, t->hs_in));
+    HIP_TRY(hipEventRecord(t->hev_in[set], t->hs_in));
+    HIP_TRY(hipStreamWaitEvent(t->hs_run, t->hev_in[set], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(t->hs_run, t->hev_out[set], 0));     // (the records buffer of chunk k - 2 has been copied out)
+    dcrx_batch_t db = *hb;
+    db.n_reads = cn;
+    db.packed = d + o_packed;
+    db.lens = hb->lens ? reinterpret_cast<const uint16_t *>(d + o_lens) : nullptr;
+    db.n_exc = ne;
+    db.exc_read = reinterpret_cast<const uint32_t *>(d + o_er);
+    db.exc_pos = reinterpret_cast<const uint16_t *>(d + o_ep);
+    db.exc_chr = d + o_ec;
+    rc = dcrx_decombine_device(t, cfg, &db, reinterpret_cast<dcrx_record_t *>(d + o_rec), reinterpret_cast<uint64_t *>(d + o_cnt), t->hs_run);
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    HIP_TRY(hipEventRecord(t->hev_run[set], t->hs_run));
+    HIP_TRY(hipStreamWaitEvent(t->hs_out, t->hev_run[set], 0));
+    HIP_TRY(hipMemcpyAsync(h + o_rec, d + o_rec, set_bytes - o_rec, hipMemcpyDeviceToHost, t->hs_out));
+    HIP_TRY(hipEventRecord(t->hev_out[set], t->hs_out));
+  }
+  for (uint64_t k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; k++) { rc = drain(k); if (rc) return rc; }
   return DCRX_OK;
 }
 

@@ -536,3 +536,26 @@ def test_thousands_of_hand_overs_to_the_list_kernel():
     orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
     pu.assert_records_equal(rec, orec, reads, "hand-overs")
     pu.assert_counters_equal(cnt, ocnt, "hand-overs")
+
+
+@pytest.mark.gpu
+def test_host_entry_pipelines_chunks_and_equals_the_device_entry():
+    """dcrx_decombine (host buffers) takes a batch in chunks of 2 M reads, three streams deep through pinned staging buffers
+    (copy in, kernels, copy out overlap): 5 M + 12 345 reads with exception bytes — three chunks, the last one short — give
+    the records and counters of the device entry over the whole batch, five times in a row."""
+    n = 5_012_345
+    ts = synth.config_tagset(2)
+    t, _ = _tables(ts)
+    cfg = nat.synth_cfg(seed=21, n_rate=0.003)
+    db = nat.synth_reads_device(t, cfg, 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec, d_cnt)
+    nat.synchronize()
+    want, want_cnt = d_rec.to_host(nat.RECORD_DTYPE, n), d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+    hb = nat.synth_reads_host(t, cfg, 0, n)
+    assert len(hb.exc_read) > 10_000
+    for _ in range(5):
+        rec, cnt = nat.decombine(t, hb)
+        assert rec.tobytes() == want.tobytes()
+        assert (cnt == want_cnt).all()
