@@ -417,6 +417,19 @@ __global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t 
   }
 }
 
+// Orientation `both` on the v2 kernels, between the two frames: the reads with exception bytes that the first frame did not
+// decombine are marked again (the first pass cleared every mark it used) ...
+__global__ void remark_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, const dcrx_record_t *__restrict__ records,
+                              uint32_t *__restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_exc) {
+    const uint32_t r = exc_read[i];
+    if (records[r].status != DCRX_S_OK) atomicOr(&flag[r >> 5], 1u << (r & 31));
+  }
+}
+// ... and at the end a read counts once however many frames it was tried in (counts["read_count"], decombine.py:991)
+__global__ void read_count_kernel(unsigned long long *__restrict__ counters, unsigned long long n_reads) { counters[DCRX_C_READ_COUNT] = n_reads; }
+
 // ------------------------------------------------------------------------------
 // Order-preserving compaction of the decombined (status OK) records: the DCR
 // tuples that leave the GPU (gathered to rank 0 in the sharded run).
@@ -560,11 +573,13 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   if (e != hipSuccess) return e;
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   // (reads beyond the register-resident scans' 320 nt: every read through the list kernel, like orientation `both`)
-  const bool all_general = cfg.orientation == DCRX_ORIENT_BOTH || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
+  // (the v2 condition: its entries keep two flags above a 30-bit read index)
+  const bool v2_ok_here = B.stride <= 4 * DCRX_NWMAX && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);
+  const bool v2_both = cfg.orientation == DCRX_ORIENT_BOTH && v2_ok_here;
+  const bool all_general = (cfg.orientation == DCRX_ORIENT_BOTH && !v2_both) || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
   // reserved_cus: compute units left to other streams (an RCCL gather running beside the scan)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
-  // (the v2 entries keep two flags above a 30-bit read index, and a scan block counts its lists' entries in 21 bits)
-  const bool v2 = B.stride <= 4 * DCRX_NWMAX && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30) && B.n_reads / cus + 256 < (1ull << 21);
+  const bool v2 = v2_ok_here;
   const uint32_t grid = all_general ? 0 : std::min<uint32_t>(P.grid, cus * (uint32_t)occ_fast);
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, cus * (uint32_t)occ_list);
   const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue, of the general
@@ -579,6 +594,25 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     hipExtLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, P.ev_step_start, nullptr, 0, B.exc_read, B.n_exc,
                           all_general ? 1 : 0, v2 ? 0 : 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
                           queue_count + 1, d_counters);
+  }
+  if (v2_both) {
+    // `both` (decombine.py:1005-1010): the reverse frame for every read, then the forward frame for the reads it did not
+    // decombine; the failure counters of both attempts add up, as the reference's do.  After each frame the list kernel
+    // takes what the v2 kernels handed over (in that frame).
+    const uint32_t lgrid = std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4));
+    CfgDev c1 = cfg, c2 = cfg;
+    c1.orientation = DCRX_ORIENT_REVERSE; c2.orientation = DCRX_ORIENT_FORWARD;
+    e = launch_v2_any(P, T, B, c1, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, 0u);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c1, rec, d_counters, queue, gqueue, queue_count);
+    if (B.n_exc) hipLaunchKernelGGL(remark_kernel, dim3((uint32_t)((B.n_exc + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc, rec, const_cast<uint32_t *>(B.exc_flag));
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_v2_any(P, T, B, c2, rec, queue, gqueue, qcap, queue_count, d_counters, s, nullptr, nullptr, 1u);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c2, rec, d_counters, queue, gqueue, queue_count);
+    hipExtLaunchKernelGGL(read_count_kernel, dim3(1), dim3(1), 0, s, nullptr, P.ev_step_stop, 0, d_counters, (unsigned long long)B.n_reads);
+    return hipGetLastError();
   }
   if (v2) {
     e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop);

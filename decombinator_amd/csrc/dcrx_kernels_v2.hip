@@ -203,7 +203,7 @@ template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint64_t per_block) {
+    uint64_t per_block, uint32_t retry) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   V2Ori V0 = T0.v2[0];
@@ -280,7 +280,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const uint64_t r = blk_lo + (uint64_t)item * WT + (uint64_t)q * 64 + lane;
-      const bool live = r < blk_hi;
+      bool live = r < blk_hi;
+      // orientation `both`, second attempt (decombine.py:1005-1010): only the reads the first frame did not decombine are
+      // tried again; the others keep their records and count nothing
+      if (retry && live) live = records[r].status != DCRX_S_OK;
       const bool exc = live && ((xm[q] >> lane) & 1ull);
       const int n = UNIFORM_LEN ? (int)B.read_len : (live ? (int)B.lens[r] : 0);
       if (!UNIFORM_LEN) mask_log2<NW>(lg[q], n);
@@ -731,18 +734,21 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 
 // The v2 kernels serve one frame; the A/B switches of the three-launch form, the forced slow
 // reader and orientation `both` keep that form.
+// The v2 kernels serve one frame per pass: `reverse` and `forward` are one pass, `both` (decombine.py:1005-1010) the reverse
+// frame and then the forward frame for the reads it did not decombine (both frames' tables must fit).
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
-  if (!T.v2_ok || cfg.orientation == DCRX_ORIENT_BOTH || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
+  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
-  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
-  return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u;
+  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u; };
+  if (cfg.orientation == DCRX_ORIENT_BOTH) return fits(0) && fits(1) && !(cfg.flags & DCRX_F_PROFILE_MASK);
+  return fits(cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
 }
 
 template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                             uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
-                            unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry) {
   auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
@@ -791,7 +797,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const bool side = finish && P.v2_side && P.v2_side2 && P.v2_ev_fork && P.v2_ev_join && P.v2_ev_join2 && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL);
   const bool fork_rides = side && !ev_stop;
   hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block);
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (finish) {
@@ -882,13 +888,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
 
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                          uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
-                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry) {
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   const bool uniform = B.lens == nullptr, nw10 = B.stride <= 40, narrow = T.v2[o].narrow != 0;
   int shape = (int)((cfg.flags >> 8) & 3u);
   if (shape == 0) shape = nw10 ? 2 : 3;      // two reads per lane (two independent chains per wave) where the registers allow: measured faster than one
-#define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
-#define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop)
+#define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry)
+#define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
   if (nw10) {
     if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);

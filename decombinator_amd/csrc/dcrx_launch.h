@@ -41,7 +41,7 @@ uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu);
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg);
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                          uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
-                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
+                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry = 0);
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
                           uint64_t *hit_index, uint64_t *ok_bitmap, int packed12, uint64_t *d_total, uint32_t *tile_count,
                           uint64_t *tile_off, hipStream_t s);
