@@ -100,6 +100,13 @@ def create_parser() -> argparse.ArgumentParser:
     col.add_argument("-in", "--infile", type=str, required=True, help=".n12 file of the decombine stage (optionally gzipped)")
     col.add_argument("-N", "--allowNs", action="store_true", help="Allow barcodes containing N")
     col.add_argument("-ln", "--lenthreshold", type=int, default=130, help="Inter-tag length threshold")
+    tr = sub.add_parser("translate", help="CDR3 extraction (translate.get_cdr3) for the DCRs of a .freq file; writes the AIRR .tsv")
+    _common(tr); _later_stage_flags(tr)
+    tr.add_argument("-in", "--infile", type=str, required=True, help=".freq file (v,j,vdel,jdel,insert,frequency,cluster size per line)")
+    tr.add_argument("-tg", "--tags", type=str, default="extended")
+    tr.add_argument("-sp", "--species", type=str, default="human")
+    tr.add_argument("-tfdir", "--tagfastadir", type=str, default="Decombinator-Tags-FASTAs")
+    tr.add_argument("-nbc", "--nobarcoding", action="store_true")
     return parser
 
 

@@ -27,11 +27,48 @@ _CODON = {a + b + c: _AAS[16 * i + 4 * j + k] for i, a in enumerate(_BASES) for 
           for k, c in enumerate(_BASES)}
 
 
+_IUPAC = {"A": "A", "C": "C", "G": "G", "T": "T", "U": "T", "M": "AC", "R": "AG", "W": "AT", "S": "CG", "Y": "CT", "K": "GT",
+          "V": "ACG", "H": "ACT", "D": "AGT", "B": "CGT", "X": "ACGT", "N": "ACGT"}     # Bio.Data.IUPACData.ambiguous_dna_values
+_AMBIGUOUS_AA = {"B": set("DN"), "Z": set("EQ"), "J": set("IL")}                      # ... .extended_protein_values, the two-residue letters
+_AMB_CACHE: dict = {}
+
+
+def _ambiguous_codon(codon: str) -> str:
+    """Bio.Seq.translate's answer for a codon that holds an ambiguity code (Bio.Data.CodonTable.AmbiguousForwardTable and
+    the fall-backs of Bio.Seq._translate_str, biopython 1.84): the residue every concrete codon it stands for gives (GCN ->
+    A, YTA -> L), B / Z / J when they give exactly D+N / E+Q / I+L (RAY -> B), '*' when all of them are stops (TAR, TRA), and X
+    otherwise (a mix of residues, or of stops and residues).  A letter that is no nucleotide code at all raises, as
+    Biopython does."""
+    hit = _AMB_CACHE.get(codon)
+    if hit is not None:
+        return hit
+    try:
+        opts = [_IUPAC[c] for c in codon]
+    except KeyError:
+        raise ValueError(f"Codon '{codon}' is invalid") from None          # Bio.Data.CodonTable.TranslationError is a ValueError
+    aas = {_CODON[a + b + c] for a in opts[0] for b in opts[1] for c in opts[2]}
+    if aas == {"*"}:
+        out = "*"
+    elif "*" in aas:
+        out = "X"
+    elif len(aas) == 1:
+        out = next(iter(aas))
+    else:
+        out = next((k for k, v in _AMBIGUOUS_AA.items() if aas == v), "X")
+    _AMB_CACHE[codon] = out
+    return out
+
+
 def translate_nt(seq: str) -> str:
-    """str(Seq(seq).translate()) (translate.py:307-309): standard table, '*' for stops, 'X' for a codon holding
-    anything but ACGT/U, a trailing partial codon dropped."""
+    """str(Seq(seq).translate()) (translate.py:307-309): standard table, '*' for stops, a trailing partial codon dropped;
+    codons with IUPAC ambiguity codes as Biopython resolves them (_ambiguous_codon)."""
     s = seq.upper().replace("U", "T")
-    return "".join(_CODON.get(s[i:i + 3], "X") for i in range(0, len(s) - len(s) % 3, 3))
+    out = []
+    for i in range(0, len(s) - len(s) % 3, 3):
+        c = s[i:i + 3]
+        aa = _CODON.get(c)
+        out.append(aa if aa is not None else _ambiguous_codon(c))
+    return "".join(out)
 
 
 @dataclass
@@ -110,3 +147,114 @@ def get_cdr3(dcr, headers, inputargs, genes: GeneInfo | None = None):
         out_data["cdr1_aa"] = G.v_cdr1[v]
         out_data["cdr2_aa"] = G.v_cdr2[v]
     return out_data
+
+
+# ---- the stage around get_cdr3 (translate.py:163-254 and :388-533), for rows this build or the reference's collapse produced ----
+counts = coll.Counter()
+
+
+def _read_fasta(path):
+    """(id, sequence) per record, in file order (the reference: SeqIO.parse(..., "fasta"), translate.py:182)."""
+    out, name, seq = [], None, []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(seq)))
+                name, seq = line[1:].split()[0] if line[1:].split() else "", []
+            elif name is not None:
+                seq.append(line.strip())
+    if name is not None:
+        out.append((name, "".join(seq)))
+    return out
+
+
+def import_gene_information(inputargs) -> GeneInfo:
+    """translate.py:163-254: regions and names from the FASTA files, conserved-residue positions, motifs and functionality from
+    the `.translate` files, germline CDR1 / CDR2 from the `.cdrs` file (human only).  Files are looked for in the working
+    directory, then in inputargs["tagfastadir"] (this build is offline: no download)."""
+    from .decombine import read_tcr_file
+    if inputargs["species"] not in ("human", "mouse"):
+        print("Species not recognised. Please select either 'human' (default) or 'mouse'.\n"
+              "If mouse is required by default, consider changing the default value in the script.")
+        raise SystemExit
+    g = GeneInfo()
+    chain = inputargs["chain"]
+    for gene in ("v", "j"):
+        recs = _read_fasta(read_tcr_file(inputargs["species"], inputargs["tags"], gene, "fasta", inputargs["tagfastadir"], chain))
+        setattr(g, gene + "_regions", [sq.upper() for _, sq in recs])
+        setattr(g, gene + "_names", [rid.upper().split("|")[1] for rid, _ in recs])
+        with open(read_tcr_file(inputargs["species"], inputargs["tags"], gene, "translate", inputargs["tagfastadir"], chain)) as fh:
+            rows = [x.rstrip() for x in fh]
+        setattr(g, gene + "_translate_position", [int(x.split(",")[1]) for x in rows])
+        setattr(g, gene + "_translate_residue", [x.split(",")[2] for x in rows])
+        setattr(g, gene + "_functionality", [x.split(",")[3] for x in rows])
+    if inputargs["species"] == "human":
+        with open(read_tcr_file(inputargs["species"], inputargs["tags"], "v", "cdrs", inputargs["tagfastadir"], chain)) as fh:
+            cdr = [x.rstrip() for x in fh]
+        g.v_cdr1, g.v_cdr2 = [x.split(" ")[1] for x in cdr], [x.split(" ")[2] for x in cdr]
+    else:
+        g.v_cdr1, g.v_cdr2 = [""] * len(g.v_regions), [""] * len(g.v_regions)
+    return g
+
+
+_CHAINS = {"A": "a", "ALPHA": "a", "TRA": "a", "TCRA": "a", "B": "b", "BETA": "b", "TRB": "b", "TCRB": "b",
+           "G": "g", "GAMMA": "g", "TRG": "g", "TCRG": "g", "D": "d", "DELTA": "d", "TRD": "d", "TCRD": "d"}
+
+
+def cdr3translator(inputargs: dict, data=None) -> list:
+    """translate.py:388-533 without the file writing: one row of `out_headers` fields per input DCR (non-productive ones too
+    unless inputargs["nonproductivefilter"]).  `data`: rows whose first five fields are the DCR, then the frequency and the
+    average UMI cluster size (what the reference's collapse returns); with inputargs["command"] == "translate" the rows are
+    read from the comma-separated file inputargs["infile"] (a `.freq`).  inputargs["nobarcoding"]: every row counts once."""
+    import gzip
+    global counts
+    counts = coll.Counter()
+    if not inputargs.get("chain"):
+        found = [x for x in ("alpha", "beta", "gamma", "delta") if x in inputargs["infile"].lower()]      # :394-407
+        if len(found) != 1:
+            print("TCR chain not recognised. Please choose from a/b/g/d (case-insensitive).")
+            raise SystemExit
+        chain = found[0][0]
+    else:
+        chain = _CHAINS.get(str(inputargs["chain"]).upper())
+        if chain is None:
+            print("TCR chain not recognised. Please choose from a/b/g/d (case-insensitive).")
+            raise SystemExit
+    inputargs["chain"] = chain
+    set_gene_information(import_gene_information(inputargs))
+    if inputargs["command"] == "translate":
+        fh = (gzip.open if inputargs["infile"].endswith(".gz") else open)(inputargs["infile"], "rt")
+        rows = list(fh)
+        fh.close()
+    else:
+        rows = data
+    out = []
+    for line in rows:
+        counts["line_count"] += 1
+        if inputargs["command"] == "translate":
+            tcr = line.rstrip().split(",")
+            tcr[5], tcr[6] = int(tcr[5]), int(tcr[6])
+        else:
+            tcr = line
+        if inputargs.get("nobarcoding"):
+            frequency, cluster = 1, ""
+        else:
+            if not isinstance(tcr[5], int):
+                print("TCR frequency could not be detected. If using non-barcoded data, please include the additional '-nbc' "
+                      "argument when running CDR3translator.")
+                raise SystemExit
+            frequency = tcr[5]
+            cluster = tcr[6] if len(tcr) > 6 and isinstance(tcr[6], (int, float)) else ""
+        rec = get_cdr3(tcr[:5], out_headers, inputargs)
+        rec["sequence_id"] = str(counts["line_count"])
+        rec["duplicate_count"] = frequency
+        rec["av_UMI_cluster_size"] = cluster
+        if rec["productive"] == "T":
+            counts["prod_recomb"] += 1
+            out.append([rec[x] for x in out_headers])
+        else:
+            counts["NP_count"] += 1
+            if not inputargs.get("nonproductivefilter"):
+                out.append([rec[x] for x in out_headers])
+    return out

@@ -66,6 +66,49 @@ def main():
     json.dump({"genes": genes, "headers": ref.out_headers, "cases": cases}, open(path, "w"), separators=(",", ":"))
     prod = sum(1 for c in cases if c["expect"] != "IndexError" and c["expect"]["productive"] == "T")
     print(len(cases), "cases,", prod, "productive ->", os.path.normpath(path), os.path.getsize(path) // 1024, "KiB")
+    stage_fixture(rng)
+
+
+def stage_fixture(rng):
+    """End-to-end fixture FASTQ -> decombine -> rows -> get_cdr3: the unique DCRs of the stage fixture's rows
+    (tests/golden/stage_human_extended_b.json: what the reference's decombinator() returned for its FASTQ files) through the
+    reference's get_cdr3 with `.translate` / `.cdrs` tables made up for that tag set (conserved-residue positions inside the V
+    region with the residue that really stands there for most genes, J motifs as regular expressions)."""
+    stage = json.load(open(os.path.join(HERE, "..", "tests", "golden", "stage_human_extended_b.json")))
+    ts = stage["tagset"]
+    from Bio.Seq import Seq
+    genes = {"v_regions": [r.upper() for r in ts["v_regions"]], "j_regions": [r.upper() for r in ts["j_regions"]],
+             "v_names": [n.upper() for n in ts["v_names"]], "j_names": [n.upper() for n in ts["j_names"]]}
+    vpos, vres = [], []
+    for r in genes["v_regions"]:
+        aa = str(Seq(r).translate())
+        p = rng.randrange(5, max(6, len(aa) - 12))
+        vpos.append(p)
+        vres.append(aa[p - 1] if rng.random() < 0.8 and aa[p - 1] != "*" else "C")
+    genes.update(v_translate_position=vpos, v_translate_residue=vres,
+                 j_translate_position=[-rng.randrange(6, 12) for _ in genes["j_regions"]],
+                 j_translate_residue=[rng.choice(["[A-Z]G.G", "F...", "....", "FG.G"]) for _ in genes["j_regions"]],
+                 v_functionality=[rng.choice("FPO") for _ in genes["v_regions"]], j_functionality=["F" for _ in genes["j_regions"]],
+                 v_cdr1=["".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(6)) for _ in genes["v_regions"]],
+                 v_cdr2=["".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(5)) for _ in genes["v_regions"]])
+    for k, v in genes.items():
+        setattr(ref, k, v)
+    seen, dcrs = set(), []
+    for row in stage["runs"][0]["rows"]:
+        d = tuple(row[:5])
+        if d not in seen:
+            seen.add(d); dcrs.append(list(d))
+    expect = []
+    for d in dcrs:
+        try:
+            expect.append(dict(ref.get_cdr3(d, ref.out_headers, {"command": "pipeline"})))
+        except IndexError:
+            expect.append("IndexError")
+    path = os.path.join(HERE, "..", "tests", "golden", "translate_stage.json")
+    json.dump({"generator": "oracle/gen_translate_golden.py: reference get_cdr3 on the unique DCRs of the stage fixture's rows",
+               "stage": "stage_human_extended_b.json", "genes": genes, "dcrs": dcrs, "expect": expect}, open(path, "w"), separators=(",", ":"))
+    print(len(dcrs), "unique DCRs,", sum(1 for e in expect if e != "IndexError" and e["productive"] == "T"), "productive,",
+          sum(1 for e in expect if e == "IndexError"), "IndexError ->", os.path.normpath(path), os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
