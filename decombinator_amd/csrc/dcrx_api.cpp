@@ -69,6 +69,7 @@ struct dcrx_tables {
   int device = -1;
   uint8_t *d_blob = nullptr;
   DevTables dev{};
+  DevTables *d_dev = nullptr;   // the same struct in device memory (what a kernel's rare paths read instead of holding it in registers)
   LaunchPlan plan{};
   bool ws_dirty = true;       // work counters / exception bitmap must be zeroed before the next launch
   uint32_t reserved_cus = 0;
@@ -96,6 +97,7 @@ struct dcrx_tables {
 
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
+  (void)hipFree(t->d_dev); t->d_dev = nullptr;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
   if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
@@ -224,6 +226,8 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     HIP_TRY(hipMalloc(&t->d_blob, t->host.blob.size()));
     HIP_TRY(hipMemcpy(t->d_blob, t->host.blob.data(), t->host.blob.size(), hipMemcpyHostToDevice));
     t->dev = t->host.resolve(t->d_blob);
+    HIP_TRY(hipMalloc(&t->d_dev, sizeof(DevTables)));
+    HIP_TRY(hipMemcpy(t->d_dev, &t->dev, sizeof(DevTables), hipMemcpyHostToDevice));
     // launch plan: persistent blocks of DCRX_BLOCK threads, the DFA resident in LDS
     const uint32_t lds_cap = 160 * 1024;
     const uint32_t want = t->host.rel.lds_image_bytes + DCRX_N_COUNTERS * 4;
@@ -239,6 +243,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     const uint32_t q_per_cu = std::min<uint32_t>(2048 / DCRX_QBLOCK, std::max<uint32_t>(1, lds_cap / std::max<uint32_t>(P.lds_bytes, 1)));
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
     P.reserved_cus = t->reserved_cus;
+    P.dev_tables = t->d_dev;
     t->plan = P;
     t->device = dev;
   }

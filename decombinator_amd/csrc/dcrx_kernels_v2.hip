@@ -422,7 +422,7 @@ template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
-    uint32_t *__restrict__ queue_count) {
+    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
   extern __shared__ __align__(64) uint32_t smem[];
   constexpr int o = ORI;      // the frame is a template argument: one frame's code per kernel
   const V2Ori V = T0.v2[ORI];
@@ -473,10 +473,10 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         for (int k = 0; k < NW; k++) strip[k] = w[k];
         if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(w[0] ^ w[NW - 1]); }
         else
-        status = tail2_fast<ORI == 1>(tt, lw, n, dg, cfg, rec, T0, C);
+        status = tail2_fast<ORI == 1>(tt, lw, n, dg, cfg, rec, *Tmem, C);      // (the tables through memory: only a walk that leaves its window reads them)
 #else
         const RegWords<NW> rw{w};
-        status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec, T0, C);
+        status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec, *Tmem, C);
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
@@ -547,7 +547,7 @@ template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
-    uint32_t *__restrict__ queue_count) {
+    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
   extern __shared__ __align__(64) uint32_t smem[];
   constexpr int o = ORI;
   const V2Ori V = T0.v2[ORI];
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
           rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
-          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
-          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, T0, C, Cdry);
+          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
+          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
         }
@@ -829,7 +829,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       if (!fork_rides) { e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e; }
       e = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
       hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue,
-                            gqueue, qcap, queue_count);
+                            gqueue, qcap, queue_count, P.dev_tables);
       e = hipGetLastError(); if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(P.v2_side2, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
       e = general(P.v2_side2, V2_L_X, false, P.v2_ev_join2); if (e != hipSuccess) return e;
@@ -839,7 +839,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       for (int which = V2_L_E; which <= V2_L_C; which++) { e = general(s, which, true, nullptr); if (e != hipSuccess) return e; }
     } else {
       hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
-                         queue_count);
+                         queue_count, P.dev_tables);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     }
@@ -847,7 +847,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
       e = hipStreamWaitEvent(s, P.v2_ev_join2, 0); if (e != hipSuccess) return e;
     } else {
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue, gqueue, qcap, queue_count);
+      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue, gqueue, qcap, queue_count, P.dev_tables);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;

@@ -21,6 +21,7 @@ struct LaunchPlan {
   bool table16_in_lds;       // the two-bases-per-step table + side tables fit beside the fast kernel's buffers
   uint32_t lds16_bytes;      // counters + that table + side tables
   uint32_t reserved_cus = 0; // compute units the persistent grids leave free (dcrx_set_reserved_cus)
+  const DevTables *dev_tables = nullptr;   // DevTables in device memory
   // v2 kernels: the per-wave lists between the scan and the finishing kernel (device memory of the tables handle)
   uint4 *v2_tail = nullptr; uint4 *v2_events = nullptr; uint32_t *v2_counts = nullptr;
   uint4 *v2_slow = nullptr;
