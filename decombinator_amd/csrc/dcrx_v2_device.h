@@ -801,16 +801,19 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
                         dcrx_record_t &rec, const DevTables &T, const Counters &C) {
   const int vpair = (int)(digest & 0xFFu), jpair = (int)((digest >> 8) & 0xFFu), jc = (int)((digest >> 16) & 3u);
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
-  if (n < 32 || Lv > 31 || Lj > 31) return TAIL2_SLOW;
+  // Straight-line up to the walks: what does not fit the lean form only sets `slow` (every load below stays inside the
+  // strip whatever the read looks like), and one branch at the end leaves — a wave pays for its branches, not its flags.
+  bool slow = n < 32 || Lv > 31 || Lj > 31;
+  const int top = max(n, 32) - 32;                         // the last place a 32-base window can start
   // ---- the windows that hold the tags (both candidate ends of a pair share one window) ----
   const int sva = 2 * vpair - Lv + 1;                      // the V tag starts here (ends at the pair's first base) or one base on
-  const int wsv = min(max(sva, 0), n - 32);
+  const int wsv = min(max(sva, 0), top);
   const uint64_t Wv = w.stored64(wsv);
   const int sja = 2 * jpair - Lj + 1;
-  const int wsj = min(max(sja, 0), n - 32);
+  const int wsj = min(max(sja, 0), top);
   const uint64_t Wj = w.stored64(wsj);
-  const uint64_t mv = (1ull << (2 * Lv)) - 1ull, mj = (1ull << (2 * Lj)) - 1ull;
-  int v = -1, sv = 0, j = -1, sj = 0;
+  const uint64_t mv = (1ull << (2 * (Lv & 31))) - 1ull, mj = (1ull << (2 * (Lj & 31))) - 1ull;
+  int v, sv, j = 0, sj = 0;
   {   // both candidate ends of the V pair and of the J pair, side by side
     const LookupQ q[4] = {
         {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
@@ -819,62 +822,64 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
         {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, jc == 1 && sja + 1 + Lj <= n}};
     int t[4];
     lookup_lockstep<4>(q, t);
-    if ((t[0] >= 0) == (t[1] >= 0)) return TAIL2_SLOW;    // none (cannot be) or two V tags inside the pair
-    v = t[0] >= 0 ? t[0] : t[1]; sv = t[0] >= 0 ? sva : sva + 1;
-    if (jc == 1) {
-      if ((t[2] >= 0) == (t[3] >= 0)) return TAIL2_SLOW;
-      j = t[2] >= 0 ? t[2] : t[3]; sj = t[2] >= 0 ? sja : sja + 1;
-    }
+    slow |= (t[0] >= 0) == (t[1] >= 0);                   // none (cannot be) or two V tags inside the pair
+    v = max(t[0] >= 0 ? t[0] : t[1], 0); sv = t[0] >= 0 ? sva : sva + 1;
+    slow |= jc == 1 && (t[2] >= 0) == (t[3] >= 0);
+    j = max(t[2] >= 0 ? t[2] : t[3], 0); sj = t[2] >= 0 ? sja : sja + 1;
   }
   // ---- the walk windows ----
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
   const int vp = REV ? n - sv - Lv : sv;                   // where the tag starts in the frame (hold_v[0][1])
   const int te = vp + jumpv - 1;                           // decombine.py:283-285
   const int fv = te + 1;
-  if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return TAIL2_SLOW;
-  const uint64_t rwv = w.stored64(REV ? n - fv : fv - 32);
-  int jumpj = 0, jp = 0, ts = 0;
-  uint64_t rwj = 0;
-  if (jc == 1) {
-    jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
-    jp = REV ? n - sj - Lj : sj;
-    ts = jp - jumpj;                                       // :407-409
-    if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return TAIL2_SLOW;
-    rwj = w.stored64(REV ? n - ts - 32 : ts);
-  }
+  // (a walk whose first window does not lie inside the read, or whose gene has no packed window, takes the general function)
+  const bool vedge = !(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v);
+  const uint64_t rwv = w.stored64(min(max(REV ? n - fv : fv - 32, 0), top));
+  const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
+  const int jp = REV ? n - sj - Lj : sj;
+  const int ts = jp - jumpj;                               // :407-409
+  const bool jedge = !(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j);
+  const uint64_t rwj = w.stored64(min(max(REV ? n - ts - 32 : ts, 0), top));
+  if (slow) return TAIL2_SLOW;
   // (nothing has been counted up to here, and from here on no path returns TAIL2_SLOW)
   // get_v_deletions (:749-785), the 32-base form; a walk that leaves that window goes on in the general function
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
   int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  if (vedge) kv = -1;
   int end_v = te - kv;
   if (kv < 0) {
     const FrameWS<REV, WS> F{w, n};
-    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, C)) return DCRX_S_V_WALK_FAIL;     // :288-290 (te < n here: v_del_failed, counted inside)
+    if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, C)) return te >= n ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;     // :288-290 (counted inside)
   }
-  if (jc == 0) return DCRX_S_J_NONE;                       // :530-531 (no J tag, no J half tag)
-  if (jc == 2) return DCRX_S_J_MULTI;                      // :402-404
-  // get_j_deletions (:788-817), the 32-base form
+  // get_j_deletions (:788-817), the 32-base form (for a read without exactly one J-tag pair the lanes compute on whatever the
+  // strip holds and the result is dropped below)
   const int end_of_v = end_v + 1;                          // :547
   const int k0 = end_of_v > ts ? end_of_v - ts : 0;
   const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
   int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  if (jedge) kj = -1;
   int start_j = ts + kj;
-  if (kj < 0) {
+  if (jc == 1 && kj < 0) {
     const FrameWS<REV, WS> F{w, n};
     if (!get_j_deletions(T.g[1], F, j, ts, end_of_v, start_j, kj, C)) return DCRX_S_J_WALK_FAIL;   // :413-418 (j_del_failed counted inside)
   }
   const int jend = jp + Lj;
-  // filters :553-569 (a clean read holds no N)
-  if ((vp - jend) >= cfg.lenthreshold) return DCRX_S_F_TOOLONG;
-  if (kv > jumpv - Lv || kj > jumpj) return DCRX_S_F_IMPOSS_DEL;
-  if (vp + Lv > jend + Lj) return DCRX_S_F_OVERLAP;
+  // the exits in the reference's order (:402-404, :530-531, then the filters :553-569: a clean read holds no N), picked
+  // without branching; a record that is not a decombined read keeps no field
+  int status = DCRX_S_OK;
+  if (vp + Lv > jend + Lj) status = DCRX_S_F_OVERLAP;
+  if (kv > jumpv - Lv || kj > jumpj) status = DCRX_S_F_IMPOSS_DEL;
+  if ((vp - jend) >= cfg.lenthreshold) status = DCRX_S_F_TOOLONG;
+  if (jc == 2) status = DCRX_S_J_MULTI;
+  if (jc == 0) status = DCRX_S_J_NONE;
   int lo, hi;
   pyslice(n, end_v + 1, start_j, lo, hi);                  // read[vdat[1]+1 : jdat[1]] :577
-  rec.v = (uint16_t)v; rec.j = (uint16_t)j;
-  rec.v_start = (uint16_t)vp; rec.j_end = (uint16_t)jend;
-  rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
-  rec.vdel = (uint8_t)kv; rec.jdel = (uint8_t)kj;
-  return DCRX_S_OK;
+  const bool ok = status == DCRX_S_OK;
+  rec.v = (uint16_t)(ok ? v : 0); rec.j = (uint16_t)(ok ? j : 0);
+  rec.v_start = (uint16_t)(ok ? vp : 0); rec.j_end = (uint16_t)(ok ? jend : 0);
+  rec.ins_start = (uint16_t)(ok ? lo : 0); rec.ins_len = (uint16_t)(ok ? hi - lo : 0);
+  rec.vdel = (uint8_t)(ok ? kv : 0); rec.jdel = (uint8_t)(ok ? kj : 0);
+  return status;
 }
 
 // the counters a status of the lean tail stands for (besides read_count)
@@ -1176,10 +1181,12 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   }
   const int jumpv = dcrx_lds_at<int32_t>(tt.jump[0], (uint32_t)v);
   const int fv = te + 1;
-  if (!(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v)) return R2S(7);
-  const uint64_t rwv = w.stored64(REV ? n - fv : fv - 32);
+  // (a walk whose first window does not lie inside the read, or whose gene has no packed window, takes the general function)
+  const bool vedge = !(fv >= 32 && fv < n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[0], (uint32_t)v);
+  const uint64_t rwv = w.stored64(min(max(REV ? n - fv : fv - 32, 0), n - 32));
   const uint64_t yv = mismatch_slots(rwv, dcrx_lds_at<uint64_t>(tt.w64[0], (uint32_t)v));
   int kv = REV ? first_clean_up(or10_up(yv), 0) : first_clean_down(or10_down(yv), 0);
+  if (vedge) kv = -1;
   int end_v = te - kv;
   // (a full-tag walk that fails is final and counts inside the walk: whatever may still send the read to the general form
   // because of the sweep has to be looked at before; the J side's own checks below come before anything they could count)
@@ -1188,7 +1195,7 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const FrameWS<REV, WS> F{w, n};
     if (!get_v_deletions(T.g[0], F, v, te, end_v, kv, vfull ? C : Cdry)) {
       if (!vfull) return R2S(8);                       // the reference goes on with the next candidate: the general form
-      return DCRX_S_V_WALK_FAIL;                       // :288-290
+      return te >= n ? DCRX_S_V_WALK_FAIL_AT_END : DCRX_S_V_WALK_FAIL;      // :288-290
     }
   }
   const int end_of_v = end_v + 1;                                                     // :547
@@ -1211,11 +1218,12 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     errs |= jhalf == 1 ? 8u : 4u;
   }
   const int jumpj = dcrx_lds_at<int32_t>(tt.jump[1], (uint32_t)j);
-  if (!(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j)) return R2S(11);
-  const uint64_t rwj = w.stored64(REV ? n - ts - 32 : ts);
+  const bool jedge = !(ts >= 0 && ts + 32 <= n) || !dcrx_lds_at<uint8_t>(tt.w64_ok[1], (uint32_t)j);
+  const uint64_t rwj = w.stored64(min(max(REV ? n - ts - 32 : ts, 0), n - 32));
   const int k0 = end_of_v > ts ? end_of_v - ts : 0;
   const uint64_t yj = mismatch_slots(rwj, dcrx_lds_at<uint64_t>(tt.w64[1], (uint32_t)j));
   int kj = REV ? first_clean_down(or10_down(yj), k0) : first_clean_up(or10_up(yj), k0);
+  if (jedge) kj = -1;
   int start_j = ts + kj;
   if (kj < 0) {
     const FrameWS<REV, WS> F{w, n};

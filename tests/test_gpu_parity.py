@@ -127,6 +127,27 @@ def test_orientations_on_mixed_strands(orientation):
     assert int(cnt[22]) > 10_000  # frame_forward
 
 
+@pytest.mark.parametrize("which", [0, 1], ids=["alpha-extended", "beta-extended"])
+def test_orientation_both_as_two_v2_passes_on_extended_sets(which):
+    """`both` on a tag set whose automaton no longer fits the three-launch form's pair scan: the v2 kernels run the reverse frame
+    for every read and then the forward frame for the reads it did not decombine (decombine.py:1005-1010).  Mixed strands, reads
+    with exception bytes, allowNs off and on: records, frames and the counters of both attempts (they add up) equal the oracle."""
+    ts = synth.config3_tagsets()[which]
+    t, ot = _tables(ts)
+    info = t.info()
+    assert info["v2_tables"]
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=31 + which, n_rate=0.004, sub_rate=0.01), 0, 300_000)
+    reads = nat.unpack_reads(hb)
+    reads = [orc.revcomp(r) if i % 3 == 1 else r for i, r in enumerate(reads)]
+    b = nat.pack_reads(reads)
+    for allow in (False, True):
+        rec, cnt = nat.decombine(t, b, orientation="both", allow_ns=allow)
+        orec, ocnt = pu.oracle_records(ot, reads, "both", allow, 130)
+        pu.assert_records_equal(rec, orec, reads, "both")
+        pu.assert_counters_equal(cnt, ocnt, "both")
+        assert int(cnt[22]) > 20_000 and int(cnt[19]) - int(cnt[22]) > 40_000          # decombined in the forward / in the reverse frame
+
+
 def test_ragged_lengths_and_empty_reads():
     ts = synth.config_tagset(2)
     t, ot = _tables(ts)
