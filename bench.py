@@ -288,7 +288,7 @@ def run_rank(args):
     events = device.make_events(args.steps, timed)
     elapsed = timed_loop(gather, args.steps, events, set(timed))
     elapsed_nogather = None
-    if gather is not None and world > 1 and not args.no_gather_ab:
+    if gather is not None and not args.no_gather_ab:
         # the same steps without the gather: the difference is the gather time the steps do not hide
         elapsed_nogather = timed_loop(None, args.steps)
 
