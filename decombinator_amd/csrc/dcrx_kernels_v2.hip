@@ -413,6 +413,58 @@ static uint32_t v2_finish_lds_bytes(const DevTables &T, int o) {
   return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
 }
 
+// One entry through the general form (dcr_frame3): the read's event list from its flag log, its slice of the exception list,
+// finish2_words; what even that form does not hold (more flagged pairs than an event list, more exception bytes than the
+// register frame, more hits than a hit list) is handed to the list kernel.
+template <bool UNIFORM_LEN, int NW, int ORI>
+__device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori &V, const BatchDev &B, const CfgDev &cfg, const uint32_t x0,
+                                                 const uint32_t (&lg)[NW], const uint32_t (&w)[NW], const Counters &C, dcrx_record_t *__restrict__ records,
+                                                 uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, const uint32_t qcap,
+                                                 uint32_t *__restrict__ queue_count, const bool tagged) {
+  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
+  const uint32_t r = x0 & V2_R_MASK;
+  const bool exc = (x0 & V2_R_EXC) != 0u;
+  const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  // the read's event list, from its flag log (a read with exception bytes keeps every flag: none is certain)
+  const Digest2 d = digest2<NW>(lg);
+  const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg, n >> 1) : 0u;
+  uint32_t ev[3];
+  const bool fits = events2<NW>(lg, d, exc ? 0xFu : bnd, ev);
+  if (!fits) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc); return; }   // more flagged pairs than a list holds: the three-launch form
+  int x0e = 0, x1e = 0;
+  if (exc) {                      // the read's slice of the (sorted) exception list
+    uint64_t lo = 0, hi = B.n_exc;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+    x0e = (int)lo;
+    while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
+    x1e = (int)lo;
+    if (x1e - x0e > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); return; }   // more exception bytes than the register frame holds
+  }
+  if (finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (x0 & V2_R_JMULTI) != 0u, x0e, x1e, C, records)) {
+    if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
+  } else {
+    v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
+  }
+}
+
+// ... as a call, for the lean kernels: what their straight-line forms do not settle (one read in two million) is finished
+// on the spot, with the tables the kernel has staged, instead of travelling to a pass of its own behind them (a launch, a join and one
+// read's latency on the critical path of every step).  Not inlined: the lean loops keep their registers.
+template <int NW>
+struct V2EntryWords { uint32_t lg[NW], w[NW]; };
+template <bool UNIFORM_LEN, int NW, int ORI>
+__device__ __attribute__((noinline)) void v2_general_call(const DevTables *__restrict__ Tmem, const uint32_t *lds_side, const uint32_t *lds_bk, const BatchDev B, const CfgDev cfg, const uint32_t x0,
+                                                           const V2EntryWords<NW> e, uint32_t *lds_counts, dcrx_record_t *__restrict__ records,
+                                                           uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, const uint32_t qcap,
+                                                           uint32_t *__restrict__ queue_count) {
+  const DevTables T0 = *Tmem;
+  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes, false);      // (the side tables and buckets the lean kernel staged)
+  V2Ori V = T0.v2[ORI];
+  V.bk = reinterpret_cast<const uint8_t *>(lds_bk);
+  const Counters C{lds_counts};
+  v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, x0, e.lg, e.w, C, records, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30));
+}
+
 // The tail kernel: `split` waves per region, 256-thread blocks, no register spills (a spill
 // reload would wait for the loads in flight).  Software pipeline over the batches of 64:
 // the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
@@ -441,16 +493,12 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
   const int lane = tid & 63;
-  const bool tagged = B.n_reads < (1ull << 30);
   // `split` waves share a region (a scan block's list): wave k of them takes the batches k, k + split, ...
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
   for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {
     const uint32_t region = job / split, part = job % split;
     const uint32_t tn = Q.counts[V2_L_COUNTS * region + V2_L_TAIL];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
-    // what the lean form does not settle: list L, as an event entry for the general form
-    const uint32_t scap = Q.lcap;
-    uint4 *eq = Q.lo + (size_t)region * scap * V2Rows<NW>::E;
     const uint32_t STEP = 64 * split;
     uint32_t x1[2 + NW];
     v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
@@ -481,27 +529,17 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
       v2_tally(lds_counts, lane, status, o == 0);
-      const unsigned long long ms = __ballot(status == TAIL2_SLOW);
-      if (ms) {      // the region's slow list is shared by the waves of the region: one atomic per batch that has such reads
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[V2_L_COUNTS * region + V2_L_LEFT], (uint32_t)__popcll(ms));
-        base = __shfl(base, 0);
-        const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-        if (status == TAIL2_SLOW) {
-          if (at < scap) {
-            // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
-            const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
-            uint32_t y[1 + 2 * NW];
-            y[0] = r | (jc == 2u ? V2_R_JMULTI : 0u);
+      if (__builtin_expect(status == TAIL2_SLOW, 0)) {      // (one read in millions) the general form, on the spot
+        // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
+        const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
+        V2EntryWords<NW> e;
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
-              uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
-              if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
-              y[1 + k] = l; y[1 + NW + k] = w[k];
-            }
-            v2_put_rows<1 + 2 * NW>(eq, scap, at, y);
-          } else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
+        for (int k = 0; k < NW; k++) {
+          uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
+          if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
+          e.lg[k] = l; e.w[k] = w[k];
         }
+        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, r | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
     }
   }
@@ -569,7 +607,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
   const Counters C{lds_counts}, Cdry{lds_bk + V.bk_bytes / 4 + (uint32_t)DCRX_V2_FBLOCK * lds_words_stride<NW>()};
   __syncthreads();
   const int lane = tid & 63;
-  const bool tagged = B.n_reads < (1ull << 30);
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
   // jobs: (list, region, part); the lists one after the other, so that the waves in flight at one time run the same code
   for (uint32_t job = gwave; job < 2u * n_regions * split && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
@@ -578,7 +615,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
     const uint32_t STEP = 64 * split;
     const V2ListRef l = v2_list<NW>(Q, which, region);
     const uint32_t en = min(Q.counts[V2_L_COUNTS * region + which], l.cap);
-    uint4 *sq = Q.lo + (size_t)region * Q.lcap * V2Rows<NW>::E;
     constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
     uint32_t x1[1 + 2 * NW];
     if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(l.rows, l.cap, 64 * part + lane, 64 * part + lane < en, x1);
@@ -612,16 +648,11 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
-      const unsigned long long ms = __ballot(status == RESCUE2_SLOW);
-      if (ms) {      // (the tail kernel appends to the same list, with atomics as well)
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&Q.counts[V2_L_COUNTS * region + V2_L_LEFT], (uint32_t)__popcll(ms));
-        base = __shfl(base, 0);
-        const uint32_t at = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-        if (status == RESCUE2_SLOW) {
-          if (at < Q.lcap) v2_put_rows<1 + 2 * NW>(sq, Q.lcap, at, x);
-          else v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, (x[0] & V2_R_EXC) != 0u);
-        }
+      if (__builtin_expect(status == RESCUE2_SLOW, 0)) {      // (one read in millions) the general form, on the spot
+        V2EntryWords<NW> e;
+#pragma unroll
+        for (int k = 0; k < NW; k++) { e.lg[k] = lg[k]; e.w[k] = w[k]; }
+        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, x[0], e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
     }
   }
@@ -664,7 +695,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   const Counters C{lds_counts};
   const int lane = tid & 63;
   const bool tagged = B.n_reads < (1ull << 30);
-  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
   __shared__ uint32_t pref[DCRX_V2_GROUP_MAX + 1];
   // `bsplit` blocks share a group of regions (a short list spread over many waves): block b of them takes the rounds b, b + bsplit, ...
   const uint32_t bpart = blockIdx.x % bsplit, bsteps = width * (DCRX_V2_FBLOCK / 64) * bsplit;
@@ -696,32 +726,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
       uint32_t lg[NW], w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
-      if (live) {
-        const uint32_t r = x[0] & V2_R_MASK;
-        const bool exc = (x[0] & V2_R_EXC) != 0u;
-        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
-        // the read's event list, from its flag log (a read with exception bytes keeps every flag: none is certain)
-        const Digest2 d = digest2<NW>(lg);
-        const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg, n >> 1) : 0u;
-        uint32_t ev[3];
-        const bool fits = events2<NW>(lg, d, exc ? 0xFu : bnd, ev);
-        const uint4 e = make_uint4(x[0], ev[0], ev[1], ev[2]);
-        if (!fits) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc); continue; }   // more flagged pairs than a list holds: the three-launch form
-        int x0 = 0, x1e = 0;
-        if (exc) {                      // the read's slice of the (sorted) exception list
-          uint64_t lo = 0, hi = B.n_exc;
-          while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
-          x0 = (int)lo;
-          while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
-          x1e = (int)lo;
-          if (x1e - x0 > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); continue; }   // more exception bytes than the register frame holds
-        }
-        if (finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (e.x & V2_R_JMULTI) != 0u, x0, x1e, C, records)) {
-          if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
-        } else {
-          v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
-        }
-      }
+      if (live) v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, x[0], lg, w, C, records, queue, gqueue, qcap, queue_count, tagged);
     }
   }
   __syncthreads();
@@ -852,7 +857,6 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       if (e != hipSuccess) return e;
       e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;
     }
-    e = general(s, V2_L_LEFT, false, nullptr);       // what the lean kernels handed on
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
       std::vector<uint32_t> h((size_t)V2_L_COUNTS * n_regions);
