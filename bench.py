@@ -255,12 +255,12 @@ def run_rank(args):
     else:
         device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
     gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps) if use_dist else None
-    if world > 1 and not dry:
-        # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the
-        # tuples of step k really move beside the scan of step k+1 (on one GPU, where the "gather" is a
-        # local copy, reserving units only costs: 0.85 ms/step with none, 0.89 with 16)
+    if use_dist and not dry:
+        # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the tuples of step k
+        # really move beside the scan of step k+1 (the compaction's blocks fit beside a scan block on any unit)
+        reserved = int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))
         for tb in all_tables:
-            nat.check(nat.lib().dcrx_set_reserved_cus(tb.handle, int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))))
+            nat.check(nat.lib().dcrx_set_reserved_cus(tb.handle, reserved))
 
     def fence(g):
         if g is not None:
@@ -505,6 +505,9 @@ def main():
     args = parse_args(argv)
     if args.cfg_flags:
         os.environ.setdefault("DCRX_DEBUG_FLAGS", "1")      # profiling switches are refused by the library without this
+    # HIP maps its streams onto 4 hardware queues by default; with the gather's streams (torch's side stream, RCCL's) beside
+    # the three of a decombine call, two of those would share a queue and run their kernels one after the other
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
     run_rank(args)
