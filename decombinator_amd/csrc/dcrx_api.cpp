@@ -129,7 +129,7 @@ extern "C" {
 
 int dcrx_abi_version(void) { return DCRX_ABI_VERSION; }
 const char *dcrx_last_error(void) { return g_err.c_str(); }
-const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; v2 scan block 1024 (16-bit pair table), finishing blocks 256; reads <= 511 nt (register-resident scans <= 320 nt)"; }
+const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; v2 scan block 1024 (16-bit pair table), finishing blocks 256; reads <= 511 nt (register shapes of 10 / 20 / 32 words per read)"; }
 
 int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
   if (!out) return set_err(DCRX_E_INVALID, "out is null");
@@ -375,10 +375,12 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
   const uint64_t n = hb->n_reads;
   if (n && !records) return set_err(DCRX_E_INVALID, "records is null");
   // host-side validation the device entry cannot afford
-  if (hb->lens)
-    for (uint64_t r = 0; r < n; r++)
+  if (hb->lens) {
+    for (uint64_t r = 0; r < n; r++) {
       if (hb->lens[r] > 4 * hb->stride) return set_err(DCRX_E_INVALID, "a read is longer than 4*stride");
-      else if (hb->lens[r] > DCRX_MAX_READ_LEN) { return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt"); }
+      if (hb->lens[r] > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt");
+    }
+  }
   for (uint64_t i = 0; i < hb->n_exc; i++) {
     const uint8_t c = hb->exc_chr[i];
     if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return set_err(DCRX_E_INVALID, "exception byte is one of ACGT");

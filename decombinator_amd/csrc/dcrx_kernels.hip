@@ -572,12 +572,12 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_list, klist, DCRX_QBLOCK, lds_list);
   if (e != hipSuccess) return e;
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
-  // (reads beyond the register-resident scans' 320 nt: every read through the list kernel, like orientation `both`)
+  // (the three-launch form holds 320 nt in registers: longer reads all go through its list kernel; the v2 kernels hold 511)
   // (the v2 condition: its entries keep two flags above a 30-bit read index)
-  const bool v2_ok_here = B.stride <= 4 * DCRX_NWMAX && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);
+  const bool v2_ok_here = B.stride <= 4 * DCRX_V2_NWLONG && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);
   // (`both` as two v2 passes: 0.69 ms per 10 M reads of config 2 against 28 ms through the list kernel)
   const bool v2_both = cfg.orientation == DCRX_ORIENT_BOTH && v2_ok_here;
-  const bool all_general = (cfg.orientation == DCRX_ORIENT_BOTH && !v2_both) || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
+  const bool all_general = (cfg.orientation == DCRX_ORIENT_BOTH && !v2_both) || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || (B.stride > 4 * DCRX_NWMAX && !v2_ok_here);
   // reserved_cus: compute units left to other streams (an RCCL gather running beside the scan)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
   const bool v2 = v2_ok_here && cfg.orientation != DCRX_ORIENT_BOTH;

@@ -500,13 +500,18 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     const uint32_t tn = Q.counts[V2_L_COUNTS * region + V2_L_TAIL];
     const uint4 *tq = Q.tail + (size_t)region * Q.tcap * V2Rows<NW>::T;
     const uint32_t STEP = 64 * split;
+    constexpr bool AHEAD = NW <= DCRX_NWMAX;      // (the longest reads: no look-ahead, the registers do not hold two entries)
     uint32_t x1[2 + NW];
-    v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
+    if constexpr (AHEAD) v2_get_rows<2 + NW>(tq, Q.tcap, 64 * part + lane, 64 * part + lane < tn, x1);
     for (uint32_t first = 64 * part; first < tn && !(cfg.flags & DCRX_F_PROFILE_NO_TAIL); first += STEP) {
       uint32_t x[2 + NW];
+      if constexpr (AHEAD) {
 #pragma unroll
-      for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
-      v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
+        for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
+        v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
+      } else {
+        v2_get_rows<2 + NW>(tq, Q.tcap, first + lane, first + lane < tn, x);
+      }
       uint32_t w[NW];
 #pragma unroll
       for (int k = 0; k < NW; k++) w[k] = x[2 + k];
@@ -745,7 +750,7 @@ bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
   if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
-  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_NWMAX>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u; };
+  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_V2_NWLONG>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u; };
   if (cfg.orientation == DCRX_ORIENT_BOTH) return fits(0) && fits(1) && !(cfg.flags & DCRX_F_PROFILE_MASK);
   return fits(cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
 }
@@ -904,8 +909,13 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
     if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);
     return narrow ? DCRX_V2(false, 10, true) : DCRX_V2(false, 10, false);
   }
-  if (uniform) return narrow ? DCRX_V2(true, DCRX_NWMAX, true) : DCRX_V2(true, DCRX_NWMAX, false);
-  return narrow ? DCRX_V2(false, DCRX_NWMAX, true) : DCRX_V2(false, DCRX_NWMAX, false);
+  if (B.stride <= 4 * DCRX_NWMAX) {
+    if (uniform) return narrow ? DCRX_V2(true, DCRX_NWMAX, true) : DCRX_V2(true, DCRX_NWMAX, false);
+    return narrow ? DCRX_V2(false, DCRX_NWMAX, true) : DCRX_V2(false, DCRX_NWMAX, false);
+  }
+  // 321-511 nt: one read per lane, no item in flight beside the one in hand (the registers hold one read and its log)
+  if (uniform) return narrow ? DCRX_V2X(true, DCRX_V2_NWLONG, 1, true, false) : DCRX_V2X(true, DCRX_V2_NWLONG, 1, false, false);
+  return narrow ? DCRX_V2X(false, DCRX_V2_NWLONG, 1, true, false) : DCRX_V2X(false, DCRX_V2_NWLONG, 1, false, false);
 #undef DCRX_V2
 #undef DCRX_V2A
 #undef DCRX_V2X
@@ -914,8 +924,8 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
 // 16-byte rows the two lists need for batches of up to max_reads reads of `stride` bytes on n_cu compute units:
 // a tail entry per read (every read can be one) and half as many event entries
 void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *tail_rows, uint64_t *event_rows) {
-  const bool nw10 = stride <= 40;
-  const uint64_t rt = nw10 ? V2Rows<10>::T : V2Rows<DCRX_NWMAX>::T, re = nw10 ? V2Rows<10>::E : V2Rows<DCRX_NWMAX>::E;
+  const uint64_t rt = stride <= 40 ? V2Rows<10>::T : stride <= 4 * DCRX_NWMAX ? V2Rows<DCRX_NWMAX>::T : V2Rows<DCRX_V2_NWLONG>::T;
+  const uint64_t re = stride <= 40 ? V2Rows<10>::E : stride <= 4 * DCRX_NWMAX ? V2Rows<DCRX_NWMAX>::E : V2Rows<DCRX_V2_NWLONG>::E;
   const uint64_t entries = max_reads + max_reads / 8 + (uint64_t)n_cu * 16 * 256;
   *tail_rows = entries * rt;
   *event_rows = (entries / 2) * re;
@@ -925,7 +935,7 @@ uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu) {
   uint64_t tr, er;
   v2_list_rows(max_reads, stride, n_cu, &tr, &er);
   // ... plus the tail kernel's slow list: an eighth of the reads, at least 256 entries per region
-  const uint64_t re = stride <= 40 ? V2Rows<10>::E : V2Rows<DCRX_NWMAX>::E;
+  const uint64_t re = stride <= 40 ? V2Rows<10>::E : stride <= 4 * DCRX_NWMAX ? V2Rows<DCRX_NWMAX>::E : V2Rows<DCRX_V2_NWLONG>::E;
   return er + (max_reads / 8 + (uint64_t)n_cu * 16 * 256) * re;
 }
 

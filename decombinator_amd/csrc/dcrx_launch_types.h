@@ -8,6 +8,8 @@
 
 // words of one read kept in registers by the fast scan: reads up to 16*20 = 320 nt
 #define DCRX_NWMAX 20
+// words of the longest reads the v2 kernels hold in registers (128-byte stride: 511 nt), one read per lane
+#define DCRX_V2_NWLONG 32
 #define DCRX_FAST_READ_LEN (16 * DCRX_NWMAX)
 // longer reads (up to 511 nt: strides of up to 128 bytes) go through the list kernel, which walks the packed words
 // in memory; its hit positions have nine bits

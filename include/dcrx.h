@@ -131,9 +131,11 @@ typedef struct dcrx_cfg {
  * as exceptions sorted by (read, pos); the device treats them exactly as the
  * reference treats the original byte.  stride is a multiple of
  * 8 with 4*stride >= the longest read and stride <= 128: reads of up to 511 nt
- * (DCRX_E_UNSUPPORTED beyond; dcrx_tables_info.max_read_len).  Batches with stride <= 80
- * (reads of up to 320 nt) take the register-resident scan kernels, longer ones a kernel
- * that walks the packed words in memory. */
+ * (DCRX_E_UNSUPPORTED beyond; dcrx_tables_info.max_read_len).  Three register
+ * shapes of the kernels by stride: <= 40 (150 nt, two reads per lane), <= 80 (320 nt) and
+ * <= 128 (511 nt, one read per lane); where the round-2 kernels do not apply
+ * (dcrx_tables_info.v2_tables == 0), batches with stride > 80 take a kernel that walks the
+ * packed words in memory. */
 typedef struct dcrx_batch {
   uint64_t n_reads;         /* < 2^32 per call */
   const uint8_t *packed;

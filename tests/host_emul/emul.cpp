@@ -170,7 +170,7 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
   std::vector<uint32_t> flag((b->n_reads + 31) / 32 + 1, 0);
   for (uint64_t i = 0; i < b->n_exc; i++) flag[b->exc_read[i] >> 5] |= 1u << (b->exc_read[i] & 31);
   // reads are copied with a padded tail so that the word-pair loads stay in bounds
-  std::vector<uint8_t> packed(b->n_reads * (size_t)b->stride + 4 * DCRX_NWMAX + 16, 0);
+  std::vector<uint8_t> packed(b->n_reads * (size_t)b->stride + 4 * DCRX_V2_NWLONG + 16, 0);
   std::memcpy(packed.data(), b->packed, b->n_reads * (size_t)b->stride);
   BatchDev B;
   B.packed = packed.data(); B.stride = b->stride; B.read_len = b->read_len; B.lens = b->lens;
@@ -188,12 +188,13 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     const uint32_t nw = b->stride / 4;
     const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
     const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
-    const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER) || B.stride > 4 * DCRX_NWMAX;
+    // the launch's choice of kernels (dcrx_kernels.hip, v2_applies); reads beyond the three-launch form's 320 nt stay on the
+    // v2 functions (32 words per read) where those apply, and all take the general list form otherwise
+    const bool v2_able = T.v2_ok && !(C.flags & (DCRX_F_V1_KERNELS | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY |
+                                                  DCRX_F_PROFILE_RESCUE_HITS_ONLY | DCRX_F_FORCE_SLOW_READER));
+    const bool all_general = C.orientation == DCRX_ORIENT_BOTH || (C.flags & DCRX_F_FORCE_SLOW_READER) || (B.stride > 4 * DCRX_NWMAX && !v2_able);
     const bool general = all_general || ((flag[r >> 5] >> (r & 31)) & 1u);
-    // the launch's choice of kernels (dcrx_kernels.hip, v2_applies)
-    const bool v2 = T.v2_ok && !all_general &&
-                    !(C.flags & (DCRX_F_V1_KERNELS | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY |
-                                 DCRX_F_PROFILE_RESCUE_HITS_ONLY));
+    const bool v2 = v2_able && !all_general;
     // the v2 kernels take every read of the batch, those with exception bytes included (with their slice of the list)
     int x0 = 0, x1 = 0;
     if (v2 && general) {
@@ -203,14 +204,14 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     }
     if (b->lens) {
       int what = FAST_TO_GENERAL;
-      if (v2) what = B.stride <= 40 ? v2_one<false, 10>(T, B, C, r, x0, x1, CC, records) : v2_one<false, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records);
+      if (v2) what = B.stride <= 40 ? v2_one<false, 10>(T, B, C, r, x0, x1, CC, records) : B.stride <= 4 * DCRX_NWMAX ? v2_one<false, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records) : v2_one<false, DCRX_V2_NWLONG>(T, B, C, r, x0, x1, CC, records);
       else if (!general) what = fast_one<false>(pair_scan, T, B, C, r, nw, CC, records);
       if (what == FAST_TO_GENERAL) general_one<false>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
       else if (what == FAST_TO_RESCUE) rescue_one<false>(pair_rescue, T, B, C, r, nw, CC, records, slot);
       else if (what != FAST_DONE) return -100;
     } else {
       int what = FAST_TO_GENERAL;
-      if (v2) what = B.stride <= 40 ? v2_one<true, 10>(T, B, C, r, x0, x1, CC, records) : v2_one<true, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records);
+      if (v2) what = B.stride <= 40 ? v2_one<true, 10>(T, B, C, r, x0, x1, CC, records) : B.stride <= 4 * DCRX_NWMAX ? v2_one<true, DCRX_NWMAX>(T, B, C, r, x0, x1, CC, records) : v2_one<true, DCRX_V2_NWLONG>(T, B, C, r, x0, x1, CC, records);
       else if (!general) what = fast_one<true>(pair_scan, T, B, C, r, nw, CC, records);
       if (what == FAST_TO_GENERAL) general_one<true>(pair_rescue && !all_general, T, B, C, r, nw, CC, records, slot);
       else if (what == FAST_TO_RESCUE) rescue_one<true>(pair_rescue, T, B, C, r, nw, CC, records, slot);

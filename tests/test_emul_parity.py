@@ -87,8 +87,8 @@ def test_emul_randomised_configurations():
 
 
 def _long_reads(kind, n):
-    """Reads of 321..511 nt (merged 2x250 amplicons): beyond the register-resident scans, through the kernel that walks
-    the packed words in memory."""
+    """Reads of 321..511 nt (merged 2x250 amplicons): the v2 kernels' third register shape (32 words per read, one read per
+    lane); with DCRX_F_V1_KERNELS the three-launch form's list kernel, which walks the packed words in memory."""
     import numpy as np
     from decombinator_amd import synth
     from oracle import oracle as orc
@@ -111,8 +111,8 @@ def _long_reads(kind, n):
         out.append(fl[:left] + r + fl[left:])
     assert 321 <= min(map(len, out)) and max(map(len, out)) <= 511
     b = nat.pack_reads(out, stride=128)
-    for orientation in ("reverse", "forward"):
-        rec, cnt = be.run(b, orientation)
+    for orientation, flags in (("reverse", 0), ("forward", 0), ("both", 0), ("reverse", nat.F_V1_KERNELS)):
+        rec, cnt = be.run(b, orientation, flags=flags)
         orec, ocnt = pu.oracle_records(ot, out, orientation, False, 130)
         pu.assert_records_equal(rec, orec, out, orientation)
         pu.assert_counters_equal(cnt, ocnt)
