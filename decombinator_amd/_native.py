@@ -168,7 +168,7 @@ EXPORTS = [
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_set_step_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
     "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
-    "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
+    "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
     "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
@@ -218,6 +218,8 @@ def lib():
         "dcrx_device_name": (i32, [C.c_char_p, C.c_size_t]),
         "dcrx_malloc_device": (i32, [C.POINTER(vp), C.c_size_t]),
         "dcrx_free_device": (i32, [vp]),
+        "dcrx_malloc_host": (i32, [C.POINTER(vp), C.c_size_t]),
+        "dcrx_free_host": (i32, [vp]),
         "dcrx_memcpy_h2d": (i32, [vp, vp, C.c_size_t]),
         "dcrx_memcpy_d2h": (i32, [vp, vp, C.c_size_t]),
         "dcrx_memset_device": (i32, [vp, i32, C.c_size_t]),
@@ -555,11 +557,41 @@ def make_cfg(orientation="reverse", allow_ns=False, lenthreshold=130, flags=0) -
     return CfgC(o, int(bool(allow_ns)), int(lenthreshold), int(flags))
 
 
+class _PinnedBlock:
+    """Page-locked host memory from dcrx_malloc_host, freed with the last array that views it."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        check(lib().dcrx_malloc_host(C.byref(self.ptr), max(1, int(nbytes))))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dcrx_free_host(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """An uninitialised numpy array in page-locked host memory: dcrx_decombine copies from / into such buffers directly."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    blk = _PinnedBlock(n)
+    buf = (C.c_uint8 * max(1, n)).from_address(blk.ptr.value)
+    buf._dcrx_block = blk           # the ctypes object, which the array keeps alive, keeps the block alive
+    return np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
+
+
 def decombine(tables: Tables, batch: PackedBatch, orientation="reverse", allow_ns=False,
-              lenthreshold=130, flags=0):
-    """dcrx_decombine on host buffers.  Returns (records[RECORD_DTYPE], counters uint64[32])."""
+              lenthreshold=130, flags=0, out: np.ndarray | None = None):
+    """dcrx_decombine on host buffers.  Returns (records[RECORD_DTYPE], counters uint64[32]).  `out`: a records array to
+    fill (e.g. pinned_empty(n, RECORD_DTYPE), reused from call to call)."""
     cfg = make_cfg(orientation, allow_ns, lenthreshold, flags)
-    rec = np.zeros(batch.n_reads, dtype=RECORD_DTYPE)
+    if out is not None:
+        assert out.dtype == RECORD_DTYPE and out.shape == (batch.n_reads,) and out.flags.c_contiguous
+    rec = out if out is not None else np.zeros(batch.n_reads, dtype=RECORD_DTYPE)
     cnt = np.zeros(N_COUNTERS, dtype=np.uint64)
     b = batch.as_c()
     check(lib().dcrx_decombine(tables.handle, C.byref(cfg), C.byref(b),
@@ -572,11 +604,11 @@ def synth_cfg(seed: int, read_len: int = 150, p_rearranged: float = 0.45, sub_ra
     return SynthCfgC(int(seed), int(read_len), float(p_rearranged), float(sub_rate), float(n_rate))
 
 
-def synth_reads_host(tables: Tables, cfg: SynthCfgC, first: int, n: int, stride: int | None = None) -> PackedBatch:
+def synth_reads_host(tables: Tables, cfg: SynthCfgC, first: int, n: int, stride: int | None = None, pinned: bool = False) -> PackedBatch:
     """Seeded synthetic reads [first, first+n) generated by the library on the host."""
     if stride is None:
         stride = stride_for(cfg.read_len)
-    packed = np.zeros((n, stride), dtype=np.uint8)
+    packed = pinned_empty((n, stride), np.uint8) if pinned else np.zeros((n, stride), dtype=np.uint8)
     check(lib().dcrx_synth_reads_host(tables.handle, C.byref(cfg), first, n, stride,
                                       packed.ctypes.data if n else None))
     er, ep, ec = synth_exceptions_host(tables, cfg, first, n)

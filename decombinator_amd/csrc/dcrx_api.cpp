@@ -193,6 +193,13 @@ int dcrx_malloc_device(void **ptr, size_t bytes) {
   HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16)); return DCRX_OK;
 }
 int dcrx_free_device(void *ptr) { HIP_TRY(hipFree(ptr)); return DCRX_OK; }
+int dcrx_malloc_host(void **ptr, size_t bytes) {
+  if (!ptr) return set_err(DCRX_E_INVALID, "null argument");
+  *ptr = nullptr;
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return DCRX_OK;
+}
+int dcrx_free_host(void *ptr) { if (ptr) HIP_TRY(hipHostFree(ptr)); return DCRX_OK; }
 int dcrx_memcpy_h2d(void *d, const void *h, size_t bytes) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return DCRX_OK; }
 int dcrx_memcpy_d2h(void *h, const void *d, size_t bytes) { HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return DCRX_OK; }
 int dcrx_memset_device(void *d, int value, size_t bytes) { HIP_TRY(hipMemset(d, value, bytes)); return DCRX_OK; }
@@ -440,6 +447,15 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     }
   }
   for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] = 0;
+  // Buffers the caller has pinned (dcrx_malloc_host, hipHostMalloc, hipHostRegister) are copied from and to directly: the
+  // staging copies — half of this call's time from pageable memory — fall away for them.
+  auto pinned = [](const void *p) {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+  };
+  const bool in_direct = n && pinned(hb->packed) && pinned(hb->packed + (size_t)n * hb->stride - 1);
+  const bool out_direct = n && pinned(records) && pinned(reinterpret_cast<const uint8_t *>(records + n) - 1);
   const uint64_t n_chunks = n ? (n + chunk - 1) / chunk : 1;
   uint64_t exc_at = 0;
   auto drain = [&](uint64_t k) -> int {       // chunk k's records and counters: from the pinned buffer to the caller's
@@ -447,7 +463,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     HIP_TRY(hipEventSynchronize(t->hev_out[set]));
     const uint8_t *h = t->h_stage + (size_t)set * set_bytes;
     const uint64_t c0 = k * chunk, cn = std::min<uint64_t>(chunk, n - c0);
-    if (cn) par_memcpy(records + c0, h + o_rec, cn * sizeof(dcrx_record_t));
+    if (cn && !out_direct) par_memcpy(records + c0, h + o_rec, cn * sizeof(dcrx_record_t));
     const uint64_t *hc = reinterpret_cast<const uint64_t *>(h + o_cnt);
     for (int c = 0; c < DCRX_N_COUNTERS; c++) counters[c] += hc[c];
     return DCRX_OK;
@@ -468,7 +484,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     uint64_t e0 = exc_at;
     while (exc_at < hb->n_exc && hb->exc_read[exc_at] < c0 + cn) exc_at++;
     const uint64_t ne = exc_at - e0;
-    if (cn) par_memcpy(h + o_packed, hb->packed + c0 * hb->stride, cn * hb->stride);
+    if (cn && !in_direct) par_memcpy(h + o_packed, hb->packed + c0 * hb->stride, cn * hb->stride);
     if (hb->lens && cn) std::memcpy(h + o_lens, hb->lens + c0, cn * 2);
     uint32_t *her = reinterpret_cast<uint32_t *>(h + o_er);
     for (uint64_t i = 0; i < ne; i++) her[i] = hb->exc_read[e0 + i] - (uint32_t)c0;      // read indices inside the chunk
@@ -477,7 +493,12 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     if (drc) return drc;
     // copy in (after the kernels that last read this set's device buffers), kernels, copy out
     if (k >= 2) HIP_TRY(hipStreamWaitEvent(t->hs_in, t->hev_run[set], 0));
-    HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, t->hs_in));
+    if (in_direct) {
+      HIP_TRY(hipMemcpyAsync(d + o_packed, hb->packed + c0 * hb->stride, cn * hb->stride, hipMemcpyHostToDevice, t->hs_in));
+      if (in_bytes > o_lens) HIP_TRY(hipMemcpyAsync(d + o_lens, h + o_lens, in_bytes - o_lens, hipMemcpyHostToDevice, t->hs_in));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, t->hs_in));
+    }
     HIP_TRY(hipEventRecord(t->hev_in[set], t->hs_in));
     HIP_TRY(hipStreamWaitEvent(t->hs_run, t->hev_in[set], 0));
     if (k >= 2) HIP_TRY(hipStreamWaitEvent(t->hs_run, t->hev_out[set], 0));     // (the records buffer of chunk k - 2 has been copied out)
@@ -493,7 +514,12 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
     HIP_TRY(hipEventRecord(t->hev_run[set], t->hs_run));
     HIP_TRY(hipStreamWaitEvent(t->hs_out, t->hev_run[set], 0));
-    HIP_TRY(hipMemcpyAsync(h + o_rec, d + o_rec, set_bytes - o_rec, hipMemcpyDeviceToHost, t->hs_out));
+    if (out_direct) {
+      if (cn) HIP_TRY(hipMemcpyAsync(records + c0, d + o_rec, cn * sizeof(dcrx_record_t), hipMemcpyDeviceToHost, t->hs_out));
+      HIP_TRY(hipMemcpyAsync(h + o_cnt, d + o_cnt, set_bytes - o_cnt, hipMemcpyDeviceToHost, t->hs_out));
+    } else {
+      HIP_TRY(hipMemcpyAsync(h + o_rec, d + o_rec, set_bytes - o_rec, hipMemcpyDeviceToHost, t->hs_out));
+    }
     HIP_TRY(hipEventRecord(t->hev_out[set], t->hs_out));
   }
   for (uint64_t k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; k++) { rc = drain(k); if (rc) return rc; }

@@ -353,6 +353,10 @@ int dcrx_set_device(int device);
 int dcrx_device_name(char *buf, size_t cap);
 int dcrx_malloc_device(void **ptr, size_t bytes);
 int dcrx_free_device(void *ptr);
+/* Page-locked host memory: dcrx_decombine copies straight from a `packed` buffer and into a `records` buffer that live in
+ * such memory (its own or any other the HIP runtime has pinned), without the staging copies pageable buffers need. */
+int dcrx_malloc_host(void **ptr, size_t bytes);
+int dcrx_free_host(void *ptr);
 int dcrx_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
 int dcrx_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
 int dcrx_memset_device(void *dst_device, int value, size_t bytes);

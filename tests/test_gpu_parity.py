@@ -580,3 +580,13 @@ def test_host_entry_pipelines_chunks_and_equals_the_device_entry():
         rec, cnt = nat.decombine(t, hb)
         assert rec.tobytes() == want.tobytes()
         assert (cnt == want_cnt).all()
+    # ... and from buffers the caller has pinned (dcrx_malloc_host): copied from and into directly, in every combination
+    hp = nat.synth_reads_host(t, cfg, 0, n, pinned=True)
+    assert hp.packed.tobytes() == hb.packed.tobytes()
+    out = nat.pinned_empty(n, nat.RECORD_DTYPE)
+    for batch, o in ((hp, out), (hb, out), (hp, None), (hp, out)):
+        if o is not None:
+            o.view(np.uint8)[:] = 0xEE
+        rec, cnt = nat.decombine(t, batch, out=o)
+        assert rec.tobytes() == want.tobytes()
+        assert (cnt == want_cnt).all()
