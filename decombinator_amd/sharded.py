@@ -107,7 +107,7 @@ class TupleGather:
       1. compaction of the step's records -> tuples, bitmap, count (on the device);
       2. count exchange: all_gather of the ranks' counts, copied to pinned host memory;
       3. one step later, when the counts have arrived: exact-size point-to-point transfers
-         (rank r sends count_r tuples and its bitmap; rank 0 receives them, rank order = read order).
+         (rank r sends one message: its bitmap, then count_r tuples; rank 0 posts the receives from all peers as one group).
 
     The caller alternates between `depth` record buffers (`records()`), the scan of step k + depth waits for
     the compaction of step k (`before_scan`), and a buffer set is reused only after its transfers completed.
@@ -130,11 +130,22 @@ class TupleGather:
         self.compact = compact
         self.slots = []
         dev = self.device
+        # a rank's message of a step: its bitmap, then its tuples — one buffer, one transfer per peer and step
+        bm_bytes = self.words * 8
+        msg_bytes = bm_bytes + n_reads * self.TUPLE_BYTES
+
+        def message():
+            m = torch.zeros(msg_bytes, dtype=torch.uint8, device=dev)
+            return m, m[:bm_bytes].view(torch.int64), m[bm_bytes:]
+
+        self.bm_bytes = bm_bytes
         for _ in range(depth):
+            msg, bitmap, hits = message()
             slot = {
                 "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=dev),
-                "hits": torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=dev),
-                "bitmap": torch.zeros(self.words, dtype=torch.int64, device=dev),
+                "msg": msg,
+                "hits": hits,
+                "bitmap": bitmap,
                 "n": torch.zeros(1, dtype=torch.int64, device=dev),
                 "counts": [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)],
                 "counts_host": torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda),
@@ -145,10 +156,10 @@ class TupleGather:
                 "step": -1,
             }
             if rank == 0:
-                slot["g_hits"] = [slot["hits"] if r == 0 else torch.empty(n_reads * self.TUPLE_BYTES, dtype=torch.uint8, device=dev)
-                                  for r in range(world)]
-                slot["g_bitmap"] = [slot["bitmap"] if r == 0 else torch.empty(self.words, dtype=torch.int64, device=dev)
-                                    for r in range(world)]
+                peers = [(slot["msg"], slot["bitmap"], slot["hits"]) if r == 0 else message() for r in range(world)]
+                slot["g_msg"] = [p[0] for p in peers]
+                slot["g_bitmap"] = [p[1] for p in peers]
+                slot["g_hits"] = [p[2] for p in peers]
             self.slots.append(slot)
 
     def records(self) -> torch.Tensor:
@@ -174,14 +185,12 @@ class TupleGather:
         s["posted"] = True
         with self._side():
             if self.rank == 0:
-                for r in range(1, self.world):
-                    if counts[r]:
-                        s["work"].append(dist.irecv(s["g_hits"][r][:counts[r] * self.TUPLE_BYTES], src=r))
-                    s["work"].append(dist.irecv(s["g_bitmap"][r], src=r))
+                # one grouped call for the receives from every peer (one launch on RCCL, not one per peer)
+                ops = [dist.P2POp(dist.irecv, s["g_msg"][r][:self.bm_bytes + counts[r] * self.TUPLE_BYTES], r) for r in range(1, self.world)]
+                if ops:
+                    s["work"].extend(dist.batch_isend_irecv(ops))
             else:
-                if counts[self.rank]:
-                    s["work"].append(dist.isend(s["hits"][:counts[self.rank] * self.TUPLE_BYTES], dst=0))
-                s["work"].append(dist.isend(s["bitmap"], dst=0))
+                s["work"].append(dist.isend(s["msg"][:self.bm_bytes + counts[self.rank] * self.TUPLE_BYTES], dst=0))
 
     def step(self, n_reads: int) -> None:
         """After the scan of this step has been queued on the current stream."""
