@@ -506,8 +506,12 @@ def main():
     if args.cfg_flags:
         os.environ.setdefault("DCRX_DEBUG_FLAGS", "1")      # profiling switches are refused by the library without this
     # HIP maps its streams onto 4 hardware queues by default; with the gather's streams (torch's side stream, RCCL's) beside
-    # the three of a decombine call, two of those would share a queue and run their kernels one after the other
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # the three of a decombine call, two of those would share a queue and run their kernels one after the other.  Only then:
+    # without the gather the default is right (the two-chain configs, two handles with three streams each, lose a third of
+    # their rate on 8 queues: 0.81 -> 1.12 ms per step).
+    gathering = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DCRX_BENCH_FORCE_GATHER") == "1"
+    if gathering and args.config in (2, 4):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
     run_rank(args)

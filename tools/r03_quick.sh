@@ -8,4 +8,4 @@ done
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/quick/trace -- python3 $R/bench.py --no-cpu-baseline --steps 20 > /dev/null 2>&1
 python3 $R/tools/timeline.py $R/gpurun_out/quick/trace
 rm -rf $R/gpurun_out/quick/trace
-cd $R && timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or 10M or flags" 2>&1 | tail -3
+cd $R && timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
