@@ -805,8 +805,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // everything on the caller's stream.
   const bool finish = !(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH));
   const bool side = finish && P.v2_side && P.v2_side2 && P.v2_ev_fork && P.v2_ev_join && P.v2_ev_join2 && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL);
-  const bool fork_rides = side && !ev_stop;
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, fork_rides ? P.v2_ev_fork : ev_stop, 0, T, B, cfg, rec,
+  // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
+  // serves as the fork event as well: one signal on the dispatch, no marker packet)
+  const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
+  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
                         d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -836,12 +838,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       return hipGetLastError();
     };
     if (side) {
-      if (!fork_rides) { e = hipEventRecord(P.v2_ev_fork, s); if (e != hipSuccess) return e; }
-      e = hipStreamWaitEvent(P.v2_side, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(P.v2_side, fork_ev, 0); if (e != hipSuccess) return e;
       hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue,
                             gqueue, qcap, queue_count, P.dev_tables);
       e = hipGetLastError(); if (e != hipSuccess) return e;
-      e = hipStreamWaitEvent(P.v2_side2, P.v2_ev_fork, 0); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(P.v2_side2, fork_ev, 0); if (e != hipSuccess) return e;
       e = general(P.v2_side2, V2_L_X, false, P.v2_ev_join2); if (e != hipSuccess) return e;
     }
     // the scan kernel's event lists E and C: the lean rescue, or — A/B — the general form at once
