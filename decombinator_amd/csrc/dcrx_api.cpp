@@ -79,9 +79,6 @@ struct dcrx_tables {
   void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
   hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
   uint32_t *d_v2_counts = nullptr;
-  uint32_t *d_tile_count = nullptr;
-  uint64_t *d_tile_off = nullptr;
-  uint64_t compact_reads = 0;
   // staging for the host-buffer entry point: two sets of device buffers and pinned host buffers, three streams
   // (copies in, kernels, copies out) and the events that order them
   uint8_t *d_stage = nullptr;
@@ -107,7 +104,7 @@ static void free_device_state(dcrx_tables *t) {
   if (t->v2_ev_join2) (void)hipEventDestroy(t->v2_ev_join2);
   t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
-  (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off); (void)hipFree(t->d_stage);
+  (void)hipFree(t->d_stage);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
   t->h_stage = nullptr; t->h_stage_bytes = 0;
   if (t->hs_in) (void)hipStreamDestroy(t->hs_in);
@@ -121,8 +118,8 @@ static void free_device_state(dcrx_tables *t) {
     t->hev_in[k] = t->hev_run[k] = t->hev_out[k] = nullptr;
   }
   t->d_blob = nullptr; t->d_exc_flag = nullptr; t->d_queue = nullptr;
-  t->d_tile_count = nullptr; t->d_tile_off = nullptr; t->d_stage = nullptr;
-  t->exc_flag_reads = 0; t->compact_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
+  t->d_stage = nullptr;
+  t->exc_flag_reads = 0; t->stage_bytes = 0; t->device = -1; t->constants_ready = false;
 }
 
 extern "C" {
@@ -305,14 +302,6 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     // later call's kernels start on a non-blocking stream of the caller's, which nothing orders against the null stream
     if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
     t->ws_dirty = false;
-  }
-  if (max_reads > t->compact_reads) {
-    (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_off);
-    t->d_tile_count = nullptr; t->d_tile_off = nullptr;
-    const size_t tiles = compact_tiles(max_reads) + 1024;
-    HIP_TRY(hipMalloc(&t->d_tile_count, tiles * 4));
-    HIP_TRY(hipMalloc(&t->d_tile_off, tiles * 8));
-    t->compact_reads = max_reads;
   }
   return DCRX_OK;
 }
