@@ -170,7 +170,7 @@ EXPORTS = [
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
-    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
 
 _lib = None
@@ -213,6 +213,9 @@ def lib():
         "dcrx_compact_hits_packed8_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_collapse_front": (C.c_int64, [vp, u64, C.POINTER(CollapseCfgC), vp, u64, vp, vp, i32]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
+        "dcrx_gzip_open": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
+        "dcrx_gzip_write": (i32, [vp, vp, u64]),
+        "dcrx_gzip_close": (i32, [vp]),
         "dcrx_device_count": (i32, []),
         "dcrx_set_device": (i32, [i32]),
         "dcrx_device_name": (i32, [C.c_char_p, C.c_size_t]),
@@ -555,6 +558,38 @@ def unpack_reads(batch: PackedBatch):
 def make_cfg(orientation="reverse", allow_ns=False, lenthreshold=130, flags=0) -> CfgC:
     o = ORIENTATIONS[orientation] if isinstance(orientation, str) else int(orientation)
     return CfgC(o, int(bool(allow_ns)), int(lenthreshold), int(flags))
+
+
+class GzipWriter:
+    """dcrx_gzip_open / write / close: a gzip file written by several threads (multi-member; any gzip reader reads it as one
+    stream).  Stands for the reference's `gzip.open(name, "wt")` + writelines (io.py:497-506)."""
+
+    def __init__(self, path: str, level: int = 6, n_threads: int = 0):
+        self._h = C.c_void_p()
+        check(lib().dcrx_gzip_open(os.fsencode(path), int(level), int(n_threads), C.byref(self._h)))
+
+    def write(self, data) -> None:
+        mv = memoryview(data).cast("B")
+        if mv.nbytes:
+            arr = np.frombuffer(mv, dtype=np.uint8)
+            check(lib().dcrx_gzip_write(self._h, arr.ctypes.data, mv.nbytes))
+
+    def close(self) -> None:
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            check(lib().dcrx_gzip_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _PinnedBlock:

@@ -9,6 +9,7 @@
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE   // memmem
 #endif
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <thread>
@@ -153,4 +154,103 @@ extern "C" int64_t dcrx_assemble_rows(const dcrx_record_t *records, uint64_t n_r
   try {
     return assemble_rows(records, n_reads, vdj, qual, id, bc, bcq, tail, field_sep, out, out_cap, n_rows);
   } catch (...) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_assemble_rows"); }
+}
+
+// ------------------------------------------------------------------------------
+// The intermediate files' gzip step (reference io.py:497-506: the text file is re-read and written through gzip.open,
+// one thread at level 9 — minutes for a run's `.n12`): the text goes out as a multi-member gzip file, its pieces deflated
+// by several threads.  Any gzip reader (zcat, Python's gzip, the reference's own opener) reads the members as one stream;
+// the decompressed bytes are the reference's, the compressed ones are not meant to be.
+// ------------------------------------------------------------------------------
+#include <zlib.h>
+#include <atomic>
+#include <cstdio>
+
+namespace {
+struct GzWriter {
+  FILE *f = nullptr;
+  int level = 6;
+  unsigned threads = 1;
+};
+constexpr size_t GZ_PIECE = 4u << 20;
+
+// one gzip member for data[0, n)
+bool gz_member(const uint8_t *data, size_t n, int level, std::vector<uint8_t> &out) {
+  z_stream z;
+  std::memset(&z, 0, sizeof z);
+  if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  out.resize(deflateBound(&z, (uLong)n) + 64);
+  z.next_in = const_cast<Bytef *>(data); z.avail_in = (uInt)n;
+  z.next_out = out.data(); z.avail_out = (uInt)out.size();
+  const int rc = deflate(&z, Z_FINISH);
+  const size_t got = out.size() - z.avail_out;
+  deflateEnd(&z);
+  if (rc != Z_STREAM_END) return false;
+  out.resize(got);
+  return true;
+}
+}  // namespace
+
+extern "C" int dcrx_gzip_open(const char *path, int level, int n_threads, void **writer) {
+  if (!path || !writer) return set_err(DCRX_E_INVALID, "null argument to dcrx_gzip_open");
+  *writer = nullptr;
+  if (level < 1 || level > 9) return set_err(DCRX_E_INVALID, "gzip level must be 1..9");
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return set_err(DCRX_E_INVALID, "cannot open the gzip output file");
+  GzWriter *w = new GzWriter;
+  w->f = f; w->level = level;
+  unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("DCRX_HOST_THREADS")) { if (n_threads <= 0) nt = (unsigned)std::atoi(e); }
+  w->threads = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+  *writer = w;
+  return DCRX_OK;
+}
+
+extern "C" int dcrx_gzip_write(void *writer, const void *data, uint64_t n_bytes) {
+  GzWriter *w = static_cast<GzWriter *>(writer);
+  if (!w || !w->f || (n_bytes && !data)) return set_err(DCRX_E_INVALID, "null argument to dcrx_gzip_write");
+  const uint8_t *p = static_cast<const uint8_t *>(data);
+  const size_t pieces = (size_t)((n_bytes + GZ_PIECE - 1) / GZ_PIECE);
+  try {
+    // rounds of `threads` x 4 pieces: deflated side by side, written in order (memory: a round's output, not the file's)
+    const size_t round = (size_t)w->threads * 4;
+    std::vector<std::vector<uint8_t>> out(std::min(round, std::max<size_t>(pieces, 1)));
+    for (size_t p0 = 0; p0 < pieces; p0 += round) {
+      const size_t cnt = std::min(round, pieces - p0);
+      std::atomic<size_t> next{0};
+      std::atomic<int> bad{0};
+      auto work = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < cnt;) {
+          const size_t off = (p0 + k) * GZ_PIECE;
+          if (!gz_member(p + off, (size_t)std::min<uint64_t>(GZ_PIECE, n_bytes - off), w->level, out[k])) bad = 1;
+        }
+      };
+      const unsigned nt = (unsigned)std::min<size_t>(w->threads, cnt);
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+      work();
+      for (auto &x : th) x.join();
+      if (bad) return set_err(DCRX_E_INVALID, "deflate failed");
+      for (size_t k = 0; k < cnt; k++)
+        if (std::fwrite(out[k].data(), 1, out[k].size(), w->f) != out[k].size()) return set_err(DCRX_E_INVALID, "short write to the gzip output file");
+    }
+  } catch (...) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_gzip_write"); }
+  return DCRX_OK;
+}
+
+extern "C" int dcrx_gzip_close(void *writer) {
+  GzWriter *w = static_cast<GzWriter *>(writer);
+  if (!w) return DCRX_OK;
+  int rc = DCRX_OK;
+  if (w->f) {
+    // (an empty file is not a gzip stream: the reference's gzip.open writes a header and trailer even for no data)
+    if (std::ftell(w->f) == 0) {
+      std::vector<uint8_t> out;
+      if (!gz_member(reinterpret_cast<const uint8_t *>(""), 0, w->level, out) || std::fwrite(out.data(), 1, out.size(), w->f) != out.size())
+        rc = set_err(DCRX_E_INVALID, "short write to the gzip output file");
+    }
+    if (std::fclose(w->f) != 0 && rc == DCRX_OK) rc = set_err(DCRX_E_INVALID, "closing the gzip output file failed");
+  }
+  delete w;
+  return rc;
 }

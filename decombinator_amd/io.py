@@ -114,6 +114,31 @@ def cli_args(argv=None) -> dict:
     return vars(create_parser().parse_args(argv))
 
 
+class _GzText:
+    """What write_text / write need of a text file object, in front of a GzipWriter: str is buffered and encoded as the
+    reference's text-mode file does (UTF-8, "\n" kept), bytes go through `buffer` as they are."""
+
+    def __init__(self, gz):
+        self._gz, self._pending, self._n = gz, [], 0
+        self.buffer = self
+
+    def write(self, x):
+        if isinstance(x, str):
+            x = x.encode("utf-8")
+            self._pending.append(x)
+            self._n += len(x)
+            if self._n >= (8 << 20):
+                self.flush()
+        else:
+            self.flush()
+            self._gz.write(x)
+
+    def flush(self):
+        if self._pending:
+            self._gz.write(b"".join(self._pending))
+            self._pending, self._n = [], 0
+
+
 def write_out_intermediate(data: list, inputargs: dict, suffix: str):
     """`<outpath><prefix><file id>_<chain name><suffix>`: one row per line, fields joined by
     ", "; gzipped unless dontgzip; mode 666 (reference io.py:480-513)."""
@@ -124,17 +149,26 @@ def write_out_intermediate(data: list, inputargs: dict, suffix: str):
     else:
         outfilename = (inputargs["outpath"] + inputargs["prefix"] + f"{filename_id}"
                        + f"_{chainnams[inputargs['chain'].lower()]}" + suffix)
-    with open(outfilename, "w") as outfile:
-        if hasattr(data, "write_text"):          # decombine.N12Rows: the rows are text already
-            data.write_text(outfile, ", ")
-        else:
-            for line in data:
-                outfile.write(", ".join(map(str, line)) + "\n")
     if not inputargs["dontgzip"]:
+        # the reference writes the text, re-reads it through gzip.open (one thread, level 9) and unlinks it; what is left
+        # is the .gz, written here at once by libdcrx's threaded gzip writer (same decompressed bytes)
+        from . import _native as nat
         print("Compressing intermediate output file to", outfilename + ".gz")
-        with open(outfilename) as infile, gzip.open(outfilename + ".gz", "wt") as outfile:
-            outfile.writelines(infile)
-        os.unlink(outfilename)
+        with nat.GzipWriter(outfilename + ".gz", level=int(os.environ.get("DCRX_GZIP_LEVEL", "6"))) as gz:
+            out = _GzText(gz)
+            if hasattr(data, "write_text"):      # decombine.N12Rows: the rows are text already
+                data.write_text(out, ", ")
+            else:
+                for line in data:
+                    out.write(", ".join(map(str, line)) + "\n")
+            out.flush()
         outfilename += ".gz"
+    else:
+        with open(outfilename, "w") as outfile:
+            if hasattr(data, "write_text"):
+                data.write_text(outfile, ", ")
+            else:
+                for line in data:
+                    outfile.write(", ".join(map(str, line)) + "\n")
     sort_permissions(outfilename)
     return outfilename

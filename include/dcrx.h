@@ -343,6 +343,14 @@ typedef struct dcrx_collapse_row {
 int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
                             uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads);
 
+/* ---- the intermediate files' gzip step (reference io.py:497-506: the text re-read and written through gzip.open) ----
+ * A multi-member gzip file whose pieces (4 MB of text each) are deflated by n_threads threads (0: the host's); any gzip
+ * reader sees one stream with exactly the bytes written.  level 1..9 (the reference's gzip.open uses 9).
+ * Errors (a path that cannot be opened, a short write) are DCRX_E_INVALID with the text in dcrx_last_error(). */
+int dcrx_gzip_open(const char *path, int level, int n_threads, void **writer);
+int dcrx_gzip_write(void *writer, const void *data, uint64_t n_bytes);
+int dcrx_gzip_close(void *writer);
+
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */
 int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);

@@ -18,6 +18,7 @@ from decombinator_amd import _native as nat, decombine as dec, io as dio, synth,
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=4_000_000)
 ap.add_argument("--gz", action="store_true")
+ap.add_argument("--py-gzip", action="store_true", help="also time the reference's gzip.open step on the same rows")
 args = ap.parse_args()
 
 ts = synth.config_tagset(2)
@@ -49,11 +50,21 @@ with tempfile.TemporaryDirectory() as td:
         t1 = time.perf_counter()
         out = dio.write_out_intermediate(rows, a, ".n12")
         dw = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        outz = dio.write_out_intermediate(rows, dict(a, dontgzip=False), ".n12")      # the reference's default: gzipped
+        dwz = time.perf_counter() - t1
+        mb, mbz = os.path.getsize(out) / 1e6, os.path.getsize(outz) / 1e6
+        dpy = None
+        if rep == 1 and args.py_gzip:          # what the reference's gzip.open step takes on the same text (one thread, level 9)
+            t1 = time.perf_counter()
+            with open(out) as fi, gzip.open(out + ".py.gz", "wt") as fo:
+                fo.writelines(fi)
+            dpy = time.perf_counter() - t1
         ph = ", ".join(f"{k} {v:.2f}s" for k, v in dec.stage_seconds.items())
         collapse.counts.clear()
         t2 = time.perf_counter()
         front = collapse.read_in_rows(rows, {"oligo": "m13", "allowNs": False, "lenthreshold": 130}, [20, 1, 30])
         df = time.perf_counter() - t2
         print(f"STAGE reads={n} gz={args.gz} input_MB={size / 1e6:.0f} rows={len(rows)} decombinator={dt:.2f}s "
-              f"({n / dt / 1e6:.2f} Mreads/s; {ph}) write_n12={dw:.2f}s collapse_front={df:.2f}s "
+              f"({n / dt / 1e6:.2f} Mreads/s; {ph}) write_n12={dw:.2f}s write_n12_gz={dwz:.2f}s ({mb:.0f} -> {mbz:.0f} MB{'' if dpy is None else f'; gzip.open level 9: {dpy:.1f}s'}) collapse_front={df:.2f}s "
               f"({len(rows) / max(df, 1e-9) / 1e6:.2f} Mrows/s, {len(front.kept())} rows kept, {int((front.status == 255).sum())} deferred to the regex)")
