@@ -222,7 +222,9 @@ extern "C" int dcrx_gzip_write(void *writer, const void *data, uint64_t n_bytes)
       auto work = [&]() {
         for (size_t k; (k = next.fetch_add(1)) < cnt;) {
           const size_t off = (p0 + k) * GZ_PIECE;
-          if (!gz_member(p + off, (size_t)std::min<uint64_t>(GZ_PIECE, n_bytes - off), w->level, out[k])) bad = 1;
+          try {
+            if (!gz_member(p + off, (size_t)std::min<uint64_t>(GZ_PIECE, n_bytes - off), w->level, out[k])) bad = 1;
+          } catch (...) { bad = 1; }      // (out of memory inside a worker: reported, not thrown across the thread)
         }
       };
       const unsigned nt = (unsigned)std::min<size_t>(w->threads, cnt);
