@@ -35,7 +35,7 @@ timeout 600 python3 $R/bench.py --no-cpu-baseline --cfg-flags 32768 2>/dev/null 
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29618 DCRX_BENCH_FORCE_GATHER=1 timeout 600 python3 $R/bench.py --no-cpu-baseline > $O/forced_gather.out 2> $O/forced_gather.err; grep "^{" $O/forced_gather.out | tail -1 > $S/bench_forced_gather_one_rank.log; tail -3 $O/forced_gather.err
 timeout 300 python3 $R/tools/both_rate.py 2>/dev/null | grep ORIENTATION > $S/orientations.log
 timeout 300 python3 $R/tools/pcie.py 2>/dev/null | grep PCIE > $S/pcie.log
-timeout 600 python3 $R/tools/stage.py --reads 4000000 2>/dev/null | grep STAGE > $S/stage.log
+timeout 900 python3 $R/tools/stage.py --reads 4000000 --py-gzip 2>/dev/null | grep STAGE > $S/stage.log
 timeout 600 python3 $R/tools/long_reads.py 2>/dev/null | tail -8 > $S/long_reads.log
 timeout 300 $R/tools/micro/valu_issue > $S/valu_issue.log 2>&1
 rm -rf $O/trace $O/pmc_*
