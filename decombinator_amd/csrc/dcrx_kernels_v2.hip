@@ -450,6 +450,14 @@ __device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori
 // ... as a call, for the lean kernels: what their straight-line forms do not settle (one read in two million) is finished
 // on the spot, with the tables the kernel has staged, instead of travelling to a pass of its own behind them (a launch, a join and one
 // read's latency on the critical path of every step).  Not inlined: the lean loops keep their registers.
+constexpr int V2_LEFT_SLOTS = 15;      // entries a wave may note per job; more (never seen) go to the list kernel
+// a lane notes the slot of an entry its lean form did not settle (LDS, per wave)
+__device__ __forceinline__ void v2_note_left(uint32_t *left, const uint32_t slot, const BatchDev &B, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue,
+                                             const uint32_t qcap, uint32_t *__restrict__ queue_count, const uint32_t r, const bool exc) {
+  const uint32_t at = atomicAdd(&left[0], 1u);
+  if (at < (uint32_t)V2_LEFT_SLOTS) left[1 + at] = slot;
+  else v2_hand_over(B, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30), r, exc);
+}
 template <int NW>
 struct V2EntryWords { uint32_t lg[NW], w[NW]; };
 template <bool UNIFORM_LEN, int NW, int ORI>
@@ -492,6 +500,8 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   strip[NW] = 0u; strip[NW + 1] = 0u;
   const LdsWords lw{dcrx_ldsaddr_of(strip)};
   __syncthreads();
+  __shared__ uint32_t s_left[DCRX_V2_TBLOCK / 64][1 + V2_LEFT_SLOTS];      // per wave: entries its lean form left (count, slots)
+  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
   const int lane = tid & 63;
   // `split` waves share a region (a scan block's list): wave k of them takes the batches k, k + split, ...
   const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
@@ -534,18 +544,29 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
       v2_tally(lds_counts, lane, status, o == 0);
-      if (__builtin_expect(status == TAIL2_SLOW, 0)) {      // (one read in millions) the general form, on the spot
+      // what the lean form does not settle (one read in millions): noted, and finished behind the job's loop, so that no
+      // value of the loop lives across a call
+      if (__builtin_expect(status == TAIL2_SLOW, 0)) v2_note_left(s_left[tid >> 6], first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, false);
+    }
+    const uint32_t n_left = min(s_left[tid >> 6][0], (uint32_t)V2_LEFT_SLOTS);
+    if (__builtin_expect(n_left != 0u, 0)) {
+      const bool live = (uint32_t)lane < n_left;
+      const uint32_t slot = live ? s_left[tid >> 6][1 + lane] : 0u;
+      uint32_t x[2 + NW];
+      v2_get_rows<2 + NW>(tq, Q.tcap, slot, live, x);
+      if (live) {
         // the entry's flag log: the V pair and (when one pair holds a J tag) the J pair, as the scan saw them
-        const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
+        const uint32_t dg = x[1], vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
         V2EntryWords<NW> e;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
           uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
           if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
-          e.lg[k] = l; e.w[k] = w[k];
+          e.lg[k] = l; e.w[k] = x[2 + k];
         }
-        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, r | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
+        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, x[0] | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
+      if (lane == 0) s_left[tid >> 6][0] = 0u;
     }
   }
   __syncthreads();
@@ -611,6 +632,8 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
   // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
   const Counters C{lds_counts}, Cdry{lds_bk + V.bk_bytes / 4 + (uint32_t)DCRX_V2_FBLOCK * lds_words_stride<NW>()};
   __syncthreads();
+  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
+  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
   const int lane = tid & 63;
   const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
   // jobs: (list, region, part); the lists one after the other, so that the waves in flight at one time run the same code
@@ -653,12 +676,21 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
-      if (__builtin_expect(status == RESCUE2_SLOW, 0)) {      // (one read in millions) the general form, on the spot
+      if (__builtin_expect(status == RESCUE2_SLOW, 0)) v2_note_left(s_left[tid >> 6], first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, (x[0] & V2_R_EXC) != 0u);
+    }
+    const uint32_t n_left = min(s_left[tid >> 6][0], (uint32_t)V2_LEFT_SLOTS);      // (as in the tail kernel)
+    if (__builtin_expect(n_left != 0u, 0)) {
+      const bool live = (uint32_t)lane < n_left;
+      const uint32_t slot = live ? s_left[tid >> 6][1 + lane] : 0u;
+      uint32_t x[1 + 2 * NW];
+      v2_get_rows<1 + 2 * NW>(l.rows, l.cap, slot, live, x);
+      if (live) {
         V2EntryWords<NW> e;
 #pragma unroll
-        for (int k = 0; k < NW; k++) { e.lg[k] = lg[k]; e.w[k] = w[k]; }
+        for (int k = 0; k < NW; k++) { e.lg[k] = x[1 + k]; e.w[k] = x[1 + NW + k]; }
         v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, x[0], e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
+      if (lane == 0) s_left[tid >> 6][0] = 0u;
     }
   }
   __syncthreads();
