@@ -3,8 +3,9 @@ formats of the reference's src/decombinator/io.py:
 
   create_args_dict        reference io.py:391-465 (same keys, same defaults)
   create_parser/cli_args  reference io.py:41-92, 95-383 (the common + decombine flags; the
-                          collapse / translate flags are accepted so that existing command
-                          lines parse, but those stages are not part of this build)
+                          collapse / translate flags as far as the front half of collapse and
+                          the translate sub-command use them, the rest accepted so that existing
+                          command lines parse)
   write_out_intermediate  reference io.py:480-513 (", "-joined rows, optional gzip, chmod 666)
 """
 from __future__ import annotations
@@ -86,12 +87,12 @@ def _later_stage_flags(p: argparse.ArgumentParser):
 def create_parser() -> argparse.ArgumentParser:
     parser = argparse.ArgumentParser(
         prog="decombinator",
-        description="Decombinator `decombine` stage on MI355X (HIP) and the per-row front half of `collapse`.  Sub-commands as in "
-                    "the reference; the grouping half of `collapse` and `translate` are not part of this build.")
+        description="Decombinator `decombine` stage on MI355X (HIP), the per-row front half of `collapse` and `translate` (CDR3 per DCR).  "
+                    "Sub-commands as in the reference; the grouping / clustering half of `collapse` is not part of this build.")
     parser.add_argument("-v", "--version", action="version", version=__version__)
     sub = parser.add_subparsers(dest="command", help="Available commands")
     sub.required = False
-    pipe = sub.add_parser("pipeline", help="decombine, then the front half of collapse (grouping and translate: not in this build)")
+    pipe = sub.add_parser("pipeline", help="decombine, then the front half of collapse (its grouping half: not in this build)")
     _common(pipe); _decombine(pipe); _later_stage_flags(pipe)
     dec = sub.add_parser("decombine", help="Decombine TCR reads")
     _common(dec); _decombine(dec)

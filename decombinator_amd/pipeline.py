@@ -41,8 +41,8 @@ def run(args: Optional[dict[str, Any]] = None, cli_args: Optional[dict[str, Any]
     print("Decombinator complete...")
     if len(data) and inp.get("oligo") and not inp.get("nobarcoding"):
         collapse_front(data, inp)
-    print("The grouping / clustering half of `collapse` and `translate` are not part of this build: feed the .n12 to the "
-          "reference's `decombinator collapse` and `decombinator translate`.")
+    print("The grouping / clustering half of `collapse` is not part of this build: feed the .n12 to the reference's "
+          "`decombinator collapse`; `decombinator translate` of this build takes its .freq.")
     print(f"Pipeline complete in {datetime.now() - start}")
     return data
 
