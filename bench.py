@@ -33,10 +33,9 @@ sharded over the ranks (sharded.shard_range), every rank working through its
 shard in 10 M-read steps — the strong-scaling curve at 1/2/4/8 GPUs.  The
 default, and the line the driver records, is config 2.
 
---dry-gloo (CPU, tests only): the same rank program over the gloo backend with
-tests/dry_device.py standing in for the GPU — it exercises the spawn path, the
-sharding and the tuple-gather protocol; its line says "dry_run": true and carries
-no rate.
+The CPU test of the spawn path, the sharding and the tuple-gather protocol lives
+in tests/bench_dry.py (it hands run_rank() a stand-in device and the gloo backend);
+nothing in this file can produce a line without a GPU.
 """
 from __future__ import annotations
 
@@ -74,14 +73,13 @@ def parse_args(argv=None):
                          "4 = a fixed total of reads sharded over the ranks (strong scaling), 5 = mouse gamma+delta")
     ap.add_argument("--total-reads", type=int, default=10**9, help="config 4: reads of the whole job")
     ap.add_argument("--no-gather-ab", action="store_true", help="N > 1: skip the second loop that prices the exposed gather time")
-    ap.add_argument("--dry-gloo", action="store_true", help="tests only: CPU ranks over gloo, tests/dry_device.py as the device")
     return ap.parse_args(argv)
 
 
-def spawn_ranks(args, argv) -> int:
-    """The parent of a plain `bench.py --gpus N`: N children of this file, one per GPU.  Nothing here imports torch or
-    initialises HIP (a process that has must not exec another program on this pool, and need not: the children are
-    fresh processes)."""
+def spawn_ranks(args, argv, script=None) -> int:
+    """The parent of a plain `bench.py --gpus N`: N children of this file (or of `script`: tests/bench_dry.py), one per
+    GPU.  Nothing here imports torch or initialises HIP (a process that has must not exec another program on this pool,
+    and need not: the children are fresh processes)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -92,7 +90,7 @@ def spawn_ranks(args, argv) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
         env.setdefault("OMP_NUM_THREADS", "1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
     out0 = ""
     failed = None
@@ -143,6 +141,35 @@ def host_cpu_report() -> dict:
     return rep
 
 
+def usable_cores() -> int:
+    """Cores this process can really use: the cgroup's CPU quota (cpu.max `quota period`, or the v1 pair) when there is
+    one, capped by the affinity mask — not the thread count that happened to win."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cores = min(cores, max(1, int(round(quota / period))))
+        except Exception:
+            pass
+    return cores
+
+
+# The reference's own path — the unmodified decombine.py loop `dcr(revcomp(read))` (:998-1001) with the stand-in matcher for
+# acora — cannot run on the GPU box (the reference does not travel); it was timed in the build container on 100 k of the same
+# reads by tools/ref_python_loop.py (BASELINE.md section 4) and rides along as a constant, labelled as such.
+REFERENCE_PYTHON = {
+    "value": 0.0084, "unit": "Mreads/s", "cores": 1, "where": "build container, 1 core, stand-in matcher for acora",
+    "script": "tools/ref_python_loop.py", "sample": "first 100000 reads of the same synthetic workload",
+    "measured_by_this_run": False,
+}
+
+
 def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     """The oracle on `sample_reads` of the very same reads (POSIX threads inside the C library; each thread owns a
     contiguous slice and repeats it until it has about a second of work, so that thread start-up does not show):
@@ -176,20 +203,24 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
         if rate > best:
             best, best_k, best_t, best_passes = rate, k, tn, passes
     return {
-        "value": round(best / 1e6, 4), "unit": "Mreads/s", "cores": best_k, "kind": "port",
+        "value": round(best / 1e6, 4), "unit": "Mreads/s", "cores": usable_cores(), "threads": best_k, "kind": "port",
         "sample": f"first {sample_reads} reads of the same synthetic workload x {best_passes} passes, oracle/dcr_oracle.c "
-                  f"(C port of the reference's Python path), {best_k} POSIX threads (the fastest of the thread counts tried), {best_t:.2f} s",
+                  f"(C port of the reference's Python path), {best_k} POSIX threads (the fastest of the thread counts tried) on "
+                  f"{usable_cores()} usable cores (cgroup quota / affinity), {best_t:.2f} s",
+        "reference_python": REFERENCE_PYTHON,
         "value_1thread": round(rate1 / 1e6, 4), "sample_1thread": f"first {n1} reads, 1 thread, {t1:.2f} s",
         "mreads_per_s_by_threads": by_threads, "host": host_cpu_report(),
     }
 
 
-def run_rank(args):
+def run_rank(args, device_factory=None):
+    """One rank.  `device_factory` is given only by tests/bench_dry.py: a CPU stand-in for the device over the gloo backend
+    (the line then says "dry_run": true and carries no rate); the command line of this file cannot set it."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
-    dry = args.dry_gloo
+    dry = device_factory is not None
 
     # torch first: its bundled HIP runtime (same soname as /opt/rocm's) must be the one
     # libdcrx binds to, so that torch/RCCL and the kernels share one runtime.
@@ -202,7 +233,6 @@ def run_rank(args):
     from decombinator_amd import sharded
 
     if dry:
-        from tests import dry_device          # CPU stand-in for the device (tests only; its line is marked dry_run)
         dev = torch.device("cpu")
     else:
         if not torch.cuda.is_available():
@@ -252,10 +282,11 @@ def run_rank(args):
         batches = [(rank * n, n)]
         job_reads_per_pass = None
     if dry:
-        device = dry_device.DryDevice(nat, all_tables, tagsets, cfg_synth, batches, n)
+        device = device_factory(nat, all_tables, tagsets, cfg_synth, batches, n)
     else:
         device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
-    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps) if use_dist else None
+    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps,
+                                 n_v=info["n_v"], n_j=info["n_j"]) if use_dist else None
     if use_dist and not dry:
         # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the tuples of step k
         # really move beside the scan of step k+1 (the compaction's blocks fit beside a scan block on any unit)
@@ -350,7 +381,7 @@ def run_rank(args):
         }
         if dry:
             line["dry_run"] = True
-            line["note"] = "CPU ranks over gloo with tests/dry_device.py in place of the GPU: a test of the launch, sharding and gather protocol, not a measurement"
+            line["note"] = "CPU ranks over gloo with a stand-in device (tests/bench_dry.py): a test of the launch, sharding and gather protocol, not a measurement"
         else:
             step_avg_ms, kern_avg_ms = sum(step_ms) / len(step_ms), sum(kern_ms) / len(kern_ms)
             # (the timed steps that carry events: for config 4 the last, shorter step of a shard may be among them; the reads of

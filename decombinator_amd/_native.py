@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -44,7 +45,8 @@ F_PROFILE_SCAN_ONLY = 2
 F_ONE_BASE_SCAN = 4
 F_V1_KERNELS = 64        # the three-launch form even where the v2 kernel applies
 F_V2_NO_LEAN_RESCUE = 8192   # A/B and tests: event entries go to the general form at once (no lean rescue kernel)
-F_V2_LEAN_SERIAL = 32768     # A/B: lean kernels one after the other instead of side by side
+F_V2_LEAN_SERIAL = 32768     # A/B: the finishing roles as launches of their own, one after the other (default: roles of one launch)
+F_V2_SIDE_STREAMS = 65536    # A/B: round 3's shape, the tail kernel and the X pass on side streams beside the rescue kernel
 
 
 def F_V2_SHAPE(k):
@@ -112,7 +114,7 @@ class SpansC(C.Structure):
     _fields_ = [("text", C.c_void_p), ("start", C.c_void_p), ("len", C.c_void_p)]
 
 
-_collapse_buf = None
+_collapse_tls = threading.local()      # per thread: the row buffer of its last collapse_front call
 
 
 class CollapseCfgC(C.Structure):
@@ -146,10 +148,13 @@ def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, q
     n = check(lib().dcrx_collapse_front(buf.ctypes.data, len(text), C.byref(cfg), None, 0, None, scratch.ctypes.data, 0))      # sizing call
     # (the per-row records of a call are written once and the pages behind a fresh allocation cost more than the rows themselves:
     # the buffer of the last call is kept and handed out again when the caller has let go of it)
-    global _collapse_buf
-    if _collapse_buf is None or len(_collapse_buf) < n or sys.getrefcount(_collapse_buf) > 2:
-        _collapse_buf = np.empty(max(n, 1), dtype=COLLAPSE_ROW_DTYPE)
-    rows = _collapse_buf
+    # (per thread: two threads never share a buffer, and a thread hands its own out again only when nothing else refers to it)
+    held = getattr(_collapse_tls, "buf", None)
+    if held is None or len(held) < n or sys.getrefcount(held) > 3:
+        held = np.empty(max(n, 1), dtype=COLLAPSE_ROW_DTYPE)
+        _collapse_tls.buf = held
+    rows = held
+    del held
     offs = np.empty(n + 1, dtype=np.uint64)
     cnt = np.zeros(len(COLLAPSE_COUNTERS), dtype=np.uint64)
     check(lib().dcrx_collapse_front(buf.ctypes.data, len(text), C.byref(cfg), rows.ctypes.data, n, offs.ctypes.data, cnt.ctypes.data, int(n_threads)))

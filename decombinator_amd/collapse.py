@@ -17,6 +17,7 @@ read the same here.
 from __future__ import annotations
 
 import collections as coll
+import collections.abc
 
 import regex
 

@@ -53,14 +53,18 @@ static void par_memcpy(void *dst, const void *src, size_t n) {
   static const unsigned want = [] { const char *e = std::getenv("DCRX_HOST_THREADS"); unsigned k = e ? (unsigned)std::atoi(e) : std::min(12u, std::max(1u, std::thread::hardware_concurrency() / 2)); return std::max(1u, std::min(k, 16u)); }();
   const unsigned nt = n < (8u << 20) ? 1u : want;
   if (nt == 1) { std::memcpy(dst, src, n); return; }
-  std::vector<std::thread> th;
+  // (a worker that cannot be started — std::system_error, or no memory for the vector — leaves its slice to this thread:
+  // nothing is thrown past the threads already running)
+  std::thread th[16];
   const size_t per = ((n / nt) + 4095) & ~(size_t)4095;
   for (unsigned k = 1; k < nt; k++) {
     const size_t a = std::min(n, per * k), b = std::min(n, per * (k + 1));
-    if (b > a) th.emplace_back([=] { std::memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); });
+    if (b <= a) continue;
+    try { th[k] = std::thread([=] { std::memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); }); }
+    catch (...) { std::memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); }
   }
   std::memcpy(dst, src, std::min(n, per));
-  for (auto &x : th) x.join();
+  for (auto &x : th) if (x.joinable()) x.join();
 }
 
 struct dcrx_tables {
@@ -76,7 +80,8 @@ struct dcrx_tables {
   uint32_t *d_exc_flag = nullptr;
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
-  void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;  // v2 kernels: the per-wave lists between scan and finishing
+  void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;
+  uint64_t *d_v2_acc = nullptr;     // the v2 kernels' tallies of the call in flight (zero between calls)  // v2 kernels: the per-wave lists between scan and finishing
   hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
   uint32_t *d_v2_counts = nullptr;
   // staging for the host-buffer entry point: two sets of device buffers and pinned host buffers, three streams
@@ -104,6 +109,7 @@ static void free_device_state(dcrx_tables *t) {
   if (t->v2_ev_join2) (void)hipEventDestroy(t->v2_ev_join2);
   t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
+  (void)hipFree(t->d_v2_acc); t->d_v2_acc = nullptr; t->plan.v2_acc = nullptr;
   (void)hipFree(t->d_stage);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
   t->h_stage = nullptr; t->h_stage_bytes = 0;
@@ -275,6 +281,8 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
       HIP_TRY(hipMalloc(&t->d_v2_events, er * 16));
       HIP_TRY(hipMalloc(&t->d_v2_slow, sr * 16));
       HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 16));
+      if (!t->d_v2_acc) { HIP_TRY(hipMalloc(&t->d_v2_acc, DCRX_N_COUNTERS * 8)); t->ws_dirty = true; }
+      t->plan.v2_acc = t->d_v2_acc;
       t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
       t->plan.v2_slow = reinterpret_cast<uint4 *>(t->d_v2_slow);
       t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;
@@ -298,6 +306,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     // on the stream the kernels will run on (a non-blocking stream does not order against the null stream)
     HIP_TRY(hipMemsetAsync(t->d_exc_flag, 0, ((t->exc_flag_reads + 31) / 32) * 4 + 16, stream));
     HIP_TRY(hipMemsetAsync(t->d_queue, 0, DCRX_QUEUE_HEADER * 4, stream));
+    if (t->d_v2_acc) HIP_TRY(hipMemsetAsync(t->d_v2_acc, 0, DCRX_N_COUNTERS * 8, stream));
     // dcrx_reserve_device and the host-buffer entry come here with the null stream: the fills must have landed before a
     // later call's kernels start on a non-blocking stream of the caller's, which nothing orders against the null stream
     if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
@@ -315,6 +324,7 @@ static int check_batch(const dcrx_batch_t *b) {
   if (!b->lens && b->read_len > 4 * b->stride) return set_err(DCRX_E_INVALID, "read_len exceeds 4*stride");
   if (b->n_reads && !b->packed) return set_err(DCRX_E_INVALID, "packed is null");
   if (b->n_exc && (!b->exc_read || !b->exc_pos || !b->exc_chr)) return set_err(DCRX_E_INVALID, "exception arrays are null");
+  if (b->n_exc >= (1ull << 32)) return set_err(DCRX_E_INVALID, "more than 2^32-1 exception entries in one call");
   return DCRX_OK;
 }
 
@@ -363,8 +373,31 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   return DCRX_OK;
 }
 
+static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *hb, dcrx_record_t *records, uint64_t *counters);
+
+// The host-buffer entry.  Whatever goes wrong inside the chunk pipeline — a HIP error, no memory, a helper thread that cannot
+// be started — comes back as a code, and only after the three streams have drained: their asynchronous copies may target the
+// caller's own (pinned) `packed` and `records` buffers, which the caller is free to release once this returns.
 int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *hb, dcrx_record_t *records,
                    uint64_t *counters) {
+  int rc;
+  try { rc = decombine_host(t, cfg, hb, records, counters); }
+  catch (const std::bad_alloc &) { rc = set_err(DCRX_E_NOMEM, "out of host memory in dcrx_decombine"); }
+  catch (const std::exception &e) { rc = set_err(DCRX_E_NOMEM, std::string("dcrx_decombine: ") + e.what()); }
+  catch (...) { rc = set_err(DCRX_E_NOMEM, "dcrx_decombine: unexpected exception"); }
+  if (rc != DCRX_OK && t && t->hs_in) {
+    const std::string keep = g_err;       // (the synchronising calls must not replace the message of what failed)
+    (void)hipStreamSynchronize(t->hs_in); (void)hipStreamSynchronize(t->hs_run); (void)hipStreamSynchronize(t->hs_out);
+    (void)hipGetLastError();
+    t->ws_dirty = true;
+    g_err = keep;
+  }
+  return rc;
+}
+
+}  // extern "C"
+
+static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *hb, dcrx_record_t *records, uint64_t *counters) {
   if (!t || !cfg || !counters) return set_err(DCRX_E_INVALID, "null argument");
   int rc = check_batch(hb);
   if (rc) return rc;
@@ -500,7 +533,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     db.exc_pos = reinterpret_cast<const uint16_t *>(d + o_ep);
     db.exc_chr = d + o_ec;
     rc = dcrx_decombine_device(t, cfg, &db, reinterpret_cast<dcrx_record_t *>(d + o_rec), reinterpret_cast<uint64_t *>(d + o_cnt), t->hs_run);
-    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    if (rc) return rc;          // (the caller of this function drains the streams)
     HIP_TRY(hipEventRecord(t->hev_run[set], t->hs_run));
     HIP_TRY(hipStreamWaitEvent(t->hs_out, t->hev_run[set], 0));
     if (out_direct) {
@@ -532,6 +565,8 @@ static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64
                          (hipStream_t)stream));
   return DCRX_OK;
 }
+
+extern "C" {
 
 int dcrx_compact_hits_device(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index,
                              dcrx_record_t *d_hits, uint64_t *d_hit_index, uint64_t *d_n_hits, void *stream) {

@@ -16,6 +16,7 @@
 #endif
 #include <cstring>
 #include <cstdlib>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -204,8 +205,20 @@ uint8_t front_row(const char *row, int len, const Cfg &c, dcrx_collapse_row_t &o
 
 }  // namespace
 
+static int64_t collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
+                              uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads);
+
+// (nothing throws across the C ABI: include/dcrx.h; allocation failures of the row index and of the per-thread tallies
+// come back as DCRX_E_NOMEM, a worker thread that cannot be started leaves its share to the calling thread)
 extern "C" int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
                                        uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads) {
+  try { return collapse_front(text, n_bytes, cfg, rows, rows_cap, row_offsets, counters, n_threads); }
+  catch (const std::bad_alloc &) { return set_err(DCRX_E_NOMEM, "out of memory in dcrx_collapse_front"); }
+  catch (...) { return set_err(DCRX_E_NOMEM, "dcrx_collapse_front: unexpected exception"); }
+}
+
+static int64_t collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
+                              uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads) {
   if (!cfg || !counters || (n_bytes && !text)) return set_err(DCRX_E_INVALID, "null argument");
   if (cfg->oligo < 0 || cfg->oligo > 4) return set_err(DCRX_E_INVALID, "oligo must be 0 (m13), 1 (i8), 2 (i8_single), 3 (nebio) or 4 (takara)");
   if (!cfg->field_sep[0]) return set_err(DCRX_E_INVALID, "field_sep is empty");
@@ -237,10 +250,15 @@ extern "C" int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const
       rows[r].status = front_row(text + starts[r], (int)(e - starts[r]), c, rows[r], part[t].data());
     }
   };
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+  std::thread th[64];
+  bool own[64] = {false};
+  for (unsigned t = 1; t < nt; t++) {
+    try { th[t] = std::thread(work, t); }
+    catch (...) { own[t] = true; }          // this share stays with the calling thread
+  }
   work(0);
-  for (auto &x : th) x.join();
+  for (unsigned t = 1; t < nt; t++) if (own[t]) work(t);
+  for (unsigned t = 1; t < nt; t++) if (th[t].joinable()) th[t].join();
   for (int k = 0; k < DCRX_CF_N_COUNTERS; k++) { uint64_t s = 0; for (unsigned t = 0; t < nt; t++) s += part[t][k]; counters[k] += s; }
   return (int64_t)n;
 }

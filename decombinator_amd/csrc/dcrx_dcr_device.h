@@ -1613,14 +1613,17 @@ DCRX_DEV void decombine_general16_one(const DevTables &T, const BatchDev &B, con
 template <bool TABLE_LDS, bool UNIFORM_LEN>
 DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B,
                                  const CfgDev &cfg, uint64_t r, const Counters &C, dcrx_record_t *records,
-                                 uint32_t *slot) {
+                                 uint32_t *slot, const bool from_general) {
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
-  if (B.n_exc && ((B.exc_flag[r >> 5] >> (r & 31)) & 1u)) {
+  // A read of the general list may have exception bytes (its slice of the list is looked up: empty for a clean read that is
+  // there because every read is — orientation `both`, the forced slow reader); a read of the rescue queue has none.  (Not the
+  // workspace bitmap: behind the v2 kernels it is all zero again by the time a handed-over read arrives here.)
+  if (from_general && B.n_exc) {
     // binary search of this read's slice in the sorted exception list
     uint64_t lo = 0, hi = B.n_exc;
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }

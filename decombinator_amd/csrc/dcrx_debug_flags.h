@@ -12,7 +12,8 @@
 #define DCRX_F_PROFILE_NO_EVENTS 1024u /* profiling: the v2 kernel finishes its tail entries but drops its event entries (records are NOT results) */
 #define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
 #define DCRX_F_PROFILE_TAIL_STREAM_ONLY 16384u /* profiling: the tail kernel reads its entries and writes records but resolves nothing (records are NOT results) */
-#define DCRX_F_V2_LEAN_SERIAL 32768u /* A/B: the two lean kernels one after the other on the caller's stream (default: the tail kernel beside the rescue kernel on the handle's side stream) */
+#define DCRX_F_V2_LEAN_SERIAL 32768u /* A/B: the lean rescue, the lean tail and the X pass as launches of their own, one after the other on the caller's stream (default: roles of one launch, finish2_kernel) */
+#define DCRX_F_V2_SIDE_STREAMS 65536u /* A/B: round 3's shape — the tail kernel and the X pass on side streams of the handle beside the rescue kernel (fork / join events) */
 #define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
 #define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */
 #define DCRX_F_V2_SHAPE(k) ((uint32_t)(k) << 8) /* v2 kernel launch shape, A/B: 0 default, 2 = two reads per lane, 3 = one read per lane (one 1024-thread block per CU either way) */

@@ -232,7 +232,13 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                                      unsigned long long *__restrict__ counters,
                                                                      const uint32_t *__restrict__ queue,
                                                                      const uint32_t *__restrict__ gqueue,
-                                                                     uint32_t *__restrict__ queue_count) {
+                                                                     uint32_t *__restrict__ queue_count,
+                                                                     unsigned long long *__restrict__ out,
+                                                                     unsigned long long read_count) {
+  // `out` (behind the v2 kernels, which tally into an accumulator of the handle: `counters`): the call's counters are handed
+  // to the caller here and the accumulator is left zeroed for the next call — by block 0 when nothing was handed over (the
+  // other blocks leave at once, without an atomic), else by the last block to finish.  read_count (orientation `both`): a
+  // read counts once however many frames it was tried in (counts["read_count"], decombine.py:991).
   uint32_t *tile_ticket = queue_count + 3;
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
@@ -248,9 +254,20 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   const uint32_t t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   // The last block to finish re-arms the work counters for the next launch (no memset between
   // launches): by then every block has read the counts above.
+  auto hand_over = [&]() {      // (one thread, when every tally of the call is in the accumulator)
+    for (int c = 0; c < DCRX_N_COUNTERS; c++) {
+      const unsigned long long v = atomicExch(&counters[c], 0ull);
+      out[c] = (c == DCRX_C_READ_COUNT && read_count != ~0ull) ? read_count : v;
+    }
+  };
+  if (out && n_rescue == 0 && n_general == 0) {      // nothing was handed over: the common case behind the v2 kernels
+    if (blockIdx.x == 0 && tid == 0) hand_over();
+    return;
+  }
   auto leave = [&]() {
     if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
       queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
+      if (out) hand_over();
       __threadfence();
       queue_count[4] = 0;
     }
@@ -281,9 +298,9 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
       if (lane < DCRX_GTILE && i < n_general) {
         const uint32_t r = gqueue[i];
         decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
-                                                   lds_slots + tid * DCRX_LSLOT);
-        // the read's exception flag has served its purpose: cleared here, so that the bitmap is
-        // all zero again when the launch ends (no memset per launch)
+                                                   lds_slots + tid * DCRX_LSLOT, true);
+        // the read's exception flag (three-launch form: set by the prologue) has served its purpose: cleared here, so that
+        // the bitmap is all zero again when the launch ends (no memset per launch)
         if (B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
       }
     } else {
@@ -293,12 +310,13 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                         &hints);
         if (r != 0xFFFFFFFFu)
           decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
-                                                     lds_slots + tid * DCRX_LSLOT);
+                                                     lds_slots + tid * DCRX_LSLOT, false);
       }
     }
   }
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+  if (out) __threadfence();      // (the first wave's adds have landed before its first lane signs the block off)
   leave();
 }
 
@@ -416,19 +434,6 @@ __global__ void prologue_kernel(const uint32_t *__restrict__ exc_read, uint64_t 
     if (i == 0) *gcount = (uint32_t)n_reads;
   }
 }
-
-// Orientation `both` on the v2 kernels, between the two frames: the reads with exception bytes that the first frame did not
-// decombine are marked again (the first pass cleared every mark it used) ...
-__global__ void remark_kernel(const uint32_t *__restrict__ exc_read, uint64_t n_exc, const dcrx_record_t *__restrict__ records,
-                              uint32_t *__restrict__ flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_exc) {
-    const uint32_t r = exc_read[i];
-    if (records[r].status != DCRX_S_OK) atomicOr(&flag[r >> 5], 1u << (r & 31));
-  }
-}
-// ... and at the end a read counts once however many frames it was tried in (counts["read_count"], decombine.py:991)
-__global__ void read_count_kernel(unsigned long long *__restrict__ counters, unsigned long long n_reads) { counters[DCRX_C_READ_COUNT] = n_reads; }
 
 // ------------------------------------------------------------------------------
 // Order-preserving compaction of the decombined (status OK) records: the DCR
@@ -585,38 +590,47 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   const uint32_t qgrid = std::min<uint32_t>(P.qgrid, cus * (uint32_t)occ_list);
   const uint32_t qcap = (uint32_t)(gqueue - queue);      // capacity of the rescue queue, of the general
                                                          // list behind it, and of the list of exception-list offsets behind that
-  // Three launches per batch and nothing else: the prologue zeroes the caller's counters (and marks
-  // / lists the reads with exception bytes), the kernels add their tallies with one atomic per
-  // counter and block, and the list kernel leaves the work counters and the exception bitmap
-  // zeroed for the next batch.
-  {
+  // The three-launch form: the prologue zeroes the caller's counters (and marks / lists the reads with exception bytes), the
+  // kernels add their tallies with one atomic per counter and block, and the list kernel leaves the work counters and the
+  // exception bitmap zeroed for the next batch.  The v2 kernels need no prologue: the scan blocks mark the exception reads of
+  // their own ranges, every kernel tallies into the handle's accumulator (zero between calls), and the list kernel — the
+  // last launch — hands the counters to the caller and re-arms the accumulator.
+  unsigned long long *acc = (v2 || v2_both) ? reinterpret_cast<unsigned long long *>(P.v2_acc) : d_counters;
+  if (!(v2 || v2_both)) {
     const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));
     // (the call's start event, when one is set, rides on this dispatch)
     hipExtLaunchKernelGGL(prologue_kernel, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, s, P.ev_step_start, nullptr, 0, B.exc_read, B.n_exc,
-                          all_general ? 1 : 0, (v2 || v2_both) ? 0 : 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
+                          all_general ? 1 : 0, 1, B.n_reads, const_cast<uint32_t *>(B.exc_flag), gqueue, gqueue + qcap,
                           queue_count + 1, d_counters);
+  }
+  // (v2: the call's start event rides on the scan's dispatch — the first launch — unless the scan's own start event claims that
+  // place, or nothing is launched for an empty batch: then it is recorded in front)
+  hipEvent_t scan_start = ev_start;
+  if ((v2 || v2_both) && P.ev_step_start) {
+    if (!ev_start && B.n_reads) scan_start = P.ev_step_start;
+    else { e = hipEventRecord(P.ev_step_start, s); if (e != hipSuccess) return e; }
   }
   if (v2_both) {
     // `both` (decombine.py:1005-1010): the reverse frame for every read, then the forward frame for the reads it did not
-    // decombine; the failure counters of both attempts add up, as the reference's do.  After each frame the list kernel
-    // takes what the v2 kernels handed over (in that frame).
+    // decombine (retry: the scan skips the reads whose record is OK); the failure counters of both attempts add up, as the
+    // reference's do.  After each frame the list kernel takes what the v2 kernels handed over (in that frame); the second one
+    // hands the counters over, with read_count set once.
     const uint32_t lgrid = std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4));
     CfgDev c1 = cfg, c2 = cfg;
     c1.orientation = DCRX_ORIENT_REVERSE; c2.orientation = DCRX_ORIENT_FORWARD;
-    e = launch_v2_any(P, T, B, c1, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, 0u);
+    e = launch_v2_any(P, T, B, c1, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop, 0u);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c1, rec, d_counters, queue, gqueue, queue_count);
-    if (B.n_exc) hipLaunchKernelGGL(remark_kernel, dim3((uint32_t)((B.n_exc + 255) / 256)), dim3(256), 0, s, B.exc_read, B.n_exc, rec, const_cast<uint32_t *>(B.exc_flag));
+    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c1, rec, acc, queue, gqueue, queue_count, (unsigned long long *)nullptr, ~0ull);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = launch_v2_any(P, T, B, c2, rec, queue, gqueue, qcap, queue_count, d_counters, s, nullptr, nullptr, 1u);
+    e = launch_v2_any(P, T, B, c2, rec, queue, gqueue, qcap, queue_count, acc, s, nullptr, nullptr, 1u);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c2, rec, d_counters, queue, gqueue, queue_count);
-    hipExtLaunchKernelGGL(read_count_kernel, dim3(1), dim3(1), 0, s, nullptr, P.ev_step_stop, 0, d_counters, (unsigned long long)B.n_reads);
+    hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, P.ev_step_stop, 0, T, B, c2, rec, acc, queue, gqueue, queue_count, d_counters,
+                          (unsigned long long)B.n_reads);
     return hipGetLastError();
   }
   if (v2) {
-    e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop);
+    e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop);
     if (e != hipSuccess) return e;
   }
   if (v2 && getenv("DCRX_DEBUG_HANDOVER")) {      // developer aid: how many reads the v2 kernels handed over
@@ -624,7 +638,6 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(qc, queue_count, sizeof qc, hipMemcpyDeviceToHost);
     fprintf(stderr, "dcrx: v2 handed over %u clean reads and %u reads with exception bytes\n", qc[0], qc[1]);
-    if (getenv("DCRX_DEBUG_SKIP_TRAILING")) { (void)hipMemset(queue_count, 0, 8); return hipSuccess; }
   }
   if (!v2 && ev_start) { e = hipEventRecord(ev_start, s); if (e != hipSuccess) return e; }
   if (!v2 && grid) {
@@ -646,7 +659,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     const uint32_t lgrid = v2 ? std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4)) : qgrid;
     const bool list_is_last = !(rescue16 && !all_general);
     hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, list_is_last ? P.ev_step_stop : nullptr, 0, T, B, cfg, rec,
-                          d_counters, queue, gqueue, queue_count);
+                          acc, queue, gqueue, queue_count, v2 ? d_counters : (unsigned long long *)nullptr, ~0ull);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

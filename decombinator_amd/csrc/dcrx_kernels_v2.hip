@@ -3,7 +3,10 @@
 // orientation `both`, tag sets the v2 tables do not express, and the few reads these kernels
 // hand over (more flagged pairs than an entry holds).
 //
-// Launches per batch:
+// Launches per batch: scan2_kernel -> finish2_kernel (the lean rescue, the lean tail and the general
+// form over list X as roles of ONE launch on the caller's stream) -> the list kernel (dcrx_kernels.hip: hand-overs, normally
+// none; its first block hands the call's counters to the caller).  No prologue launch: the scan blocks mark the reads with
+// exception bytes of their own ranges, and the kernels tally into an accumulator the handle owns.
 //
 //   scan2_kernel    persistent, one 1024-thread block per CU.  LDS holds the frame's 16-bit pair
 //                   table (at LDS address 0) and nothing else.  Per tile of 1024 * RPL reads: the
@@ -81,16 +84,15 @@ constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block ca
 //   region `ev`:  E = one gene has its full tag, the other needs the half-tag rescue (V2_SHAPE_ONE): one sweep per wave
 //   region `sx`:  C = half-tag rescue of both genes (V2_SHAPE_BOTH)  |  X = reads with exception bytes, flags on an odd read's
 //                     last half pair: the general form            (half of the region each)
-//   region `lo`:  L = what the lean kernels hand on (appended with atomics)
-// (a list that outgrows its room hands the rest to the three-launch form)
-enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_LEFT = 4, V2_L_COUNTS = 8 };
+// (a list that outgrows its room hands the rest to the list kernel; what a lean kernel does not settle it finishes itself,
+// behind its job's loop: v2_general_call)
+enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_COUNTS = 8 };
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
   uint4 *ev;          // [regions][rows_e][ecap]
   uint4 *sx;          // [regions][rows_e][scap]
-  uint4 *lo;          // [regions][rows_e][lcap]
   uint32_t *counts;   // [regions][V2_L_COUNTS]: entries of each list (V2_L_*)
-  uint32_t tcap, ecap, scap, lcap;      // scap: a multiple of 128 (two lists of whole chunks)
+  uint32_t tcap, ecap, scap;      // scap: a multiple of 128 (two lists of whole chunks)
 };
 template <int NW>
 struct V2Rows {
@@ -102,8 +104,7 @@ template <int NW>
 __device__ __forceinline__ V2ListRef v2_list(const V2Lists &Q, const int which, const size_t region) {
   constexpr size_t E = V2Rows<NW>::E;
   if (which == V2_L_E) return V2ListRef{Q.ev + region * Q.ecap * E, Q.ecap};
-  if (which == V2_L_C || which == V2_L_X) return V2ListRef{Q.sx + (region * Q.scap + (which == V2_L_X ? Q.scap / 2 : 0u)) * E, Q.scap / 2};
-  return V2ListRef{Q.lo + region * Q.lcap * E, Q.lcap};
+  return V2ListRef{Q.sx + (region * Q.scap + (which == V2_L_X ? Q.scap / 2 : 0u)) * E, Q.scap / 2};
 }
 // dwords x[0 .. N) of slot `at` of a region.  Layout: chunks of 64 slots, inside a chunk structure of arrays
 // (row k of slot i at rows[((i / 64) * R + k) * 64 + i % 64], R = rows per entry): a wave's batch of 64
@@ -195,9 +196,52 @@ __device__ __forceinline__ void v2_load_item(const BatchDev &B, const uint32_t n
   }
 }
 
+
+// The reads with exception bytes of a scan block's own range, marked by the block itself (no prologue launch): the block's
+// slice of the sorted exception list — [lower_bound(blk_lo), lower_bound(blk_hi)) — is found by all its threads together
+// (k-ary search: one probe per thread and round, half the block per bound; two or three rounds), then one thread per entry
+// sets (or, when the block has scanned its range, clears) the read's bit in the workspace bitmap.  A block's range is a
+// multiple of 512 reads, so its bits fill whole 64-byte lines that no other block reads or writes: neither a vector nor a
+// scalar cache can hold a line of them from before the marks.  s: 6 words of LDS.
+__device__ __forceinline__ void v2_exc_slice(const BatchDev &B, const uint64_t blk_lo, const uint64_t blk_hi, uint32_t *s, const int tid) {
+  const uint32_t half = blockDim.x >> 1;
+  const int which = (uint32_t)tid >= half ? 1 : 0;
+  const uint32_t j = (uint32_t)tid - (which ? half : 0u);
+  const uint64_t key = which ? blk_hi : blk_lo;             // (read indices are < 2^32: check_batch)
+  if (tid < 2) { s[2 * tid] = 0u; s[2 * tid + 1] = (uint32_t)B.n_exc; }
+  for (;;) {
+    __syncthreads();
+    const uint32_t lo = s[2 * which], hi = s[2 * which + 1], span = hi - lo;
+    const bool done = s[1] == s[0] && s[3] == s[2];
+    __syncthreads();                                         // (everyone has read the bounds before anyone moves them)
+    if (done) break;
+    if (tid < 2) s[4 + tid] = 0u;
+    __syncthreads();
+    const uint32_t step = span ? (span + half - 1) / half : 1u;
+    const uint64_t idx = (uint64_t)lo + (uint64_t)j * step;
+    const bool below = span && idx < hi && (uint64_t)B.exc_read[idx] < key;
+    const unsigned long long m = __ballot(below);
+    if ((tid & 63) == 0 && m) atomicAdd(&s[4 + which], (uint32_t)__popcll(m));
+    __syncthreads();
+    if (j == 0 && span) {                                    // the probes below the key are a prefix of the probes
+      const uint32_t c = s[4 + which], probes = (span + step - 1) / step;
+      s[2 * which] = c ? lo + (c - 1) * step + 1 : lo;
+      s[2 * which + 1] = c < probes ? lo + c * step : hi;
+    }
+  }
+}
+__device__ __forceinline__ void v2_exc_marks(const BatchDev &B, const uint32_t e_lo, const uint32_t e_hi, const bool set, const int tid) {
+  uint32_t *flag = const_cast<uint32_t *>(B.exc_flag);
+  for (uint64_t i = (uint64_t)e_lo + (uint32_t)tid; i < e_hi; i += blockDim.x) {
+    const uint32_t r = B.exc_read[i];
+    if (set) atomicOr(&flag[r >> 5], 1u << (r & 31));
+    else flag[r >> 5] = 0u;                                  // (all of a word's bits belong to this block)
+  }
+}
+
 // LDS of the scan kernel behind the pair table and the counters: the block's work counters
 // next item; entries of each list (V2_WK_LIST + V2_L_*)
-enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_WORDS = 8 };
+enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_WORDS = 16 };      // (V2_WK_EXC: six words of v2_exc_slice)
 
 template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
@@ -226,13 +270,21 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   const int lane = tid & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const bool tagged = B.n_reads < (1ull << 30);
-  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
 
   // The block owns the reads [blk_lo, blk_hi) and one region of each list; its waves draw items of 64 * RPL reads
   // from a counter in LDS.  (The four waves that share a SIMD are served oldest first: with the same reads for each, the
   // first ended a quarter earlier than the last — 148 against 193 us — and idled until the launch was over.)
   const uint64_t blk_lo = (uint64_t)blockIdx.x * per_block;
   const uint64_t blk_hi = blk_lo + per_block < B.n_reads ? blk_lo + per_block : B.n_reads;
+  // the reads with exception bytes of this range: marked here, cleared below (the bitmap is all zero between launches)
+  uint32_t e_lo = 0u, e_hi = 0u;
+  if (B.n_exc) {
+    v2_exc_slice(B, blk_lo < blk_hi ? blk_lo : blk_hi, blk_hi, lds_work + V2_WK_EXC, tid);
+    e_lo = lds_work[V2_WK_EXC]; e_hi = lds_work[V2_WK_EXC + 2];
+    v2_exc_marks(B, e_lo, e_hi, true, tid);
+    __threadfence();           // the marks are in memory before a wave of this block fetches them with its first item
+    __syncthreads();
+  }
   constexpr uint32_t WT = 64u * RPL;
   const uint32_t n_items = blk_lo < blk_hi ? (uint32_t)((blk_hi - blk_lo + WT - 1) / WT) : 0u;
   const size_t region = blockIdx.x;
@@ -315,7 +367,6 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         rec.status = (uint8_t)(vnone ? DCRX_S_V_NONE : (vmulti ? DCRX_S_V_MULTI : DCRX_S_DEFER));
         rec.frame = (uint8_t)(o == 0 ? 1 : 0);
         DCRX_STORE_SCAN(records + r, rec);
-        if (exc && (vnone || vmulti)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));   // the flag has served: the bitmap is all zero again when the batch ends
       }
       const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
       if (lane == 0) {
@@ -393,6 +444,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     item = next;
   }
   __syncthreads();
+  if (B.n_exc) v2_exc_marks(B, e_lo, e_hi, false, tid);      // the marks have served (an entry carries V2_R_EXC from here on)
 #ifdef DCRX_SCAN_STAMPS
   if (lane == 0) {      // instrumented build (tools/): per wave (not per region; its runs finish nothing) start and end in the 100 MHz counter, clocks inside / between scans
     uint32_t *c = Q.counts + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));      // (the counts array holds 8 words per compute unit's 16 waves: room for these)
@@ -421,7 +473,6 @@ __device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori
                                                  const uint32_t (&lg)[NW], const uint32_t (&w)[NW], const Counters &C, dcrx_record_t *__restrict__ records,
                                                  uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, const uint32_t qcap,
                                                  uint32_t *__restrict__ queue_count, const bool tagged) {
-  uint32_t *exc_flag = const_cast<uint32_t *>(B.exc_flag);
   const uint32_t r = x0 & V2_R_MASK;
   const bool exc = (x0 & V2_R_EXC) != 0u;
   const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
@@ -440,17 +491,42 @@ __device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori
     x1e = (int)lo;
     if (x1e - x0e > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); return; }   // more exception bytes than the register frame holds
   }
-  if (finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (x0 & V2_R_JMULTI) != 0u, x0e, x1e, C, records)) {
-    if (exc) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
-  } else {
-    v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);     // its flag (if any) is cleared by the list kernel
-  }
+  if (!finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (x0 & V2_R_JMULTI) != 0u, x0e, x1e, C, records))
+    v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);
 }
 
-// ... as a call, for the lean kernels: what their straight-line forms do not settle (one read in two million) is finished
-// on the spot, with the tables the kernel has staged, instead of travelling to a pass of its own behind them (a launch, a join and one
-// read's latency on the critical path of every step).  Not inlined: the lean loops keep their registers.
+// ---- the finishing roles ---------------------------------------------------------------------------
+// What a block of a finishing kernel holds in LDS: counters, side tables, the frame's keyword buckets, a strip per lane for
+// the read in hand, the scratch counters of the lean rescue; per wave the slots of the entries its lean form left.
 constexpr int V2_LEFT_SLOTS = 15;      // entries a wave may note per job; more (never seen) go to the list kernel
+struct V2FinishLds {
+  uint32_t *counts, *side, *bk, *strip, *dry;
+  uint32_t (*left)[1 + V2_LEFT_SLOTS];
+};
+template <int NW, int BLOCK>
+__device__ __forceinline__ V2FinishLds v2_finish_stage(const DevTables &T0, const V2Ori &V, uint32_t *smem, uint32_t (*s_left)[1 + V2_LEFT_SLOTS], const int tid) {
+  V2FinishLds L;
+  L.counts = smem;
+  L.side = smem + DCRX_N_COUNTERS;
+  L.bk = L.side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
+  if (tid < DCRX_N_COUNTERS) L.counts[tid] = 0;
+  stage_lds<BLOCK>(T0.image + T0.dfa_bytes, L.side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+  stage_lds<BLOCK>(V.bk, L.bk, V.bk_bytes / 16, 0, 0, tid);
+  // each lane's strip of LDS for the read in hand (its two zero words are written once)
+  L.strip = L.bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
+  L.strip[NW] = 0u; L.strip[NW + 1] = 0u;
+  // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
+  L.dry = L.bk + V.bk_bytes / 4 + (uint32_t)BLOCK * lds_words_stride<NW>();
+  L.left = s_left;
+  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
+  return L;
+}
+// (bytes of that image: the launcher's size of the dynamic LDS)
+template <int NW>
+static uint32_t v2_finish_block_lds(const DevTables &T, int o, int block) {
+  return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + (uint32_t)block * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4;
+}
+
 // a lane notes the slot of an entry its lean form did not settle (LDS, per wave)
 __device__ __forceinline__ void v2_note_left(uint32_t *left, const uint32_t slot, const BatchDev &B, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue,
                                              const uint32_t qcap, uint32_t *__restrict__ queue_count, const uint32_t r, const bool exc) {
@@ -460,51 +536,38 @@ __device__ __forceinline__ void v2_note_left(uint32_t *left, const uint32_t slot
 }
 template <int NW>
 struct V2EntryWords { uint32_t lg[NW], w[NW]; };
+// ... the general form as a call, for the lean roles: what their straight-line forms do not settle (one read in two million)
+// is finished on the spot, with the tables the block has staged, instead of travelling to a pass of its own behind them (a
+// launch, a join and one read's latency on the critical path of every step).  Not inlined: the lean loops keep their
+// registers.  The same call serves list X (reads with exception bytes), a few lanes per wave.
 template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __attribute__((noinline)) void v2_general_call(const DevTables *__restrict__ Tmem, const uint32_t *lds_side, const uint32_t *lds_bk, const BatchDev B, const CfgDev cfg, const uint32_t x0,
                                                            const V2EntryWords<NW> e, uint32_t *lds_counts, dcrx_record_t *__restrict__ records,
                                                            uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, const uint32_t qcap,
                                                            uint32_t *__restrict__ queue_count) {
   const DevTables T0 = *Tmem;
-  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes, false);      // (the side tables and buckets the lean kernel staged)
+  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes, false);      // (the side tables and buckets the block staged)
   V2Ori V = T0.v2[ORI];
   V.bk = reinterpret_cast<const uint8_t *>(lds_bk);
   const Counters C{lds_counts};
   v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, x0, e.lg, e.w, C, records, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30));
 }
 
-// The tail kernel: `split` waves per region, 256-thread blocks, no register spills (a spill
-// reload would wait for the loads in flight).  Software pipeline over the batches of 64:
-// the entries are read two batches ahead and a read's words one batch ahead, so that the batch in
-// hand finds everything in registers.  What the lean form does not settle becomes an entry of the
-// region's slow list (full waves in a later event-kernel launch, not two lanes here).
+// The lean tail: wave `gwave` of `n_gwaves` takes the jobs (region, part) gwave, gwave + n_gwaves, ...: `split` waves share a
+// region (a scan block's list), wave k of them its batches k, k + split, ...  Software pipeline over the batches of 64: the
+// entries are read one batch ahead, the read in hand sits in the lane's LDS strip.  What the lean form does not settle is
+// noted per wave and finished behind the job's loop (v2_general_call), so that no value of the loop lives across a call.
 template <bool UNIFORM_LEN, int NW, int ORI>
-__global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
-    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
-    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
-  extern __shared__ __align__(64) uint32_t smem[];
-  constexpr int o = ORI;      // the frame is a template argument: one frame's code per kernel
-  const V2Ori V = T0.v2[ORI];
-  uint32_t *lds_counts = smem;
-  uint32_t *lds_side = smem + DCRX_N_COUNTERS;
-  uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
-  const int tid = threadIdx.x;
-  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  stage_lds<DCRX_V2_TBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
-  stage_lds<DCRX_V2_TBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
-  const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1);
-  const Counters C{lds_counts};
-  // each lane's strip of LDS for the read in hand (its two zero words are written once)
-  uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
-  strip[NW] = 0u; strip[NW + 1] = 0u;
-  const LdsWords lw{dcrx_ldsaddr_of(strip)};
-  __syncthreads();
-  __shared__ uint32_t s_left[DCRX_V2_TBLOCK / 64][1 + V2_LEFT_SLOTS];      // per wave: entries its lean form left (count, slots)
-  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
+__device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
+                                             const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
+                                             uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
+                                             const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid) {
+  constexpr int o = ORI;
+  const Counters C{L.counts};
+  const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
+  uint32_t *strip = L.strip, *lds_counts = L.counts;
+  uint32_t *s_left = L.left[tid >> 6];
   const int lane = tid & 63;
-  // `split` waves share a region (a scan block's list): wave k of them takes the batches k, k + split, ...
-  const uint32_t gwave = blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_TBLOCK / 64);
   for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {
     const uint32_t region = job / split, part = job % split;
     const uint32_t tn = Q.counts[V2_L_COUNTS * region + V2_L_TAIL];
@@ -544,14 +607,12 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
       }
       v2_tally(lds_counts, lane, status, o == 0);
-      // what the lean form does not settle (one read in millions): noted, and finished behind the job's loop, so that no
-      // value of the loop lives across a call
-      if (__builtin_expect(status == TAIL2_SLOW, 0)) v2_note_left(s_left[tid >> 6], first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, false);
+      if (__builtin_expect(status == TAIL2_SLOW, 0)) v2_note_left(s_left, first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, false);
     }
-    const uint32_t n_left = min(s_left[tid >> 6][0], (uint32_t)V2_LEFT_SLOTS);
+    const uint32_t n_left = min(s_left[0], (uint32_t)V2_LEFT_SLOTS);
     if (__builtin_expect(n_left != 0u, 0)) {
       const bool live = (uint32_t)lane < n_left;
-      const uint32_t slot = live ? s_left[tid >> 6][1 + lane] : 0u;
+      const uint32_t slot = live ? s_left[1 + lane] : 0u;
       uint32_t x[2 + NW];
       v2_get_rows<2 + NW>(tq, Q.tcap, slot, live, x);
       if (live) {
@@ -564,13 +625,11 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
           if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
           e.lg[k] = l; e.w[k] = x[2 + k];
         }
-        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, x[0] | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
+        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0] | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
-      if (lane == 0) s_left[tid >> 6][0] = 0u;
+      if (lane == 0) s_left[0] = 0u;
     }
   }
-  __syncthreads();
-  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
 // counters of a wave's lean-rescue statuses (rescue2_count, by ballot)
@@ -604,39 +663,20 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
   }
 }
 
-// The lean rescue kernel: the scan kernel's event lists E and C in straight-line code (rescue2_fast compiled for the
-// list's shape), `split` waves per region and list, entries read one batch ahead.  What that form does not settle is
-// copied to the region's list L and takes the general form in the event kernel's last pass.
+// The lean rescue: the scan kernel's event lists E and C in straight-line code (rescue2_fast compiled for the list's shape),
+// `split` waves per region and list, entries read one batch ahead; jobs (list, region, part), the lists one after the other,
+// so that the waves in flight at one time run the same code.  Leftovers as in the lean tail.
 template <bool UNIFORM_LEN, int NW, int ORI>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel(
-    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
-    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
-  extern __shared__ __align__(64) uint32_t smem[];
+__device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
+                                               const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
+                                               uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
+                                               const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid) {
   constexpr int o = ORI;
-  const V2Ori V = T0.v2[ORI];
-  uint32_t *lds_counts = smem;
-  uint32_t *lds_side = smem + DCRX_N_COUNTERS;
-  uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
-  const int tid = threadIdx.x;
-  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
-  stage_lds<DCRX_V2_FBLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
-  stage_lds<DCRX_V2_FBLOCK>(V.bk, lds_bk, V.bk_bytes / 16, 0, 0, tid);
-  uint32_t kw_base[K_NCLASS];
-#pragma unroll
-  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
-  const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), o == 1, kw_base);
-  uint32_t *strip = lds_bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();      // as in the tail kernel
-  strip[NW] = 0u; strip[NW + 1] = 0u;
-  const LdsWords lw{dcrx_ldsaddr_of(strip)};
-  // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
-  const Counters C{lds_counts}, Cdry{lds_bk + V.bk_bytes / 4 + (uint32_t)DCRX_V2_FBLOCK * lds_words_stride<NW>()};
-  __syncthreads();
-  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
-  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
+  const Counters C{L.counts}, Cdry{L.dry};
+  const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
+  uint32_t *strip = L.strip, *lds_counts = L.counts;
+  uint32_t *s_left = L.left[tid >> 6];
   const int lane = tid & 63;
-  const uint32_t gwave = blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), n_gwaves = gridDim.x * (DCRX_V2_FBLOCK / 64);
-  // jobs: (list, region, part); the lists one after the other, so that the waves in flight at one time run the same code
   for (uint32_t job = gwave; job < 2u * n_regions * split && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
     const int which = job < n_regions * split ? V2_L_E : V2_L_C;
     const uint32_t region = (job / split) % n_regions, part = job % split;
@@ -676,25 +716,135 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
-      if (__builtin_expect(status == RESCUE2_SLOW, 0)) v2_note_left(s_left[tid >> 6], first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, (x[0] & V2_R_EXC) != 0u);
+      if (__builtin_expect(status == RESCUE2_SLOW, 0)) v2_note_left(s_left, first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, (x[0] & V2_R_EXC) != 0u);
     }
-    const uint32_t n_left = min(s_left[tid >> 6][0], (uint32_t)V2_LEFT_SLOTS);      // (as in the tail kernel)
+    const uint32_t n_left = min(s_left[0], (uint32_t)V2_LEFT_SLOTS);      // (as in the lean tail)
     if (__builtin_expect(n_left != 0u, 0)) {
       const bool live = (uint32_t)lane < n_left;
-      const uint32_t slot = live ? s_left[tid >> 6][1 + lane] : 0u;
+      const uint32_t slot = live ? s_left[1 + lane] : 0u;
       uint32_t x[1 + 2 * NW];
       v2_get_rows<1 + 2 * NW>(l.rows, l.cap, slot, live, x);
       if (live) {
         V2EntryWords<NW> e;
 #pragma unroll
         for (int k = 0; k < NW; k++) { e.lg[k] = x[1 + k]; e.w[k] = x[1 + NW + k]; }
-        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, lds_side, lds_bk, B, cfg, x[0], e, lds_counts, records, queue, gqueue, qcap, queue_count);
+        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0], e, lds_counts, records, queue, gqueue, qcap, queue_count);
       }
-      if (lane == 0) s_left[tid >> 6][0] = 0u;
+      if (lane == 0) s_left[0] = 0u;
     }
   }
+}
+
+// List X (reads with exception bytes whose flag log is not empty, flags on an odd read's last half pair: a few thousand of a
+// 10 M-read batch) through the general form as the same call: `width` lanes of a wave take entries — the general form costs a
+// wave the longest of its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit`
+// blocks share a region.  Block `vblock` of the role's n_regions * bsplit.
+template <bool UNIFORM_LEN, int NW, int ORI, int BLOCK>
+__device__ __forceinline__ void v2_slow_jobs(const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records, const V2Lists &Q,
+                                             const uint32_t n_regions, const uint32_t bsplit, const uint32_t width, uint32_t *__restrict__ queue,
+                                             uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
+                                             const DevTables *__restrict__ Tmem, const uint32_t vblock, const int tid) {
+  const uint32_t region = vblock / bsplit, bpart = vblock % bsplit;
+  if (region >= n_regions || (cfg.flags & DCRX_F_PROFILE_NO_EVENTS)) return;
+  const V2ListRef l = v2_list<NW>(Q, V2_L_X, region);
+  const uint32_t total = min(Q.counts[V2_L_COUNTS * region + V2_L_X], l.cap);
+  const int lane = tid & 63;
+  for (uint32_t first = width * ((uint32_t)(tid >> 6) + (BLOCK / 64) * bpart); first < total; first += width * (BLOCK / 64) * bsplit) {
+    const uint32_t i = first + (uint32_t)lane;
+    const bool live = (uint32_t)lane < width && i < total;
+    uint32_t x[1 + 2 * NW];
+    v2_get_rows<1 + 2 * NW>(l.rows, l.cap, i, live, x);
+    if (live) {
+      V2EntryWords<NW> e;
+#pragma unroll
+      for (int k = 0; k < NW; k++) { e.lg[k] = x[1 + k]; e.w[k] = x[1 + NW + k]; }
+      v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0], e, L.counts, records, queue, gqueue, qcap, queue_count);
+    }
+  }
+}
+
+// ONE launch for everything behind the scan, on the caller's stream — no side streams, no fork and no join (each wait of one
+// queue for another cost the waiting queue 8-10 us).  A block's role follows from its index: first the blocks of list X
+// (single reads with long dependent chains: they start at once and run under everything else), then blocks of the lean
+// rescue and of the lean tail in turn, so that every compute unit holds waves of both at any time — the rescue is bound by
+// instruction issue, the tail by its stream of entries.
+struct V2Roles { uint32_t xgrid, rgrid, tgrid, rsplit, tsplit, bsplit, width; };
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t n_regions, V2Roles R, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
+  const int tid = threadIdx.x;
+  // the role of this block
+  uint32_t b = blockIdx.x;
+  int role;                 // 0 list X, 1 rescue, 2 tail
+  if (b < R.xgrid) {
+    role = 0;
+    // (most blocks of a short list's pass find their share empty: they leave before they stage anything)
+    const uint32_t g = b / R.bsplit;
+    if (g >= n_regions || R.width * (DCRX_V2_FBLOCK / 64) * (b % R.bsplit) >= Q.counts[V2_L_COUNTS * g + V2_L_X]) return;
+  } else {
+    b -= R.xgrid;
+    const uint32_t paired = 2u * min(R.rgrid, R.tgrid);
+    if (b < paired) { role = (b & 1u) ? 2 : 1; b >>= 1; }
+    else { b -= paired; role = R.rgrid > R.tgrid ? 1 : 2; b += min(R.rgrid, R.tgrid); }
+  }
+  const V2Ori V = T0.v2[ORI];
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(T0, V, smem, s_left, tid);
+  uint32_t kw_base[K_NCLASS];
+#pragma unroll
+  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
+  const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
   __syncthreads();
-  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+  constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
+  if (role == 1) v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, B, cfg, records, Q, n_regions, R.rsplit, queue, gqueue, qcap, queue_count, Tmem, b * WPB + (uint32_t)(tid >> 6), R.rgrid * WPB, tid);
+  else if (role == 2) v2_tail_jobs<UNIFORM_LEN, NW, ORI>(rt.t, L, B, cfg, records, Q, n_regions, R.tsplit, queue, gqueue, qcap, queue_count, Tmem, b * WPB + (uint32_t)(tid >> 6), R.tgrid * WPB, tid);
+  else v2_slow_jobs<UNIFORM_LEN, NW, ORI, DCRX_V2_FBLOCK>(L, B, cfg, records, Q, n_regions, R.bsplit, R.width, queue, gqueue, qcap, queue_count, Tmem, b, tid);
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
+}
+
+// The roles as launches of their own (A/B: DCRX_F_V2_SIDE_STREAMS, the tail kernel beside the rescue kernel on a side stream of
+// the handle; DCRX_F_V2_LEAN_SERIAL, one after the other on the caller's stream; tests run all three forms).
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  __shared__ uint32_t s_left[DCRX_V2_TBLOCK / 64][1 + V2_LEFT_SLOTS];
+  const int tid = threadIdx.x;
+  const V2Ori V = T0.v2[ORI];
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_TBLOCK>(T0, V, smem, s_left, tid);
+  const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1);
+  __syncthreads();
+  v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
+                                     blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_TBLOCK / 64), tid);
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
+}
+
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel(
+    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
+    V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
+    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
+  const int tid = threadIdx.x;
+  const V2Ori V = T0.v2[ORI];
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(T0, V, smem, s_left, tid);
+  uint32_t kw_base[K_NCLASS];
+#pragma unroll
+  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
+  const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
+  __syncthreads();
+  v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
+                                       blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_FBLOCK / 64), tid);
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
 }
 
 // The event kernel: the general form (dcr_frame3) on reads held in registers.  Reads with exception bytes
@@ -709,7 +859,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
     uint32_t *__restrict__ queue_count) {
   extern __shared__ __align__(64) uint32_t smem[];
   V2Ori V = T0.v2[ORI];
-  // which: the list (V2_L_E .. V2_L_LEFT)
+  // which: the list (V2_L_E .. V2_L_X)
   const uint32_t lcap = v2_list<NW>(Q, which, 0).cap;
   // ext: the packed germline regions are staged behind the side tables (the launcher found room for them)
   const uint32_t side_bytes = (ext ? T0.lds_image2_bytes : T0.lds_image_bytes) - T0.dfa_bytes;
@@ -779,10 +929,10 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // The v2 kernels serve one frame per pass: `reverse` and `forward` are one pass, `both` (decombine.py:1005-1010) the reverse
 // frame and then the forward frame for the reads it did not decombine (both frames' tables must fit).
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
-  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow) return false;
+  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow || !P.v2_acc) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
-  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_lds_bytes(T, o) + DCRX_V2_FBLOCK * lds_words_stride<DCRX_V2_NWLONG>() * 4 + DCRX_N_COUNTERS * 4 <= 64u * 1024u; };
+  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_block_lds<DCRX_V2_NWLONG>(T, o, DCRX_V2_FBLOCK) <= 64u * 1024u; };
   if (cfg.orientation == DCRX_ORIENT_BOTH) return fits(0) && fits(1) && !(cfg.flags & DCRX_F_PROFILE_MASK);
   return fits(cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
 }
@@ -796,6 +946,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
   auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
+  auto kf = o ? finish2_kernel<UNIFORM, NW, 1> : finish2_kernel<UNIFORM, NW, 0>;
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
@@ -807,36 +958,36 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
     attributes_set_on_device(seen);
   }
-  if (B.n_reads == 0) return hipSuccess;       // the prologue has zeroed the counters
+  if (B.n_reads == 0) return hipSuccess;       // (the tallies stay zero; the list kernel hands them over)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
-  // One scan block per compute unit, each with a contiguous range of the reads (a multiple of its waves' item size) and one
-  // region of every list, sized for the reads the block can meet; a small batch takes fewer blocks, 16 items each at least.
+  // One scan block per compute unit, each with a contiguous range of the reads — a multiple of 512: whole items of its waves and
+  // whole 64-byte lines of the exception bitmap (v2_exc_slice) — and one region of every list, sized for the reads the block can
+  // meet; a small batch takes fewer blocks, 16 items each at least.
   const uint64_t wt = 64ull * RPL;
   const uint64_t n_items = (B.n_reads + wt - 1) / wt;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, (n_items + 15) / 16));
-  const uint64_t per_block = (((B.n_reads + grid - 1) / grid + wt - 1) / wt) * wt;
+  const uint64_t per_block = (((B.n_reads + grid - 1) / grid + 511) / 512) * 512;
   V2Lists Q;
   Q.tail = P.v2_tail; Q.ev = P.v2_events; Q.sx = P.v2_slow; Q.counts = P.v2_counts;
   const uint32_t n_regions = grid;
   const uint64_t pb128 = (per_block + 255) & ~127ull;           // (a block's reads, rounded up to whole chunks)
   Q.tcap = (uint32_t)std::min<uint64_t>(pb128, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
   Q.ecap = (uint32_t)std::min<uint64_t>(pb128, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~127u;    // (region `sx`, of the same size, holds two lists of whole chunks)
-  // the second allocation holds region `sx` (sized like `ev`) and, in what is left, region `lo`
-  Q.scap = Q.ecap;
-  Q.lo = Q.sx + (size_t)n_regions * Q.scap * V2Rows<NW>::E;
-  const uint64_t rows1 = (uint64_t)n_regions * Q.scap * V2Rows<NW>::E;
-  Q.lcap = P.v2_slow_rows > rows1 ? (uint32_t)std::min<uint64_t>(pb128, (P.v2_slow_rows - rows1) / V2Rows<NW>::E / n_regions) & ~63u : 0u;
-  if (Q.tcap < 64 || Q.ecap < 128 || Q.lcap < 64) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
-  // Launch order.  Caller's stream: scan -> rescue (lists E, C) -> [join] -> general form over list L (what the lean
-  // kernels handed on) -> (dcrx_kernels.hip) the list kernel.  Side stream 1: the tail kernel; side stream 2: the general
-  // form over list X (reads with exception bytes: known when the scan ends, their long single-read latencies run under
-  // the lean kernels).  The fork event is the scan dispatch's own stop event when no timing event claims that place, the
-  // join events are the side kernels' own stop events: no marker packets on the queues.  DCRX_F_V2_LEAN_SERIAL (A/B, tests):
-  // everything on the caller's stream.
+  Q.scap = (uint32_t)std::min<uint64_t>(Q.ecap, P.v2_slow_rows / V2Rows<NW>::E / n_regions) & ~127u;
+  if (Q.tcap < 64 || Q.ecap < 128 || Q.scap < 128) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  // Launch order, all on the caller's stream: scan -> finish2 (the lean rescue over lists E and C, the lean tail and the general
+  // form over list X as roles of one launch) -> (dcrx_kernels.hip) the list kernel.  A/B and tests: DCRX_F_V2_SIDE_STREAMS puts the
+  // tail kernel and the X pass on two side streams of the handle beside the rescue kernel (round 3's shape: forked from the scan
+  // dispatch's stop event, joined through the side kernels' own stop events), DCRX_F_V2_LEAN_SERIAL runs the three as launches of
+  // their own one after the other.
   const bool finish = !(cfg.flags & (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_NO_FINISH));
-  const bool side = finish && P.v2_side && P.v2_side2 && P.v2_ev_fork && P.v2_ev_join && P.v2_ev_join2 && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL);
+  const bool separate = (cfg.flags & (DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE)) != 0u;
+  const bool side = finish && (cfg.flags & DCRX_F_V2_SIDE_STREAMS) && !(cfg.flags & DCRX_F_V2_LEAN_SERIAL) && P.v2_side && P.v2_side2 && P.v2_ev_fork &&
+                    P.v2_ev_join && P.v2_ev_join2;
   // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
   // serves as the fork event as well: one signal on the dispatch, no marker packet)
   const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
@@ -845,7 +996,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (finish) {
-    // waves of the finishing kernels that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
+    // waves of the finishing roles that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
     // 4096 on each rescue list of a full-size launch
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
     const uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
@@ -853,57 +1004,66 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of a short list's pass that share a region
     const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
-    const uint32_t llds = flds + DCRX_V2_FBLOCK * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4;      // the lean kernels: + a strip per lane (+ the rescue kernel's scratch counters)
+    const uint32_t llds = v2_finish_block_lds<NW>(T, o, DCRX_V2_FBLOCK);      // the lean roles: + a strip per lane (+ the rescue's scratch counters)
+    const uint32_t tlds = v2_finish_block_lds<NW>(T, o, DCRX_V2_TBLOCK);
     const uint32_t elds_ext = flds + (T.lds_image2_bytes - T.lds_image_bytes);
     const uint32_t ext = elds_ext <= 64u * 1024u ? 1u : 0u;      // the event kernel's LDS with the germline regions in it
     const uint32_t elds = ext ? elds_ext : flds;
     const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a short list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
-    const dim3 tgrid((n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64));
-    const uint32_t tlds = flds + DCRX_V2_TBLOCK * lds_words_stride<NW>() * 4;
-    auto general = [&](hipStream_t st, const int which, const bool whole_list, hipEvent_t stop) -> hipError_t {
-      if (whole_list)
-        hipExtLaunchKernelGGL(ke, dim3(egrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, 1u, ext,
-                              n_regions, queue, gqueue, qcap, queue_count);
-      else
-        hipExtLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, 1u, slow_width, bsplit, ext, n_regions, queue,
-                              gqueue, qcap, queue_count);
-      return hipGetLastError();
-    };
-    if (side) {
-      e = hipStreamWaitEvent(P.v2_side, fork_ev, 0); if (e != hipSuccess) return e;
-      hipExtLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue,
-                            gqueue, qcap, queue_count, P.dev_tables);
-      e = hipGetLastError(); if (e != hipSuccess) return e;
-      e = hipStreamWaitEvent(P.v2_side2, fork_ev, 0); if (e != hipSuccess) return e;
-      e = general(P.v2_side2, V2_L_X, false, P.v2_ev_join2); if (e != hipSuccess) return e;
-    }
-    // the scan kernel's event lists E and C: the lean rescue, or — A/B — the general form at once
-    if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE) {
-      for (int which = V2_L_E; which <= V2_L_C; which++) { e = general(s, which, true, nullptr); if (e != hipSuccess) return e; }
-    } else {
-      hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
+    const uint32_t tgrid = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
+    if (!separate) {
+      V2Roles R;
+      R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+      R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
+      hipLaunchKernelGGL(kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, R, queue, gqueue, qcap,
                          queue_count, P.dev_tables);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
-    }
-    if (side) {
-      e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
-      e = hipStreamWaitEvent(s, P.v2_ev_join2, 0); if (e != hipSuccess) return e;
     } else {
-      hipLaunchKernelGGL(kt, tgrid, dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue, gqueue, qcap, queue_count, P.dev_tables);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
-      e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;
+      auto general = [&](hipStream_t st, const int which, const bool whole_list, hipEvent_t stop) -> hipError_t {
+        if (whole_list)
+          hipExtLaunchKernelGGL(ke, dim3(egrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, (uint32_t)(DCRX_V2_FBLOCK / 64), 64u, 1u, ext,
+                                n_regions, queue, gqueue, qcap, queue_count);
+        else
+          hipExtLaunchKernelGGL(ke, dim3(sgrid), dim3(DCRX_V2_FBLOCK), elds, st, nullptr, stop, 0, T, B, cfg, rec, d_counters, Q, which, 1u, slow_width, bsplit, ext, n_regions, queue,
+                                gqueue, qcap, queue_count);
+        return hipGetLastError();
+      };
+      if (side) {
+        e = hipStreamWaitEvent(P.v2_side, fork_ev, 0); if (e != hipSuccess) return e;
+        hipExtLaunchKernelGGL(kt, dim3(tgrid), dim3(DCRX_V2_TBLOCK), tlds, P.v2_side, nullptr, P.v2_ev_join, 0, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue,
+                              gqueue, qcap, queue_count, P.dev_tables);
+        e = hipGetLastError(); if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(P.v2_side2, fork_ev, 0); if (e != hipSuccess) return e;
+        e = general(P.v2_side2, V2_L_X, false, P.v2_ev_join2); if (e != hipSuccess) return e;
+      }
+      // the scan kernel's event lists E and C: the lean rescue, or — A/B — the general form at once
+      if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE) {
+        for (int which = V2_L_E; which <= V2_L_C; which++) { e = general(s, which, true, nullptr); if (e != hipSuccess) return e; }
+      } else {
+        hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
+                           queue_count, P.dev_tables);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      if (side) {
+        e = hipStreamWaitEvent(s, P.v2_ev_join, 0); if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(s, P.v2_ev_join2, 0); if (e != hipSuccess) return e;
+      } else {
+        hipLaunchKernelGGL(kt, dim3(tgrid), dim3(DCRX_V2_TBLOCK), tlds, s, T, B, cfg, rec, d_counters, Q, n_regions, tsplit, queue, gqueue, qcap, queue_count, P.dev_tables);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;
+      }
     }
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
       std::vector<uint32_t> h((size_t)V2_L_COUNTS * n_regions);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
-      unsigned long long t[V2_L_COUNTS] = {0}, lmax = 0;
-      for (uint32_t r = 0; r < n_regions; r++) { for (int k = 0; k < V2_L_COUNTS; k++) t[k] += h[(size_t)V2_L_COUNTS * r + k]; lmax = std::max<unsigned long long>(lmax, h[(size_t)V2_L_COUNTS * r + V2_L_LEFT]); }
-      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu E %llu C %llu X %llu left %llu (max per region %llu)\n", n_regions, t[V2_L_TAIL], t[V2_L_E],
-              t[V2_L_C], t[V2_L_X], t[V2_L_LEFT], lmax);
+      unsigned long long t[V2_L_COUNTS] = {0};
+      for (uint32_t r = 0; r < n_regions; r++) for (int k = 0; k < V2_L_COUNTS; k++) t[k] += h[(size_t)V2_L_COUNTS * r + k];
+      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu E %llu C %llu X %llu\n", n_regions, t[V2_L_TAIL], t[V2_L_E], t[V2_L_C], t[V2_L_X]);
     }
   }
 #ifdef DCRX_SCAN_STAMPS
@@ -963,13 +1123,11 @@ void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *
   *tail_rows = entries * rt;
   *event_rows = (entries / 2) * re;
 }
-// ... and for the slow list (what the lean rescue and the lean tail do not settle): as many entries as the event list
+// ... and for lists C and X (half of a region of this allocation each): as many entries as the event list
 uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu) {
   uint64_t tr, er;
   v2_list_rows(max_reads, stride, n_cu, &tr, &er);
-  // ... plus the tail kernel's slow list: an eighth of the reads, at least 256 entries per region
-  const uint64_t re = stride <= 40 ? V2Rows<10>::E : stride <= 4 * DCRX_NWMAX ? V2Rows<DCRX_NWMAX>::E : V2Rows<DCRX_V2_NWLONG>::E;
-  return er + (max_reads / 8 + (uint64_t)n_cu * 16 * 256) * re;
+  return er;
 }
 
 }  // namespace dcrx

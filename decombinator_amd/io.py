@@ -173,3 +173,37 @@ def write_out_intermediate(data: list, inputargs: dict, suffix: str):
                     outfile.write(", ".join(map(str, line)) + "\n")
     sort_permissions(outfilename)
     return outfilename
+
+
+def write_out_translated(rows, headers, inputargs: dict):
+    """The AIRR table of the translate stage (reference io.py:516-548: `DataFrame.to_csv(sep="\t", index=False)`, then the
+    gzip step unless dontgzip, then mode 666): `<outpath><file id>.tsv[.gz]` for the translate / collapse commands, the
+    pipeline's `<prefix><file id>_<chain name>.tsv[.gz]` otherwise.  A missing value (None) is an empty field, as to_csv
+    writes it."""
+    chainnams = {"a": "alpha", "b": "beta", "g": "gamma", "d": "delta"}
+    filename_id = os.path.basename(inputargs["infile"]).split(".")[0]
+    if inputargs["command"] in ["collapse", "translate"]:
+        outfilename = inputargs["outpath"] + f"{filename_id}" + ".tsv"
+    else:
+        outfilename = (inputargs["outpath"] + inputargs["prefix"] + f"{filename_id}"
+                       + f"_{chainnams[inputargs['chain'].lower()]}" + ".tsv")
+
+    def lines():
+        yield "\t".join(headers) + "\n"
+        for r in rows:
+            yield "\t".join("" if x is None else str(x) for x in r) + "\n"
+
+    if not inputargs["dontgzip"]:
+        from . import _native as nat
+        print("Compressing pipeline output file to", outfilename + ".gz")
+        with nat.GzipWriter(outfilename + ".gz", level=int(os.environ.get("DCRX_GZIP_LEVEL", "6"))) as gz:
+            out = _GzText(gz)
+            for ln in lines():
+                out.write(ln)
+            out.flush()
+        outfilename += ".gz"
+    else:
+        with open(outfilename, "w") as fh:
+            fh.writelines(lines())
+    sort_permissions(outfilename)
+    return outfilename

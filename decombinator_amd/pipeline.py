@@ -61,15 +61,12 @@ def main(argv=None):
         out = [list(front[k][2]) + [front[k][5], front[k][3], front[k][4], front[k][0], front[k][1]] for k in front.kept().tolist()]
         write_out_intermediate(out, inp, ".n12u")
     elif inp["command"] == "translate":
-        # translate.py:388-560 for a `.freq` file: the AIRR `.tsv` (tab-separated, a header line, no index: io.py:531)
-        import os
+        # translate.py:388-560 for a `.freq` file: the AIRR `.tsv` (tab-separated, a header line, no index), gzipped unless
+        # -dz, mode 666 — the reference's write_out_translated (io.py:516-548)
         from . import translate
+        from .io import write_out_translated
         rows = translate.cdr3translator(inp)
-        name = inp["outpath"] + os.path.basename(inp["infile"]).split(".")[0] + ".tsv"
-        with open(name, "w") as fh:
-            fh.write("\t".join(translate.out_headers) + "\n")
-            for r in rows:
-                fh.write("\t".join(str(x) for x in r) + "\n")
+        name = write_out_translated(rows, translate.out_headers, inp)
         print("Translated", translate.counts["line_count"], "DCRs,", translate.counts["prod_recomb"], "productive ->", name)
     else:
         from .io import create_parser

@@ -116,10 +116,19 @@ class TupleGather:
 
     TUPLE_BYTES = 12      # (the class default; an instance with v_jumps carries 8)
 
-    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None, v_jumps=None):
+    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None, v_jumps=None,
+                 n_v: int = None, n_j: int = None):
         from . import _native as nat
         self.nat = nat
         self.v_jumps = None if v_jumps is None else list(v_jumps)
+        # the 8-byte tuple holds v in 11 bits and j in 9 (include/dcrx.h, dcrx_compact_hits_packed8_device) and re-derives
+        # ins_start from the V tag's jump: a table it does not describe (n_v / n_j from dcrx_tables_info, when the caller gives
+        # them) or a tag set too large for those fields travels as 12-byte tuples instead — never as masked garbage
+        if self.v_jumps is not None:
+            if n_v is not None and n_v != len(self.v_jumps):
+                raise ValueError(f"TupleGather: {len(self.v_jumps)} V jumps for a table of {n_v} V tags")
+            if len(self.v_jumps) >= 2048 or (n_j is not None and n_j >= 512):
+                self.v_jumps = None
         self.TUPLE_BYTES = 8 if self.v_jumps is not None else 12
         self.world, self.rank, self.n_reads = world, rank, n_reads
         self.cuda = device is not None and torch.device(device).type == "cuda"

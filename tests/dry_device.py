@@ -1,6 +1,6 @@
-"""CPU stand-in for the GPU in `bench.py --dry-gloo` (tests only): the rank program of the bench — sharding, the step
+"""CPU stand-in for the GPU in tests/bench_dry.py (tests only): the rank program of the bench — sharding, the step
 loop, the TupleGather protocol, the counters, the JSON line — runs over gloo with the oracle producing the records a
-device would.  Nothing here is a measurement; bench.py marks the line "dry_run": true and prints no rate."""
+device would.  Nothing here is a measurement; the line is marked "dry_run": true and carries no rate."""
 from __future__ import annotations
 
 import numpy as np

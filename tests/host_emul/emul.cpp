@@ -31,7 +31,7 @@ static int fast_one(bool pair_scan, const DevTables &T, const BatchDev &B, const
 template <bool UNIFORM>
 static void rescue_one(bool pair_rescue, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
                        const Counters &CC, dcrx_record_t *records, uint32_t *slot) {
-  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot); return; }
+  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot, false); return; }
   if (B.stride <= 40) decombine_rescue16_one<false, UNIFORM, 10>(T, B, C, r, 3u, nw, CC, records, slot);
   else decombine_rescue16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, 3u, nw, CC, records, slot);
 }
@@ -40,7 +40,7 @@ static void rescue_one(bool pair_rescue, const DevTables &T, const BatchDev &B, 
 template <bool UNIFORM>
 static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B, const CfgDev &C, uint64_t r, uint32_t nw,
                         const Counters &CC, dcrx_record_t *records, uint32_t *slot) {
-  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot); return; }
+  if (!pair_rescue) { decombine_list_one<false, UNIFORM>(T, nullptr, B, C, r, CC, records, slot, true); return; }
   uint32_t e0 = 0;
   while (e0 < B.n_exc && B.exc_read[e0] < (uint32_t)r) e0++;
   if (B.stride <= 40) decombine_general16_one<false, UNIFORM, 10>(T, B, C, r, e0, nw, CC, records, slot);

@@ -225,3 +225,14 @@ def test_fastq_to_front_half_with_oracle_as_device(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_fastq_to_front_half_through_hip_path(tmp_path):
     _stage_to_front(tmp_path)
+
+
+def test_module_imports_in_a_clean_interpreter():
+    """`from decombinator import collapse` as a library: nothing before it has imported collections.abc."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mod in ("collapse", "translate", "io", "decombine", "sharded", "pipeline"):
+        p = subprocess.run([sys.executable, "-S", "-c", f"import sys; sys.path.insert(0, {root!r}); "
+                            f"import site; site.main(); import decombinator_amd.{mod}"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, (mod, p.stderr[-2000:])

@@ -29,16 +29,16 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_ONE_BASE_SCAN,
-                                   nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
-                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "v2-general-form-only", "v2-one-stream", "onebase", "slowreader",
-                              "listrescue"])
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS,
+                                   nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
+                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "v2-general-form-only", "v2-separate-launches", "v2-side-streams", "onebase",
+                              "slowreader", "listrescue"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
 
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL],
-                         ids=["v2", "v1", "v2-general-form-only", "v2-one-stream"])
+@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS],
+                         ids=["v2", "v1", "v2-general-form-only", "v2-separate-launches", "v2-side-streams"])
 @pytest.mark.parametrize("config,seed,sub,n", [(2, 2, 0.005, 1_000_000), (5, 5, 0.02, 300_000)])
 def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n, flags):
     ts = synth.config_tagset(config)

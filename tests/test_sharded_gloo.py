@@ -330,3 +330,15 @@ def test_a_rank_that_fails_alone_fails_every_rank_without_a_hang(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "RAISED_PEER" in outs[0] and "RAISED_OWN" in outs[1], outs
+
+
+def test_tuple_gather_refuses_tables_the_8_byte_tuple_cannot_hold():
+    """the 8-byte tuple masks v to 11 and j to 9 bits — a larger tag set travels as 12-byte tuples, and a jump table
+    that does not match the V tags is an error."""
+    from decombinator_amd import sharded
+    g = sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 60, n_v=60, n_j=13)
+    assert g.TUPLE_BYTES == 8
+    assert sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 2048).TUPLE_BYTES == 12
+    assert sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 60, n_v=60, n_j=512).TUPLE_BYTES == 12
+    with pytest.raises(ValueError):
+        sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 59, n_v=60, n_j=13)

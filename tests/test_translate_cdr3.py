@@ -82,10 +82,21 @@ def test_translate_stage_from_files_and_the_cli(tmp_path):
     assert translate.counts["prod_recomb"] + translate.counts["NP_count"] == len(cases)
     args2 = dict(args, nonproductivefilter=True, chain="TRB")
     assert len(translate.cdr3translator(args2)) == translate.counts["prod_recomb"]
+    # the reference's write_out_translated (io.py:516-548): `.tsv.gz` by default, plain `.tsv` with -dz, mode 666
+    import gzip
+    import stat
     pipeline.main(["translate", "-in", str(tmp_path / "x_beta.freq"), "-tfdir", str(tmp_path), "-op", str(tmp_path) + os.sep])
-    lines = open(tmp_path / "x_beta.tsv").read().splitlines()
+    assert not os.path.exists(tmp_path / "x_beta.tsv")
+    lines = gzip.open(tmp_path / "x_beta.tsv.gz", "rt").read().splitlines()
     assert lines[0].split("\t") == translate.out_headers and len(lines) == 1 + len(cases)
     assert lines[1].split("\t")[1] == rows[0][1]
+    assert stat.S_IMODE(os.stat(tmp_path / "x_beta.tsv.gz").st_mode) == 0o666
+    pipeline.main(["translate", "-in", str(tmp_path / "x_beta.freq"), "-tfdir", str(tmp_path), "-op", str(tmp_path) + os.sep, "-dz"])
+    assert open(tmp_path / "x_beta.tsv").read().splitlines() == lines
+    from decombinator_amd.io import write_out_translated
+    name = write_out_translated([["a", None, 3]], ["x", "y", "z"], {"command": "translate", "infile": str(tmp_path / "n.freq"), "outpath": str(tmp_path) + os.sep,
+                                                                     "dontgzip": True, "chain": "b"})
+    assert open(name).read() == "x\ty\tz\na\t\t3\n"           # a missing value is an empty field, as DataFrame.to_csv writes it
 
 
 STAGE_FX = os.path.join(os.path.dirname(GOLDEN), "translate_stage.json")

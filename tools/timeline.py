@@ -13,7 +13,8 @@ for p in paths:
 rows.sort()
 steps, cur = [], []
 for s, e, n in rows:
-    if n == "prologue_kernel" and cur:
+    # a step starts with the prologue (three-launch form) or with the scan that follows a list kernel (v2: no prologue)
+    if cur and (n == "prologue_kernel" or (n == "scan2_kernel" and cur[-1][2] == "decombine_list_kernel")):
         steps.append(cur); cur = []
     cur.append((s, e, n))
 if cur:
