@@ -4,13 +4,15 @@
 //   set_barcode :278-326, check_umi_quality :343-353, the inter-tag length filter :553-556 —
 // on the text libdcrx assembled (dcrx_assemble_rows: fields separated by `field_sep`, one row per line).
 //
-// The spacer searches are the reference's three steps (:204-212): the spacer verbatim; else with up to two substitutions
-// (regex "(spacer){1s<=2}": the leftmost windows within Hamming distance 2, non-overlapping, left to right); else the
-// indel form "(spacer){2i+2d+1s<=2}".  The first two are decided here, and so is the third when it cannot match: what it
-// adds to the second is the spacer with one base deleted or one inserted, and a text that holds no such window holds no
-// match.  A row where such a window exists is NOT decided here: it comes back with status DCRX_CF_DEFER and nothing
-// counted, and the caller runs the reference's own regex on it (decombinator_amd/collapse.py) — the regex module's choice
-// among the indel alignments of one window is its backtracking order, which this file does not restate.
+// The spacer searches are the reference's three steps (:204-212), all decided here: the spacer verbatim; else with up to two
+// substitutions (regex "(spacer){1s<=2}": the leftmost windows within Hamming distance 2, non-overlapping, left to right);
+// else the indel form "(spacer){2i+2d+1s<=2}" — what it adds to the second is the spacer with one base inserted (a window
+// of m + 1 bases) or one base deleted (m - 1 bases): a substitution beside an indel would cost 3.  regex.findall takes the
+// leftmost start at which either holds, non-overlapping, left to right; where both hold at one start it returns the
+// insertion (its backtracking tries the deepest error position first and, there, insertion before deletion — and the
+// alignments of one kind that a start admits all reach down to the first mismatch).  Pinned against the regex module
+// itself: tests/test_collapse_front.py (differential, mutated barcode regions over the five oligos) and
+// tools/fuzz_spacer_search.py (10^6 and more per oligo).  DCRX_CF_DEFER is left for rows that are not 10 fields of ASCII.
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE
 #endif
@@ -45,11 +47,12 @@ inline int find_from(const char *s, int n, const char *sub, int m, int from) {
   return p ? (int)((const char *)p - s) : -1;
 }
 
-// spacerSearch(spacer, s[0..n)) :204-212 as far as this file goes.  Returns the number of non-overlapping matches (left to
-// right) and, for the first one, its start; `exact` tells whether they are verbatim occurrences; -1: defer (indel form).
-int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, bool &exact) {
+// spacerSearch(spacer, s[0..n)) :204-212.  Returns the number of non-overlapping matches (left to right) and, for the first
+// one, its start and its length (m; m + 1 / m - 1 for an indel match); `exact` tells whether they are verbatim occurrences.
+int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, int &first_len, bool &exact) {
   int cnt = 0;
   first_at = -1;
+  first_len = m;
   exact = true;
   for (int at = find_from(s, n, sp, m, 0); at >= 0; at = find_from(s, n, sp, m, at + m)) {     // regex.findall(spacer, s)
     if (!cnt) first_at = at;
@@ -63,25 +66,24 @@ int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, bo
     if (d <= 2) { if (!cnt) first_at = i; cnt++; i += m; } else i++;
   }
   if (cnt) return cnt;
-  // {2i+2d+1s<=2} (:198-201): what is left after the two searches above is the spacer with one base deleted (a window
-  // of m - 1 bases) or one base inserted (m + 1 bases) — a substitution beside an indel would cost 3.  If no window of the
-  // text can be that, the regex finds nothing either: no spacer.  If one can, the regex decides (which window, which
-  // string): deferred.
-  for (int i = 0; i < n; i++) {
+  // {2i+2d+1s<=2} (:198-201), given that neither search above found anything
+  for (int i = 0; i < n;) {
     int a = 0;
     while (a < m && i + a < n && s[i + a] == sp[a]) a++;                 // the spacer's prefix at i
-    if (i + m - 1 <= n && m >= 2) {                                      // one base deleted
-      int b = 0;
-      while (b < m - 1 && s[i + m - 2 - b] == sp[m - 1 - b]) b++;
-      if (a + b >= m - 1) return -1;
-    }
-    if (i + m + 1 <= n) {                                                // one base inserted
+    int span = 0;
+    if (i + m + 1 <= n) {                                                // one base inserted: prefix + one base + the rest
       int b = 0;
       while (b < m && s[i + m - b] == sp[m - 1 - b]) b++;
-      if (a + b >= m) return -1;
+      if (a + b >= m) span = m + 1;
     }
+    if (!span && m >= 2 && i + m - 1 <= n) {                             // one base deleted
+      int b = 0;
+      while (b < m - 1 && s[i + m - 2 - b] == sp[m - 1 - b]) b++;
+      if (a + b >= m - 1) span = m - 1;
+    }
+    if (span) { if (!cnt) { first_at = i; first_len = span; } cnt++; i += span; } else i++;
   }
-  return 0;
+  return cnt;
 }
 
 struct Cfg { int oligo, allow_ns, lenthreshold; double min_q, below_min, avg_q; const char *sep; int sep_len; };
@@ -125,16 +127,14 @@ uint8_t front_row(const char *row, int len, const Cfg &c, dcrx_collapse_row_t &o
     const int ws = c.oligo == 3 ? 18 : 0, we = c.oligo == 3 ? 28 : (c.oligo == 4 ? 19 : 10 + m1);               // :398-409
     const int a = ws < nbc ? ws : nbc, b = we < nbc ? we : nbc;
     int at = -1;
-    const int n1 = spacer_search(bc + a, b - a, ol.s1, m1, at, ex0);
-    if (n1 < 0) return DCRX_CF_DEFER;
+    const int n1 = spacer_search(bc + a, b - a, ol.s1, m1, at, l0, ex0);
     if (n1 != 1) { add[DCRX_CF_C_FAIL_NOSPACER]++; have = false; }                                             // :413-416
     else p0 = a + at;
   }
   if (have && ol.s2) {
     const int a = m1 < nbc ? m1 : nbc;
     int at = -1;
-    const int n2 = spacer_search(bc + a, nbc - a, ol.s2, m2, at, ex1);
-    if (n2 < 0) return DCRX_CF_DEFER;
+    const int n2 = spacer_search(bc + a, nbc - a, ol.s2, m2, at, l1, ex1);
     if (n2 != 1) { add[DCRX_CF_C_FAIL_NOT2SPACERS]++; have = false; }                                          // :423-426
     else p1 = a + at;
   }

@@ -282,7 +282,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     v2_exc_slice(B, blk_lo < blk_hi ? blk_lo : blk_hi, blk_hi, lds_work + V2_WK_EXC, tid);
     e_lo = lds_work[V2_WK_EXC]; e_hi = lds_work[V2_WK_EXC + 2];
     v2_exc_marks(B, e_lo, e_hi, true, tid);
-    __threadfence();           // the marks are in memory before a wave of this block fetches them with its first item
+    // the marks are atomics at the L2 this unit reads through: they need only have been performed before a wave of this
+    // block fetches them with its first item (no write-back of the L2, no invalidation: __threadfence() here cost the scan
+    // a quarter of its time, every wave of the chip writing back an L2 full of the previous step's records)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   constexpr uint32_t WT = 64u * RPL;
@@ -500,31 +503,38 @@ __device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori
 // the read in hand, the scratch counters of the lean rescue; per wave the slots of the entries its lean form left.
 constexpr int V2_LEFT_SLOTS = 15;      // entries a wave may note per job; more (never seen) go to the list kernel
 struct V2FinishLds {
-  uint32_t *counts, *side, *bk, *strip, *dry;
-  uint32_t (*left)[1 + V2_LEFT_SLOTS];
+  uint32_t *counts, *side, *bk, *strip, *dry, *left;      // left: this wave's 1 + V2_LEFT_SLOTS words
 };
+// where those pieces lie in the block's dynamic LDS (addresses only) ...
 template <int NW, int BLOCK>
-__device__ __forceinline__ V2FinishLds v2_finish_stage(const DevTables &T0, const V2Ori &V, uint32_t *smem, uint32_t (*s_left)[1 + V2_LEFT_SLOTS], const int tid) {
+__device__ __forceinline__ V2FinishLds v2_finish_layout(const DevTables &T0, const V2Ori &V, uint32_t *smem, const int tid) {
   V2FinishLds L;
   L.counts = smem;
   L.side = smem + DCRX_N_COUNTERS;
   L.bk = L.side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
+  // each lane's strip of LDS for the read in hand
+  L.strip = L.bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
+  // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
+  L.dry = L.bk + V.bk_bytes / 4 + (uint32_t)BLOCK * lds_words_stride<NW>();
+  L.left = L.dry + DCRX_N_COUNTERS + (uint32_t)(tid >> 6) * (1 + V2_LEFT_SLOTS);
+  return L;
+}
+// ... and their staging (the caller synchronises)
+template <int NW, int BLOCK>
+__device__ __forceinline__ V2FinishLds v2_finish_stage(const DevTables &T0, const V2Ori &V, uint32_t *smem, const int tid) {
+  const V2FinishLds L = v2_finish_layout<NW, BLOCK>(T0, V, smem, tid);
   if (tid < DCRX_N_COUNTERS) L.counts[tid] = 0;
   stage_lds<BLOCK>(T0.image + T0.dfa_bytes, L.side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
   stage_lds<BLOCK>(V.bk, L.bk, V.bk_bytes / 16, 0, 0, tid);
-  // each lane's strip of LDS for the read in hand (its two zero words are written once)
-  L.strip = L.bk + V.bk_bytes / 4 + (uint32_t)tid * lds_words_stride<NW>();
-  L.strip[NW] = 0u; L.strip[NW + 1] = 0u;
-  // behind the strips: a block of counters nobody reads (what a walk counts that turns out not to be final)
-  L.dry = L.bk + V.bk_bytes / 4 + (uint32_t)BLOCK * lds_words_stride<NW>();
-  L.left = s_left;
-  if ((tid & 63) == 0) s_left[tid >> 6][0] = 0u;
+  L.strip[NW] = 0u; L.strip[NW + 1] = 0u;      // (the strip's two zero words are written once)
+  if ((tid & 63) == 0) L.left[0] = 0u;
   return L;
 }
 // (bytes of that image: the launcher's size of the dynamic LDS)
 template <int NW>
 static uint32_t v2_finish_block_lds(const DevTables &T, int o, int block) {
-  return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + (uint32_t)block * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4;
+  return DCRX_N_COUNTERS * 4 + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + (uint32_t)block * lds_words_stride<NW>() * 4 + DCRX_N_COUNTERS * 4 +
+         (uint32_t)(block / 64) * (1 + V2_LEFT_SLOTS) * 4;
 }
 
 // a lane notes the slot of an entry its lean form did not settle (LDS, per wave)
@@ -566,7 +576,7 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
   const Counters C{L.counts};
   const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
   uint32_t *strip = L.strip, *lds_counts = L.counts;
-  uint32_t *s_left = L.left[tid >> 6];
+  uint32_t *s_left = L.left;
   const int lane = tid & 63;
   for (uint32_t job = gwave; job < n_regions * split; job += n_gwaves) {
     const uint32_t region = job / split, part = job % split;
@@ -675,7 +685,7 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
   const Counters C{L.counts}, Cdry{L.dry};
   const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
   uint32_t *strip = L.strip, *lds_counts = L.counts;
-  uint32_t *s_left = L.left[tid >> 6];
+  uint32_t *s_left = L.left;
   const int lane = tid & 63;
   for (uint32_t job = gwave; job < 2u * n_regions * split && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
     const int which = job < n_regions * split ? V2_L_E : V2_L_C;
@@ -768,15 +778,55 @@ __device__ __forceinline__ void v2_slow_jobs(const V2FinishLds &L, const BatchDe
 // (single reads with long dependent chains: they start at once and run under everything else), then blocks of the lean
 // rescue and of the lean tail in turn, so that every compute unit holds waves of both at any time — the rescue is bound by
 // instruction issue, the tail by its stream of entries.
+// The lean roles are functions of their own (not inlined): each keeps the register allocation it has as a kernel — inlined side
+// by side, the scalars of both stayed live across the role switch and the launch spilled twice as many as either kernel (311
+// against 156; 287 us for what the two kernels did in 185).  A role reads the launch's arguments where the kernel found
+// them, in the kernarg segment (its address is the one thing handed down, made scalar again by two v_readfirstlane):
+// uniform scalar loads, nothing else travels through vector registers or the stack.
 struct V2Roles { uint32_t xgrid, rgrid, tgrid, rsplit, tsplit, bsplit, width; };
+struct V2FinishArgs {
+  DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; unsigned long long *counters; V2Lists Q; uint32_t n_regions; V2Roles R;
+  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
+};
+__device__ __forceinline__ const V2FinishArgs &v2_finish_args(const uint32_t lo, const uint32_t hi) {
+  typedef const __attribute__((address_space(4))) V2FinishArgs *KArgs;      // (constant address space: scalar loads)
+  const uint64_t p = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+  return *(const V2FinishArgs *)reinterpret_cast<KArgs>(p);
+}
 template <bool UNIFORM_LEN, int NW, int ORI>
-__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(
-    DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
-    V2Lists Q, uint32_t n_regions, V2Roles R, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
-    uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
+__device__ __attribute__((noinline)) void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
+  const V2FinishArgs &A = v2_finish_args(ka_lo, ka_hi);
+  const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
   const int tid = threadIdx.x;
+  const V2Ori V = A.T0.v2[ORI];
+  const V2FinishLds L = v2_finish_layout<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
+  uint32_t kw_base[K_NCLASS];
+#pragma unroll
+  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = A.T0.kw_base[c];
+  const Rescue2Tabs rt = rescue2_tabs(A.T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
+  constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
+  v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.rsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
+                                       vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid);
+}
+template <bool UNIFORM_LEN, int NW, int ORI>
+__device__ __attribute__((noinline)) void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const V2FinishArgs &A = v2_finish_args(ka_lo, ka_hi);
+  const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
+  const int tid = threadIdx.x;
+  const V2Ori V = A.T0.v2[ORI];
+  const V2FinishLds L = v2_finish_layout<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
+  const Tail2Tabs tt = tail2_tabs(A.T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1);
+  constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
+  v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.tsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
+                                     vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid);
+}
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(const V2FinishArgs A) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const int tid = threadIdx.x;
+  const V2Roles R = A.R;
   // the role of this block
   uint32_t b = blockIdx.x;
   int role;                 // 0 list X, 1 rescue, 2 tail
@@ -784,26 +834,22 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
     role = 0;
     // (most blocks of a short list's pass find their share empty: they leave before they stage anything)
     const uint32_t g = b / R.bsplit;
-    if (g >= n_regions || R.width * (DCRX_V2_FBLOCK / 64) * (b % R.bsplit) >= Q.counts[V2_L_COUNTS * g + V2_L_X]) return;
+    if (g >= A.n_regions || R.width * (DCRX_V2_FBLOCK / 64) * (b % R.bsplit) >= A.Q.counts[V2_L_COUNTS * g + V2_L_X]) return;
   } else {
     b -= R.xgrid;
     const uint32_t paired = 2u * min(R.rgrid, R.tgrid);
     if (b < paired) { role = (b & 1u) ? 2 : 1; b >>= 1; }
     else { b -= paired; role = R.rgrid > R.tgrid ? 1 : 2; b += min(R.rgrid, R.tgrid); }
   }
-  const V2Ori V = T0.v2[ORI];
-  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(T0, V, smem, s_left, tid);
-  uint32_t kw_base[K_NCLASS];
-#pragma unroll
-  for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
-  const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
+  const V2Ori V = A.T0.v2[ORI];
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
   __syncthreads();
-  constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
-  if (role == 1) v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, B, cfg, records, Q, n_regions, R.rsplit, queue, gqueue, qcap, queue_count, Tmem, b * WPB + (uint32_t)(tid >> 6), R.rgrid * WPB, tid);
-  else if (role == 2) v2_tail_jobs<UNIFORM_LEN, NW, ORI>(rt.t, L, B, cfg, records, Q, n_regions, R.tsplit, queue, gqueue, qcap, queue_count, Tmem, b * WPB + (uint32_t)(tid >> 6), R.tgrid * WPB, tid);
-  else v2_slow_jobs<UNIFORM_LEN, NW, ORI, DCRX_V2_FBLOCK>(L, B, cfg, records, Q, n_regions, R.bsplit, R.width, queue, gqueue, qcap, queue_count, Tmem, b, tid);
+  const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();      // (where this launch's V2FinishArgs lies)
+  if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+  else if (role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+  else v2_slow_jobs<UNIFORM_LEN, NW, ORI, DCRX_V2_FBLOCK>(L, A.B, A.cfg, A.records, A.Q, A.n_regions, R.bsplit, R.width, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem, b, tid);
   __syncthreads();
-  if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
+  if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
 }
 
 // The roles as launches of their own (A/B: DCRX_F_V2_SIDE_STREAMS, the tail kernel beside the rescue kernel on a side stream of
@@ -814,10 +860,9 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
     V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
   extern __shared__ __align__(64) uint32_t smem[];
-  __shared__ uint32_t s_left[DCRX_V2_TBLOCK / 64][1 + V2_LEFT_SLOTS];
   const int tid = threadIdx.x;
   const V2Ori V = T0.v2[ORI];
-  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_TBLOCK>(T0, V, smem, s_left, tid);
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_TBLOCK>(T0, V, smem, tid);
   const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1);
   __syncthreads();
   v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
@@ -832,10 +877,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
     V2Lists Q, uint32_t n_regions, uint32_t split, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap,
     uint32_t *__restrict__ queue_count, const DevTables *__restrict__ Tmem) {
   extern __shared__ __align__(64) uint32_t smem[];
-  __shared__ uint32_t s_left[DCRX_V2_FBLOCK / 64][1 + V2_LEFT_SLOTS];
   const int tid = threadIdx.x;
   const V2Ori V = T0.v2[ORI];
-  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(T0, V, smem, s_left, tid);
+  const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(T0, V, smem, tid);
   uint32_t kw_base[K_NCLASS];
 #pragma unroll
   for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
@@ -1015,8 +1059,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       V2Roles R;
       R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
       R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
-      hipLaunchKernelGGL(kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, R, queue, gqueue, qcap,
-                         queue_count, P.dev_tables);
+      V2FinishArgs A;
+      A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
+      A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables;
+      hipLaunchKernelGGL(kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     } else {
