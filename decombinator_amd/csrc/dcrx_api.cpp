@@ -81,6 +81,7 @@ struct dcrx_tables {
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
   void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;
+  void *d_v2_left = nullptr;        // the finishing launch's left list
   uint64_t *d_v2_acc = nullptr;     // the v2 kernels' tallies of the call in flight (zero between calls)  // v2 kernels: the per-wave lists between scan and finishing
   hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
   uint32_t *d_v2_counts = nullptr;
@@ -110,6 +111,7 @@ static void free_device_state(dcrx_tables *t) {
   t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
   (void)hipFree(t->d_v2_acc); t->d_v2_acc = nullptr; t->plan.v2_acc = nullptr;
+  (void)hipFree(t->d_v2_left); t->d_v2_left = nullptr; t->plan.v2_left = nullptr;
   (void)hipFree(t->d_stage);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
   t->h_stage = nullptr; t->h_stage_bytes = 0;
@@ -283,6 +285,12 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
       HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 16));
       if (!t->d_v2_acc) { HIP_TRY(hipMalloc(&t->d_v2_acc, DCRX_N_COUNTERS * 8)); t->ws_dirty = true; }
       t->plan.v2_acc = t->d_v2_acc;
+      if (!t->d_v2_left) {      // V2_LEFT_CAP entries of 32-word reads, and a valid word per entry (zero between launches)
+        const size_t left_bytes = (size_t)1024 * ((1 + 2 * DCRX_V2_NWLONG + 3) / 4) * 16 + 1024 * 4;
+        HIP_TRY(hipMalloc(&t->d_v2_left, left_bytes));
+        HIP_TRY(hipMemset(t->d_v2_left, 0, left_bytes));
+      }
+      t->plan.v2_left = reinterpret_cast<uint4 *>(t->d_v2_left);
       t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
       t->plan.v2_slow = reinterpret_cast<uint4 *>(t->d_v2_slow);
       t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;

@@ -254,20 +254,23 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
   const uint32_t t_rescue = (n_rescue + 64 * DCRX_CHUNK - 1) / (64 * DCRX_CHUNK);
   // The last block to finish re-arms the work counters for the next launch (no memset between
   // launches): by then every block has read the counts above.
-  auto hand_over = [&]() {      // (one thread, when every tally of the call is in the accumulator)
-    for (int c = 0; c < DCRX_N_COUNTERS; c++) {
-      const unsigned long long v = atomicExch(&counters[c], 0ull);
-      out[c] = (c == DCRX_C_READ_COUNT && read_count != ~0ull) ? read_count : v;
-    }
+  auto hand_over = [&](const int c) {      // (a thread per counter, when every tally of the call is in the accumulator)
+    const unsigned long long v = atomicExch(&counters[c], 0ull);
+    out[c] = (c == DCRX_C_READ_COUNT && read_count != ~0ull) ? read_count : v;
   };
   if (out && n_rescue == 0 && n_general == 0) {      // nothing was handed over: the common case behind the v2 kernels
-    if (blockIdx.x == 0 && tid == 0) hand_over();
+    if (blockIdx.x == 0 && tid < DCRX_N_COUNTERS) hand_over(tid);
     return;
   }
-  auto leave = [&]() {
-    if (tid == 0 && atomicAdd(queue_count + 4, 1u) == gridDim.x - 1) {
+  auto leave = [&]() {      // (the block's first wave: its lanes hold the block's tallies, lane 0 signs the block off)
+    if (tid >= 64) return;
+    uint32_t last = 0;
+    if (tid == 0) last = atomicAdd(queue_count + 4, 1u) == gridDim.x - 1 ? 1u : 0u;
+    last = (uint32_t)__shfl((int)last, 0);
+    if (!last) return;
+    if (out && tid < DCRX_N_COUNTERS) hand_over(tid);
+    if (tid == 0) {
       queue_count[0] = queue_count[1] = queue_count[2] = queue_count[3] = 0;
-      if (out) hand_over();
       __threadfence();
       queue_count[4] = 0;
     }

@@ -31,6 +31,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -85,12 +86,15 @@ constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block ca
 //   region `sx`:  C = half-tag rescue of both genes (V2_SHAPE_BOTH)  |  X = reads with exception bytes, flags on an odd read's
 //                     last half pair: the general form            (half of the region each)
 // (a list that outgrows its room hands the rest to the list kernel; what a lean kernel does not settle it finishes itself,
-// behind its job's loop: v2_general_call)
+// behind the launch's last block: v2_left_push, v2_general_role)
 enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_COUNTS = 8 };
+constexpr uint32_t V2_LEFT_CAP = 1024;      // entries of the left list (a handful per 10 M reads; more go to the list kernel)
+enum { V2_QC_LEFT = 5, V2_QC_DONE = 6 };    // words of the queue header (DCRX_QUEUE_HEADER): entries of the left list, finishing blocks done
 struct V2Lists {
   uint4 *tail;        // [regions][rows_t][tcap]
   uint4 *ev;          // [regions][rows_e][ecap]
   uint4 *sx;          // [regions][rows_e][scap]
+  uint4 *left;        // [rows_e][V2_LEFT_CAP]: event entries of what the lean roles did not settle (count: queue_count[V2_QC_LEFT])
   uint32_t *counts;   // [regions][V2_L_COUNTS]: entries of each list (V2_L_*)
   uint32_t tcap, ecap, scap;      // scap: a multiple of 128 (two lists of whole chunks)
 };
@@ -546,27 +550,32 @@ __device__ __forceinline__ void v2_note_left(uint32_t *left, const uint32_t slot
 }
 template <int NW>
 struct V2EntryWords { uint32_t lg[NW], w[NW]; };
-// ... the general form as a call, for the lean roles: what their straight-line forms do not settle (one read in two million)
-// is finished on the spot, with the tables the block has staged, instead of travelling to a pass of its own behind them (a
-// launch, a join and one read's latency on the critical path of every step).  Not inlined: the lean loops keep their
-// registers.  The same call serves list X (reads with exception bytes), a few lanes per wave.
-template <bool UNIFORM_LEN, int NW, int ORI>
-__device__ __attribute__((noinline)) void v2_general_call(const DevTables *__restrict__ Tmem, const uint32_t *lds_side, const uint32_t *lds_bk, const BatchDev B, const CfgDev cfg, const uint32_t x0,
-                                                           const V2EntryWords<NW> e, uint32_t *lds_counts, dcrx_record_t *__restrict__ records,
-                                                           uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, const uint32_t qcap,
-                                                           uint32_t *__restrict__ queue_count) {
-  const DevTables T0 = *Tmem;
-  const DevTables T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_side), T0.dfa_bytes, false);      // (the side tables and buckets the block staged)
-  V2Ori V = T0.v2[ORI];
-  V.bk = reinterpret_cast<const uint8_t *>(lds_bk);
-  const Counters C{lds_counts};
-  v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, x0, e.lg, e.w, C, records, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30));
+// What a lean role does not settle (one read in two million) becomes an event entry of the launch's left list; one wave of the
+// launch — of the first block of list X's role, which stays for it — takes the entries through the general form as they
+// arrive (v2_general_role, mode 1) and leaves when every other block has signed off.  Neither a call inside the lean loops — the
+// general form as a call there kept 58 vector and 80 scalar registers of the tail loop spilled around a call site that one
+// batch in ten thousand reaches — nor a pass of its own behind them (a launch and one read's latency on every step's path).
+// (behind the rows of the list: one word per entry, set when the entry is whole)
+template <int NW>
+__device__ __forceinline__ uint32_t *v2_left_valid(uint4 *left_rows) { return reinterpret_cast<uint32_t *>(left_rows + (size_t)V2_LEFT_CAP * V2Rows<NW>::E); }
+template <int NW>
+__device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restrict__ queue_count, const uint32_t x0, const uint32_t (&lg)[NW], const uint32_t (&w)[NW]) {
+  const uint32_t at = atomicAdd(queue_count + V2_QC_LEFT, 1u);
+  if (at >= V2_LEFT_CAP) return false;      // (the count runs on; its reader clamps it)
+  uint32_t x[1 + 2 * NW];
+  x[0] = x0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { x[1 + k] = lg[k]; x[1 + NW + k] = w[k]; }
+  v2_put_rows<1 + 2 * NW>(left_rows, 0u, at, x);
+  __threadfence();                          // the entry is in memory ...
+  __hip_atomic_store(v2_left_valid<NW>(left_rows) + at, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before it is called valid
+  return true;
 }
 
 // The lean tail: wave `gwave` of `n_gwaves` takes the jobs (region, part) gwave, gwave + n_gwaves, ...: `split` waves share a
 // region (a scan block's list), wave k of them its batches k, k + split, ...  Software pipeline over the batches of 64: the
 // entries are read one batch ahead, the read in hand sits in the lane's LDS strip.  What the lean form does not settle is
-// noted per wave and finished behind the job's loop (v2_general_call), so that no value of the loop lives across a call.
+// noted per wave and pushed to the launch's left list behind the job's loop (v2_left_push).
 template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
                                              const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
@@ -635,7 +644,7 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
           if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
           e.lg[k] = l; e.w[k] = x[2 + k];
         }
-        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0] | (jc == 2u ? V2_R_JMULTI : 0u), e, lds_counts, records, queue, gqueue, qcap, queue_count);
+        if (!v2_left_push<NW>(Q.left, queue_count, x[0] | (jc == 2u ? V2_R_JMULTI : 0u), e.lg, e.w)) v2_hand_over(B, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30), x[0], false);
       }
       if (lane == 0) s_left[0] = 0u;
     }
@@ -738,40 +747,21 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
         V2EntryWords<NW> e;
 #pragma unroll
         for (int k = 0; k < NW; k++) { e.lg[k] = x[1 + k]; e.w[k] = x[1 + NW + k]; }
-        v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0], e, lds_counts, records, queue, gqueue, qcap, queue_count);
+        if (!v2_left_push<NW>(Q.left, queue_count, x[0], e.lg, e.w)) v2_hand_over(B, queue, gqueue, qcap, queue_count, B.n_reads < (1ull << 30), x[0] & V2_R_MASK, (x[0] & V2_R_EXC) != 0u);
       }
       if (lane == 0) s_left[0] = 0u;
     }
   }
 }
 
-// List X (reads with exception bytes whose flag log is not empty, flags on an odd read's last half pair: a few thousand of a
-// 10 M-read batch) through the general form as the same call: `width` lanes of a wave take entries — the general form costs a
-// wave the longest of its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit`
-// blocks share a region.  Block `vblock` of the role's n_regions * bsplit.
-template <bool UNIFORM_LEN, int NW, int ORI, int BLOCK>
-__device__ __forceinline__ void v2_slow_jobs(const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records, const V2Lists &Q,
-                                             const uint32_t n_regions, const uint32_t bsplit, const uint32_t width, uint32_t *__restrict__ queue,
-                                             uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
-                                             const DevTables *__restrict__ Tmem, const uint32_t vblock, const int tid) {
-  const uint32_t region = vblock / bsplit, bpart = vblock % bsplit;
-  if (region >= n_regions || (cfg.flags & DCRX_F_PROFILE_NO_EVENTS)) return;
-  const V2ListRef l = v2_list<NW>(Q, V2_L_X, region);
-  const uint32_t total = min(Q.counts[V2_L_COUNTS * region + V2_L_X], l.cap);
-  const int lane = tid & 63;
-  for (uint32_t first = width * ((uint32_t)(tid >> 6) + (BLOCK / 64) * bpart); first < total; first += width * (BLOCK / 64) * bsplit) {
-    const uint32_t i = first + (uint32_t)lane;
-    const bool live = (uint32_t)lane < width && i < total;
-    uint32_t x[1 + 2 * NW];
-    v2_get_rows<1 + 2 * NW>(l.rows, l.cap, i, live, x);
-    if (live) {
-      V2EntryWords<NW> e;
-#pragma unroll
-      for (int k = 0; k < NW; k++) { e.lg[k] = x[1 + k]; e.w[k] = x[1 + NW + k]; }
-      v2_general_call<UNIFORM_LEN, NW, ORI>(Tmem, L.side, L.bk, B, cfg, x[0], e, L.counts, records, queue, gqueue, qcap, queue_count);
-    }
-  }
-}
+// The general form (dcr_frame3) as a role of the finishing launch, a function of its own like the lean roles:
+//   mode 0  list X (reads with exception bytes whose flag log is not empty, flags on an odd read's last half pair: a few
+//           thousand of a 10 M-read batch).  `width` lanes of a wave take entries — the general form costs a wave the longest of
+//           its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit` blocks share
+//           a region; block `vblock` of n_regions * bsplit;
+//   mode 1  the launch's left list, by the last block to finish.
+template <bool UNIFORM_LEN, int NW, int ORI>
+__device__ __attribute__((noinline)) void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi);
 
 // ONE launch for everything behind the scan, on the caller's stream — no side streams, no fork and no join (each wait of one
 // queue for another cost the waiting queue 8-10 us).  A block's role follows from its index: first the blocks of list X
@@ -788,15 +778,57 @@ struct V2FinishArgs {
   DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; unsigned long long *counters; V2Lists Q; uint32_t n_regions; V2Roles R;
   uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
 };
-__device__ __forceinline__ const V2FinishArgs &v2_finish_args(const uint32_t lo, const uint32_t hi) {
-  typedef const __attribute__((address_space(4))) V2FinishArgs *KArgs;      // (constant address space: scalar loads)
+// (every field through a pointer typed for the constant address space, dword by dword: scalar loads by construction — a
+// reference into the segment through a generic pointer left half of the accesses as vector loads inside the hot loops,
+// where their waits also drained the entry loads in flight: the tail role took 162 us for the kernel's 93)
+typedef const __attribute__((address_space(4))) uint32_t *dcrx_kwords;
+template <class T>
+__device__ __forceinline__ T v2_karg(const dcrx_kwords base, const size_t offset) {
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  T out;
+  uint32_t *d = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; i++) d[i] = base[offset / 4 + i];
+  return out;
+}
+template <class T>
+__device__ __forceinline__ T *v2_global(T *p) {      // (through the integer: a cast there and back between pointer types folds away)
+  return (T *)(__attribute__((address_space(1))) T *)(uintptr_t)p;
+}
+// ... and what no kernel of the launch writes — the tables in device memory, the lists' counts the scan left — is constant
+// memory to a role: uniform loads of it are scalar loads (a function, unlike a kernel, cannot show that nothing clobbers global
+// memory before its loads, and would fetch the tables' fields of the rare paths with vector loads in the middle of the loop,
+// where the wait for them also drains the entry loads in flight)
+template <class T>
+__device__ __forceinline__ T *v2_constant(T *p) { return (T *)(__attribute__((address_space(4))) T *)(uintptr_t)p; }
+struct V2FinishLocals {      // a role's copy of the launch's arguments (what it does not use is never loaded)
+  DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; V2Lists Q; uint32_t n_regions; V2Roles R;
+  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
+};
+__device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, const uint32_t hi) {
   const uint64_t p = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
-  return *(const V2FinishArgs *)reinterpret_cast<KArgs>(p);
+  const dcrx_kwords k = reinterpret_cast<dcrx_kwords>(p);
+  V2FinishLocals A;
+#define DCRX_KARG(F) A.F = v2_karg<decltype(A.F)>(k, offsetof(V2FinishArgs, F))
+  DCRX_KARG(T0); DCRX_KARG(B); DCRX_KARG(cfg); DCRX_KARG(records); DCRX_KARG(Q); DCRX_KARG(R);
+  DCRX_KARG(queue); DCRX_KARG(gqueue); DCRX_KARG(queue_count); DCRX_KARG(Tmem);
+#undef DCRX_KARG
+  A.n_regions = k[offsetof(V2FinishArgs, n_regions) / 4];
+  A.qcap = k[offsetof(V2FinishArgs, qcap) / 4];
+  // (a kernel knows that its pointer arguments are global memory; a pointer put together from two dwords is a generic one, and
+  // every access through it a flat one, until it is told)
+#define DCRX_GLOBAL(P) P = v2_global(P)
+  DCRX_GLOBAL(A.records); DCRX_GLOBAL(A.Q.tail); DCRX_GLOBAL(A.Q.ev); DCRX_GLOBAL(A.Q.sx); DCRX_GLOBAL(A.queue);
+  DCRX_GLOBAL(A.gqueue); DCRX_GLOBAL(A.queue_count); DCRX_GLOBAL(A.B.packed); DCRX_GLOBAL(A.B.lens); DCRX_GLOBAL(A.B.exc_read);
+  DCRX_GLOBAL(A.B.exc_pos); DCRX_GLOBAL(A.B.exc_chr); DCRX_GLOBAL(A.B.exc_flag); DCRX_GLOBAL(A.T0.image);
+#undef DCRX_GLOBAL
+  A.Tmem = v2_constant(A.Tmem); A.Q.counts = v2_constant(A.Q.counts); A.T0.kw_base = v2_constant(A.T0.kw_base);
+  return A;
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __attribute__((noinline)) void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const V2FinishArgs &A = v2_finish_args(ka_lo, ka_hi);
+  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
   const int tid = threadIdx.x;
   const V2Ori V = A.T0.v2[ORI];
@@ -812,7 +844,7 @@ __device__ __attribute__((noinline)) void v2_rescue_role(const uint32_t vblock_,
 template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __attribute__((noinline)) void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const V2FinishArgs &A = v2_finish_args(ka_lo, ka_hi);
+  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
   const int tid = threadIdx.x;
   const V2Ori V = A.T0.v2[ORI];
@@ -823,18 +855,93 @@ __device__ __attribute__((noinline)) void v2_tail_role(const uint32_t vblock_, c
                                      vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid);
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
+__device__ __attribute__((noinline)) void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_), mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode_);
+  const int tid = threadIdx.x, lane = tid & 63;
+  V2Ori V = A.T0.v2[ORI];
+  const V2FinishLds L = v2_finish_layout<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
+  const DevTables T = tables_in_lds(A.T0, reinterpret_cast<const uint8_t *>(L.side), A.T0.dfa_bytes, false);      // (the side tables and buckets the block staged)
+  V.bk = reinterpret_cast<const uint8_t *>(L.bk);
+  const Counters C{L.counts};
+  const bool tagged = A.B.n_reads < (1ull << 30);
+  const uint4 *rows;
+  uint32_t total, first, step;
+  const uint32_t width = A.R.width;
+  if (mode == 0u) {
+    const uint32_t region = vblock / A.R.bsplit, bpart = vblock % A.R.bsplit;
+    if (region >= A.n_regions || (A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS)) return;
+    const V2ListRef l = v2_list<NW>(A.Q, V2_L_X, region);
+    rows = l.rows;
+    total = min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], l.cap);
+    first = width * ((uint32_t)(tid >> 6) + (DCRX_V2_FBLOCK / 64) * bpart);
+    step = width * (DCRX_V2_FBLOCK / 64) * A.R.bsplit;
+  } else {
+    // the left list, as its entries arrive: one wave polls, a lane per entry, in order; every other block signs off in
+    // queue_count[V2_QC_DONE] when its role is done (its pushes before that)
+    if (tid >= 64) return;
+    uint4 *lrows = A.Q.left;
+    uint32_t *valid = v2_left_valid<NW>(lrows);
+    const uint32_t others = A.R.xgrid + A.R.rgrid + A.R.tgrid - 1u;
+    uint32_t consumed = 0;
+    for (uint32_t spins = 0;; spins++) {
+      const uint32_t done = __hip_atomic_load(A.queue_count + V2_QC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t n = min(__hip_atomic_load(A.queue_count + V2_QC_LEFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), V2_LEFT_CAP);
+      // the valid entries in front (an entry becomes valid a moment after its slot was drawn)
+      const uint32_t i = consumed + (uint32_t)lane;
+      const bool ok = i < n && __hip_atomic_load(valid + (i < V2_LEFT_CAP ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      const unsigned long long m = __ballot(ok);
+      const uint32_t run = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;   // lanes 0 .. run-1 hold valid entries
+      if (run) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // (this unit's cache may hold older bytes of the entries' lines)
+        const bool live = (uint32_t)lane < run;
+        uint32_t x[1 + 2 * NW];
+        v2_get_rows<1 + 2 * NW>(lrows, 0u, i, live, x);
+        uint32_t lg[NW], w[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
+        if (live) {
+          v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
+          valid[i] = 0u;                                                // (re-armed for the next launch)
+        }
+        consumed += run;
+        continue;
+      }
+      if (done >= others && consumed >= n) break;                      // every pusher has signed off (its pushes before that) and nothing is left
+      if (spins > (1u << 22)) break;                                    // (never seen: a block that does not sign off; the records it owed keep status 255)
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (lane == 0) { A.queue_count[V2_QC_LEFT] = 0u; A.queue_count[V2_QC_DONE] = 0u; }
+    return;
+  }
+  for (; first < total; first += step) {
+    const uint32_t i = first + (uint32_t)lane;
+    const bool live = (uint32_t)lane < width && i < total;
+    uint32_t x[1 + 2 * NW];
+    v2_get_rows<1 + 2 * NW>(rows, 0u, i, live, x);
+    uint32_t lg[NW], w[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
+    if (live) v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
+  }
+}
+
+template <bool UNIFORM_LEN, int NW, int ORI>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(const V2FinishArgs A) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int tid = threadIdx.x;
   const V2Roles R = A.R;
+  const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();      // (where this launch's V2FinishArgs lies)
   // the role of this block
   uint32_t b = blockIdx.x;
   int role;                 // 0 list X, 1 rescue, 2 tail
+  bool work = true;
   if (b < R.xgrid) {
     role = 0;
-    // (most blocks of a short list's pass find their share empty: they leave before they stage anything)
+    // (most blocks of a short list's pass find their share empty: they stage nothing)
     const uint32_t g = b / R.bsplit;
-    if (g >= A.n_regions || R.width * (DCRX_V2_FBLOCK / 64) * (b % R.bsplit) >= A.Q.counts[V2_L_COUNTS * g + V2_L_X]) return;
+    work = g < A.n_regions && R.width * (DCRX_V2_FBLOCK / 64) * (b % R.bsplit) < A.Q.counts[V2_L_COUNTS * g + V2_L_X];
   } else {
     b -= R.xgrid;
     const uint32_t paired = 2u * min(R.rgrid, R.tgrid);
@@ -842,12 +949,43 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
     else { b -= paired; role = R.rgrid > R.tgrid ? 1 : 2; b += min(R.rgrid, R.tgrid); }
   }
   const V2Ori V = A.T0.v2[ORI];
+  V2FinishLds L = v2_finish_layout<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
+  bool staged = false;
+  if (work) {
+    L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
+    staged = true;
+    __syncthreads();
+    if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    else if (role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    else v2_general_role<UNIFORM_LEN, NW, ORI>(0u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
+  }
+  // the block signs off (its left-list pushes are in memory, each behind a fence of its own); block 0 — of list X's role — stays
+  // to take the left list as it fills and leaves last
+  __syncthreads();
+  if (blockIdx.x != 0) {
+    if (tid == 0) atomicAdd(A.queue_count + V2_QC_DONE, 1u);
+  } else {
+    if (!staged) { L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid); staged = true; }
+    __syncthreads();
+    v2_general_role<UNIFORM_LEN, NW, ORI>(1u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
+  }
+  __syncthreads();
+  if (staged && tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
+}
+
+// (the A/B forms below launch the roles as kernels of their own: their left list is taken by one block of this kernel at the end)
+template <bool UNIFORM_LEN, int NW, int ORI>
+__global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void left2_kernel(const V2FinishArgs A) {
+  extern __shared__ __align__(64) uint32_t smem[];
+  const int tid = threadIdx.x;
+  if (A.queue_count[V2_QC_LEFT] == 0u) return;
+  if (tid == 0) A.queue_count[V2_QC_DONE] = A.R.xgrid + A.R.rgrid + A.R.tgrid;      // (every pusher ended with its kernel)
+  __syncthreads();
+  const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const V2Ori V = A.T0.v2[ORI];
   const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
   __syncthreads();
-  const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();      // (where this launch's V2FinishArgs lies)
-  if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
-  else if (role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
-  else v2_slow_jobs<UNIFORM_LEN, NW, ORI, DCRX_V2_FBLOCK>(L, A.B, A.cfg, A.records, A.Q, A.n_regions, R.bsplit, R.width, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem, b, tid);
+  v2_general_role<UNIFORM_LEN, NW, ORI>(1u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -973,7 +1111,7 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // The v2 kernels serve one frame per pass: `reverse` and `forward` are one pass, `both` (decombine.py:1005-1010) the reverse
 // frame and then the forward frame for the reads it did not decombine (both frames' tables must fit).
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
-  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow || !P.v2_acc) return false;
+  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow || !P.v2_acc || !P.v2_left) return false;
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
   auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_block_lds<DCRX_V2_NWLONG>(T, o, DCRX_V2_FBLOCK) <= 64u * 1024u; };
@@ -991,6 +1129,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
   auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
   auto kf = o ? finish2_kernel<UNIFORM, NW, 1> : finish2_kernel<UNIFORM, NW, 0>;
+  auto kl = o ? left2_kernel<UNIFORM, NW, 1> : left2_kernel<UNIFORM, NW, 0>;
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
@@ -1004,6 +1143,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
     attributes_set_on_device(seen);
   }
   if (B.n_reads == 0) return hipSuccess;       // (the tallies stay zero; the list kernel hands them over)
@@ -1016,7 +1157,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus, (n_items + 15) / 16));
   const uint64_t per_block = (((B.n_reads + grid - 1) / grid + 511) / 512) * 512;
   V2Lists Q;
-  Q.tail = P.v2_tail; Q.ev = P.v2_events; Q.sx = P.v2_slow; Q.counts = P.v2_counts;
+  Q.tail = P.v2_tail; Q.ev = P.v2_events; Q.sx = P.v2_slow; Q.left = P.v2_left; Q.counts = P.v2_counts;
   const uint32_t n_regions = grid;
   const uint64_t pb128 = (per_block + 255) & ~127ull;           // (a block's reads, rounded up to whole chunks)
   Q.tcap = (uint32_t)std::min<uint64_t>(pb128, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
@@ -1055,13 +1196,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t elds = ext ? elds_ext : flds;
     const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a short list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
     const uint32_t tgrid = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
+    V2Roles R;
+    R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
+    V2FinishArgs A;
+    A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
+    A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables;
     if (!separate) {
-      V2Roles R;
-      R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
-      R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
-      V2FinishArgs A;
-      A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
-      A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables;
       hipLaunchKernelGGL(kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
@@ -1101,6 +1242,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
         if (e != hipSuccess) return e;
         e = general(s, V2_L_X, false, nullptr); if (e != hipSuccess) return e;
       }
+      hipLaunchKernelGGL(kl, dim3(1), dim3(DCRX_V2_FBLOCK), llds, s, A);      // what the lean kernels left
+      e = hipGetLastError(); if (e != hipSuccess) return e;
     }
     static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)

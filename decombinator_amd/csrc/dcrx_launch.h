@@ -25,6 +25,7 @@ struct LaunchPlan {
   // v2 kernels: the per-wave lists between the scan and the finishing kernel (device memory of the tables handle)
   uint4 *v2_tail = nullptr; uint4 *v2_events = nullptr; uint32_t *v2_counts = nullptr;
   uint4 *v2_slow = nullptr;
+  uint4 *v2_left = nullptr;             // the finishing launch's left list (V2_LEFT_CAP event entries of the longest shape)
   uint64_t *v2_acc = nullptr;           // the call's tallies (uint64[DCRX_N_COUNTERS]): zero between calls, handed to the caller by the list kernel
   uint64_t v2_tail_rows = 0, v2_event_rows = 0, v2_slow_rows = 0;       // 16-byte rows allocated for each list
   hipStream_t v2_side = nullptr, v2_side2 = nullptr;  // the tail kernel / the general form over the reads with exception bytes run here, beside the rescue kernel
