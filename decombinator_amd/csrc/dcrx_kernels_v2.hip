@@ -72,6 +72,14 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #ifndef DCRX_V2_FULL_LINE_RECORDS
 #define DCRX_V2_FULL_LINE_RECORDS 1   /* the scan kernel writes a record for every read (a placeholder where a later kernel settles it): whole lines leave the wave; A/B: 0.545 against 0.554 ms per step */
 #endif
+#ifndef DCRX_V2_ROLE_CALLS
+#define DCRX_V2_ROLE_CALLS 0   /* 1: the roles of the finishing launch are functions (calls); 0: inlined, each re-reading the launch's arguments behind a barrier the optimiser cannot look through */
+#endif
+#if DCRX_V2_ROLE_CALLS
+#define DCRX_V2_ROLE __device__ __attribute__((noinline))
+#else
+#define DCRX_V2_ROLE __device__ __forceinline__
+#endif
 #ifndef DCRX_LEAN_LDS_WORDS
 #define DCRX_LEAN_LDS_WORDS 1   /* the lean kernels keep the read in hand in LDS strips (0: in registers, A/B) */
 #endif
@@ -755,13 +763,13 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
 }
 
 // The general form (dcr_frame3) as a role of the finishing launch, a function of its own like the lean roles:
-//   mode 0  list X (reads with exception bytes whose flag log is not empty, flags on an odd read's last half pair: a few
-//           thousand of a 10 M-read batch).  `width` lanes of a wave take entries — the general form costs a wave the longest of
-//           its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit` blocks share
-//           a region; block `vblock` of n_regions * bsplit;
-//   mode 1  the launch's left list, by the last block to finish.
+//   mode bit 0  list X (reads with exception bytes whose flag log is not empty, flags on an odd read's last half pair: a few
+//               thousand of a 10 M-read batch).  `width` lanes of a wave take entries — the general form costs a wave the longest
+//               of its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit` blocks
+//               share a region; block `vblock` of n_regions * bsplit;
+//   mode bit 1  then the launch's left list, as it fills, by one wave (block 0 of the launch).
 template <bool UNIFORM_LEN, int NW, int ORI>
-__device__ __attribute__((noinline)) void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi);
+DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi);
 
 // ONE launch for everything behind the scan, on the caller's stream — no side streams, no fork and no join (each wait of one
 // queue for another cost the waiting queue 8-10 us).  A block's role follows from its index: first the blocks of list X
@@ -806,7 +814,9 @@ struct V2FinishLocals {      // a role's copy of the launch's arguments (what it
   uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
 };
 __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, const uint32_t hi) {
-  const uint64_t p = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+  uint32_t slo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo), shi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+  asm volatile("" : "+s"(slo), "+s"(shi));      // (inlined roles: each reads the arguments for itself, none kept live across the role switch)
+  const uint64_t p = (uint64_t)slo | ((uint64_t)shi << 32);
   const dcrx_kwords k = reinterpret_cast<dcrx_kwords>(p);
   V2FinishLocals A;
 #define DCRX_KARG(F) A.F = v2_karg<decltype(A.F)>(k, offsetof(V2FinishArgs, F))
@@ -826,7 +836,7 @@ __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, cons
   return A;
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
-__device__ __attribute__((noinline)) void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
+DCRX_V2_ROLE void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
   const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
@@ -842,7 +852,7 @@ __device__ __attribute__((noinline)) void v2_rescue_role(const uint32_t vblock_,
                                        vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid);
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
-__device__ __attribute__((noinline)) void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
+DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
   const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
@@ -855,7 +865,7 @@ __device__ __attribute__((noinline)) void v2_tail_role(const uint32_t vblock_, c
                                      vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid);
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
-__device__ __attribute__((noinline)) void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
+DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
   const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_), mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode_);
@@ -866,65 +876,62 @@ __device__ __attribute__((noinline)) void v2_general_role(const uint32_t mode_, 
   V.bk = reinterpret_cast<const uint8_t *>(L.bk);
   const Counters C{L.counts};
   const bool tagged = A.B.n_reads < (1ull << 30);
-  const uint4 *rows;
-  uint32_t total, first, step;
   const uint32_t width = A.R.width;
-  if (mode == 0u) {
-    const uint32_t region = vblock / A.R.bsplit, bpart = vblock % A.R.bsplit;
-    if (region >= A.n_regions || (A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS)) return;
-    const V2ListRef l = v2_list<NW>(A.Q, V2_L_X, region);
-    rows = l.rows;
-    total = min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], l.cap);
-    first = width * ((uint32_t)(tid >> 6) + (DCRX_V2_FBLOCK / 64) * bpart);
-    step = width * (DCRX_V2_FBLOCK / 64) * A.R.bsplit;
-  } else {
-    // the left list, as its entries arrive: one wave polls, a lane per entry, in order; every other block signs off in
-    // queue_count[V2_QC_DONE] when its role is done (its pushes before that)
-    if (tid >= 64) return;
-    uint4 *lrows = A.Q.left;
-    uint32_t *valid = v2_left_valid<NW>(lrows);
-    const uint32_t others = A.R.xgrid + A.R.rgrid + A.R.tgrid - 1u;
-    uint32_t consumed = 0;
-    for (uint32_t spins = 0;; spins++) {
+  // one loop for both lists (one copy of the general form's code): entries of list X by (region, slot), `width` lanes of a wave
+  // at a time; then — mode bit 1, one wave — the left list as its entries arrive, a lane per entry, in order; every other block
+  // signs off in queue_count[V2_QC_DONE] when its role is done (its pushes before that)
+  const uint32_t region = vblock / A.R.bsplit, bpart = vblock % A.R.bsplit;
+  const bool do_x = (mode & 1u) && region < A.n_regions && !(A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS);
+  const V2ListRef lx = v2_list<NW>(A.Q, V2_L_X, do_x ? region : 0u);
+  const uint32_t x_total = do_x ? min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], lx.cap) : 0u;
+  uint32_t first = width * ((uint32_t)(tid >> 6) + (DCRX_V2_FBLOCK / 64) * bpart);
+  const uint32_t step = width * (DCRX_V2_FBLOCK / 64) * A.R.bsplit;
+  uint4 *lrows = A.Q.left;
+  uint32_t *valid = v2_left_valid<NW>(lrows);
+  const uint32_t others = A.R.xgrid + A.R.rgrid + A.R.tgrid - 1u;
+  bool polling = false;
+  uint32_t consumed = 0, spins = 0;
+  for (;;) {
+    const uint4 *rows;
+    uint32_t i;
+    bool live;
+    if (!polling) {
+      if (first >= x_total) {
+        if (!(mode & 2u) || tid >= 64) break;
+        polling = true;
+        continue;
+      }
+      rows = lx.rows; i = first + (uint32_t)lane; live = (uint32_t)lane < width && i < x_total;
+      first += step;
+    } else {
       const uint32_t done = __hip_atomic_load(A.queue_count + V2_QC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t n = min(__hip_atomic_load(A.queue_count + V2_QC_LEFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), V2_LEFT_CAP);
       // the valid entries in front (an entry becomes valid a moment after its slot was drawn)
-      const uint32_t i = consumed + (uint32_t)lane;
+      i = consumed + (uint32_t)lane;
       const bool ok = i < n && __hip_atomic_load(valid + (i < V2_LEFT_CAP ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
       const unsigned long long m = __ballot(ok);
       const uint32_t run = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;   // lanes 0 .. run-1 hold valid entries
-      if (run) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // (this unit's cache may hold older bytes of the entries' lines)
-        const bool live = (uint32_t)lane < run;
-        uint32_t x[1 + 2 * NW];
-        v2_get_rows<1 + 2 * NW>(lrows, 0u, i, live, x);
-        uint32_t lg[NW], w[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
-        if (live) {
-          v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
-          valid[i] = 0u;                                                // (re-armed for the next launch)
-        }
-        consumed += run;
+      if (!run) {
+        if (done >= others && consumed >= n) break;                    // every pusher has signed off (its pushes before that) and nothing is left
+        if (++spins > (1u << 22)) break;                               // (never seen: a block that does not sign off; the records it owed keep status 255)
+        __builtin_amdgcn_s_sleep(16);
         continue;
       }
-      if (done >= others && consumed >= n) break;                      // every pusher has signed off (its pushes before that) and nothing is left
-      if (spins > (1u << 22)) break;                                    // (never seen: a block that does not sign off; the records it owed keep status 255)
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // (this unit's cache may hold older bytes of the entries' lines)
+      rows = lrows; live = (uint32_t)lane < run;
+      consumed += run;
     }
-    if (lane == 0) { A.queue_count[V2_QC_LEFT] = 0u; A.queue_count[V2_QC_DONE] = 0u; }
-    return;
-  }
-  for (; first < total; first += step) {
-    const uint32_t i = first + (uint32_t)lane;
-    const bool live = (uint32_t)lane < width && i < total;
     uint32_t x[1 + 2 * NW];
     v2_get_rows<1 + 2 * NW>(rows, 0u, i, live, x);
     uint32_t lg[NW], w[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
-    if (live) v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
+    if (live) {
+      v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
+      if (polling) valid[i] = 0u;                                      // (re-armed for the next launch)
+    }
   }
+  if (polling && lane == 0) { A.queue_count[V2_QC_LEFT] = 0u; A.queue_count[V2_QC_DONE] = 0u; }
 }
 
 template <bool UNIFORM_LEN, int NW, int ORI>
@@ -950,25 +957,18 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
   }
   const V2Ori V = A.T0.v2[ORI];
   V2FinishLds L = v2_finish_layout<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
-  bool staged = false;
-  if (work) {
+  // block 0 — of list X's role — stays to take the left list as it fills and leaves last; every other block signs off when its
+  // role is done (its left-list pushes are in memory, each behind a fence of its own)
+  const bool staged = work || blockIdx.x == 0;
+  if (staged) {
     L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
-    staged = true;
     __syncthreads();
     if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
     else if (role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
-    else v2_general_role<UNIFORM_LEN, NW, ORI>(0u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    else v2_general_role<UNIFORM_LEN, NW, ORI>(blockIdx.x == 0 ? 3u : 1u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
   }
-  // the block signs off (its left-list pushes are in memory, each behind a fence of its own); block 0 — of list X's role — stays
-  // to take the left list as it fills and leaves last
   __syncthreads();
-  if (blockIdx.x != 0) {
-    if (tid == 0) atomicAdd(A.queue_count + V2_QC_DONE, 1u);
-  } else {
-    if (!staged) { L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid); staged = true; }
-    __syncthreads();
-    v2_general_role<UNIFORM_LEN, NW, ORI>(1u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
-  }
+  if (blockIdx.x != 0 && tid == 0) atomicAdd(A.queue_count + V2_QC_DONE, 1u);
   __syncthreads();
   if (staged && tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void left2_kernel(c
   const V2Ori V = A.T0.v2[ORI];
   const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
   __syncthreads();
-  v2_general_role<UNIFORM_LEN, NW, ORI>(1u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
+  v2_general_role<UNIFORM_LEN, NW, ORI>(2u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
 }
