@@ -46,6 +46,7 @@ F_ONE_BASE_SCAN = 4
 F_V1_KERNELS = 64        # the three-launch form even where the v2 kernel applies
 F_V2_NO_LEAN_RESCUE = 8192   # A/B and tests: event entries go to the general form at once (no lean rescue kernel)
 F_V2_LEAN_SERIAL = 32768     # A/B: the finishing roles as launches of their own, one after the other (default: roles of one launch)
+F_V2_NO_FUSE = 131072       # A/B: no tail inside the scan kernel
 F_V2_SIDE_STREAMS = 65536    # A/B: round 3's shape, the tail kernel and the X pass on side streams beside the rescue kernel
 
 

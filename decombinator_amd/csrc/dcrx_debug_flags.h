@@ -13,6 +13,7 @@
 #define DCRX_F_PROFILE_NO_TAIL 2048u /* profiling: the v2 finishing kernel skips its tail entries (records are NOT results) */
 #define DCRX_F_PROFILE_TAIL_STREAM_ONLY 16384u /* profiling: the tail kernel reads its entries and writes records but resolves nothing (records are NOT results) */
 #define DCRX_F_V2_LEAN_SERIAL 32768u /* A/B: the lean rescue, the lean tail and the X pass as launches of their own, one after the other on the caller's stream (default: roles of one launch, finish2_kernel) */
+#define DCRX_F_V2_NO_FUSE 131072u /* A/B: the tail as a role of the finishing launch even where the scan kernel could take it (scan2_kernel, FUSE) */
 #define DCRX_F_V2_SIDE_STREAMS 65536u /* A/B: round 3's shape — the tail kernel and the X pass on side streams of the handle beside the rescue kernel (fork / join events) */
 #define DCRX_F_V2_NO_LEAN_RESCUE 8192u /* A/B: the scan kernel's event entries go to the general form at once, without the lean rescue kernel */
 #define DCRX_F_V1_KERNELS 64u         /* the three-launch form (fast kernel with 32-bit pair entries, rescue kernel) even where the v2 kernel applies (A/B, tests) */

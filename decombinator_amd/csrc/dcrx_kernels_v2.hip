@@ -251,17 +251,58 @@ __device__ __forceinline__ void v2_exc_marks(const BatchDev &B, const uint32_t e
   }
 }
 
+// What a lean role does not settle (one read in two million) becomes an event entry of the launch's left list; one wave of the
+// launch — of the first block of list X's role, which stays for it — takes the entries through the general form as they
+// arrive (v2_general_role, mode 1) and leaves when every other block has signed off.  Neither a call inside the lean loops — the
+// general form as a call there kept 58 vector and 80 scalar registers of the tail loop spilled around a call site that one
+// batch in ten thousand reaches — nor a pass of its own behind them (a launch and one read's latency on every step's path).
+// (behind the rows of the list: one word per entry, set when the entry is whole)
+template <int NW>
+__device__ __forceinline__ uint32_t *v2_left_valid(uint4 *left_rows) { return reinterpret_cast<uint32_t *>(left_rows + (size_t)V2_LEFT_CAP * V2Rows<NW>::E); }
+template <int NW>
+__device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restrict__ queue_count, const uint32_t x0, const uint32_t (&lg)[NW], const uint32_t (&w)[NW]) {
+  const uint32_t at = atomicAdd(queue_count + V2_QC_LEFT, 1u);
+  if (at >= V2_LEFT_CAP) return false;      // (the count runs on; its reader clamps it)
+  uint32_t x[1 + 2 * NW];
+  x[0] = x0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { x[1 + k] = lg[k]; x[1 + NW + k] = w[k]; }
+  v2_put_rows<1 + 2 * NW>(left_rows, 0u, at, x);
+  __threadfence();                          // the entry is in memory ...
+  __hip_atomic_store(v2_left_valid<NW>(left_rows) + at, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before it is called valid
+  return true;
+}
+
 // LDS of the scan kernel behind the pair table and the counters: the block's work counters
 // next item; entries of each list (V2_WK_LIST + V2_L_*)
-enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_WORDS = 16 };      // (V2_WK_EXC: six words of v2_exc_slice)
+enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_FILLED = 32, V2_WK_GEN = 48,
+       V2_WK_WORDS = 64 };      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form)
+// The fused form (FUSE >= 0 = the frame): the block's last four waves — one per SIMD — do not scan: they take the tail entries
+// the scanning waves produce, in batches of 64, out of a ring in LDS, and finish them (tail2_fast) while the scan goes on.  The
+// scan is bound by its LDS look-ups, the tail by instruction issue: on one SIMD the two share what neither uses up, where the
+// tail as a kernel of its own ran behind the scan and beside the rescue (bound by issue as well).  The 168 MB of tail entries
+// of a 10 M-read batch never leave the compute unit.
+//   ring slot (15 words, odd: the lanes of a wave spread over the banks): the read's NW words, two zero words (a window may
+//   read two words past the read), the read's index, its digest (tail2_pack), one word of padding
+//   HEAD     slots drawn so far (a wave draws the slots of its tail lanes with one LDS atomic)
+//   FILLED   per ring batch of 64 slots: slots written (a wave adds its share behind its writes: LDS keeps a wave's order)
+//   CLAIM    next batch to finish (a tail wave takes batch c when FILLED[c % NB] == 64, or what is left once every scanning
+//            wave has signed off in SCANNED)
+//   GEN      per ring batch: times it has been finished — a scanning wave writes into occurrence k of a ring batch when GEN == k
+#ifndef DCRX_V2_FUSE_TAILWAVES
+#define DCRX_V2_FUSE_TAILWAVES 4
+#endif
+constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
+constexpr int V2_RING_STRIDE = 15;
+constexpr uint32_t V2_RING_MAXBATCHES = 16;
 
-template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true>
+template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, int FUSE = -1>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint64_t per_block, uint32_t retry) {
+    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  const int o = FUSE >= 0 ? FUSE : (cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
   V2Ori V0 = T0.v2[0];
   if (o) V0 = T0.v2[1];
   uint32_t *lds_trans = smem;                                         // the pair table, at LDS address 0
@@ -277,6 +318,16 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     for (uint32_t i = tid; i < V0.trans_bytes / 16; i += blockDim.x) dst[i] = src[i];
   }
   const V2Tab tab{};
+  // the fused form: side tables and keyword buckets behind the work words (what the lean tail reads), then the ring
+  uint32_t *lds_side = lds_work + V2_WK_WORDS;
+  uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
+  uint32_t *ring = lds_bk + V0.bk_bytes / 4;
+  const uint32_t ring_mask = 64u * ring_batches - 1u;
+  if (FUSE >= 0) {
+    stage_lds<DCRX_V2_BLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
+    stage_lds<DCRX_V2_BLOCK>(V0.bk, lds_bk, V0.bk_bytes / 16, 0, 0, tid);
+    for (uint32_t i = tid; i <= ring_mask; i += blockDim.x) { ring[i * V2_RING_STRIDE + NW] = 0u; ring[i * V2_RING_STRIDE + NW + 1] = 0u; }
+  }
   __syncthreads();
   const uint32_t nw = B.stride >> 2;
   const int lane = tid & 63;
@@ -300,9 +351,90 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? (uint32_t)V2_FUSE_TAILWAVES : 0u);
+  const size_t region = blockIdx.x;
+  if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
+   if constexpr (FUSE >= 0) {
+    // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
+    constexpr bool REV = FUSE == 1;
+    const Tail2Tabs tt = tail2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV);
+    const Counters C{lds_counts};
+    const uint32_t nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
+    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
+    for (uint32_t spins = 0;;) {
+      uint32_t c = 0, nvalid = 0;
+      if (lane == 0) {
+        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (FILLED speaks of batch c only once the ring batch's earlier occupants have been finished: with a short ring a wave may
+        // still be at work on batch c - NB, its count not yet taken back)
+        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
+        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!mine) nvalid = 0;
+        else if (f == 64u) nvalid = 64u;
+        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
+          // every scanning wave has signed off (its last entries and its share of FILLED before that): what is left is final
+          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t rem = h - 64u * c;
+          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
+        }
+        if (nvalid && nvalid != V2_RING_EXIT) {
+          uint32_t expect = c;
+          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
+        }
+      }
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
+      if (nvalid == V2_RING_EXIT) break;
+      if (!nvalid) {
+        if (++spins > (1u << 24)) break;      // (never seen: a scanning wave that does not sign off)
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries were written before FILLED said so: nothing is read early)
+      uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
+      int status = -2;
+      uint32_t r = 0, dg = 0;
+      if ((uint32_t)lane < nvalid) {
+        r = sl[NW + 2]; dg = sl[NW + 3];
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+        const LdsWords lw{dcrx_ldsaddr_of(sl)};
+        status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
+        rec.frame = (uint8_t)(o ? 0 : 1);
+        if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
+      }
+      v2_tally(lds_counts, lane, status, o == 0);
+      if (__builtin_expect(status == TAIL2_SLOW, 0)) {
+        // what the lean form does not settle (one read in millions): an event entry of the launch's left list (the finishing
+        // launch's polling wave takes it), behind a placeholder record
+        __align__(16) dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+        rec.status = (uint8_t)DCRX_S_DEFER; rec.frame = (uint8_t)(o ? 0 : 1);
+        DCRX_STORE_FINISH(records + r, rec);
+        const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
+        uint32_t lg[NW], ww[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
+          if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
+          lg[k] = l; ww[k] = sl[k];
+        }
+        if (!v2_left_push<NW>(Q.left, queue_count, r | (jc == 2u ? V2_R_JMULTI : 0u), lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
+      }
+      // the ring batch is free again: FILLED back to zero, then GEN (a scanning wave looks at GEN first)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_store(&lds_work[V2_WK_FILLED + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        atomicAdd(&lds_work[V2_WK_GEN + (c & nb_mask)], 1u);
+      }
+      spins = 0;
+    }
+   }
+  } else {
   constexpr uint32_t WT = 64u * RPL;
   const uint32_t n_items = blk_lo < blk_hi ? (uint32_t)((blk_hi - blk_lo + WT - 1) / WT) : 0u;
-  const size_t region = blockIdx.x;
   uint4 *tq = Q.tail + region * Q.tcap * V2Rows<NW>::T;
   uint4 *eq = Q.ev + region * Q.ecap * V2Rows<NW>::E;
   auto draw = [&]() -> uint32_t {
@@ -372,7 +504,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       if (exc && what != V2_VNONE) what = V2_EVENTS;
       const bool vnone = what == V2_VNONE, vmulti = what == V2_VMULTI;
 #if DCRX_V2_FULL_LINE_RECORDS
-      if (live) {     // every lane writes: whole lines of records leave the wave (reads that go on get a placeholder, rewritten by the kernel that settles them)
+      // every lane writes: whole lines of records leave the wave (reads that go on get a placeholder, rewritten by the kernel that
+      // settles them) — but for the tail reads of the fused form: a tail wave of this block writes their records, and two stores to
+      // one address from two waves have no order
+      if (live && !(FUSE >= 0 && what == V2_TAIL)) {
 #else
       if (vnone || vmulti) {
 #endif
@@ -392,7 +527,34 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       if (cfg.flags & DCRX_F_PROFILE_NO_FINISH) continue;
       bool to_tail = what == V2_TAIL;
       const unsigned long long mt0 = __ballot(to_tail);
-      if (mt0) {           // the block's tail list: one LDS atomic per wave and group of 64 reads
+      if (FUSE >= 0 && mt0) {      // the fused form: the tail entries into the block's ring
+        const uint32_t cnt = (uint32_t)__popcll(mt0), nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
+        uint32_t base = 0;
+        if (lane == 0) {
+          base = atomicAdd(&lds_work[V2_WK_HEAD], cnt);
+          // the slots lie in one or two ring batches: free once their last occupants have been finished (GEN)
+          const uint32_t gb0 = base >> 6, gb1 = (base + cnt - 1u) >> 6;
+          for (uint32_t spins = 0; spins < (1u << 24); spins++) {      // (the bound is never reached: a tail wave that does not come back)
+            if (__hip_atomic_load(&lds_work[V2_WK_GEN + (gb0 & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (gb0 >> nb_shift) &&
+                __hip_atomic_load(&lds_work[V2_WK_GEN + (gb1 & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (gb1 >> nb_shift)) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        asm volatile("" ::: "memory");
+        if (to_tail) {
+          uint32_t *sl = ring + ((base + (uint32_t)__popcll(mt0 & lt_mask)) & ring_mask) * V2_RING_STRIDE;
+#pragma unroll
+          for (int k = 0; k < NW; k++) sl[k] = w[q][k];
+          sl[NW + 2] = (uint32_t)r; sl[NW + 3] = tail2_pack(d);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries before the count that announces them)
+        if (lane == 0) {
+          const uint32_t n0 = min(cnt, 64u - (base & 63u));
+          atomicAdd(&lds_work[V2_WK_FILLED + ((base >> 6) & nb_mask)], n0);
+          if (cnt > n0) atomicAdd(&lds_work[V2_WK_FILLED + (((base >> 6) + 1u) & nb_mask)], cnt - n0);
+        }
+      } else if (mt0) {           // the block's tail list: one LDS atomic per wave and group of 64 reads
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + V2_L_TAIL], (uint32_t)__popcll(mt0));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -457,6 +619,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       }
     }
     item = next;
+  }
+  if (FUSE >= 0 && lane == 0) {      // this wave's last entries are in the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    atomicAdd(&lds_work[V2_WK_SCANNED], 1u);
+  }
   }
   __syncthreads();
   if (B.n_exc) v2_exc_marks(B, e_lo, e_hi, false, tid);      // the marks have served (an entry carries V2_R_EXC from here on)
@@ -558,28 +725,6 @@ __device__ __forceinline__ void v2_note_left(uint32_t *left, const uint32_t slot
 }
 template <int NW>
 struct V2EntryWords { uint32_t lg[NW], w[NW]; };
-// What a lean role does not settle (one read in two million) becomes an event entry of the launch's left list; one wave of the
-// launch — of the first block of list X's role, which stays for it — takes the entries through the general form as they
-// arrive (v2_general_role, mode 1) and leaves when every other block has signed off.  Neither a call inside the lean loops — the
-// general form as a call there kept 58 vector and 80 scalar registers of the tail loop spilled around a call site that one
-// batch in ten thousand reaches — nor a pass of its own behind them (a launch and one read's latency on every step's path).
-// (behind the rows of the list: one word per entry, set when the entry is whole)
-template <int NW>
-__device__ __forceinline__ uint32_t *v2_left_valid(uint4 *left_rows) { return reinterpret_cast<uint32_t *>(left_rows + (size_t)V2_LEFT_CAP * V2Rows<NW>::E); }
-template <int NW>
-__device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restrict__ queue_count, const uint32_t x0, const uint32_t (&lg)[NW], const uint32_t (&w)[NW]) {
-  const uint32_t at = atomicAdd(queue_count + V2_QC_LEFT, 1u);
-  if (at >= V2_LEFT_CAP) return false;      // (the count runs on; its reader clamps it)
-  uint32_t x[1 + 2 * NW];
-  x[0] = x0;
-#pragma unroll
-  for (int k = 0; k < NW; k++) { x[1 + k] = lg[k]; x[1 + NW + k] = w[k]; }
-  v2_put_rows<1 + 2 * NW>(left_rows, 0u, at, x);
-  __threadfence();                          // the entry is in memory ...
-  __hip_atomic_store(v2_left_valid<NW>(left_rows) + at, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before it is called valid
-  return true;
-}
-
 // The lean tail: wave `gwave` of `n_gwaves` takes the jobs (region, part) gwave, gwave + n_gwaves, ...: `split` waves share a
 // region (a scan block's list), wave k of them its batches k, k + split, ...  Software pipeline over the batches of 64: the
 // entries are read one batch ahead, the read in hand sits in the lane's LDS strip.  What the lean form does not settle is
@@ -1123,8 +1268,22 @@ template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                             uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
                             unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry) {
-  auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
+  // The fused form (the tail inside the scan kernel, through a ring in LDS: scan2_kernel, FUSE) for the 150-nt shape when the
+  // frame's pair table leaves room for the side tables, the buckets and a ring of at least four batches; the A/B forms and the
+  // profiling switches keep the tail a launch of its own.
+  constexpr bool CAN_FUSE = NW == 10 && RPL == 2 && PREFETCH;
+  uint32_t ring_batches = 0;
+  if (CAN_FUSE && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | DCRX_F_PROFILE_MASK))) {
+    const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
+    for (uint32_t nb = V2_RING_MAXBATCHES; nb >= 4u; nb >>= 1)
+      if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches = nb; break; }
+  }
+  auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
+  if constexpr (CAN_FUSE) {
+    if (ring_batches) ks = o ? scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1> : scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0>;
+  }
+  const uint32_t scan_lds = v2_scan_lds_bytes(T, o) + (ring_batches ? (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + ring_batches * 64u * V2_RING_STRIDE * 4u : 0u);
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
   auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
@@ -1133,8 +1292,14 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    if constexpr (CAN_FUSE) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1176,8 +1341,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
   // serves as the fork event as well: one signal on the dispatch, no marker packet)
   const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), v2_scan_lds_bytes(T, o), s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry);
+  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (finish) {
@@ -1197,7 +1362,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t slow_width = 4u;        // lanes of a wave that take entries of a short list (64 / 16 / 4 / 2 / 1: 97 / 62 / 57 / 65 / 79 us)
     const uint32_t tgrid = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
     V2Roles R;
-    R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = ring_batches ? 0u : (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // (fused: the tail list is empty)
     R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
     V2FinishArgs A;
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
