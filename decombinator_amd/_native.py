@@ -137,6 +137,17 @@ COLLAPSE_COUNTERS = [
 CF_OK, CF_NO_BCLOCS, CF_LOW_QUALITY, CF_OVERLONG, CF_DEFER = 0, 1, 2, 3, 255
 
 
+def spacer_search(seq: str, spacer: str):
+    """dcrx_spacer_search: ([(start, length), ...] of every match, kind) — kind 0 verbatim, 1 substitutions, 2 indel."""
+    sb, pb = seq.encode("latin-1", "replace"), spacer.encode("latin-1", "replace")
+    cap = len(sb) + 1
+    starts = np.zeros(cap, dtype=np.int32)
+    lens = np.zeros(cap, dtype=np.int32)
+    kind = C.c_int32(0)
+    n = check(lib().dcrx_spacer_search(sb, len(sb), pb, len(pb), starts.ctypes.data, lens.ctypes.data, cap, C.byref(kind)))
+    return [(int(starts[k]), int(lens[k])) for k in range(min(n, cap))], int(kind.value)
+
+
 def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, quality_parameters, field_sep: str = ", ", n_threads: int = 0):
     """dcrx_collapse_front over `.n12` text: (rows as COLLAPSE_ROW_DTYPE, row offsets (n + 1), counters uint64[len(COLLAPSE_COUNTERS)])."""
     cfg = CollapseCfgC()
@@ -176,7 +187,7 @@ EXPORTS = [
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
-    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_spacer_search", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
 
 _lib = None
@@ -218,6 +229,7 @@ def lib():
         "dcrx_compact_hits_packed_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed8_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_collapse_front": (C.c_int64, [vp, u64, C.POINTER(CollapseCfgC), vp, u64, vp, vp, i32]),
+        "dcrx_spacer_search": (i32, [C.c_char_p, i32, C.c_char_p, i32, vp, vp, i32, C.POINTER(C.c_int32)]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
         "dcrx_gzip_open": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
         "dcrx_gzip_write": (i32, [vp, vp, u64]),

@@ -47,26 +47,23 @@ inline int find_from(const char *s, int n, const char *sub, int m, int from) {
   return p ? (int)((const char *)p - s) : -1;
 }
 
-// spacerSearch(spacer, s[0..n)) :204-212.  Returns the number of non-overlapping matches (left to right) and, for the first
-// one, its start and its length (m; m + 1 / m - 1 for an indel match); `exact` tells whether they are verbatim occurrences.
-int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, int &first_len, bool &exact) {
+// spacerSearch(spacer, s[0..n)) :204-212.  Returns the number of non-overlapping matches (left to right); the first `cap` of
+// them go to starts[] / lens[] (length m; m + 1 / m - 1 for an indel match); kind: 0 verbatim, 1 substitutions, 2 indel.
+int spacer_search_all(const char *s, int n, const char *sp, int m, int *starts, int *lens, int cap, int &kind) {
   int cnt = 0;
-  first_at = -1;
-  first_len = m;
-  exact = true;
-  for (int at = find_from(s, n, sp, m, 0); at >= 0; at = find_from(s, n, sp, m, at + m)) {     // regex.findall(spacer, s)
-    if (!cnt) first_at = at;
-    cnt++;
-  }
+  auto put = [&](int at, int len) { if (cnt < cap) { starts[cnt] = at; lens[cnt] = len; } cnt++; };
+  kind = 0;
+  for (int at = find_from(s, n, sp, m, 0); at >= 0; at = find_from(s, n, sp, m, at + m)) put(at, m);     // regex.findall(spacer, s)
   if (cnt) return cnt;
-  exact = false;
+  kind = 1;
   for (int i = 0; i + m <= n;) {                                                               // {1s<=2}
     int d = 0;
     for (int k = 0; k < m && d <= 2; k++) d += s[i + k] != sp[k];
-    if (d <= 2) { if (!cnt) first_at = i; cnt++; i += m; } else i++;
+    if (d <= 2) { put(i, m); i += m; } else i++;
   }
   if (cnt) return cnt;
   // {2i+2d+1s<=2} (:198-201), given that neither search above found anything
+  kind = 2;
   for (int i = 0; i < n;) {
     int a = 0;
     while (a < m && i + a < n && s[i + a] == sp[a]) a++;                 // the spacer's prefix at i
@@ -81,8 +78,15 @@ int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, in
       while (b < m - 1 && s[i + m - 2 - b] == sp[m - 1 - b]) b++;
       if (a + b >= m - 1) span = m - 1;
     }
-    if (span) { if (!cnt) { first_at = i; first_len = span; } cnt++; i += span; } else i++;
+    if (span) { put(i, span); i += span; } else i++;
   }
+  return cnt;
+}
+// ... as get_barcode_positions uses it: the count, the first match, whether the matches are verbatim
+int spacer_search(const char *s, int n, const char *sp, int m, int &first_at, int &first_len, bool &exact) {
+  int at = -1, len = m, kind = 0;
+  const int cnt = spacer_search_all(s, n, sp, m, &at, &len, 1, kind);
+  first_at = cnt ? at : -1; first_len = cnt ? len : m; exact = kind == 0;
   return cnt;
 }
 
@@ -207,6 +211,15 @@ uint8_t front_row(const char *row, int len, const Cfg &c, dcrx_collapse_row_t &o
 
 static int64_t collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
                               uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads);
+
+extern "C" int32_t dcrx_spacer_search(const char *seq, int32_t n, const char *spacer, int32_t m, int32_t *starts, int32_t *lens, int32_t cap,
+                                      int32_t *kind) {
+  if (!seq || !spacer || n < 0 || m < 1 || cap < 0 || (cap && (!starts || !lens))) return set_err(DCRX_E_INVALID, "dcrx_spacer_search: bad argument");
+  int k = 0;
+  const int cnt = spacer_search_all(seq, n, spacer, m, starts, lens, cap, k);
+  if (kind) *kind = k;
+  return cnt;
+}
 
 // (nothing throws across the C ABI: include/dcrx.h; allocation failures of the row index and of the per-thread tallies
 // come back as DCRX_E_NOMEM, a worker thread that cannot be started leaves its share to the calling thread)

@@ -357,6 +357,9 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
    if constexpr (FUSE >= 0) {
     // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
     constexpr bool REV = FUSE == 1;
+#ifdef DCRX_V2_PRIO_TAIL
+    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
+#endif
     const Tail2Tabs tt = tail2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV);
     const Counters C{lds_counts};
     const uint32_t nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
@@ -433,6 +436,9 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     }
    }
   } else {
+#ifdef DCRX_V2_PRIO_SCAN
+  if (FUSE >= 0) __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_SCAN);
+#endif
   constexpr uint32_t WT = 64u * RPL;
   const uint32_t n_items = blk_lo < blk_hi ? (uint32_t)((blk_hi - blk_lo + WT - 1) / WT) : 0u;
   uint4 *tq = Q.tail + region * Q.tcap * V2Rows<NW>::T;
@@ -1276,7 +1282,12 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   uint32_t ring_batches = 0;
   if (CAN_FUSE && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | DCRX_F_PROFILE_MASK))) {
     const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
-    for (uint32_t nb = V2_RING_MAXBATCHES; nb >= 4u; nb >>= 1)
+    static const uint32_t nb_max = [] {      // (tests: DCRX_DEBUG_RING_BATCHES=4 forces the shortest ring)
+      const char *e = getenv("DCRX_DEBUG_RING_BATCHES");
+      const uint32_t v = e ? (uint32_t)atoi(e) : V2_RING_MAXBATCHES;
+      return (v == 4u || v == 8u || v == 16u) ? v : V2_RING_MAXBATCHES;
+    }();
+    for (uint32_t nb = nb_max; nb >= 4u; nb >>= 1)
       if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches = nb; break; }
   }
   auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;

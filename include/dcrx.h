@@ -299,9 +299,10 @@ int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_
  * get_barcode_positions :367-479 (spacer searches :192-236), set_barcode :278-326, check_umi_quality :343-353 and the
  * inter-tag length filter :553-556, with the reference's counter keys.  `text`: rows as dcrx_assemble_rows writes them
  * (fields separated by cfg->field_sep, one row per line).  Per row a dcrx_collapse_row_t; counters are ADDED to
- * counters[DCRX_CF_N_COUNTERS].  A row whose spacers occur neither verbatim nor with up to two substitutions reaches the
- * reference's indel search ("{2i+2d+1s<=2}", :198-201): it is returned as DCRX_CF_DEFER with nothing counted, for the
- * caller to decide with the same regex (decombinator_amd/collapse.py does).  rows == NULL: returns the number of rows.
+ * counters[DCRX_CF_N_COUNTERS].  All three spacer searches of the reference are decided here: the spacer verbatim, with up
+ * to two substitutions ("{1s<=2}"), and the indel form ("{2i+2d+1s<=2}", :198-201: the spacer with one base inserted or one
+ * deleted, the leftmost start first, the insertion where both hold).  DCRX_CF_DEFER (nothing counted) is left for rows
+ * that are not ten fields of ASCII text: the caller's own error path.  rows == NULL: returns the number of rows.
  * row_offsets (optional, n + 1 entries): where each row starts in `text`.  Returns the number of rows or an error. */
 enum dcrx_collapse_status { DCRX_CF_OK = 0, DCRX_CF_NO_BCLOCS = 1, DCRX_CF_LOW_QUALITY = 2, DCRX_CF_OVERLONG = 3, DCRX_CF_DEFER = 255 };
 enum dcrx_collapse_counter {
@@ -340,6 +341,12 @@ typedef struct dcrx_collapse_row {
   uint8_t pad;
   char barcode[24], barcode_qual[24];      /* set_barcode's two strings */
 } dcrx_collapse_row_t;
+/* spacerSearch (collapse.py:204-212) on its own: every non-overlapping match of `spacer` in seq[0, n), left to right, found by
+ * the first of the three searches that finds any — regex.findall(spacer, seq), "(spacer){1s<=2}", "(spacer){2i+2d+1s<=2}".
+ * starts[k] / lens[k] (up to `cap` of them) receive the matches; *kind: 0 verbatim, 1 substitutions, 2 indel.  Returns the
+ * number of matches (it may exceed cap) or an error. */
+int32_t dcrx_spacer_search(const char *seq, int32_t n, const char *spacer, int32_t m, int32_t *starts, int32_t *lens, int32_t cap,
+                           int32_t *kind);
 int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const dcrx_collapse_cfg_t *cfg, dcrx_collapse_row_t *rows,
                             uint64_t rows_cap, uint64_t *row_offsets, uint64_t *counters, int n_threads);
 

@@ -1,9 +1,10 @@
-"""The per-row front half of `collapse` (decombinator_amd/collapse.py) against (1) the reference's own test
-cases for it (reference tests/test_collapse.py:55-195: TestGetBarcodePositions, TestFindFirstSpacer), restated
-here with the same inputs and expected values, and (2) tests/golden/collapse_front.json, generated from the
-imported reference by oracle/gen_collapse_golden.py (1 500 barcode regions over the five oligos with
-substituted / inserted / deleted / truncated spacers, Ns, every N1 length; plus the row loop of
-read_in_data up to where grouping starts)."""
+"""The front half of `collapse` (decombinator_amd/collapse.py over libdcrx: dcrx_collapse_front, dcrx_spacer_search — every
+spacer search decided natively, the indel form included) against (1) the reference's own test cases for it (reference
+tests/test_collapse.py:55-195: TestGetBarcodePositions, TestFindFirstSpacer), restated here with the same inputs and expected
+values, (2) tests/golden/collapse_front.json, generated from the imported reference by oracle/gen_collapse_golden.py (1 500
+barcode regions over the five oligos with substituted / inserted / deleted / truncated spacers, Ns, every N1 length; plus the
+row loop of read_in_data up to where grouping starts), and (3) the reference's own `regex` patterns
+(tests/collapse_regex_ref.py, itself checked against that fixture here) on mutated barcode regions the fixture does not hold."""
 import collections as coll
 import json
 import os
@@ -11,6 +12,7 @@ import os
 import pytest
 
 from decombinator_amd import collapse
+from tests import collapse_regex_ref as ref
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collapse_front.json")
 
@@ -40,6 +42,8 @@ def test_find_first_spacer_reference_cases(spcr1, seq, start, end):
 
 
 def test_golden_cases_positions_barcodes_quality_and_counters():
+    """Every fixture case through the native get_barcode_positions (positions and getbarcode_* counters) and through the regex
+    checker (positions, counters, set_barcode, check_umi_quality): the checker is pinned here before it serves as an oracle."""
     fx = json.load(open(GOLDEN))
     params = fx["params"]
     n_fuzzy = 0
@@ -49,15 +53,17 @@ def test_golden_cases_positions_barcodes_quality_and_counters():
         locs = collapse.get_barcode_positions(cs["bcseq"], args, c)
         assert locs == cs["locs"], cs
         assert dict(c) == cs["counts"], cs
+        c2 = coll.Counter()
+        assert ref.get_barcode_positions(cs["bcseq"], args, c2) == cs["locs"] and dict(c2) == cs["counts"], cs
         n_fuzzy += c["getbarcode_pass_regexmatch"]
         if locs:
-            collapse.counts = coll.Counter()
+            ref.counts = coll.Counter()
             fields = ["1", "2", "3", "4", "ACGT", "id", "SEQ", "QUAL", cs["bcseq"], cs["bcqual"]]
-            bc, bq = collapse.set_barcode(fields, locs, args)
+            bc, bq = ref.set_barcode(fields, locs, args)
             assert (bc, bq) == (cs["barcode"], cs["barcode_qual"]), cs
-            assert dict(collapse.counts) == cs["set_counts"], cs
+            assert dict(ref.counts) == cs["set_counts"], cs
             if bq:
-                assert bool(collapse.check_umi_quality(bq, params)) == cs["low_quality"], cs
+                assert bool(ref.check_umi_quality(bq, params)) == cs["low_quality"], cs
     assert len(fx["cases"]) >= 1500 and n_fuzzy > 100
 
 
@@ -144,38 +150,73 @@ def _random_rows(rng, oligo, n):
 
 @pytest.mark.parametrize("oligo", ["m13", "i8", "i8_single", "nebio", "takara"])
 def test_library_batch_equals_the_regex_functions_row_for_row(oligo):
-    """dcrx_collapse_front (threaded C++: verbatim spacers and the {1s<=2} search decided natively, the indel search deferred)
-    against the per-row functions — the reference's own regex patterns — on 6 000 random rows per oligo: the same entry for
-    every row and the same counters, with allowNs off and on."""
+    """dcrx_collapse_front (threaded C++: verbatim spacers, the {1s<=2} search and the indel search {2i+2d+1s<=2} all decided
+    natively) against the reference's own regex patterns on 6 000 random rows per oligo: the same entry for every row and the
+    same counters, with allowNs off and on, and not one row deferred."""
     import random
     rng = random.Random(77 + len(oligo))
     rows = _random_rows(rng, oligo, 6000)
     params = [20, 1, 30]
     for allow in (False, True):
         args = {"oligo": oligo, "allowNs": allow, "lenthreshold": 130}
-        collapse.counts = coll.Counter()
+        ref.counts = coll.Counter()
         want = []
         for r in rows:
             try:
-                want.append(collapse._row_front(r, args, params))
+                want.append(ref._row_front(r, args, params))
             except ZeroDivisionError:              # (an empty barcode quality string: the reference's own crash)
                 want.append("CRASH")
-        want_counts = dict(collapse.counts)
+        want_counts = dict(ref.counts)
         keep = [i for i, w in enumerate(want) if w != "CRASH"]
-        collapse.counts = coll.Counter()
+        ref.counts = coll.Counter()
         for r in (rows[i] for i in range(len(rows)) if want[i] == "CRASH"):     # what the crash rows had counted before they crashed
             try:
-                collapse._row_front(r, args, params)
+                ref._row_front(r, args, params)
             except ZeroDivisionError:
                 pass
-        crash_counts = collapse.counts
+        crash_counts = ref.counts
         collapse.counts = coll.Counter()
         got = collapse.read_in_rows([rows[i] for i in keep], args, params)
         assert list(got) == [want[i] for i in keep]
         diff = coll.Counter(want_counts); diff.subtract(crash_counts)
         assert {k: v for k, v in collapse.counts.items() if v} == {k: v for k, v in diff.items() if v}
-        n_defer = int((got.status == 255).sum())
-        assert n_defer < len(keep) // 4          # (only rows where the spacer could occur with one base inserted or deleted; the mutated spacers above make that far more common than real data do)
+        assert int((got.status == 255).sum()) == 0
+
+
+def test_spacer_search_equals_regex_findall_on_mutated_spacers():
+    """dcrx_spacer_search against regex.findall for the three patterns of spacerSearch (collapse.py:204-212): every match string, in
+    order, on 60 000 windows built around mutated spacers (insertions, deletions, substitutions, repeats, truncations) — the
+    indel stage's choice among alignments is the regex module's backtracking order, restated natively; tools/fuzz_spacer_search.py
+    runs the same comparison over millions."""
+    import random
+    rng = random.Random(4242)
+    spacers = [v for o in collapse.OLIGOS.values() for v in o.values()]
+    n_indel = 0
+    for it in range(60000):
+        sp = rng.choice(spacers)
+        parts = []
+        for _ in range(rng.randrange(1, 4)):
+            t = list(sp)
+            for _ in range(rng.randrange(0, 3)):
+                r = rng.random()
+                if r < 0.4 and len(t) > 1:
+                    del t[rng.randrange(len(t))]
+                elif r < 0.8:
+                    t.insert(rng.randrange(len(t) + 1), rng.choice("ACGT"))
+                else:
+                    t[rng.randrange(len(t))] = rng.choice("ACGT")
+            parts.append("".join(t))
+            parts.append("".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 4))))
+        s = "".join(parts)
+        if rng.random() < 0.3:
+            s = s[rng.randrange(0, 4):]
+        if rng.random() < 0.3:
+            s = s[:len(s) - rng.randrange(0, 4)]
+        want = ref.spacerSearch(sp, s)
+        got = collapse.spacerSearch(sp, s)
+        assert got == want, (sp, s, got, want)
+        n_indel += bool(want) and len(want[0]) != len(sp)
+    assert n_indel > 3000
 
 
 STAGE_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collapse_stage.json")

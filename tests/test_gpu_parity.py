@@ -3,6 +3,7 @@ against (1) the golden vectors captured from the reference, (2) the CPU oracle
 on seeded synthetic reads, and (3) size-independent properties at
 BASELINE.json's full size.  Bit-exact: every field of every 16-byte record and
 every counter."""
+import os
 import numpy as np
 import pytest
 
@@ -29,16 +30,16 @@ def test_gpu_present_and_native_library_loaded():
 
 
 @pytest.mark.parametrize("path", gu.golden_files(), ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS,
+@pytest.mark.parametrize("flags", [0, nat.F_V2_NO_FUSE, nat.F_V1_KERNELS, nat.F_V2_SHAPE(3), nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS,
                                    nat.F_ONE_BASE_SCAN, nat.F_FORCE_SLOW_READER, nat.F_LIST_RESCUE],
-                         ids=["v2", "v1-pairscan", "v2-one-read-per-lane", "v2-general-form-only", "v2-separate-launches", "v2-side-streams", "onebase",
-                              "slowreader", "listrescue"])
+                         ids=["v2", "v2-tail-as-a-role", "v1-pairscan", "v2-one-read-per-lane", "v2-general-form-only", "v2-separate-launches", "v2-side-streams",
+                              "onebase", "slowreader", "listrescue"])
 def test_hip_matches_golden_and_oracle(path, flags):
     assert pu.check_fixture("hip", path, flags) > 500
 
 
-@pytest.mark.parametrize("flags", [0, nat.F_V1_KERNELS, nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS],
-                         ids=["v2", "v1", "v2-general-form-only", "v2-separate-launches", "v2-side-streams"])
+@pytest.mark.parametrize("flags", [0, nat.F_V2_NO_FUSE, nat.F_V1_KERNELS, nat.F_V2_NO_LEAN_RESCUE, nat.F_V2_LEAN_SERIAL, nat.F_V2_SIDE_STREAMS],
+                         ids=["v2", "v2-tail-as-a-role", "v1", "v2-general-form-only", "v2-separate-launches", "v2-side-streams"])
 @pytest.mark.parametrize("config,seed,sub,n", [(2, 2, 0.005, 1_000_000), (5, 5, 0.02, 300_000)])
 def test_synthetic_reads_bit_exact_vs_oracle(config, seed, sub, n, flags):
     ts = synth.config_tagset(config)
@@ -590,3 +591,46 @@ def test_host_entry_pipelines_chunks_and_equals_the_device_entry():
         rec, cnt = nat.decombine(t, batch, out=o)
         assert rec.tobytes() == want.tobytes()
         assert (cnt == want_cnt).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring", ["4", "16"])
+def test_fused_tail_ring_under_pressure(ring):
+    """The tail inside the scan kernel (scan2_kernel, FUSE): every read a tail read (all rearranged, no substitutions, so that the
+    scanning waves fill the ring as fast as they can) and a workload with many reads the lean tail leaves to the left list
+    (short, ragged reads), with the shortest ring (4 batches: tail waves at work on a ring batch's earlier occupant) and the
+    longest — in a process of its own (the ring length is read from the environment once)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from decombinator_amd import _native as nat, synth
+from tests import parity_util as pu
+from tests.test_gpu_parity import _tables
+from oracle import oracle as orc
+ts = synth.config_tagset(2)
+t, ot = _tables(ts)
+hb = nat.synth_reads_host(t, nat.synth_cfg(seed=77, p_rearranged=1.0, sub_rate=0.0, n_rate=0.0), 0, 600_000)
+rec, cnt = nat.decombine(t, hb)
+reads = nat.unpack_reads(hb)
+orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+pu.assert_records_equal(rec, orec, reads, "all-tail")
+assert (cnt == ocnt).all()
+assert int(cnt[nat.COUNTER_NAMES.index("vj_count")]) > 500_000
+rng = np.random.default_rng(5)
+hb = nat.synth_reads_host(t, nat.synth_cfg(seed=78, p_rearranged=0.9, sub_rate=0.01, n_rate=0.001), 0, 200_000)
+reads = nat.unpack_reads(hb)
+cut = rng.integers(40, 151, size=len(reads))
+reads = [r[:c] if i % 2 else r[len(r) - c:] for i, (r, c) in enumerate(zip(reads, cut))]
+b = nat.pack_reads(reads, stride=40)
+for orientation in ("reverse", "forward"):
+    rec, cnt = nat.decombine(t, b, orientation=orientation)
+    orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+    pu.assert_records_equal(rec, orec, reads, "ragged " + orientation)
+    assert (cnt == ocnt).all()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DCRX_DEBUG_RING_BATCHES=ring, PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
