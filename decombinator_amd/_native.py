@@ -181,7 +181,7 @@ class SynthCfgC(C.Structure):
 # every symbol include/dcrx.h and include/dcrx_synth.h declare
 EXPORTS = [
     "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
-    "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
+    "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_open_range", "dcrx_fastq_lines", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_set_step_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
     "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
@@ -214,6 +214,8 @@ def lib():
         "dcrx_unpack_reads": (i32, [C.POINTER(BatchC), vp, vp]),
         "dcrx_fastq_open": (i32, [C.c_char_p, i32, C.POINTER(vp)]),
         "dcrx_fastq_close": (None, [vp]),
+        "dcrx_fastq_open_range": (i32, [C.c_char_p, u64, u64, C.POINTER(vp)]),
+        "dcrx_fastq_lines": (i32, [C.c_char_p, u64, u64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]),
         "dcrx_fastq_next": (i32, [vp, u64, C.POINTER(FastqBatchC)]),
         "dcrx_count_prefix_byte": (u64, [vp, vp, vp, u64, u32, i32]),
         "dcrx_assemble_rows": (C.c_int64, [vp, u64, C.POINTER(SpansC), C.POINTER(SpansC), C.POINTER(SpansC),
@@ -473,11 +475,15 @@ class FastqBatch:
 class FastqReader:
     """Batch FASTQ / FASTA reader in libdcrx (dcrx_fastq_*): same records as readfq()."""
 
-    def __init__(self, path: str, gzipped: bool | None = None):
+    def __init__(self, path: str, gzipped: bool | None = None, byte_range=None):
+        """byte_range = (begin, end): the records of that byte range of a plain four-line FASTQ file only (a shard)."""
         if gzipped is None:
             gzipped = str(path).endswith(".gz")
         self._h = C.c_void_p()
-        check(lib().dcrx_fastq_open(os.fsencode(path), int(bool(gzipped)), C.byref(self._h)))
+        if byte_range is not None:
+            check(lib().dcrx_fastq_open_range(os.fsencode(path), int(byte_range[0]), int(byte_range[1]), C.byref(self._h)))
+        else:
+            check(lib().dcrx_fastq_open(os.fsencode(path), int(bool(gzipped)), C.byref(self._h)))
 
     def next(self, max_records: int) -> FastqBatch:
         c = FastqBatchC()
@@ -500,6 +506,15 @@ class FastqReader:
             self.close()
         except Exception:
             pass
+
+
+def fastq_lines(path: str, begin: int, end: int, nth: int = 0, count: bool = True):
+    """(newlines in the bytes [begin, end) of the file, offset just behind the nth of them or None, a carriage return occurs,
+    file size) — dcrx_fastq_lines; count=False: only the offset (the scan stops at the nth newline)."""
+    n, off, cr, size = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_uint64(0)
+    check(lib().dcrx_fastq_lines(os.fsencode(path), int(begin), int(end), int(nth), C.byref(n) if count else None, C.byref(off), C.byref(cr),
+                                 C.byref(size)))
+    return int(n.value), (None if off.value == 0xFFFFFFFFFFFFFFFF else int(off.value)), bool(cr.value), int(size.value)
 
 
 def count_prefix_byte(text: bytes, start, length, prefix: int, byte: str) -> int:

@@ -28,12 +28,14 @@
 // DCRX_FASTQ_SERIAL=1 switches the fast paths off, DCRX_FASTQ_NO_MMAP=1 the mapping (tests compare them).
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <future>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,8 +100,10 @@ struct dcrx_fastq {
   bool fast_ok = true;             // false: DCRX_FASTQ_SERIAL was set when the file was opened
   // the plain file mapped: the fast path parses straight from the page cache while everything so far was strict records
   const char *mm = nullptr;
-  size_t mm_size = 0, mm_off = 0;
+  size_t mm_size = 0, mm_off = 0;      // (mm_size: where reading ends — the file's end, or a shard's: dcrx_fastq_open_range)
+  size_t mm_map = 0;                   // bytes mapped
   bool mm_ok = false;
+  bool ranged = false;                 // a byte range of a plain file: strict records only, nothing read beyond the range
   int strict_block(const char *b, size_t len, bool at_eof, uint64_t max_records, Store &S, size_t &used);
   bool parse_mapped(Store &S, uint64_t max_records);
 
@@ -327,6 +331,10 @@ bool dcrx_fastq::parse_mapped(Store &S, uint64_t max_records) {
   if (!mm_ok || !fast_ok || finished || max_records == 0) return false;
   auto leave = [&]() {
     mm_ok = false;
+    if (ranged) {      // a shard is read by the mapped path alone (the buffered paths know no end but the file's)
+      finished = true; err_msg = "the FASTQ shard is not plain four-line records (multi-line records, FASTA records, carriage returns): read the file unsharded";
+      return false;
+    }
     if (fseeko(fp, (off_t)mm_off, SEEK_SET) != 0) { finished = true; err_msg = "cannot seek in the FASTQ file"; }
     pos = end = 0; eof = false; pending_cr = false; have_last = false; last.clear();
     return false;
@@ -509,7 +517,7 @@ int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out) {
     if (fstat(fileno(f->fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
       void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(f->fp), 0);
       if (m != MAP_FAILED) {
-        f->mm = (const char *)m; f->mm_size = (size_t)sb.st_size; f->mm_ok = true;
+        f->mm = (const char *)m; f->mm_size = f->mm_map = (size_t)sb.st_size; f->mm_ok = true;
         (void)madvise(m, f->mm_size, MADV_SEQUENTIAL);
       }
     }
@@ -518,11 +526,77 @@ int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out) {
   return DCRX_OK;
 }
 
+// A byte range [begin, end) of a plain four-line FASTQ file, `begin` a record's first byte (dcrx_fastq_lines finds such
+// offsets): what one rank of a sharded stage reads — its records and nothing else of the file.
+int dcrx_fastq_open_range(const char *path, uint64_t begin, uint64_t end, dcrx_fastq_t **out) {
+  if (!path || !out) return set_err(DCRX_E_INVALID, "null argument to dcrx_fastq_open_range");
+  *out = nullptr;
+  if (end < begin) return set_err(DCRX_E_INVALID, "dcrx_fastq_open_range: end < begin");
+  dcrx_fastq *f = new (std::nothrow) dcrx_fastq();
+  if (!f) return set_err(DCRX_E_NOMEM, "out of memory");
+  f->fp = std::fopen(path, "rb");
+  if (!f->fp) { delete f; return set_err(DCRX_E_INVALID, "cannot open FASTQ file"); }
+  struct stat sb;
+  if (fstat(fileno(f->fp), &sb) != 0 || !S_ISREG(sb.st_mode) || (uint64_t)sb.st_size < end) {
+    std::fclose(f->fp); delete f;
+    return set_err(DCRX_E_INVALID, "dcrx_fastq_open_range: the range lies beyond the file");
+  }
+  f->ranged = true;
+  f->fast_ok = true;
+  if (end == begin) { f->finished = true; *out = f; return DCRX_OK; }
+  // (the mapping starts on the page that holds `begin`; the pages of other ranks' ranges are never touched)
+  const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE), base = begin / page * page;
+  void *m = mmap(nullptr, (size_t)(end - base), PROT_READ, MAP_PRIVATE, fileno(f->fp), (off_t)base);
+  if (m == MAP_FAILED) { std::fclose(f->fp); delete f; return set_err(DCRX_E_INVALID, "cannot map the FASTQ file"); }
+  f->mm = (const char *)m; f->mm_map = (size_t)(end - base); f->mm_size = (size_t)(end - base); f->mm_off = (size_t)(begin - base);
+  f->mm_ok = true;
+  (void)madvise(m, f->mm_map, MADV_SEQUENTIAL);
+  *out = f;
+  return DCRX_OK;
+}
+
+// Newlines of the bytes [begin, end) of a file (mapped, counted at memory speed), and — nth >= 1 — the offset just behind the
+// nth of them (where line number nth of the range starts; *nth_off = UINT64_MAX when the range holds fewer); *has_cr tells
+// whether the range holds a carriage return (such a file is not read in shards).  How the ranks of a sharded stage agree on
+// record boundaries without any of them reading another's bytes: record k of a plain four-line file starts at line 4 k.
+int dcrx_fastq_lines(const char *path, uint64_t begin, uint64_t end, uint64_t nth, uint64_t *n_lines, uint64_t *nth_off, int *has_cr,
+                     uint64_t *file_size) {
+  if (!path || (!n_lines && !nth_off)) return set_err(DCRX_E_INVALID, "null argument to dcrx_fastq_lines");
+  FILE *fp = std::fopen(path, "rb");
+  if (!fp) return set_err(DCRX_E_INVALID, "cannot open FASTQ file");
+  struct stat sb;
+  if (fstat(fileno(fp), &sb) != 0 || !S_ISREG(sb.st_mode)) { std::fclose(fp); return set_err(DCRX_E_INVALID, "not a regular file"); }
+  if (file_size) *file_size = (uint64_t)sb.st_size;
+  if (end > (uint64_t)sb.st_size) end = (uint64_t)sb.st_size;
+  if (n_lines) *n_lines = 0;
+  if (nth_off) *nth_off = UINT64_MAX;
+  if (has_cr) *has_cr = 0;
+  if (begin >= end) { std::fclose(fp); return DCRX_OK; }
+  const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE), base = begin / page * page;
+  void *m = mmap(nullptr, (size_t)(end - base), PROT_READ, MAP_PRIVATE, fileno(fp), (off_t)base);
+  if (m == MAP_FAILED) { std::fclose(fp); return set_err(DCRX_E_INVALID, "cannot map the FASTQ file"); }
+  (void)madvise(m, (size_t)(end - base), MADV_SEQUENTIAL);
+  const char *b = (const char *)m + (begin - base), *e = (const char *)m + (end - base);
+  uint64_t n = 0;
+  for (const char *p = b; p < e;) {
+    const char *q = (const char *)std::memchr(p, '\n', (size_t)(e - p));
+    if (!q) break;
+    n++;
+    if (nth_off && n == nth) { *nth_off = begin + (uint64_t)(q + 1 - b); if (!n_lines) break; }      // (n_lines == NULL: only the offset is wanted)
+    p = q + 1;
+  }
+  if (has_cr && n_lines && std::memchr(b, '\r', (size_t)(e - b))) *has_cr = 1;
+  if (n_lines) *n_lines = n;
+  munmap(m, (size_t)(end - base));
+  std::fclose(fp);
+  return DCRX_OK;
+}
+
 void dcrx_fastq_close(dcrx_fastq_t *f) {
   if (!f) return;
   if (f->ahead_valid) { f->ahead.get(); f->ahead_valid = false; }
   if (f->gz) gzclose(f->gz);
-  if (f->mm) munmap(const_cast<char *>(f->mm), f->mm_size);
+  if (f->mm) munmap(const_cast<char *>(f->mm), f->mm_map);
   if (f->fp) std::fclose(f->fp);
   delete f;
 }

@@ -40,6 +40,7 @@ BATCH_READS = 1 << 20
 # wall seconds of the last decombinator() call by phase: FASTQ read, 2-bit pack, device call (H2D + kernels
 # + D2H), row assembly
 stage_seconds: dict = {}
+stage_info: dict = {}          # how the last stage read its input: sharded_input, byte_ranges (this rank's), rank, world
 
 # module-level state kept for callers that used the reference's globals
 counts: coll.Counter = coll.Counter()
@@ -574,9 +575,9 @@ def _summary_text(inputargs, chain, samplenam, date, timetaken):
     return "\n".join(lines)
 
 
-def _decombinator_part(inputargs: dict, rank: int, world: int, state: dict) -> None:
-    """This rank's part of the stage up to the first collective: tables, (rank 0) log directory and FASTQ check, the read
-    loop.  Leaves its results in `state`."""
+def _decombinator_setup(inputargs: dict, rank: int, world: int, state: dict) -> None:
+    """This rank's part of the stage before anything is read: tables, (rank 0) log directory and FASTQ check.  No collective
+    in here: a sharded run exchanges what this raised before it goes on (decombinator())."""
     print("Running Decombinator (MI355X / HIP build) version", __version__)
     opener = opener_check(inputargs)
     tcr = import_tcr_info(inputargs)
@@ -599,22 +600,42 @@ def _decombinator_part(inputargs: dict, rank: int, world: int, state: dict) -> N
         # (the reference crashes here with suppresssummary=True; this build checks anyway)
         fastq_check(inputargs, opener, samplenam, summaryname, logpath, chain)
 
+    if inputargs["orientation"] not in nat.ORIENTATIONS:
+        raise ValueError("orientation must be forward, reverse or both")
+    if inputargs["nobarcoding"] == False and inputargs["bc_read"] not in ("R1", "R2"):  # noqa: E712
+        raise ValueError("bc_read must be R1 or R2")
+    state.update(tcr=tcr, chain=chain, samplenam=samplenam, summaryname=summaryname, logpath=logpath, date=date)
+
+
+def _decombinator_loop(inputargs: dict, rank: int, world: int, state: dict, plan_shards=None) -> None:
+    """The read loop (reference :948-1050) over this rank's records: every rank of a sharded run comes here (the shard plan is
+    a collective), and leaves its rows in `state`."""
+    tcr = state["tcr"]
     bclength = inputargs["bclength"]
     counts["start_time"] = time()
     stage_seconds.clear()
     print("Decombining FASTQ data...")
     outdata = N12Rows()
     orientation = inputargs["orientation"]
-    if orientation not in nat.ORIENTATIONS:
-        raise ValueError("orientation must be forward, reverse or both")
 
     if inputargs["nobarcoding"] == False:  # noqa: E712
-        if inputargs["bc_read"] not in ("R1", "R2"):
-            raise ValueError("bc_read must be R1 or R2")
         paired = inputargs["bc_read"] == "R2"
         gz = inputargs["infile"].endswith(".gz")       # opener_check: one opener for both files (:118-123)
-        rd1 = nat.FastqReader(inputargs["infile"], gz)
-        rd2 = nat.FastqReader(inputargs["infile"].replace("1.f", "2.f"), gz) if paired else None
+        path1 = inputargs["infile"]
+        path2 = inputargs["infile"].replace("1.f", "2.f") if paired else None
+        # a sharded run reads its own records only (sharded.plan_fastq_shards: byte ranges of whole records, the files of a
+        # pair cut at the same record); files that cannot be cut are read whole by every rank and the batches dealt round-robin
+        ranges = None
+        if world > 1 and plan_shards is not None:
+            ranges = plan_shards([path1] + ([path2] if paired else []), world, rank, 1 if paired else 2)
+        stage_info.clear()
+        stage_info.update(sharded_input=ranges is not None, byte_ranges=ranges, rank=rank, world=world)
+        if ranges is not None:
+            rd1 = nat.FastqReader(path1, False, byte_range=ranges[0])
+            rd2 = nat.FastqReader(path2, False, byte_range=ranges[1]) if paired else None
+        else:
+            rd1 = nat.FastqReader(path1, gz)
+            rd2 = nat.FastqReader(path2, gz) if paired else None
         sampling = bool(inputargs.get("sampling_analysis"))
         try:
             batch_index = -1
@@ -624,11 +645,11 @@ def _decombinator_part(inputargs: dict, rank: int, world: int, state: dict) -> N
                 if spans is None:
                     break
                 batch_index += 1
-                if batch_index % world != rank:     # another rank's batch: read, not processed
+                if ranges is None and batch_index % world != rank:     # another rank's batch: read, not processed
                     if spans.last:
                         break
                     continue
-                outdata._tag = batch_index
+                outdata._tag = rank if ranges is not None else batch_index
                 n = len(spans.v_start)
                 if inputargs["allowNs"] == False:  # noqa: E712    counted, never dropped (:985-989)
                     counts["dcrfilter_barcodeN"] += nat.count_prefix_byte(spans.bc_text, spans.bc_start, spans.bc_len,
@@ -665,16 +686,17 @@ def _decombinator_part(inputargs: dict, rank: int, world: int, state: dict) -> N
             print("Non-barcoding option selected, but default output file extension (n12) detected. "
                   "Automatically changing to 'nbc'.")
 
-    state.update(outdata=outdata, chain=chain, samplenam=samplenam, summaryname=summaryname, logpath=logpath, date=date)
+    state.update(outdata=outdata)
 
 
-def decombinator(inputargs: dict, shard=None, reduce_counts=None, exchange_error=None) -> list:
+def decombinator(inputargs: dict, shard=None, reduce_counts=None, exchange_error=None, plan_shards=None) -> list:
     """The decombine stage (reference decombinator(), :881-1202): returns the 10-field rows
     that write_out_intermediate() turns into the `.n12` file, as an N12Rows sequence (a lazy
     list of lists).
 
-    shard = (rank, world): this process decombines the batches whose index is `rank` modulo `world` (it still reads
-    the whole file: the reader is two orders of magnitude faster than the rest) and tags its rows with their batch;
+    shard = (rank, world): this process reads and decombines its contiguous share of the records (plan_shards, given by
+    decombinator_sharded: byte ranges of whole records; rows tagged with the rank) — or, for files that cannot be cut, the
+    batches whose index is `rank` modulo `world` of the whole file (rows tagged with their batch);
     reduce_counts(counts), when given, is called once the loop is over and must leave the sums over all ranks in
     `counts`; only rank 0 creates the log directory, checks the FASTQ, prints the totals and writes the summary log.
     exchange_error(exc_or_None), when given, is called by every rank before the first collective with whatever this
@@ -682,15 +704,19 @@ def decombinator(inputargs: dict, shard=None, reduce_counts=None, exchange_error
     others waiting in reduce_counts for ever).  decombinator_amd.sharded.decombinator_sharded drives this."""
     rank, world = shard if shard is not None else (0, 1)
     state = {}
-    err = None
-    try:
-        _decombinator_part(inputargs, rank, world, state)
-    except BaseException as e:      # (SystemExit too: the reference leaves through sys.exit() for bad chains and tag sets)
-        if exchange_error is None:
-            raise
-        err = e
-    if exchange_error is not None:
-        exchange_error(err)
+    for part in (_decombinator_setup, _decombinator_loop):
+        err = None
+        try:
+            if part is _decombinator_setup:
+                part(inputargs, rank, world, state)
+            else:
+                part(inputargs, rank, world, state, plan_shards)
+        except BaseException as e:      # (SystemExit too: the reference leaves through sys.exit() for bad chains and tag sets)
+            if exchange_error is None:
+                raise
+            err = e
+        if exchange_error is not None:
+            exchange_error(err)
     outdata, chain, samplenam, summaryname, logpath, date = (state[k] for k in ("outdata", "chain", "samplenam", "summaryname", "logpath", "date"))
     if reduce_counts is not None:
         reduce_counts(counts)

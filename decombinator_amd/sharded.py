@@ -278,6 +278,121 @@ class TupleGather:
                     raise RuntimeError(f"rank {r}: {len(rec)} tuples, {len(idx)} bitmap bits, {counts[r]} announced")
 
 
+def _backend_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_bytes(blob: bytes, dst: int = 0):
+    """Every rank's bytes on `dst`, in rank order (a list of bytes objects there, None elsewhere): the sizes first (one small
+    all_gather), then one padded gather of uint8 tensors — over RCCL from device memory on the GPU box, over gloo in the CPU
+    tests.  What the sharded stage sends to rank 0: the rows' text, assembled on the rank that holds the reads."""
+    import numpy as np
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _backend_device()
+    k = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k)
+    sizes = [int(x.item()) for x in ks]
+    kmax = max(max(sizes), 1)
+    pad = torch.zeros(kmax, dtype=torch.uint8, device=dev)
+    if len(blob):
+        pad[:len(blob)] = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    if rank == dst:
+        got = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, got, dst=dst)
+        return [g[:n].cpu().numpy().tobytes() for g, n in zip(got, sizes)]
+    dist.gather(pad, None, dst=dst)
+    return None
+
+
+def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
+    """Byte ranges [(begin, end) per file] of the records this rank reads — contiguous shards in rank order, whole records, the
+    files of a pair cut at the same record — or None when the files cannot be read in shards (gzipped, carriage returns, not
+    whole four-line records, pairs of different length): the caller then reads unsharded.
+
+    No rank reads another rank's bytes to find the cuts: each counts the newlines of its own S/W bytes of every file (memory
+    speed: dcrx_fastq_lines), the counts are all-gathered, and record k of a four-line file starts at line 4 k — a rank owns the
+    records whose first line starts behind a newline of its range of the FIRST file (line 0: rank 0); the offsets of the cut
+    lines are looked up by the ranks whose ranges hold them (a second pass that stops at the line) and all-gathered.
+    records_per_unit = 2 keeps the record pairs of bc_read R1 together (reference decombine.py:956-961: zip over one generator
+    consumes two records per iteration).  Every rank must call this (three small collectives)."""
+    import os
+    from . import _native as nat
+    if any(str(p).endswith(".gz") for p in paths):
+        return None
+    # (whatever goes wrong on one rank — a file it cannot open — is part of what is exchanged: no rank leaves before the
+    # collectives below, and all of them then read unsharded, where the readers report the file in their own words)
+    mine, sizes = "ERR", None
+    try:
+        sizes = [os.path.getsize(p) for p in paths]
+        mine = []
+        for p, size in zip(paths, sizes):
+            b, e = rank * size // world, (rank + 1) * size // world
+            n, _, cr, _ = nat.fastq_lines(p, b, e)
+            last_nl = True
+            if rank == world - 1 and size:
+                with open(p, "rb") as fh:
+                    fh.seek(size - 1)
+                    last_nl = fh.read(1) == b"\n"
+            mine.append((n, cr, last_nl, size))
+    except Exception:
+        mine = "ERR"
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if any(x == "ERR" for x in every):
+        return None
+    counts = [[every[r][f][0] for r in range(world)] for f in range(len(paths))]
+    totals = [sum(c) for c in counts]
+    if any(every[r][f][1] or not every[r][f][2] or every[r][f][3] != sizes[f] for r in range(world) for f in range(len(paths))):
+        return None
+    if any(t % 4 for t in totals) or len(set(totals)) != 1:
+        return None
+    n_records = totals[0] // 4
+    unit = 4 * records_per_unit
+    # the first record (a multiple of records_per_unit) of each rank: ownership by the first file's newlines
+    prefix = [0] * (world + 1)
+    for r in range(world):
+        prefix[r + 1] = prefix[r] + counts[0][r]
+    first = [0] * (world + 1)
+    for r in range(1, world):
+        first[r] = min(-(-(prefix[r] + 1) // unit) * records_per_unit, n_records)      # smallest unit start line >= prefix + 1
+        first[r] = max(first[r], first[r - 1])
+    first[world] = n_records
+    # offsets of the cut lines, each looked up by the rank whose byte range of that file holds the line's newline
+    found = {}
+    for f, (p, size) in enumerate(zip(paths, sizes)):
+        pre = [0] * (world + 1)
+        for r in range(world):
+            pre[r + 1] = pre[r] + counts[f][r]
+        b, e = rank * size // world, (rank + 1) * size // world
+        for r in range(1, world):
+            line = 4 * first[r]
+            if line == 0:
+                found[(f, r)] = 0
+            elif line >= totals[f]:
+                if rank == world - 1:
+                    found[(f, r)] = size
+            elif pre[rank] < line <= pre[rank + 1]:
+                try:
+                    _, off, _, _ = nat.fastq_lines(p, b, e, nth=line - pre[rank], count=False)
+                except Exception:
+                    off = None
+                found[(f, r)] = off
+    allfound = [None] * world
+    dist.all_gather_object(allfound, found)
+    cuts = {}
+    for d in allfound:
+        cuts.update(d)
+    out = []
+    for f, size in enumerate(sizes):
+        begin = 0 if rank == 0 else cuts.get((f, rank))
+        end = size if rank == world - 1 else cuts.get((f, rank + 1))
+        if begin is None or end is None:
+            return None                   # (cannot happen for consistent counts; be safe)
+        out.append((begin, max(begin, end)))
+    return out
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -290,12 +405,14 @@ def decombinator_sharded(inputargs: dict, device_index: int | None = None):
     """The decombine stage over all ranks of the initialised process group (one process per GPU): the multi-GPU form
     of decombinator_amd.decombine.decombinator().
 
-    Batches of the input (BATCH_READS records) are dealt to the ranks round-robin — every rank reads the whole FASTQ
-    (the reader is far faster than the rest of the stage) and decombines its own batches on its own GPU; the rows
-    travel to rank 0 as text, tagged with their batch, and are put back in input order there (the order contract of
-    the reference's outdata.append, decombine.py:1039); the counters are summed over the ranks before rank 0 prints
-    the totals and writes the summary log.  Returns the rows (an N12Rows, as decombinator() does) on rank 0 and None
-    on the other ranks.  No data-path collective: one gather of text at the end and one all-reduce of 64 integers."""
+    The input is read in shards: rank r reads the records of its contiguous share of the FASTQ bytes and nothing else of the
+    files (plan_fastq_shards: plain four-line files; the R1 / R2 files of a pair are cut at the same record), decombines them
+    on its own GPU and assembles their rows; the rows' bytes are gathered on rank 0 (gather_bytes: one padded gather, RCCL on
+    the GPU box) and concatenated in rank order — contiguous shards, so that this is the input order the reference's
+    outdata.append keeps (decombine.py:1039); the counters are summed over the ranks before rank 0 prints the totals and
+    writes the summary log.  Files that cannot be cut (gzipped, multi-line records, carriage returns) are read whole by
+    every rank, batches dealt round-robin, as before.  Returns the rows (an N12Rows, as decombinator() does) on rank 0 and
+    None on the other ranks.  No data-path collective: the gather of the rows at the end and one all-reduce of 64 integers."""
     import numpy as np
 
     from decombinator_amd import _native as nat
@@ -338,14 +455,25 @@ def decombinator_sharded(inputargs: dict, device_index: int | None = None):
             raise err
         raise RuntimeError("decombinator_sharded: " + "; ".join(f"rank {r}: {m}" for r, m in enumerate(said) if m))
 
-    rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts, exchange_error=exchange_error)
+    rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts, exchange_error=exchange_error,
+                            plan_shards=plan_fastq_shards)
     chunks = rows._tagged_chunks()
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(chunks, gathered, dst=0)
+    # a rank's message: per chunk (tag, rows, bytes) — three int64 — then the chunks' text
+    head = np.array([[t, n, len(b)] for t, b, n in chunks], dtype=np.int64).reshape(-1, 3)
+    msg = np.int64(len(chunks)).tobytes() + head.tobytes() + b"".join(b for _, b, _ in chunks)
+    parts = gather_bytes(msg, dst=0)
     if rank != 0:
         return None
+    tagged = []
+    for r, part in enumerate(parts):
+        k = int(np.frombuffer(part[:8], dtype=np.int64)[0])
+        hd = np.frombuffer(part[8:8 + 24 * k], dtype=np.int64).reshape(-1, 3)
+        at = 8 + 24 * k
+        for t, n, nb in hd.tolist():
+            tagged.append(((t, r), part[at:at + nb], n))
+            at += nb
     merged = dec.N12Rows()
-    for tag, blob, n in sorted((c for part in gathered for c in part), key=lambda c: c[0]):
-        merged._tag = tag
+    for (t, r), blob, n in sorted(tagged, key=lambda c: c[0]):      # (sharded input: every tag is its rank; round-robin: the batch index)
+        merged._tag = t
         merged._add_blob(blob, n)
     return merged

@@ -194,6 +194,15 @@ typedef struct {
 
 /* gzipped != 0: the file must be gzip (gzip.open); 0: read as it is (open). */
 int dcrx_fastq_open(const char *path, int gzipped, dcrx_fastq_t **out);
+/* One rank's part of a sharded stage (no counterpart in the single-process reference; its order contract is the read loop's,
+ * decombine.py:951-1050): the bytes [begin, end) of a plain four-line FASTQ file, `begin` a record's first byte — the reader
+ * touches no other byte of the file, and fails (DCRX_E_INVALID) on anything but plain four-line records. */
+int dcrx_fastq_open_range(const char *path, uint64_t begin, uint64_t end, dcrx_fastq_t **out);
+/* Newlines among the bytes [begin, end) of a file; nth >= 1: *nth_off = the offset just behind the nth of them (UINT64_MAX when
+ * there are fewer; with n_lines == NULL the scan stops there); *has_cr: a carriage return occurs; *file_size.  With it the
+ * ranks agree on record boundaries (record k of a four-line file starts at line 4 k) while each reads only its own byte range. */
+int dcrx_fastq_lines(const char *path, uint64_t begin, uint64_t end, uint64_t nth, uint64_t *n_lines, uint64_t *nth_off, int *has_cr,
+                     uint64_t *file_size);
 void dcrx_fastq_close(dcrx_fastq_t *reader);
 /* Up to max_records further records; n_records == 0 means the file is exhausted. */
 int dcrx_fastq_next(dcrx_fastq_t *reader, uint64_t max_records, dcrx_fastq_batch_t *out);

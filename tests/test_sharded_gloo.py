@@ -191,9 +191,11 @@ STAGE_WORKER = textwrap.dedent('''
     dec.BATCH_READS = 7                       # many small batches: every rank gets several, the last one is short
     args = json.load(open(os.path.join(work, "args.json")))
     rows = sharded.decombinator_sharded(args)
+    info = [None] * world
+    dist.all_gather_object(info, dict(dec.stage_info))
     if rank == 0:
-        json.dump({"rows": [list(r) for r in rows], "counts": {k: int(v) for k, v in dec.counts.items() if k not in ("start_time", "end_time")}},
-                  open(os.path.join(work, "sharded.json"), "w"))
+        json.dump({"rows": [list(r) for r in rows], "counts": {k: int(v) for k, v in dec.counts.items() if k not in ("start_time", "end_time")},
+                   "info": info}, open(os.path.join(work, "sharded.json"), "w"))
     else:
         assert rows is None
     dist.barrier()
@@ -201,24 +203,29 @@ STAGE_WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_sharded_stage_equals_single_process(tmp_path, monkeypatch):
-    """decombinator_sharded() on two gloo ranks (the oracle standing in for the GPUs) against decombinator() in this
-    process on the same files: the same rows in the same order, the same counters, one summary log."""
+@pytest.mark.parametrize("world,run_index,cut", [(2, 0, "shards"), (3, 0, "shards"), (2, 1, "shards"), (3, 2, "shards"), (2, 0, "crlf")])
+def test_sharded_stage_equals_single_process(tmp_path, monkeypatch, world, run_index, cut):
+    """decombinator_sharded() on two and three gloo ranks (the oracle standing in for the GPUs) against decombinator() in this
+    process on the same files: the same rows in the same order, the same counters, one summary log — with the input read in
+    shards (every rank its own byte ranges of the FASTQ files: disjoint, in rank order, covering the files, the R1 / R2 files
+    of a pair cut at the same record; bc_read R1 keeps its record pairs together), and, for a file that cannot be cut (CRLF
+    line ends), with every rank reading the whole file as before."""
     import json
     from decombinator_amd import decombine as dec, io as dio, _native as nat
     from tests import golden_util as gu, parity_util as pu
     from decombinator_amd import synth
     from tests import test_host_stage as ths
     stage = json.load(open(os.path.join(ROOT, "tests", "golden", "stage_human_extended_b.json")))
-    run = stage["runs"][0]
+    run = stage["runs"][run_index % len(stage["runs"])]
     work = tmp_path / "w"
     work.mkdir()
     ts = stage["tagset"]
     synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
                  v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
                  j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(work / "tags"))
-    (work / "SYNTH_1.fq").write_text(stage["fastq_r1"])
-    (work / "SYNTH_2.fq").write_text(stage["fastq_r2"])
+    eol = "\r\n" if cut == "crlf" else "\n"
+    (work / "SYNTH_1.fq").write_bytes(stage["fastq_r1"].replace("\n", eol).encode())
+    (work / "SYNTH_2.fq").write_bytes(stage["fastq_r2"].replace("\n", eol).encode())
     (work / "single").mkdir()
     (work / "sharded").mkdir()
 
@@ -240,17 +247,42 @@ def test_two_rank_sharded_stage_equals_single_process(tmp_path, monkeypatch):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    DCRX_ROOT=ROOT, DCRX_WORK=str(work), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     got = json.load(open(work / "sharded.json"))
-    assert len(want_rows) > 20
+    assert len(want_rows) > (20 if run["bc_read"] == "R2" else 10)
     assert got["rows"] == want_rows
     assert got["counts"] == want_counts
+    # how the ranks read: their own byte ranges only — or, for the file that cannot be cut, the whole file each
+    info = got["info"]
+    assert [i["rank"] for i in info] == list(range(world))
+    if cut == "crlf":
+        assert not any(i["sharded_input"] for i in info)
+    else:
+        assert all(i["sharded_input"] for i in info)
+        files = [work / "SYNTH_1.fq"] + ([work / "SYNTH_2.fq"] if run["bc_read"] == "R2" else [])
+        for f, path in enumerate(files):
+            data = path.read_bytes()
+            at, n_rec = 0, []
+            for i in info:
+                b, e = i["byte_ranges"][f]
+                assert b == at and e >= b              # disjoint, in rank order, no gap
+                at = e
+                piece = data[b:e]
+                assert piece == b"" or piece.startswith(b"@")
+                assert piece.count(b"\n") % (4 if run["bc_read"] == "R2" else 8) == 0 or i["rank"] == world - 1
+                n_rec.append(piece.count(b"\n") // 4)
+            assert at == len(data)
+            if f == 0:
+                first_counts = n_rec
+                assert sum(1 for k in n_rec if k) >= 2          # (more than one rank really read something)
+            else:
+                assert n_rec == first_counts                   # the files of a pair are cut at the same records
     logs = list((work / "sharded" / "Logs").glob("*.csv"))          # written once, by rank 0, from the summed counters
     assert len(logs) == 1
     keep = [ln for ln in logs[0].read_text().split("\n") if not ln.startswith(("Directory,", "DateFinished,", "TimeFinished,", "TimeTaken"))]
