@@ -427,6 +427,7 @@ def pack_reads_span(text, start, length, stride: int | None = None) -> PackedBat
 
 
 NO_QUAL = 0xFFFFFFFF
+FAST_MAX_READ_LEN = 511      # reads up to this length run on the register shapes; longer ones (to dcrx_tables_info.max_read_len) in batches of their own
 
 
 class FastqBatch:

@@ -134,7 +134,7 @@ extern "C" {
 
 int dcrx_abi_version(void) { return DCRX_ABI_VERSION; }
 const char *dcrx_last_error(void) { return g_err.c_str(); }
-const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; v2 scan block 1024 (16-bit pair table), finishing blocks 256; reads <= 511 nt (register shapes of 10 / 20 / 32 words per read)"; }
+const char *dcrx_build_info(void) { return "dcrx hip kernels: gfx950; v2 scan block 1024 (16-bit pair table), finishing blocks 256; reads <= 511 nt on register shapes of 10 / 20 / 32 words per read, 512 .. 65535 nt one read per lane from memory"; }
 
 int dcrx_tables_create(const dcrx_tagset_t *tagset, dcrx_tables_t **out) {
   if (!out) return set_err(DCRX_E_INVALID, "out is null");
@@ -268,7 +268,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     t->exc_flag_reads = max_reads;
     t->ws_dirty = true;
   }
-  if (t->host.rel.v2_ok) {
+  if (t->host.rel.v2_ok && stride <= DCRX_FAST_MAX_STRIDE) {
     // the lists between the v2 kernels: every wave of the scan kernel (16 per CU) owns a region of tail and of event
     // entries; an entry carries the read's packed words, so the size follows the stride
     uint64_t tr = 0, er = 0;
@@ -327,8 +327,8 @@ static int check_batch(const dcrx_batch_t *b) {
   if (!b) return set_err(DCRX_E_INVALID, "batch is null");
   if (b->n_reads >= (1ull << 32)) return set_err(DCRX_E_INVALID, "more than 2^32-1 reads in one call");
   if (b->stride == 0 || (b->stride & 7u)) return set_err(DCRX_E_INVALID, "stride must be a positive multiple of 8");
-  if (b->stride > DCRX_MAX_STRIDE) return set_err(DCRX_E_UNSUPPORTED, "stride > 128 bytes: reads longer than 511 nt are not supported");
-  if (!b->lens && b->read_len > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "reads longer than 511 nt are not supported");
+  if (b->stride > DCRX_MAX_STRIDE) return set_err(DCRX_E_UNSUPPORTED, "stride > 16384 bytes: reads longer than 65535 nt are not supported");
+  if (!b->lens && b->read_len > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "reads longer than 65535 nt are not supported");
   if (!b->lens && b->read_len > 4 * b->stride) return set_err(DCRX_E_INVALID, "read_len exceeds 4*stride");
   if (b->n_reads && !b->packed) return set_err(DCRX_E_INVALID, "packed is null");
   if (b->n_exc && (!b->exc_read || !b->exc_pos || !b->exc_chr)) return set_err(DCRX_E_INVALID, "exception arrays are null");
@@ -415,7 +415,7 @@ static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   if (hb->lens) {
     for (uint64_t r = 0; r < n; r++) {
       if (hb->lens[r] > 4 * hb->stride) return set_err(DCRX_E_INVALID, "a read is longer than 4*stride");
-      if (hb->lens[r] > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 511 nt");
+      if (hb->lens[r] > DCRX_MAX_READ_LEN) return set_err(DCRX_E_UNSUPPORTED, "a read is longer than 65535 nt");
     }
   }
   for (uint64_t i = 0; i < hb->n_exc; i++) {
@@ -432,7 +432,8 @@ static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   // k + 1 is copied in and the records of chunk k - 1 are copied out (PCIe is full duplex: 40 bytes per read one way, 16 the
   // other), through pinned staging buffers (a copy from pageable memory would not overlap anything).  The loop it stands
   // for is the reference's read loop (decombine.py:963-1050).
-  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), DCRX_HOST_CHUNK);
+  // (long reads: a chunk's packed bytes stay within what 2 M reads of 150 nt take)
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), std::max<uint64_t>(1024, std::min<uint64_t>(DCRX_HOST_CHUNK, ((uint64_t)DCRX_HOST_CHUNK * 40) / hb->stride)));
   rc = ensure_device(t, chunk, hb->stride);
   if (rc) return rc;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

@@ -1669,4 +1669,87 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
   dcrx_store_record(records + r, rec);
 }
 
+// ------------------------------------------------------------------------------
+// Reads beyond the register shapes and the packed hit lists (512 .. 65 535 nt: merged pairs, long amplicons — the
+// reference has no length limit, decombine.py:228-265, :534-585): one read per lane in the plainest form there is.
+// One scan per frame over the packed words in memory with the one-base table in global memory — OR of the entry flags,
+// and per full-tag class the count and the first hit's state and end, all in plain integers (the accumulators and hit
+// lists of the forms above pack a position into nine bits) —, then dcr_frame with the rescue by re-scanning.
+// Slow by design: such reads are rare, and everything else of their batch stays on the fast shapes.
+// ------------------------------------------------------------------------------
+template <bool REV>
+DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const ReadView &rv) {
+  const Frame<REV> F(rv);
+  ScanOut so;
+  so.acc = 0; so.vcount = so.jcount = 0; so.vstate = so.jstate = 0; so.vend = so.jend = 0;
+  const int n = F.n();
+  if (n <= 0) return so;
+  uint32_t e = T.row0;
+  ExcCursor<REV> xc(F.r);
+  const int top = (n - 1) >> 4;
+  int i = 0;
+  for (int wi = 0; wi <= top; wi++) {
+    const int kk = REV ? top - wi : wi;                       // word index in scan order
+    const int cnt = (kk == top) ? ((n - 1) & 15) + 1 : 16;    // bases it holds
+    uint32_t wv = F.r.words[kk];
+    if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
+#pragma unroll 1
+    for (int k = 0; k < cnt; k++, i++) {
+      const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
+      wv = REV ? (wv << 2) : (wv >> 2);
+      if (xc.hit(i)) { e = T.row0; continue; }                // unknown byte: machine back to the root
+      e = trans_at<false>(nullptr, T, (e & TE_ROW_MASK) + (code << 2));
+      const uint32_t fl = e & ~TE_ROW_MASK;
+      if (!fl) continue;
+      so.acc |= fl;
+      const uint32_t st = ((e & TE_ROW_MASK) - T.row0) >> 4;
+      if ((fl >> TE_VFULL_BIT) & 1u) { if (so.vcount == 0) { so.vstate = st; so.vend = i; } so.vcount++; }
+      if ((fl >> TE_JFULL_BIT) & 1u) { if (so.jcount == 0) { so.jstate = st; so.jend = i; } so.jcount++; }
+      if ((fl >> TE_VMULTI_BIT) & 1u) so.vcount = so.vcount < 2 ? 2 : so.vcount;      // two tags ended at one position
+      if ((fl >> TE_JMULTI_BIT) & 1u) so.jcount = so.jcount < 2 ? 2 : so.jcount;
+    }
+  }
+  return so;
+}
+
+template <bool UNIFORM_LEN>
+DCRX_DEV void decombine_long_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, const uint64_t r, const Counters &C,
+                                 dcrx_record_t *records) {
+  ReadView rv;
+  rv.comp = T.comp;
+  rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
+  rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+  rv.e0 = rv.e1 = 0;
+  rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
+  if (B.n_exc) {      // this read's slice of the sorted exception list
+    uint64_t lo = 0, hi = B.n_exc;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
+    rv.e0 = (int)lo;
+    while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
+    rv.e1 = (int)lo;
+  }
+  __align__(16) dcrx_record_t rec;
+  rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
+  rec.vdel = rec.jdel = 0;
+  // (the orientation dispatch of decombine.py:999-1010, as decombine_list_one has it)
+  int status = DCRX_S_V_NONE, frame = 0;
+  for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
+    if (attempt == 0) {
+      const ScanOut so = scan_plain<true>(T, rv);
+      status = dcr_frame<true, false, false>(T, nullptr, rv, so, cfg, C, rec, nullptr); frame = 0;
+      if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
+    } else {
+      const ScanOut so = scan_plain<false>(T, rv);
+      status = dcr_frame<false, false, false>(T, nullptr, rv, so, cfg, C, rec, nullptr); frame = 1;
+    }
+  }
+  C.add(DCRX_C_READ_COUNT);                                           // :991
+  if (status == DCRX_S_OK) {
+    C.add(DCRX_C_VJ_COUNT);                                           // :1013
+    if (frame) C.add(DCRX_C_FRAME_FORWARD);
+  }
+  rec.status = (uint8_t)status; rec.frame = (uint8_t)frame;
+  dcrx_store_record(records + r, rec);
+}
+
 }  // namespace dcrx

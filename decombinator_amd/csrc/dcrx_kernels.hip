@@ -682,11 +682,41 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   return e;
 }
 
+// Reads of 512 .. 65 535 nt (strides beyond 128 bytes): every read through decombine_long_one, one read per lane, tables in
+// global memory (the L2 keeps them); the first launch zeroes the caller's counters (on the stream: a kernel of one block).
+__global__ void zero_counters_kernel(unsigned long long *__restrict__ counters) {
+  if (threadIdx.x < DCRX_N_COUNTERS) counters[threadIdx.x] = 0;
+}
+template <bool UNIFORM_LEN>
+__global__ __launch_bounds__(256) void decombine_long_kernel(DevTables T, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records,
+                                                             unsigned long long *__restrict__ counters) {
+  __shared__ uint32_t lds_counts[DCRX_N_COUNTERS];
+  const int tid = threadIdx.x;
+  if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  __syncthreads();
+  const Counters C{lds_counts};
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + tid; r < B.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
+    decombine_long_one<UNIFORM_LEN>(T, B, cfg, r, C, records);
+  __syncthreads();
+  if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
+                              unsigned long long *d_counters, hipStream_t s) {
+  hipExtLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, s, P.ev_step_start, nullptr, 0, d_counters);
+  const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, (B.n_reads + 63) / 64));      // (a wave per block where the batch is small: long chains, few reads)
+  const uint32_t block = B.n_reads > (uint64_t)grid * 64 ? 256u : 64u;
+  if (B.lens) hipExtLaunchKernelGGL(decombine_long_kernel<false>, dim3(grid), dim3(block), 0, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
+  else hipExtLaunchKernelGGL(decombine_long_kernel<true>, dim3(grid), dim3(block), 0, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
+  return hipGetLastError();
+}
+
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
                             dcrx_record_t *rec, uint32_t *queue, uint32_t *gqueue, uint32_t *queue_count,
                             uint64_t *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   hipError_t e;
   unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_counters);
+  if (B.stride > DCRX_FAST_MAX_STRIDE) return launch_long(P, T, B, cfg, rec, ctr, s);      // reads of 512 nt and more
   const bool uniform = B.lens == nullptr;
   const bool nw10 = B.stride <= 40;  // 150-nt reads: ten words in registers instead of DCRX_NWMAX
 #define DCRX_LAUNCH(TL, UN, NW_, AR_) launch_all<TL, UN, NW_, AR_>(P, T, B, cfg, rec, queue, gqueue, queue_count, ctr, s, ev_start, ev_stop)

@@ -11,10 +11,13 @@
 // words of the longest reads the v2 kernels hold in registers (128-byte stride: 511 nt), one read per lane
 #define DCRX_V2_NWLONG 32
 #define DCRX_FAST_READ_LEN (16 * DCRX_NWMAX)
-// longer reads (up to 511 nt: strides of up to 128 bytes) go through the list kernel, which walks the packed words
-// in memory; its hit positions have nine bits
-#define DCRX_MAX_STRIDE 128
-#define DCRX_MAX_READ_LEN 511
+// reads of up to 511 nt (strides of up to 128 bytes) run on the register shapes / the list kernel, whose hit positions have
+// nine bits; longer ones — to 65 535 nt: the 16-bit lengths, exception positions and record offsets of the ABI — in batches of
+// their own through decombine_long_kernel, which keeps every position in a plain integer
+#define DCRX_FAST_MAX_STRIDE 128
+#define DCRX_FAST_MAX_READ_LEN 511
+#define DCRX_MAX_STRIDE 16384
+#define DCRX_MAX_READ_LEN 65535
 #define DCRX_BLOCK 512   /* fast kernel, one base per step */
 #define DCRX_BLOCK16 1024 /* fast kernel, two bases per step (one block per CU: the table takes most of the LDS) */
 #define DCRX_QBLOCK 512  /* list kernel */

@@ -659,15 +659,32 @@ def _decombinator_loop(inputargs: dict, rank: int, world: int, state: dict, plan
                 if inputargs["dontcount"] == False and counts["read_count"] // 100000 > before // 100000:  # noqa: E712
                     print("\t read", (counts["read_count"] // 100000) * 100000)
                 t1 = time()
+                # reads of up to 511 nt run on the register shapes; longer ones (merged pairs, long amplicons: the reference has no
+                # length limit, decombine.py:228-265, :534-585) leave the batch for a call of their own — one read per lane from
+                # memory, dcrx's long form — and come back into their places; beyond 65 535 nt (the 16-bit lengths and offsets of
+                # the record) nothing decombines them: said before anything of the batch is processed
                 longest = int(spans.v_len.max()) if n else 0
                 if longest > tcr.max_read_len:
-                    # the reference has no length limit (decombine.py:534-585); this build's kernels do, and
-                    # there is no CPU path to fall back to: say so before anything of this batch is processed
                     raise ValueError(f"a read of {longest} nt exceeds the {tcr.max_read_len} nt this build decombines "
                                      f"(dcrx_tables_info.max_read_len); trim or split the reads")
-                batch = nat.pack_reads_span(spans.v_text, spans.v_start, spans.v_len)
-                t2 = time()
-                rec, cnt = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])
+                t2 = t1
+                if longest > nat.FAST_MAX_READ_LEN:
+                    is_long = spans.v_len > nat.FAST_MAX_READ_LEN
+                    rec = np.empty(n, dtype=nat.RECORD_DTYPE)
+                    cnt = np.zeros(nat.N_COUNTERS, dtype=np.uint64)
+                    for idx in (np.nonzero(~is_long)[0], np.nonzero(is_long)[0]):
+                        if len(idx) == 0:
+                            continue
+                        tp = time()
+                        batch = nat.pack_reads_span(spans.v_text, spans.v_start[idx], spans.v_len[idx])
+                        t2 += time() - tp
+                        r_part, c_part = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])
+                        rec[idx] = r_part
+                        cnt += c_part.astype(np.uint64)
+                else:
+                    batch = nat.pack_reads_span(spans.v_text, spans.v_start, spans.v_len)
+                    t2 = time()
+                    rec, cnt = nat.decombine(tcr.tables, batch, orientation, inputargs["allowNs"], inputargs["lenthreshold"])
                 t3 = time()
                 _add_counts(cnt, skip=("read_count",))
                 assemble_rows_spans(rec, spans, into=outdata)

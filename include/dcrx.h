@@ -130,12 +130,14 @@ typedef struct dcrx_cfg {
  * are not one of "ACGT" (N, IUPAC codes, lower case) are packed as 0 and listed
  * as exceptions sorted by (read, pos); the device treats them exactly as the
  * reference treats the original byte.  stride is a multiple of
- * 8 with 4*stride >= the longest read and stride <= 128: reads of up to 511 nt
- * (DCRX_E_UNSUPPORTED beyond; dcrx_tables_info.max_read_len).  Three register
- * shapes of the kernels by stride: <= 40 (150 nt, two reads per lane), <= 80 (320 nt) and
- * <= 128 (511 nt, one read per lane); where the round-2 kernels do not apply
- * (dcrx_tables_info.v2_tables == 0), batches with stride > 80 take a kernel that walks the
- * packed words in memory. */
+ * 8 with 4*stride >= the longest read and stride <= 16384: reads of up to 65 535 nt — the 16-bit
+ * lengths, exception positions and record offsets of this ABI (DCRX_E_UNSUPPORTED beyond;
+ * dcrx_tables_info.max_read_len; the reference itself has no limit, decombine.py:228-265).  By stride:
+ * <= 40 (150 nt, two reads per lane in registers), <= 80 (320 nt) and <= 128 (511 nt, one read per lane)
+ * run on the v2 kernels' register shapes (where those do not apply — dcrx_tables_info.v2_tables == 0 —
+ * batches with stride > 80 take a kernel that walks the packed words in memory); a batch with a larger
+ * stride takes the long form, one read per lane from memory, far slower per read: a caller puts its
+ * reads of 512 nt and more into batches of their own (decombinator_amd/decombine.py does). */
 typedef struct dcrx_batch {
   uint64_t n_reads;         /* < 2^32 per call */
   const uint8_t *packed;
@@ -285,12 +287,13 @@ int dcrx_compact_hits_bitmap_device(const dcrx_record_t *d_records, uint64_t n_r
                                     dcrx_record_t *d_hits, uint64_t *d_ok_bitmap, uint64_t *d_n_hits,
                                     void *hip_stream);
 
-/* The same with each decombined record squeezed into 12 bytes (three little-endian uint32):
+/* The same with each decombined record squeezed into 12 bytes (three little-endian uint32; offsets of nine bits: batches of
+ * reads of up to 511 nt only):
  *   word 0: v (bits 0-11) | j (12-23) | vdel (24-31)
  *   word 1: v_start (0-8) | j_end (9-17) | ins_start (18-26)
  *   word 2: ins_len (0-8) | jdel (9-16) | frame (17)
- * status is DCRX_S_OK by construction.  Requires < 4096 V and J tags (any real tag set); positions
- * are < 512 by the 320-nt read limit.  d_tuples12: 12 bytes per record. */
+ * status is DCRX_S_OK by construction.  Requires < 4096 V and J tags (any real tag set) and reads of up to 511 nt (positions
+ * < 512).  d_tuples12: 12 bytes per record. */
 int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples12,
                                     uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
 
