@@ -102,12 +102,15 @@ def test_translate_stage_from_files_and_the_cli(tmp_path):
 STAGE_FX = os.path.join(os.path.dirname(GOLDEN), "translate_stage.json")
 
 
-def _fastq_to_cdr3(tmp_path):
+CODING_FX = os.path.join(os.path.dirname(GOLDEN), "translate_stage_coding.json")
+
+
+def _fastq_to_cdr3(tmp_path, fixture=None):
     """FASTQ files -> decombinator() -> rows -> their unique DCRs -> cdr3translator (gene tables imported from files), against
     the reference's get_cdr3 on the same DCRs (tests/golden/translate_stage.json, oracle/gen_translate_golden.py)."""
     from decombinator_amd import decombine as dec, io as dio, synth
-    fx = json.load(open(STAGE_FX))
-    stage = json.load(open(os.path.join(os.path.dirname(GOLDEN), fx["stage"])))
+    fx = json.load(open(fixture or STAGE_FX))
+    stage = fx if "stage" not in fx else json.load(open(os.path.join(os.path.dirname(GOLDEN), fx["stage"])))      # (the coding fixture holds its own files)
     ts = stage["tagset"]
     tags = tmp_path / "tags"
     synth.TagSet(species=ts["species"], tags=ts["tags"], chain=ts["chain"], v_tags=ts["v_tags"], v_jumps=ts["v_jumps"],
@@ -129,6 +132,8 @@ def _fastq_to_cdr3(tmp_path):
                                 orientation="reverse", allowNs=False, tagfastadir=str(tags), suppresssummary=True, dontcheck=True,
                                 tags=ts["tags"], species=ts["species"], outpath=str(tmp_path) + os.sep, command="pipeline")
     rows = dec.decombinator(args)
+    if "rows" in fx:
+        assert [list(r) for r in rows] == fx["rows"]              # what the reference's decombinator() returned for these files
     seen, uniq = set(), []
     for r in rows:
         d = tuple(r[:5])
@@ -144,6 +149,7 @@ def _fastq_to_cdr3(tmp_path):
         assert want != "IndexError"
         want = dict(want, sequence_id=str(k + 1), duplicate_count=1, av_UMI_cluster_size="")
         assert dict(zip(translate.out_headers, row)) == want
+    return sum(1 for e in fx["expect"] if e["productive"] == "T"), len(fx["expect"])
 
 
 def test_fastq_to_cdr3_with_oracle_as_device(tmp_path, monkeypatch):
@@ -158,3 +164,42 @@ def test_fastq_to_cdr3_with_oracle_as_device(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_fastq_to_cdr3_through_hip_path(tmp_path):
     _fastq_to_cdr3(tmp_path)
+
+
+def _coding_oracle_device(fx):
+    from tests import golden_util as gu, parity_util as pu
+    from decombinator_amd import _native as nat
+    ot = gu.oracle_tables(fx["tagset"])
+
+    def device(tables, batch, orientation="reverse", allow_ns=False, lenthreshold=130, flags=0):
+        return pu.oracle_records(ot, nat.unpack_reads(batch), orientation, allow_ns, lenthreshold)
+    return device
+
+
+def test_fastq_to_productive_cdr3_with_oracle_as_device(tmp_path, monkeypatch):
+    """The coding fixture (oracle/gen_translate_golden.py coding_stage_fixture: germlines that code, in-frame rearrangements):
+    FASTQ -> decombine -> rows (= the reference's) -> get_cdr3 (= the reference's), most rows through the productive branch of
+    translate.py:312-350."""
+    from decombinator_amd import _native as nat
+    fx = json.load(open(CODING_FX))
+    monkeypatch.setattr(nat, "decombine", _coding_oracle_device(fx))
+    prod, total = _fastq_to_cdr3(tmp_path, CODING_FX)
+    assert prod >= 0.3 * total and total > 400
+
+
+@pytest.mark.gpu
+def test_fastq_to_productive_cdr3_through_hip_path(tmp_path):
+    prod, total = _fastq_to_cdr3(tmp_path, CODING_FX)
+    assert prod >= 0.3 * total and total > 400
+
+
+def test_fixture_cases_with_ambiguity_codes_cover_every_kind_of_answer():
+    """The ambiguous-codon rules of translate_nt are pinned by generated cases (the reference's get_cdr3 through the shim's
+    translate), not by hand: the fixture holds junctions with X, with B / Z / J, and with a shared residue behind an ambiguous
+    codon (those cases run in test_get_cdr3_matches_the_reference_on_every_field with all the others)."""
+    fx = json.load(open(GOLDEN))
+    amb = [c for c in fx["cases"] if c.get("ambiguous") and c["expect"] != "IndexError"]
+    assert len(amb) >= 350
+    jun = "".join(c["expect"]["junction_aa"] + c["expect"]["sequence_aa"] for c in amb)
+    assert all(x in jun for x in "XBZJ")
+    assert any(c["expect"]["productive"] == "T" for c in amb)
