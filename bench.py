@@ -454,6 +454,25 @@ class HipDevice:
                 e_r, e_p, e_c = nat.synth_exceptions_host(tb, cfg_synth, first + lo, hi - lo)
                 ers.append(e_r.astype(np.int64) + lo); eps.append(e_p); ecs.append(e_c)
             er, ep, ec = np.concatenate(ers), np.concatenate(eps), np.concatenate(ecs)
+            cluster = os.environ.get("DCRX_BENCH_N_CLUSTER")      # experiments only: "all:0.01" / "tail20:0.05" — that share of the reads all N / with a 20-nt N tail
+            if cluster and cnt:
+                kind, share = cluster.split(":")
+                rs = np.random.default_rng(1234 + first)
+                pick = np.nonzero(rs.random(cnt) < float(share))[0].astype(np.int64)
+                span = np.arange(READ_LEN, dtype=np.int64) if kind == "all" else np.arange(READ_LEN - int(kind[4:]), READ_LEN, dtype=np.int64)
+                cr = np.repeat(pick, len(span)); cp = np.tile(span, len(pick))
+                key = np.concatenate([er.astype(np.int64) * 65536 + ep.astype(np.int64), cr * 65536 + cp])
+                key, idx = np.unique(key, return_index=True)      # sorted by (read, position), one entry per place
+                er, ep = key // 65536, key % 65536
+                ec = np.concatenate([ec, np.full(len(cr), ord("N"), dtype=ec.dtype)])[idx]
+                # ... packed as the packer packs such bytes: zero bits (dcrx_pack_reads; the device generator leaves the drawn base)
+                rows2d = self.d_packed[at * stride:(at + cnt) * stride].view(cnt, stride)
+                tp = torch.from_numpy(pick).to(dev)
+                lo_b, hi_b = int(span[0]) // 4, (READ_LEN + 3) // 4
+                if int(span[0]) % 4:
+                    rows2d[tp, lo_b] &= (1 << (2 * (int(span[0]) % 4))) - 1
+                    lo_b += 1
+                rows2d[tp, lo_b:hi_b] = 0
             d_er = torch.from_numpy(er.astype(np.int64)).to(dev).to(torch.int32)  # same bits as uint32
             d_ep = torch.from_numpy(ep.astype(np.int32)).to(dev).to(torch.int16)
             d_ec = torch.from_numpy(ec).to(dev)

@@ -246,7 +246,8 @@ __device__ __forceinline__ void v2_exc_marks(const BatchDev &B, const uint32_t e
   uint32_t *flag = const_cast<uint32_t *>(B.exc_flag);
   for (uint64_t i = (uint64_t)e_lo + (uint32_t)tid; i < e_hi; i += blockDim.x) {
     const uint32_t r = B.exc_read[i];
-    if (set) atomicOr(&flag[r >> 5], 1u << (r & 31));
+    // (a read's first entry marks it: an all-N read has 150 entries, and as many atomics on one word serialise)
+    if (set) { if (i == e_lo || B.exc_read[i - 1] != r) atomicOr(&flag[r >> 5], 1u << (r & 31)); }
     else flag[r >> 5] = 0u;                                  // (all of a word's bits belong to this block)
   }
 }
@@ -394,6 +395,15 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         continue;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries were written before FILLED said so: nothing is read early)
+#ifdef DCRX_EXP_TAIL_NOOP
+      if (lane == 0) {
+        __hip_atomic_store(&lds_work[V2_WK_FILLED + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        atomicAdd(&lds_work[V2_WK_GEN + (c & nb_mask)], 1u);
+      }
+      spins = 0;
+      continue;
+#endif
       uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
       int status = -2;
       uint32_t r = 0, dg = 0;
@@ -403,6 +413,8 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         dcrx_record_t rec;
         rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
         const LdsWords lw{dcrx_ldsaddr_of(sl)};
+        if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(sl[0] ^ sl[NW - 1]); }      // profiling: the ring without the arithmetic
+        else
         status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
         rec.frame = (uint8_t)(o ? 0 : 1);
         if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
@@ -482,6 +494,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     if (stamp_prev) stamp_rest += st0 - stamp_prev;
     stamp_prev = st1;
 #endif
+    unsigned long long tmask[RPL];      // (fused form) the tail lanes of each of the item's reads, and their digests
+    uint32_t tdg[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) { tmask[q] = 0ull; tdg[q] = 0u; }
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const uint64_t r = blk_lo + (uint64_t)item * WT + (uint64_t)q * 64 + lane;
@@ -533,33 +549,8 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       if (cfg.flags & DCRX_F_PROFILE_NO_FINISH) continue;
       bool to_tail = what == V2_TAIL;
       const unsigned long long mt0 = __ballot(to_tail);
-      if (FUSE >= 0 && mt0) {      // the fused form: the tail entries into the block's ring
-        const uint32_t cnt = (uint32_t)__popcll(mt0), nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
-        uint32_t base = 0;
-        if (lane == 0) {
-          base = atomicAdd(&lds_work[V2_WK_HEAD], cnt);
-          // the slots lie in one or two ring batches: free once their last occupants have been finished (GEN)
-          const uint32_t gb0 = base >> 6, gb1 = (base + cnt - 1u) >> 6;
-          for (uint32_t spins = 0; spins < (1u << 24); spins++) {      // (the bound is never reached: a tail wave that does not come back)
-            if (__hip_atomic_load(&lds_work[V2_WK_GEN + (gb0 & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (gb0 >> nb_shift) &&
-                __hip_atomic_load(&lds_work[V2_WK_GEN + (gb1 & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (gb1 >> nb_shift)) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        asm volatile("" ::: "memory");
-        if (to_tail) {
-          uint32_t *sl = ring + ((base + (uint32_t)__popcll(mt0 & lt_mask)) & ring_mask) * V2_RING_STRIDE;
-#pragma unroll
-          for (int k = 0; k < NW; k++) sl[k] = w[q][k];
-          sl[NW + 2] = (uint32_t)r; sl[NW + 3] = tail2_pack(d);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries before the count that announces them)
-        if (lane == 0) {
-          const uint32_t n0 = min(cnt, 64u - (base & 63u));
-          atomicAdd(&lds_work[V2_WK_FILLED + ((base >> 6) & nb_mask)], n0);
-          if (cnt > n0) atomicAdd(&lds_work[V2_WK_FILLED + (((base >> 6) + 1u) & nb_mask)], cnt - n0);
-        }
+      if (FUSE >= 0) {             // the fused form: the item's tail entries go into the block's ring together, behind the loop over its reads
+        tmask[q] = mt0; tdg[q] = tail2_pack(d);
       } else if (mt0) {           // the block's tail list: one LDS atomic per wave and group of 64 reads
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + V2_L_TAIL], (uint32_t)__popcll(mt0));
@@ -612,6 +603,53 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
             const uint32_t at = base + (uint32_t)__popcll(mr & lt_mask);
             if (at >= l.cap) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, (uint32_t)r, exc);
             else put_event(l.rows, at);
+          }
+        }
+      }
+    }
+    if constexpr (FUSE >= 0) {
+      // One ring transaction per item: the slots of all its tail lanes drawn with one LDS atomic, and with it — the same wait —
+      // every ring batch's GEN (lane l reads GEN[l % NB]: a value read a moment early only errs towards waiting); the entries;
+      // the batches' FILLED counts behind them (LDS keeps a wave's order: nothing to wait for).  Per read of the item the same
+      // cost 43 us of a 10 M-read step: three dependent LDS round trips behind the look-ups of fifteen other waves, twice per item.
+      uint32_t cnts[RPL], total = 0;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) { cnts[q] = (uint32_t)__popcll(tmask[q]); total += cnts[q]; }
+      if (total) {
+        const uint32_t nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
+        const uint32_t genv = __hip_atomic_load(&lds_work[V2_WK_GEN + ((uint32_t)lane & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&lds_work[V2_WK_HEAD], total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t gb0 = base >> 6, gbl = (base + total - 1u) >> 6;
+        bool room = true;
+        for (uint32_t g = gb0; g <= gbl; g++) room = room && (uint32_t)__builtin_amdgcn_readlane((int)genv, (int)(g & nb_mask)) >= (g >> nb_shift);
+        if (!room && lane == 0) {      // a ring batch's last occupants are still being finished: wait for them
+          for (uint32_t spins = 0; spins < (1u << 24); spins++) {      // (the bound is never reached: a tail wave that does not come back)
+            bool ok = true;
+            for (uint32_t g = gb0; g <= gbl; g++)
+              ok = ok && __hip_atomic_load(&lds_work[V2_WK_GEN + (g & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (g >> nb_shift);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        asm volatile("" ::: "memory");
+        uint32_t at0 = base;
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+          if ((tmask[q] >> lane) & 1ull) {
+            uint32_t *sl = ring + ((at0 + (uint32_t)__popcll(tmask[q] & lt_mask)) & ring_mask) * V2_RING_STRIDE;
+#pragma unroll
+            for (int k = 0; k < NW; k++) sl[k] = w[q][k];
+            sl[NW + 2] = (uint32_t)(blk_lo + (uint64_t)item * WT + (uint64_t)q * 64 + lane); sl[NW + 3] = tdg[q];
+          }
+          at0 += cnts[q];
+        }
+        asm volatile("" ::: "memory");       // (the entries before the counts that announce them, in program order: LDS keeps it)
+        if (lane == 0) {
+          for (uint32_t g = gb0; g <= gbl; g++) {
+            const uint32_t lo = max(base, g << 6), hi = min(base + total, (g + 1u) << 6);
+            atomicAdd(&lds_work[V2_WK_FILLED + (g & nb_mask)], hi - lo);
           }
         }
       }
@@ -677,7 +715,10 @@ __device__ __forceinline__ void v2_general_entry(const DevTables &T, const V2Ori
     x0e = (int)lo;
     while (lo < B.n_exc && B.exc_read[lo] == r) lo++;
     x1e = (int)lo;
-    if (x1e - x0e > V2_MAX_EXC) { v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); return; }   // more exception bytes than the register frame holds
+    ExcLayout xl;
+    if (x1e - x0e > V2_MAX_EXC && !exc_layout(B.exc_pos, B.exc_chr, x0e, x1e, xl)) {      // more than a run of Ns and four single bytes: the list kernel
+      v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, true); return;
+    }
   }
   if (!finish2_words<UNIFORM_LEN, NW, ORI>(T, V, B, cfg, (uint64_t)r, w, ev, (x0 & V2_R_JMULTI) != 0u, x0e, x1e, C, records))
     v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, exc);
@@ -1027,7 +1068,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   V.bk = reinterpret_cast<const uint8_t *>(L.bk);
   const Counters C{L.counts};
   const bool tagged = A.B.n_reads < (1ull << 30);
-  const uint32_t width = A.R.width;
+  uint32_t width = A.R.width;
   // one loop for both lists (one copy of the general form's code): entries of list X by (region, slot), `width` lanes of a wave
   // at a time; then — mode bit 1, one wave — the left list as its entries arrive, a lane per entry, in order; every other block
   // signs off in queue_count[V2_QC_DONE] when its role is done (its pushes before that)
@@ -1035,6 +1076,9 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   const bool do_x = (mode & 1u) && region < A.n_regions && !(A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS);
   const V2ListRef lx = v2_list<NW>(A.Q, V2_L_X, do_x ? region : 0u);
   const uint32_t x_total = do_x ? min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], lx.cap) : 0u;
+  // (a long list — a run with many N tails — fills its waves: few lanes per wave pay only while the list is a handful per region)
+  if (x_total > 64u * A.R.bsplit * (DCRX_V2_FBLOCK / 64)) width = 64u;
+  else if (x_total > 16u * A.R.bsplit * (DCRX_V2_FBLOCK / 64)) width = 16u;
   uint32_t first = width * ((uint32_t)(tid >> 6) + (DCRX_V2_FBLOCK / 64) * bpart);
   const uint32_t step = width * (DCRX_V2_FBLOCK / 64) * A.R.bsplit;
   uint4 *lrows = A.Q.left;
@@ -1280,7 +1324,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // profiling switches keep the tail a launch of its own.
   constexpr bool CAN_FUSE = NW == 10 && RPL == 2 && PREFETCH;
   uint32_t ring_batches = 0;
-  if (CAN_FUSE && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | DCRX_F_PROFILE_MASK))) {
+  if (CAN_FUSE && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
     const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
     static const uint32_t nb_max = [] {      // (tests: DCRX_DEBUG_RING_BATCHES=4 forces the shortest ring)
       const char *e = getenv("DCRX_DEBUG_RING_BATCHES");
@@ -1362,7 +1406,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
     const uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
-    const uint32_t bsplit = std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions));  // blocks of a short list's pass that share a region
+    // blocks of a short list's pass that share a region: as a pass of its own (A/B forms) the list's latency is the launch's, and
+    // four blocks per region halve it; as a role under the lean rescue one block per region does (its rounds run hidden)
+    const uint32_t bsplit = separate ? std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions)) : 1u;
     const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
     const uint32_t llds = v2_finish_block_lds<NW>(T, o, DCRX_V2_FBLOCK);      // the lean roles: + a strip per lane (+ the rescue's scratch counters)

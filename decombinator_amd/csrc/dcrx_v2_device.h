@@ -260,19 +260,45 @@ DCRX_DEV void tail2_events(const uint32_t t, uint32_t (&ev)[3], bool &jmulti) {
 // the NW registers.  The finishing code of the v2 kernel works on this: one round of loads per
 // read, then no load at all.
 // ------------------------------------------------------------------------------
-constexpr int V2_MAX_EXC = 4;        // exception bytes of a read the register frame holds (a read with more takes the three-launch form)
+constexpr int V2_MAX_EXC = 4;        // single exception bytes of a read the register frame holds beside one run of Ns (a read with more takes the list kernel)
+// A read's exception bytes as the register frame holds them: its longest run of consecutive 'N' bytes (an N tail, an N head, a
+// stretch of Ns, a whole read of Ns: what a sequencer writes where it cannot call bases) as a range of stored positions, and up
+// to V2_MAX_EXC further bytes one by one.  False when the read has more than that.
+struct ExcLayout { int run_lo, run_hi; uint64_t xpos; uint32_t xchr; int nx; };
+DCRX_DEVNI bool exc_layout(const uint16_t *exc_pos, const uint8_t *exc_chr, const int e0, const int e1, ExcLayout &L) {
+  L.run_lo = L.run_hi = 0; L.xpos = 0; L.xchr = 0; L.nx = 0;
+  if (e1 - e0 > V2_MAX_EXC) {      // the longest run of Ns (entries are sorted by position)
+    int best_a = e0, best_n = 0;
+    for (int a = e0; a < e1;) {
+      int b = a;
+      if (exc_chr[a] == (uint8_t)'N') { b = a + 1; while (b < e1 && exc_chr[b] == (uint8_t)'N' && (int)exc_pos[b] == (int)exc_pos[b - 1] + 1) b++; }
+      if (b - a > best_n) { best_n = b - a; best_a = a; }
+      a = b > a ? b : a + 1;
+    }
+    if (e1 - e0 - best_n > V2_MAX_EXC) return false;
+    L.run_lo = (int)exc_pos[best_a]; L.run_hi = L.run_lo + best_n;
+    for (int k = e0; k < e1; k++) {
+      if (k >= best_a && k < best_a + best_n) continue;
+      L.xpos |= (uint64_t)exc_pos[k] << (16 * L.nx); L.xchr |= (uint32_t)exc_chr[k] << (8 * L.nx); L.nx++;
+    }
+    return true;
+  }
+  for (int k = e0; k < e1; k++) { L.xpos |= (uint64_t)exc_pos[k] << (16 * L.nx); L.xchr |= (uint32_t)exc_chr[k] << (8 * L.nx); L.nx++; }
+  return true;
+}
 template <bool REV_, int NW>
 struct FrameReg {
   static constexpr bool kRev = REV_;
   static constexpr bool kWindowedWalks = true;
   const uint32_t (&w)[NW];
   const ReadView &r;       // length and complement table (r.words and the exception list are not read after construction)
-  // the read's exception bytes, loaded once: stored position (16 bits each) and byte (8 bits each) of up to V2_MAX_EXC
-  uint64_t xpos; uint32_t xchr; int nx;
-  DCRX_DEVNI FrameReg(const uint32_t (&words)[NW], const ReadView &rv) : w(words), r(rv), xpos(0), xchr(0), nx(rv.e1 - rv.e0) {
-#pragma unroll
-    for (int k = 0; k < V2_MAX_EXC; k++)
-      if (k < nx) { xpos |= (uint64_t)rv.exc_pos[rv.e0 + k] << (16 * k); xchr |= (uint32_t)rv.exc_chr[rv.e0 + k] << (8 * k); }
+  // the read's exception bytes, loaded once: a run of Ns [run_lo, run_hi) in stored positions, and stored position (16 bits each)
+  // and byte (8 bits each) of up to V2_MAX_EXC single ones
+  uint64_t xpos; uint32_t xchr; int nx; int run_lo, run_hi;
+  DCRX_DEVNI FrameReg(const uint32_t (&words)[NW], const ReadView &rv) : w(words), r(rv), xpos(0), xchr(0), nx(0), run_lo(0), run_hi(0) {
+    ExcLayout L;
+    (void)exc_layout(rv.exc_pos, rv.exc_chr, rv.e0, rv.e1, L);      // (the caller has checked that the read fits)
+    xpos = L.xpos; xchr = L.xchr; nx = L.nx; run_lo = L.run_lo; run_hi = L.run_hi;
   }
   DCRX_DEV int xp(int k) const { return (int)((xpos >> (16 * k)) & 0xFFFFu); }
   DCRX_DEV uint8_t xc(int k) const { return (uint8_t)((xchr >> (8 * k)) & 0xFFu); }
@@ -289,16 +315,19 @@ struct FrameReg {
     const int c = (int)((word(m >> 4) >> ((m & 15) * 2)) & 3u);
     return REV_ ? (c ^ 3) : c;
   }
-  DCRX_DEV int exc_index(int i) const {          // index into the held exceptions, or -1
+  DCRX_DEV int exc_index(int i) const {          // index into the held single exceptions, -2 inside the run of Ns, or -1
     const int m = fpos(i);
-    int at = -1;
+    int at = (m >= run_lo && m < run_hi) ? -2 : -1;
     for (int k = 0; k < nx; k++)
       if (xp(k) == m) at = k;
     return at;
   }
-  DCRX_DEV bool has_exc() const { return nx > 0; }
+  DCRX_DEV bool has_exc() const { return nx > 0 || run_hi > run_lo; }
+  // the run in frame positions: [flo, fhi)
+  DCRX_DEV int run_flo() const { return REV_ ? r.n - run_hi : run_lo; }
+  DCRX_DEV int run_fhi() const { return REV_ ? r.n - run_lo : run_hi; }
   DCRX_DEV bool clean(int a, int b) const {
-    bool ok = true;
+    bool ok = !(run_hi > run_lo && run_flo() < b && run_fhi() > a);
     for (int k = 0; k < nx; k++) {
       const int i = REV_ ? r.n - 1 - xp(k) : xp(k);
       if (i >= a && i < b) ok = false;
@@ -311,10 +340,15 @@ struct FrameReg {
       const int d = xp(k) - b;
       if (d >= 0 && d < 32) m |= 1ull << (2 * d);
     }
+    const int lo = max(run_lo - b, 0), hi = min(run_hi - b, 32);      // the run's share of the window
+    if (hi > lo) {
+      const uint64_t upto_hi = hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull);
+      m |= 0x5555555555555555ull & upto_hi & ~((1ull << (2 * lo)) - 1ull);
+    }
     return m;
   }
   DCRX_DEVNI bool has_N(int lo, int hi) const {
-    bool hasN = false;
+    bool hasN = run_hi > run_lo && run_flo() < hi && run_fhi() > lo;      // (N is its own complement: the run reads N in either frame)
     for (int k = 0; k < nx; k++) {
       const int i = REV_ ? r.n - 1 - xp(k) : xp(k);
       const uint8_t b = REV_ ? r.comp[xc(k)] : xc(k);
@@ -325,6 +359,7 @@ struct FrameReg {
   DCRX_DEVNI uint8_t chr(int i) const {
     if (has_exc()) {
       const int k = exc_index(i);
+      if (k == -2) return (uint8_t)'N';
       if (k >= 0) { const uint8_t b = xc(k); return REV_ ? r.comp[b] : b; }
     }
     return (uint8_t)("ACGT"[code(i)]);

@@ -84,7 +84,10 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
   int what = classify2(d, bnd);
   if (exc && what != V2_VNONE) what = V2_EVENTS;
   g_v2_stats[what]++;
-  if (what == V2_EVENTS && x1 - x0 > V2_MAX_EXC) return FAST_TO_GENERAL;      // more exception bytes than the register frame holds
+  if (what == V2_EVENTS && x1 - x0 > V2_MAX_EXC) {      // more exception bytes than the register frame holds beside a run of Ns
+    ExcLayout xl;
+    if (!exc_layout(B.exc_pos, B.exc_chr, x0, x1, xl)) return FAST_TO_GENERAL;
+  }
   if (what == V2_VNONE || what == V2_VMULTI) {
     dcrx_record_t rec;
     std::memset(&rec, 0, sizeof rec);

@@ -189,3 +189,57 @@ def test_lean_forms_settle_nearly_all_reads_of_the_bench_workload():
     lean_rescue = int(stats[62])
     assert lean_tail > 0.999 * tail, (lean_tail, tail)
     assert lean_rescue > 0.93 * events, (lean_rescue, events)
+
+
+def _n_clustered_reads(ts, n, seed):
+    """Reads with CLUSTERED exception bytes, as sequencers write them: N tails and N heads of 1-40 nt, stretches of Ns inside the
+    read (also across a tag or a junction), whole reads of Ns, and — beside such a run — up to five single exception bytes
+    (N, IUPAC codes, lower case), so that both sides of the register frame's limit are met."""
+    import random
+    from oracle import oracle as orc
+    vs, js = ts.half_splits
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=vs, j_half_split=js)
+    t = pu.native_tables(d)
+    reads = nat.unpack_reads(nat.synth_reads_host(t, nat.synth_cfg(seed=seed, p_rearranged=0.85, sub_rate=0.01, n_rate=0.0), 0, n))
+    rng = random.Random(seed)
+    out = []
+    for r in reads:
+        s = list(r)
+        kind = rng.random()
+        if kind < 0.3:
+            k = rng.randrange(1, 41); s[len(s) - k:] = "N" * k
+        elif kind < 0.5:
+            k = rng.randrange(1, 41); s[:k] = "N" * k
+        elif kind < 0.8:
+            k = rng.randrange(2, 30); a = rng.randrange(0, len(s) - k); s[a:a + k] = "N" * k
+        elif kind < 0.85:
+            s = list("N" * len(s))
+        for _ in range(rng.choice([0, 0, 1, 2, 3, 4, 5])):
+            s[rng.randrange(len(s))] = rng.choice("NNNRYacgtn")
+        out.append("".join(s))
+    return d, out
+
+
+@pytest.mark.parametrize("orientation", ["reverse", "forward", "both"])
+def test_clustered_exception_bytes_through_the_register_frame(orientation):
+    """N tails, N heads, stretches of Ns and all-N reads — the register frame holds a run of Ns as a range
+    beside four single bytes (FrameReg, exc_layout) instead of leaving for the list kernel at the fifth exception byte — on the
+    host emulation of the same device functions, records and counters against the oracle; allowNs on and off (the inter-tag N
+    filter, decombine.py:553-556, sees the run)."""
+    from oracle import oracle as orc
+    from decombinator_amd import synth
+    ts = synth.config_tagset(2)
+    d, reads = _n_clustered_reads(ts, 6000, 91)
+    vs, js = ts.half_splits
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], vs, js)
+    if orientation != "reverse":
+        reads = [orc.revcomp(r) if k % 2 else r for k, r in enumerate(reads)]
+    hb = nat.pack_reads(reads)
+    for allow in (False, True):
+        rec, cnt = pu.Backend("emul", d).run(hb, orientation, allow_ns=allow)
+        orec, ocnt = pu.oracle_records(ot, reads, orientation, allow, 130)
+        pu.assert_records_equal(rec, orec, reads, orientation)
+        pu.assert_counters_equal(cnt, ocnt)
+    assert int((orec["status"] == 0).sum()) > 800

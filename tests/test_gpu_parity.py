@@ -695,3 +695,22 @@ def test_reads_of_512_nt_and_more_decombine_in_all_orientations(tmp_path):
         for row, k in zip(rows, ok.tolist()):
             assert row[5] == f"m{k}" and [int(x) for x in row[:4]] == [int(orec["v"][k]), int(orec["j"][k]), int(orec["vdel"][k]), int(orec["jdel"][k])]
         assert int(dec.counts["vj_count"]) == len(ok)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orientation", ["reverse", "both"])
+def test_clustered_exception_bytes_on_the_gpu(orientation):
+    """N tails, N heads, stretches of Ns, all-N reads (tests/test_emul_parity.py: _n_clustered_reads) through libdcrx: the general
+    form's register frame holds a run of Ns beside four single bytes; records and counters against the oracle."""
+    from tests import test_emul_parity as tep
+    ts = synth.config_tagset(2)
+    d, reads = tep._n_clustered_reads(ts, 40_000, 17)
+    t, ot = _tables(ts)
+    if orientation != "reverse":
+        reads = [orc.revcomp(r) if k % 2 else r for k, r in enumerate(reads)]
+    hb = nat.pack_reads(reads)
+    for allow in (False, True):
+        rec, cnt = nat.decombine(t, hb, orientation=orientation, allow_ns=allow)
+        orec, ocnt = pu.oracle_records(ot, reads, orientation, allow, 130)
+        pu.assert_records_equal(rec, orec, reads, orientation)
+        pu.assert_counters_equal(cnt, ocnt)
