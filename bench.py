@@ -316,6 +316,8 @@ def run_rank(args, device_factory=None):
     # HIP events around the kernels are not free (a step that carries its four costs ~20 us more): every
     # EVENT_EVERY-th step of the timed region carries them, and the device-side averages below are over those steps
     every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
+    # (the step's pair rides on the step's first and last dispatch, the dominant kernel's pair on that kernel's dispatch: the scan
+    # is also a step's first launch, so the two pairs go on different steps — one dispatch carries one start event)
     timed = [k for k in range(args.steps) if k % every == every - 1 or args.steps < every]
     events = device.make_events(args.steps, timed)
     elapsed = timed_loop(gather, args.steps, events, set(timed))
@@ -404,10 +406,10 @@ def run_rank(args, device_factory=None):
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_read": algo_bytes,
                 "step_device_ms_avg": round(step_avg_ms, 5), "step_device_ms_min": round(min(step_ms), 5),
-                "dominant_kernel": "dcrx::scan2_kernel" if v2 else "dcrx::decombine_kernel", "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
+                "dominant_kernel": ("dcrx::scan2_kernel (scan + lean tail fused: the tail entries go through a ring in LDS)" if v2 else "dcrx::decombine_kernel"), "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
                 "dominant_kernel_ms_min": round(min(kern_ms), 5),
-                "events": f"HIP events on {len(timed)} of the {args.steps} timed steps (every {every}th: a step that carries them runs a few % "
-                          "longer, so the device-side averages can exceed ms_per_step)",
+                "events": f"HIP events on {len(timed)} of the {args.steps} timed steps (every {every}th, in turn the step's pair — on its first and last "
+                          "dispatch — and the dominant kernel's pair: a step that carries them runs a few % longer, so the device-side averages can exceed ms_per_step)",
             }
             # the same algorithmic bytes over the host-side time of a step (launch gaps included)
             line["step_frac"] = round(algo_bytes * total_reads / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5)
@@ -490,6 +492,7 @@ class HipDevice:
         for tb in all_tables:
             nat.check(nat.lib().dcrx_reserve_device(tb.handle, n))
         self.accumulate = len(batches) > 1
+        self.event_every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
         self.compact = None            # TupleGather then compacts with dcrx_compact_hits_packed_device
 
     def name(self):
@@ -499,10 +502,12 @@ class HipDevice:
         return "v2" if bool(info.get("v2_tables")) and not (self.cfg_flags & 64) else "v1"
 
     def kernels(self, info):
-        return "v2 (scan2 / rescue2 + tail2 / events2)" if self.kernels_tag(info) == "v2" else "three-launch form"
+        return "v2 (scan2 with the lean tail inside / finish2: lean rescue + general form / list kernel)" if self.kernels_tag(info) == "v2" else "three-launch form"
 
     def make_events(self, steps, timed):
         nat = self.nat
+        # (in turn the step's pair and the dominant kernel's pair; a run with one event-carrying step gets both on it)
+        self.event_kind = {k: (i % 2 if len(timed) > 1 else 2) for i, k in enumerate(timed)}
         return {k: [tuple(nat.Event() for _ in range(4)) for _ in self.all_tables] for k in timed}
 
     def step(self, k, gather, ev):
@@ -514,9 +519,12 @@ class HipDevice:
             rec = gather.records()
         for c, tb in enumerate(self.all_tables):
             last = c == len(self.all_tables) - 1
-            if ev is not None:           # events: (step start, step stop, kernel start, kernel stop) per chain
-                nat.check(nat.lib().dcrx_set_step_events(tb.handle, ev[c][0].ptr, ev[c][1].ptr))
-                nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[c][2].ptr, ev[c][3].ptr))
+            if ev is not None:           # events: (step start, step stop, kernel start, kernel stop) per chain; the step's pair on
+                kind = self.event_kind[k]             # every other event-carrying step, the kernel's pair on the ones between
+                if kind in (0, 2):
+                    nat.check(nat.lib().dcrx_set_step_events(tb.handle, ev[c][0].ptr, ev[c][1].ptr))
+                if kind in (1, 2):
+                    nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[c][2].ptr, ev[c][3].ptr))
             nat.check(nat.lib().dcrx_decombine_device(tb.handle, nat.C.byref(self.cfg), nat.C.byref(b),
                                                       (rec if last else self.d_recs[c]).data_ptr(), self.d_cnts[c].data_ptr(), self.sptr))
             if ev is not None:
@@ -530,8 +538,10 @@ class HipDevice:
             gather.step(b.n_reads)
 
     def event_times(self, events, timed):
-        step_ms = [sum(e[0].elapsed_ms(e[1]) for e in events[k]) for k in timed]         # all launches of a step, on the device
-        kern_ms = [sum(e[2].elapsed_ms(e[3]) for e in events[k]) for k in timed]         # the dominant kernel(s) alone
+        st = [k for k in timed if self.event_kind[k] in (0, 2)]
+        kt = [k for k in timed if self.event_kind[k] in (1, 2)]
+        step_ms = [sum(e[0].elapsed_ms(e[1]) for e in events[k]) for k in st]         # all launches of a step, on the device
+        kern_ms = [sum(e[2].elapsed_ms(e[3]) for e in events[k]) for k in kt]         # the dominant kernel(s) alone
         return step_ms, kern_ms
 
     def _counter(self, name):

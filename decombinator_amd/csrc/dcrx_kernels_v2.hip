@@ -1129,7 +1129,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   if (polling && lane == 0) { A.queue_count[V2_QC_LEFT] = 0u; A.queue_count[V2_QC_DONE] = 0u; }
 }
 
-template <bool UNIFORM_LEN, int NW, int ORI>
+template <bool UNIFORM_LEN, int NW, int ORI, bool TAIL_ROLE = true>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(const V2FinishArgs A) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int tid = threadIdx.x;
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
     L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
     __syncthreads();
     if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
-    else if (role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    else if (TAIL_ROLE && role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));      // (TAIL_ROLE false: the scan kernel has taken the tail, the launch holds no such block)
     else v2_general_role<UNIFORM_LEN, NW, ORI>(blockIdx.x == 0 ? 3u : 1u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
   }
   __syncthreads();
@@ -1324,14 +1324,20 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // profiling switches keep the tail a launch of its own.
   constexpr bool CAN_FUSE = NW == 10 && RPL == 2 && PREFETCH;
   uint32_t ring_batches = 0;
-  if (CAN_FUSE && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
+  // (measured, profiles/r04: config 2's 57 KB table 0.413 ms per step fused against 0.429 with the tail as a role; the extended
+  // beta set's 76 KB table 0.752 against 0.726 for config 3's two chains: pair tables of up to 64 KB fuse)
+  if (CAN_FUSE && T.v2[o].trans_bytes <= 64u * 1024u && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
     const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
     static const uint32_t nb_max = [] {      // (tests: DCRX_DEBUG_RING_BATCHES=4 forces the shortest ring)
       const char *e = getenv("DCRX_DEBUG_RING_BATCHES");
       const uint32_t v = e ? (uint32_t)atoi(e) : V2_RING_MAXBATCHES;
       return (v == 4u || v == 8u || v == 16u) ? v : V2_RING_MAXBATCHES;
     }();
-    for (uint32_t nb = nb_max; nb >= 4u; nb >>= 1)
+    // (the whole ring or none: with the extended alpha set's 119 KB table only four batches fit, the scanning waves wait for
+    // room, and config 3 took 7.26 ms per 100 M reads against 5.91 with the tail as a role of the finishing launch;
+    // tests force shorter rings through DCRX_DEBUG_RING_BATCHES)
+    const uint32_t nb_min = getenv("DCRX_DEBUG_RING_BATCHES") ? 4u : V2_RING_MAXBATCHES;
+    for (uint32_t nb = nb_max; nb >= nb_min; nb >>= 1)
       if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches = nb; break; }
   }
   auto ks = scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>;
@@ -1343,6 +1349,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
   auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
   auto kf = o ? finish2_kernel<UNIFORM, NW, 1> : finish2_kernel<UNIFORM, NW, 0>;
+  auto kf0 = o ? finish2_kernel<UNIFORM, NW, 1, false> : finish2_kernel<UNIFORM, NW, 0, false>;      // ... without the tail role's code
   auto kl = o ? left2_kernel<UNIFORM, NW, 1> : left2_kernel<UNIFORM, NW, 0>;
   static bool seen[64];
   hipError_t e;
@@ -1362,6 +1369,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf0), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
@@ -1425,7 +1434,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
     A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables;
     if (!separate) {
-      hipLaunchKernelGGL(kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
+      hipLaunchKernelGGL(ring_batches ? kf0 : kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     } else {
