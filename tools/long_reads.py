@@ -1,6 +1,7 @@
 """Throughput of the hot path on reads longer than the bench's 150 nt (device-resident, like bench.py): the 250 and
 300 nt of 2x250 / 2x300 libraries take the kernels' second register shape (20 words per read), 321-511 nt the third
-(32 words, one read per lane).  usage (GPU box): python tools/long_reads.py [read_len ...]"""
+(32 words, one read per lane); 512 nt and more the long form (one read per lane from memory, plain-integer positions: fewer
+reads per launch here).  usage (GPU box): python tools/long_reads.py [read_len ...]"""
 import os
 import sys
 import time
@@ -11,8 +12,8 @@ from decombinator_amd import _native as nat, synth
 
 ts = synth.config_tagset(2)
 t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
-for L in [int(x) for x in sys.argv[1:]] or [150, 250, 300, 400, 500]:
-    n = 4_000_000
+for L in [int(x) for x in sys.argv[1:]] or [150, 250, 300, 400, 500, 600, 2000]:
+    n = 4_000_000 if L <= 511 else 200_000
     db = nat.synth_reads_device(t, nat.synth_cfg(seed=2, read_len=L), 0, n)
     d_rec = nat.DeviceBuffer(n * 16)
     d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
