@@ -285,11 +285,17 @@ def run_rank(args, device_factory=None):
         device = device_factory(nat, all_tables, tagsets, cfg_synth, batches, n)
     else:
         device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
+    # what travels: the narrow tuple of the tag set (5 bytes here) left by the decombine call itself (the handle's tuple sink);
+    # A/B (DCRX_BENCH_GATHER_MODE): "narrow" = the same tuples compacted from the records on a side stream, "tuple8" = round 3's
+    # 8-byte tuples, compacted
+    gmode = os.environ.get("DCRX_BENCH_GATHER_MODE", "sink")
     gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps,
-                                 n_v=info["n_v"], n_j=info["n_j"]) if use_dist else None
-    if use_dist and not dry:
+                                 n_v=info["n_v"], n_j=info["n_j"], tables=tables if gmode in ("sink", "narrow") else None,
+                                 max_read_len=READ_LEN, use_sink=gmode == "sink") if use_dist else None
+    if use_dist and not dry and (world > 1 or os.environ.get("DCRX_BENCH_RESERVED_CUS")):
         # the persistent scan kernels would fill every compute unit; a few are left to RCCL so that the tuples of step k
-        # really move beside the scan of step k+1 (the compaction's blocks fit beside a scan block on any unit)
+        # really move beside the scan of step k+1 (one rank alone — DCRX_BENCH_FORCE_GATHER — sends nothing: none reserved
+        # unless asked for)
         reserved = int(os.environ.get("DCRX_BENCH_RESERVED_CUS", "16"))
         for tb in all_tables:
             nat.check(nat.lib().dcrx_set_reserved_cus(tb.handle, reserved))
@@ -418,6 +424,7 @@ def run_rank(args, device_factory=None):
             tuple_mb = hits_per_step * gather.TUPLE_BYTES / 1e6
             line["gather"] = {
                 "tuple_bytes": gather.TUPLE_BYTES,
+                "mode": "sink (the decombine call leaves the message)" if gather.sink else "compaction of the records on a side stream",
                 "mb_per_step_all_ranks": round(tuple_mb + world * ((n + 63) // 64) * 8 / 1e6, 3),
                 "ms_per_step_without_gather": None if elapsed_nogather is None else round(elapsed_nogather / args.steps * 1e3, 4),
                 "exposed_ms_per_step": None if elapsed_nogather is None else round((elapsed - elapsed_nogather) / args.steps * 1e3, 4),

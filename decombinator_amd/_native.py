@@ -90,6 +90,11 @@ class TablesInfoC(C.Structure):
     ]
 
 
+class TupleLayoutC(C.Structure):
+    _fields_ = [("w_v", C.c_uint8), ("w_j", C.c_uint8), ("w_vdel", C.c_uint8), ("w_jdel", C.c_uint8), ("w_pos", C.c_uint8),
+                ("bits", C.c_uint8), ("bytes", C.c_uint8), ("reserved", C.c_uint8), ("max_read_len", C.c_uint32)]
+
+
 class CfgC(C.Structure):
     _fields_ = [("orientation", C.c_int32), ("allow_ns", C.c_int32), ("lenthreshold", C.c_int32),
                 ("flags", C.c_uint32)]
@@ -187,7 +192,7 @@ EXPORTS = [
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
-    "dcrx_compact_hits_packed8_device", "dcrx_collapse_front", "dcrx_spacer_search", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_compact_hits_packed8_device", "dcrx_tuple_layout", "dcrx_tuple_message_bytes", "dcrx_compact_hits_narrow_device", "dcrx_set_tuple_sink", "dcrx_collapse_front", "dcrx_spacer_search", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
 ]
 
 _lib = None
@@ -230,6 +235,10 @@ def lib():
         "dcrx_compact_hits_bitmap_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "dcrx_compact_hits_packed8_device": (i32, [vp, u64, vp, vp, vp, vp]),
+        "dcrx_tuple_layout": (i32, [vp, u32, C.POINTER(TupleLayoutC)]),
+        "dcrx_tuple_message_bytes": (u64, [C.POINTER(TupleLayoutC), u64, u64]),
+        "dcrx_compact_hits_narrow_device": (i32, [vp, C.POINTER(TupleLayoutC), vp, u64, u64, vp, vp, vp]),
+        "dcrx_set_tuple_sink": (i32, [vp, C.POINTER(TupleLayoutC), vp, u64, vp]),
         "dcrx_collapse_front": (C.c_int64, [vp, u64, C.POINTER(CollapseCfgC), vp, u64, vp, vp, i32]),
         "dcrx_spacer_search": (i32, [C.c_char_p, i32, C.c_char_p, i32, vp, vp, i32, C.POINTER(C.c_int32)]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
@@ -302,6 +311,11 @@ class Tables:
         check(lib().dcrx_tables_create(C.byref(ts), C.byref(h)))
         self._h = h
         self.n_v, self.n_j = len(v_tags), len(j_tags)
+        # what a receiver of narrow tuples re-derives positions from (TupleCodec)
+        self.v_jumps = [int(x) for x in v_jumps]
+        self.j_jumps = [int(x) for x in j_jumps]
+        self.j_lens = [len(x) for x in j_tags]
+        self.j_half_split = int(j_half_split)
 
     @property
     def handle(self):
@@ -859,6 +873,86 @@ def unpack_tuples8(words: np.ndarray, v_jumps) -> np.ndarray:
     jumps = np.asarray(v_jumps, dtype=np.int64)
     rec["ins_start"] = rec["v_start"].astype(np.int64) + jumps[rec["v"].astype(np.int64)] - rec["vdel"].astype(np.int64)
     return rec
+
+
+class TupleCodec:
+    """The narrow tuple of include/dcrx.h (dcrx_tuple_layout) on the host: the layout of a tag set for reads of up to
+    max_read_len nt, the host-side twin of dcrx_compact_hits_narrow_device (`pack`) and the receiver's side (`unpack`)."""
+
+    def __init__(self, tables: "Tables", max_read_len: int):
+        self.layout = TupleLayoutC()
+        check(lib().dcrx_tuple_layout(tables.handle, int(max_read_len), C.byref(self.layout)))
+        L = self.layout
+        self.bytes, self.bits = int(L.bytes), int(L.bits)
+        self.widths = [int(L.w_v), int(L.w_j), int(L.w_vdel), int(L.w_jdel), int(L.w_pos), int(L.w_pos), 1, 1]
+        self.v_jumps = np.asarray(tables.v_jumps, dtype=np.int64)
+        self.j_jumps = np.asarray(tables.j_jumps, dtype=np.int64)
+        self.j_lens = np.asarray(tables.j_lens, dtype=np.int64)
+        self.j_short = 2 * int(tables.j_half_split)
+
+    def message_bytes(self, n_reads: int, n_hits: int) -> int:
+        return ((n_reads + 63) // 64) * 8 + n_hits * self.bytes
+
+    def pack(self, rec, n_slots: int = None) -> np.ndarray:
+        """The message of a batch's records (uint8): bitmap (over n_slots >= len(rec) read slots), low words, high bytes."""
+        n_slots = len(rec) if n_slots is None else n_slots
+        ok = rec["status"] == 0
+        r = rec[ok]
+        j = r["j"].astype(np.int64)
+        tagpos = r["ins_start"].astype(np.int64) + r["ins_len"].astype(np.int64) - r["jdel"].astype(np.int64) + self.j_jumps[j]
+        short_end = ((r["j_end"].astype(np.int64) - tagpos) != self.j_lens[j]).astype(np.uint64)
+        fields = [r["v"], r["j"], r["vdel"], r["jdel"], r["v_start"], r["j_end"], short_end, r["frame"] & 1]
+        t = np.zeros(len(r), dtype=np.uint64)
+        sh = 0
+        for f, w in zip(fields, self.widths):
+            t |= f.astype(np.uint64) << np.uint64(sh)
+            sh += w
+        bits = np.zeros(((n_slots + 63) // 64) * 64, dtype=np.uint8)
+        bits[:len(rec)] = ok
+        bitmap = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+        lo = (t & np.uint64(0xFFFFFFFF)).astype("<u4").view(np.uint8)
+        hi = (t >> np.uint64(32)).astype("<u8").view(np.uint8).reshape(-1, 8)[:, :self.bytes - 4].reshape(-1)
+        return np.concatenate([bitmap, lo, hi])
+
+    def unpack(self, message, n_reads: int, n_hits: int):
+        """(records (status OK), read indices) of a message of n_hits tuples over n_reads reads."""
+        m = np.ascontiguousarray(message, dtype=np.uint8)
+        bm = ((n_reads + 63) // 64) * 8
+        idx = np.nonzero(np.unpackbits(m[:bm], bitorder="little")[:n_reads])[0]
+        t = m[bm:bm + 4 * n_hits].view("<u4").astype(np.uint64)
+        hb = self.bytes - 4
+        if hb:
+            hi = np.zeros((n_hits, 8), dtype=np.uint8)
+            hi[:, :hb] = m[bm + 4 * n_hits:bm + self.bytes * n_hits].reshape(n_hits, hb)
+            t |= hi.view("<u8").reshape(-1) << np.uint64(32)
+        vals = []
+        sh = 0
+        for w in self.widths:
+            vals.append(((t >> np.uint64(sh)) & np.uint64((1 << w) - 1)).astype(np.int64))
+            sh += w
+        v, j, vdel, jdel, v_start, j_end, short_end, frame = vals
+        rec = np.zeros(n_hits, dtype=RECORD_DTYPE)
+        for name, x in (("v", v), ("j", j), ("vdel", vdel), ("jdel", jdel), ("v_start", v_start), ("j_end", j_end), ("frame", frame)):
+            rec[name] = x
+        ins_start = v_start + self.v_jumps[v] - vdel
+        start_j = j_end - np.where(short_end == 1, self.j_short, self.j_lens[j]) - self.j_jumps[j] + jdel
+        rec["ins_start"] = ins_start
+        rec["ins_len"] = start_j - ins_start
+        return rec, idx
+
+
+def compact_hits_narrow_device(tables: "Tables", codec: TupleCodec, d_records_ptr: int, n_reads: int, d_message_ptr: int,
+                               d_n_hits_ptr: int, stream=None, n_slots: int = None):
+    check(lib().dcrx_compact_hits_narrow_device(tables.handle, C.byref(codec.layout), d_records_ptr, n_reads,
+                                                n_reads if n_slots is None else n_slots, d_message_ptr, d_n_hits_ptr, stream))
+
+
+def set_tuple_sink(tables: "Tables", codec, d_message_ptr: int = 0, n_slots: int = 0, d_n_hits_ptr: int = 0):
+    """dcrx_set_tuple_sink: the next dcrx_decombine_device calls on `tables` also leave the batch's message; codec None: off."""
+    if codec is None:
+        check(lib().dcrx_set_tuple_sink(tables.handle, None, None, 0, None))
+    else:
+        check(lib().dcrx_set_tuple_sink(tables.handle, C.byref(codec.layout), d_message_ptr, n_slots, d_n_hits_ptr))
 
 
 def unpack_tuples12(words: np.ndarray) -> np.ndarray:

@@ -96,13 +96,25 @@ struct dcrx_tables {
   bool constants_ready = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // around the dominant kernel
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;  // around every launch of a call
+  // the tuple sink (dcrx_set_tuple_sink): where the next calls leave their message, and the kernels' side of it on the device
+  bool sink_on = false;
+  dcrx_tuple_layout_t sink_layout{};
+  uint8_t *sink_msg = nullptr; uint64_t sink_slots = 0; uint64_t *sink_total = nullptr;
+  V2SinkDev *d_sink = nullptr;
+  void *d_sink_items = nullptr, *d_sink_hi = nullptr; uint32_t *d_sink_ctr = nullptr;
+  uint64_t sink_items_cap = 0; uint32_t sink_regions_cap = 0;
 };
+
+static int layout_dev(dcrx_tables *t, const dcrx_tuple_layout_t *L, TupleLayoutDev *D);
+static int compact_workspace(uint64_t n_reads, uint32_t **tc, uint64_t **to);
 
 static void free_device_state(dcrx_tables *t) {
   if (t->device < 0) return;
   (void)hipFree(t->d_dev); t->d_dev = nullptr;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
+  (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_hi); (void)hipFree(t->d_sink_ctr);
+  t->d_sink = nullptr; t->d_sink_items = nullptr; t->d_sink_hi = nullptr; t->d_sink_ctr = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
   if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
   if (t->v2_side2) (void)hipStreamDestroy(t->v2_side2);
   if (t->v2_ev_fork) (void)hipEventDestroy(t->v2_ev_fork);
@@ -323,6 +335,29 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
   return DCRX_OK;
 }
 
+// The device side of the tuple sink for batches of up to max_reads reads: the regions' slabs of items, their counters and
+// the descriptor the kernels read (allocated on the first call that needs them, grown by a larger batch: synchronises).
+static int ensure_sink(dcrx_tables *t, uint64_t max_reads, hipStream_t stream) {
+  const uint64_t want = v2_sink_items(std::max<uint64_t>(max_reads, 4096), t->plan.n_cu);
+  const uint32_t regions = t->plan.n_cu;
+  if (t->d_sink && want <= t->sink_items_cap && regions <= t->sink_regions_cap) return DCRX_OK;
+  HIP_TRY(hipStreamSynchronize(stream));
+  (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_hi); (void)hipFree(t->d_sink_ctr); (void)hipFree(t->d_sink);
+  t->d_sink_items = nullptr; t->d_sink_hi = nullptr; t->d_sink_ctr = nullptr; t->d_sink = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
+  HIP_TRY(hipMalloc(&t->d_sink_items, want * 8));
+  HIP_TRY(hipMalloc(&t->d_sink_hi, want));
+  HIP_TRY(hipMalloc(&t->d_sink_ctr, ((size_t)2 * regions + 16) * 4));
+  HIP_TRY(hipMemset(t->d_sink_ctr, 0, ((size_t)2 * regions + 16) * 4));
+  HIP_TRY(hipMalloc(&t->d_sink, sizeof(V2SinkDev)));
+  V2SinkDev D;
+  D.items = static_cast<uint2 *>(t->d_sink_items); D.hi = static_cast<uint8_t *>(t->d_sink_hi);
+  D.hits = t->d_sink_ctr; D.late = t->d_sink_ctr + regions; D.ticket = t->d_sink_ctr + 2 * regions;
+  D.j_tag_len = t->dev.g[1].tag_len; D.j_jump = t->dev.g[1].jump;
+  HIP_TRY(hipMemcpy(t->d_sink, &D, sizeof D, hipMemcpyHostToDevice));
+  t->sink_items_cap = want; t->sink_regions_cap = regions;
+  return DCRX_OK;
+}
+
 static int check_batch(const dcrx_batch_t *b) {
   if (!b) return set_err(DCRX_E_INVALID, "batch is null");
   if (b->n_reads >= (1ull << 32)) return set_err(DCRX_E_INVALID, "more than 2^32-1 reads in one call");
@@ -374,10 +409,35 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   B.exc_chr = b->exc_chr; B.exc_flag = t->d_exc_flag;
   CfgDev C{cfg->orientation, cfg->allow_ns, cfg->lenthreshold, cfg->flags};
   t->plan.ev_step_start = t->ev_step_start; t->plan.ev_step_stop = t->ev_step_stop;
+  // the call's tuple sink: the kernels' own (tuples of up to 40 bits, the shipped launch shape: launch_v2), else a compaction
+  // of the records behind the call, on the same stream
+  bool sink_done = false;
+  t->plan.sink = V2SinkJob{};
+  TupleLayoutDev LD{};
+  if (t->sink_on) {
+    if (t->sink_slots < b->n_reads) return set_err(DCRX_E_INVALID, "tuple sink: the message holds fewer read slots than the batch has reads");
+    rc = layout_dev(t, &t->sink_layout, &LD);
+    if (rc) return rc;
+    if (t->sink_layout.bits <= 40 && t->host.rel.v2_ok && b->stride <= DCRX_FAST_MAX_STRIDE) {
+      rc = ensure_sink(t, b->n_reads, (hipStream_t)stream);
+      if (rc) return rc;
+      V2SinkJob &J = t->plan.sink;
+      J.dev = t->d_sink; J.items_cap = t->sink_items_cap; J.regions_cap = t->sink_regions_cap;
+      J.wpack = LD.w_v | (LD.w_j << 5) | (LD.w_vdel << 10) | (LD.w_jdel << 15) | (LD.w_pos << 20);
+      J.bytes = LD.bytes; J.msg = t->sink_msg; J.n_slots = t->sink_slots; J.d_total = t->sink_total; J.done = &sink_done;
+    }
+  }
   const hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
                                          t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
                                          (hipStream_t)stream, t->ev_start, t->ev_stop);
+  t->plan.sink = V2SinkJob{};
   if (le != hipSuccess) { t->ws_dirty = true; return hip_err(le, "launch_decombine"); }
+  if (t->sink_on && !sink_done) {
+    uint32_t *tc = nullptr; uint64_t *to = nullptr;
+    rc = compact_workspace(b->n_reads, &tc, &to);
+    if (rc) return rc;
+    HIP_TRY(launch_compact_narrow(d_records, b->n_reads, t->sink_msg, t->sink_slots, LD, t->sink_total, tc, to, (hipStream_t)stream));
+  }
   return DCRX_OK;
 }
 
@@ -389,6 +449,8 @@ static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
 int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *hb, dcrx_record_t *records,
                    uint64_t *counters) {
   int rc;
+  const bool sink_was_on = t && t->sink_on;      // (the tuple sink concerns the device entry: a chunked host call has no one message)
+  if (t) t->sink_on = false;
   try { rc = decombine_host(t, cfg, hb, records, counters); }
   catch (const std::bad_alloc &) { rc = set_err(DCRX_E_NOMEM, "out of host memory in dcrx_decombine"); }
   catch (const std::exception &e) { rc = set_err(DCRX_E_NOMEM, std::string("dcrx_decombine: ") + e.what()); }
@@ -400,6 +462,7 @@ int dcrx_decombine(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_batch_t *
     t->ws_dirty = true;
     g_err = keep;
   }
+  if (t) t->sink_on = sink_was_on;
   return rc;
 }
 
@@ -557,20 +620,29 @@ static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   return DCRX_OK;
 }
 
-static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index, dcrx_record_t *d_hits,
-                        uint64_t *d_hit_index, uint64_t *d_ok_bitmap, int packed12, uint64_t *d_n_hits, void *stream) {
-  // workspace lives in a process-wide slot keyed by device: compaction does not need tables
+// tile counts and offsets of a compaction: a process-wide slot keyed by device (compaction does not need tables)
+static int compact_workspace(uint64_t n_reads, uint32_t **tc, uint64_t **to) {
   static thread_local struct { int dev = -1; uint32_t *tc = nullptr; uint64_t *to = nullptr; uint64_t cap = 0; } ws;
-  if (!d_n_hits || (n_reads && (!d_records || !d_hits || (!d_hit_index && !d_ok_bitmap)))) return set_err(DCRX_E_INVALID, "null argument");
   int dev = -1; HIP_TRY(hipGetDevice(&dev));
   if (ws.dev != dev || n_reads > ws.cap) {
     if (ws.dev == dev) { (void)hipFree(ws.tc); (void)hipFree(ws.to); }
+    ws.tc = nullptr; ws.to = nullptr; ws.cap = 0; ws.dev = -1;
     const size_t tiles = compact_tiles(n_reads) + 1024;
     HIP_TRY(hipMalloc(&ws.tc, tiles * 4));
     HIP_TRY(hipMalloc(&ws.to, tiles * 8));
     ws.dev = dev; ws.cap = n_reads;
   }
-  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_ok_bitmap, packed12, d_n_hits, ws.tc, ws.to,
+  *tc = ws.tc; *to = ws.to;
+  return DCRX_OK;
+}
+
+static int compact_hits(const dcrx_record_t *d_records, uint64_t n_reads, uint64_t first_index, dcrx_record_t *d_hits,
+                        uint64_t *d_hit_index, uint64_t *d_ok_bitmap, int packed12, uint64_t *d_n_hits, void *stream) {
+  if (!d_n_hits || (n_reads && (!d_records || !d_hits || (!d_hit_index && !d_ok_bitmap)))) return set_err(DCRX_E_INVALID, "null argument");
+  uint32_t *tc = nullptr; uint64_t *to = nullptr;
+  int rc = compact_workspace(n_reads, &tc, &to);
+  if (rc) return rc;
+  HIP_TRY(launch_compact(d_records, n_reads, first_index, d_hits, d_hit_index, d_ok_bitmap, packed12, d_n_hits, tc, to,
                          (hipStream_t)stream));
   return DCRX_OK;
 }
@@ -599,6 +671,76 @@ int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_
                                      uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *stream) {
   if (n_reads && !d_ok_bitmap) return set_err(DCRX_E_INVALID, "null argument");
   return compact_hits(d_records, n_reads, 0, reinterpret_cast<dcrx_record_t *>(d_tuples8), nullptr, d_ok_bitmap, 2, d_n_hits, stream);
+}
+
+static uint8_t bits_of(uint64_t x) { uint8_t b = 1; while (b < 64 && (x >> b)) b++; return b; }   // bits that hold 0..x (at least one)
+
+int dcrx_tuple_layout(const dcrx_tables_t *t, uint32_t max_read_len, dcrx_tuple_layout_t *L) {
+  if (!t || !L) return set_err(DCRX_E_INVALID, "null argument");
+  std::memset(L, 0, sizeof *L);
+  const GeneHost &V = t->host.g[0], &J = t->host.g[1];
+  int64_t max_vdel = 0, max_jdel = 0;
+  for (uint32_t k = 0; k < V.n; k++) max_vdel = std::max<int64_t>(max_vdel, (int64_t)V.jumps[k] - (int64_t)V.tags[k].size());
+  for (uint32_t k = 0; k < J.n; k++) max_jdel = std::max<int64_t>(max_jdel, (int64_t)J.jumps[k]);
+  // (a record's vdel / jdel are bytes: deletions beyond 255 never reach a record)
+  L->w_v = bits_of(V.n ? V.n - 1 : 0); L->w_j = bits_of(J.n ? J.n - 1 : 0);
+  L->w_vdel = bits_of((uint64_t)std::min<int64_t>(max_vdel, 255)); L->w_jdel = bits_of((uint64_t)std::min<int64_t>(max_jdel, 255));
+  L->w_pos = bits_of(max_read_len);
+  const uint32_t bits = L->w_v + L->w_j + L->w_vdel + L->w_jdel + 2u * L->w_pos + 2u;
+  L->max_read_len = max_read_len;
+  if (bits > 64) return set_err(DCRX_E_UNSUPPORTED, "narrow tuple wider than 64 bits");
+  L->bits = (uint8_t)bits;
+  L->bytes = (uint8_t)std::max<uint32_t>(4, (bits + 7) / 8);
+  return DCRX_OK;
+}
+
+uint64_t dcrx_tuple_message_bytes(const dcrx_tuple_layout_t *L, uint64_t n_reads, uint64_t n_hits) {
+  if (!L) return 0;
+  return ((n_reads + 63) / 64) * 8 + n_hits * L->bytes;
+}
+
+// the layout as a caller handed it back: what dcrx_tuple_layout would say for these tables
+static int layout_dev(dcrx_tables *t, const dcrx_tuple_layout_t *L, TupleLayoutDev *D) {
+  dcrx_tuple_layout_t want;
+  int rc = dcrx_tuple_layout(t, L->max_read_len, &want);
+  if (rc) return rc;
+  if (std::memcmp(&want, L, sizeof want) != 0) return set_err(DCRX_E_INVALID, "tuple layout does not belong to these tables");
+  D->w_v = L->w_v; D->w_j = L->w_j; D->w_vdel = L->w_vdel; D->w_jdel = L->w_jdel; D->w_pos = L->w_pos; D->bytes = L->bytes;
+  D->j_tag_len = t->dev.g[1].tag_len; D->j_jump = t->dev.g[1].jump;
+  return DCRX_OK;
+}
+
+int dcrx_compact_hits_narrow_device(dcrx_tables_t *t, const dcrx_tuple_layout_t *L, const dcrx_record_t *d_records,
+                                    uint64_t n_reads, uint64_t n_slots, void *d_message, uint64_t *d_n_hits, void *stream) {
+  if (!t || !L || !d_n_hits || (n_reads && !d_records) || (n_slots && !d_message)) return set_err(DCRX_E_INVALID, "null argument");
+  if (n_slots < n_reads) return set_err(DCRX_E_INVALID, "n_slots < n_reads");
+  try {
+    int rc = ensure_device(t, 0, 40, (hipStream_t)stream);
+    if (rc) return rc;
+    TupleLayoutDev D;
+    rc = layout_dev(t, L, &D);
+    if (rc) return rc;
+    uint32_t *tc = nullptr; uint64_t *to = nullptr;
+    rc = compact_workspace(n_reads, &tc, &to);
+    if (rc) return rc;
+    HIP_TRY(launch_compact_narrow(d_records, n_reads, static_cast<uint8_t *>(d_message), n_slots, D, d_n_hits, tc, to, (hipStream_t)stream));
+  } catch (const std::exception &e) {
+    return set_err(DCRX_E_NOMEM, e.what());
+  }
+  return DCRX_OK;
+}
+
+int dcrx_set_tuple_sink(dcrx_tables_t *t, const dcrx_tuple_layout_t *L, void *d_message, uint64_t n_slots, uint64_t *d_n_hits) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  if (!L) { t->sink_on = false; t->sink_msg = nullptr; t->sink_slots = 0; t->sink_total = nullptr; return DCRX_OK; }
+  if (!d_message || !d_n_hits || !n_slots) return set_err(DCRX_E_INVALID, "null argument");
+  dcrx_tuple_layout_t want;
+  int rc = dcrx_tuple_layout(t, L->max_read_len, &want);
+  if (rc) return rc;
+  if (std::memcmp(&want, L, sizeof want) != 0) return set_err(DCRX_E_INVALID, "tuple layout does not belong to these tables");
+  t->sink_on = true; t->sink_layout = *L;
+  t->sink_msg = static_cast<uint8_t *>(d_message); t->sink_slots = n_slots; t->sink_total = d_n_hits;
+  return DCRX_OK;
 }
 
 int dcrx_set_reserved_cus(dcrx_tables_t *t, uint32_t n_cus) {

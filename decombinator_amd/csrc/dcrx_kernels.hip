@@ -40,6 +40,7 @@
 #include "dcrx_device.h"
 #include "dcrx_launch.h"
 #include "dcrx_dcr_device.h"
+#include "dcrx_sink_device.h"
 
 namespace dcrx {
 
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
                                                                      const uint32_t *__restrict__ gqueue,
                                                                      uint32_t *__restrict__ queue_count,
                                                                      unsigned long long *__restrict__ out,
-                                                                     unsigned long long read_count) {
+                                                                     unsigned long long read_count, V2SinkCall S) {
   // `out` (behind the v2 kernels, which tally into an accumulator of the handle: `counters`): the call's counters are handed
   // to the caller here and the accumulator is left zeroed for the next call — by block 0 when nothing was handed over (the
   // other blocks leave at once, without an atomic), else by the last block to finish.  read_count (orientation `both`): a
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
         const uint32_t r = gqueue[i];
         decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                    lds_slots + tid * DCRX_LSLOT, true);
+        if (S.dev) sink_late(S, records, r);      // tuple sink (behind the v2 kernels): the read's tuple, when it decombined here
         // the read's exception flag (three-launch form: set by the prologue) has served its purpose: cleared here, so that
         // the bitmap is all zero again when the launch ends (no memset per launch)
         if (B.n_exc && ((exc_flag[r >> 5] >> (r & 31)) & 1u)) atomicAnd(&exc_flag[r >> 5], ~(1u << (r & 31)));
@@ -311,9 +313,11 @@ __global__ __launch_bounds__(DCRX_QBLOCK) void decombine_list_kernel(DevTables T
         uint32_t hints;
         const uint32_t r = rescue_entry(queue, n_rescue, ticket - t_general, 64 * DCRX_CHUNK, (uint32_t)c * 64 + lane, tagged,
                                         &hints);
-        if (r != 0xFFFFFFFFu)
+        if (r != 0xFFFFFFFFu) {
           decombine_list_one<TABLE_LDS, UNIFORM_LEN>(T, lds_trans, B, cfg, (uint64_t)r, C, records,
                                                      lds_slots + tid * DCRX_LSLOT, false);
+          if (S.dev) sink_late(S, records, r);
+        }
       }
     }
   }
@@ -538,6 +542,70 @@ __global__ __launch_bounds__(CP_BLOCK) void compact_scatter_kernel(const dcrx_re
   }
 }
 
+// The narrow tuple of include/dcrx.h (dcrx_tuple_layout): fields least significant first, widths from the tag tables.
+// short_end: the record's j_end is not the J tag's end but its start + 2 * j_half_split (J half1 rescue, decombine.py:450-454).
+DCRX_DEV uint64_t narrow_tuple(const dcrx_record_t &r, const TupleLayoutDev &L) {
+  const int tagpos = (int)r.ins_start + (int)r.ins_len - (int)r.jdel + L.j_jump[r.j];
+  const uint64_t short_end = ((int)r.j_end - tagpos) != (int)L.j_tag_len[r.j] ? 1u : 0u;
+  uint64_t t = r.v;
+  uint32_t sh = L.w_v;
+  t |= (uint64_t)r.j << sh; sh += L.w_j;
+  t |= (uint64_t)r.vdel << sh; sh += L.w_vdel;
+  t |= (uint64_t)r.jdel << sh; sh += L.w_jdel;
+  t |= (uint64_t)r.v_start << sh; sh += L.w_pos;
+  t |= (uint64_t)r.j_end << sh; sh += L.w_pos;
+  t |= short_end << sh; sh += 1;
+  t |= (uint64_t)(r.frame & 1u) << sh;
+  return t;
+}
+// tuple k of a message: low 32 bits in plane A, the other bytes in plane B
+DCRX_DEV void narrow_store(uint32_t *plane_a, uint8_t *plane_b, const uint32_t hi_bytes, const uint64_t k, const uint64_t t) {
+  plane_a[k] = (uint32_t)t;
+  uint32_t hi = (uint32_t)(t >> 32);
+  for (uint32_t b = 0; b < hi_bytes; b++) { plane_b[k * hi_bytes + b] = (uint8_t)hi; hi >>= 8; }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void compact_scatter_narrow_kernel(const dcrx_record_t *__restrict__ rec, uint64_t n,
+                                                                           const uint64_t *__restrict__ tile_off,
+                                                                           const uint64_t *__restrict__ total,
+                                                                           uint8_t *__restrict__ msg, uint64_t n_slots, TupleLayoutDev L) {
+  __shared__ uint32_t s_wave[CP_PER_THREAD][CP_BLOCK / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CP_TILE;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t *ok_bitmap = reinterpret_cast<uint64_t *>(msg);
+  const uint64_t bm_bytes = ((n_slots + 63) / 64) * 8;      // the bitmap spans n_slots >= n reads: no bit beyond read n
+  if (blockIdx.x == 0)
+    for (uint64_t wd = (n + 63) / 64 + threadIdx.x; wd < bm_bytes / 8; wd += CP_BLOCK) ok_bitmap[wd] = 0;
+  uint32_t *plane_a = reinterpret_cast<uint32_t *>(msg + bm_bytes);
+  uint8_t *plane_b = msg + bm_bytes + *total * 4;
+  const uint32_t hi_bytes = L.bytes - 4;
+  bool ok[CP_PER_THREAD];
+  uint32_t rank[CP_PER_THREAD];
+  for (int k = 0; k < CP_PER_THREAD; k++) {
+    const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
+    ok[k] = i < n && rec[i].status == DCRX_S_OK;
+    const unsigned long long m = __ballot(ok[k]);
+    rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) {
+      s_wave[k][wave] = (uint32_t)__popcll(m);
+      const uint64_t i0 = base + (uint64_t)k * CP_BLOCK + (uint64_t)wave * 64;
+      if (i0 < n) ok_bitmap[i0 >> 6] = m;
+    }
+  }
+  __syncthreads();
+  const uint64_t off = tile_off[blockIdx.x];
+  for (int k = 0; k < CP_PER_THREAD; k++) {
+    uint32_t before = 0;
+    for (int kk = 0; kk < k; kk++)
+      for (int wv = 0; wv < CP_BLOCK / 64; wv++) before += s_wave[kk][wv];
+    for (int wv = 0; wv < wave; wv++) before += s_wave[k][wv];
+    if (ok[k]) {
+      const uint64_t i = base + (uint64_t)k * CP_BLOCK + threadIdx.x;
+      narrow_store(plane_a, plane_b, hi_bytes, off + before + rank[k], narrow_tuple(rec[i], L));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------
 // launchers (called from dcrx_api.cpp)
 // ------------------------------------------------------------------------------
@@ -623,17 +691,20 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     c1.orientation = DCRX_ORIENT_REVERSE; c2.orientation = DCRX_ORIENT_FORWARD;
     e = launch_v2_any(P, T, B, c1, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop, 0u);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c1, rec, acc, queue, gqueue, queue_count, (unsigned long long *)nullptr, ~0ull);
+    hipLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, T, B, c1, rec, acc, queue, gqueue, queue_count, (unsigned long long *)nullptr, ~0ull, V2SinkCall{});
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = launch_v2_any(P, T, B, c2, rec, queue, gqueue, qcap, queue_count, acc, s, nullptr, nullptr, 1u);
     if (e != hipSuccess) return e;
     hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, P.ev_step_stop, 0, T, B, c2, rec, acc, queue, gqueue, queue_count, d_counters,
-                          (unsigned long long)B.n_reads);
+                          (unsigned long long)B.n_reads, V2SinkCall{});
     return hipGetLastError();
   }
+  // (a tuple sink, when the call has one and the launch shape serves it: the kernels leave the tuples' items, the place
+  // kernel behind the list kernel puts the message together; else the caller compacts the records)
+  V2SinkLaunch K;
   if (v2) {
-    e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop);
+    e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop, 0u, P.sink.dev ? &K : nullptr);
     if (e != hipSuccess) return e;
   }
   if (v2 && getenv("DCRX_DEBUG_HANDOVER")) {      // developer aid: how many reads the v2 kernels handed over
@@ -661,10 +732,15 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     // not the handful of reads, is what the launch costs there)
     const uint32_t lgrid = v2 ? std::max<uint32_t>(1u, std::min<uint32_t>(qgrid, cus / 4)) : qgrid;
     const bool list_is_last = !(rescue16 && !all_general);
-    hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, list_is_last ? P.ev_step_stop : nullptr, 0, T, B, cfg, rec,
-                          acc, queue, gqueue, queue_count, v2 ? d_counters : (unsigned long long *)nullptr, ~0ull);
+    hipExtLaunchKernelGGL(klist, dim3(lgrid), dim3(DCRX_QBLOCK), lds_list, s, nullptr, list_is_last && !K.S.dev ? P.ev_step_stop : nullptr, 0, T, B, cfg, rec,
+                          acc, queue, gqueue, queue_count, v2 ? d_counters : (unsigned long long *)nullptr, ~0ull, K.S);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (K.S.dev) {
+      e = launch_v2_place(P, K, B.n_reads, s, P.ev_step_stop);
+      if (e != hipSuccess) return e;
+      if (P.sink.done) *P.sink.done = true;
+    }
   }
   if (rescue16 && !all_general) {
     auto kresc = decombine_rescue_kernel<UNIFORM, NW>;
@@ -745,6 +821,18 @@ hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_i
   if (n_tiles)
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, first_index, tile_off,
                        hits, hit_index, ok_bitmap, packed12);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_narrow(const dcrx_record_t *rec, uint64_t n, uint8_t *msg, uint64_t n_slots, const TupleLayoutDev &L, uint64_t *d_total,
+                                 uint32_t *tile_count, uint64_t *tile_off, hipStream_t s) {
+  const uint32_t n_tiles = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
+  if (n_tiles)
+    hipLaunchKernelGGL(compact_count_kernel, dim3(n_tiles), dim3(CP_BLOCK), 0, s, rec, n, tile_count);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, n_tiles, tile_off, d_total);
+  // (an empty batch still clears the bitmap of its slots: one block)
+  if (n_tiles || n_slots)
+    hipLaunchKernelGGL(compact_scatter_narrow_kernel, dim3(n_tiles ? n_tiles : 1), dim3(CP_BLOCK), 0, s, rec, n, tile_off, d_total, msg, n_slots, L);
   return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@
 #include "dcrx_launch.h"
 #include "dcrx_dcr_device.h"
 #include "dcrx_v2_device.h"
+#include "dcrx_sink_device.h"
 
 namespace dcrx {
 
@@ -95,7 +96,7 @@ constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block ca
 //                     last half pair: the general form            (half of the region each)
 // (a list that outgrows its room hands the rest to the list kernel; what a lean kernel does not settle it finishes itself,
 // behind the launch's last block: v2_left_push, v2_general_role)
-enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_COUNTS = 8 };
+enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_RING = 4, V2_L_COUNTS = 8 };      // (V2_L_RING: tail entries that went through the fused scan's ring)
 constexpr uint32_t V2_LEFT_CAP = 1024;      // entries of the left list (a handful per 10 M reads; more go to the list kernel)
 enum { V2_QC_LEFT = 5, V2_QC_DONE = 6 };    // words of the queue header (DCRX_QUEUE_HEADER): entries of the left list, finishing blocks done
 struct V2Lists {
@@ -276,8 +277,8 @@ __device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restr
 
 // LDS of the scan kernel behind the pair table and the counters: the block's work counters
 // next item; entries of each list (V2_WK_LIST + V2_L_*)
-enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_FILLED = 32, V2_WK_GEN = 48,
-       V2_WK_WORDS = 64 };      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form)
+enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_SINK = 19, V2_WK_FILLED = 32, V2_WK_GEN = 48,
+       V2_WK_WORDS = 64 };      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form; V2_WK_SINK: decombined reads of the tail waves, tuple sink)
 // The fused form (FUSE >= 0 = the frame): the block's last four waves — one per SIMD — do not scan: they take the tail entries
 // the scanning waves produce, in batches of 64, out of a ring in LDS, and finish them (tail2_fast) while the scan goes on.  The
 // scan is bound by its LDS look-ups, the tail by instruction issue: on one SIMD the two share what neither uses up, where the
@@ -301,8 +302,11 @@ template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, 
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches) {
+    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S) {
   extern __shared__ __align__(64) uint32_t smem[];
+#ifdef DCRX_NO_SINK
+  S.dev = nullptr;      // (A/B build, tools/: the kernels without the tuple sink's code)
+#endif
   const int o = FUSE >= 0 ? FUSE : (cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
   V2Ori V0 = T0.v2[0];
   if (o) V0 = T0.v2[1];
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
       int status = -2;
       uint32_t r = 0, dg = 0;
+      uint64_t tup = 0;
       if ((uint32_t)lane < nvalid) {
         r = sl[NW + 2]; dg = sl[NW + 3];
         const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
@@ -418,8 +423,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
         rec.frame = (uint8_t)(o ? 0 : 1);
         if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
+        if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
       }
       v2_tally(lds_counts, lane, status, o == 0);
+      // tuple sink: the item of every entry of the batch, at the entry's place in the ring's sequence
+      if (S.dev) sink_put(S, (uint32_t)region, 0u, 64u * c + (uint32_t)lane, (uint32_t)lane < nvalid, status == DCRX_S_OK, r, tup, lane, &lds_work[V2_WK_SINK]);
       if (__builtin_expect(status == TAIL2_SLOW, 0)) {
         // what the lean form does not settle (one read in millions): an event entry of the launch's left list (the finishing
         // launch's polling wave takes it), behind a placeholder record
@@ -680,8 +688,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   if (tid < V2_L_COUNTS) {      // (entries beyond a list's capacity were handed over, not stored; L starts empty)
     uint32_t c = tid <= V2_L_X ? lds_work[V2_WK_LIST + tid] : 0u;
     c = min(c, tid == V2_L_TAIL ? Q.tcap : (tid == V2_L_E ? Q.ecap : Q.scap / 2));
+    if (tid == V2_L_RING) c = lds_work[V2_WK_HEAD];      // (fused form: entries that went through the ring — the tuple sink's tail section)
     Q.counts[V2_L_COUNTS * region + tid] = c;
   }
+  if (S.dev && tid == 0 && lds_work[V2_WK_SINK]) (void)__hip_atomic_fetch_add(S.dev->hits + region, lds_work[V2_WK_SINK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -780,7 +790,7 @@ template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
                                              const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
                                              uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
-                                             const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid) {
+                                             const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid, const V2SinkCall &S) {
   constexpr int o = ORI;
   const Counters C{L.counts};
   const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
@@ -808,6 +818,7 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
 #pragma unroll
       for (int k = 0; k < NW; k++) w[k] = x[2 + k];
       int status = -2;
+      uint64_t tup = 0;
       const uint32_t r = x[0], dg = x[1];
       if (first + lane < tn) {
         const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
@@ -824,8 +835,10 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
         status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec, *Tmem, C);
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
+        if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
       }
       v2_tally(lds_counts, lane, status, o == 0);
+      if (S.dev) sink_put(S, region, 0u, first + (uint32_t)lane, first + lane < tn, status == DCRX_S_OK, r, tup, lane, nullptr);      // tuple sink: the entry's item
       if (__builtin_expect(status == TAIL2_SLOW, 0)) v2_note_left(s_left, first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, false);
     }
     const uint32_t n_left = min(s_left[0], (uint32_t)V2_LEFT_SLOTS);
@@ -889,7 +902,7 @@ template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
                                                const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
                                                uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
-                                               const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid) {
+                                               const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid, const V2SinkCall &S) {
   constexpr int o = ORI;
   const Counters C{L.counts}, Cdry{L.dry};
   const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
@@ -919,6 +932,7 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
       for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
       int status = -2;
       uint32_t errs = 0;
+      uint64_t tup = 0;
       const uint32_t r = x[0] & V2_R_MASK;
       if (first + lane < en) {
         status = RESCUE2_SLOW;
@@ -932,9 +946,11 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
           else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
+          if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
+      if (S.dev) sink_put(S, region, which == V2_L_E ? S.e_off : S.c_off, first + (uint32_t)lane, first + lane < en, status == DCRX_S_OK, r, tup, lane, nullptr);      // tuple sink
       if (__builtin_expect(status == RESCUE2_SLOW, 0)) v2_note_left(s_left, first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, (x[0] & V2_R_EXC) != 0u);
     }
     const uint32_t n_left = min(s_left[0], (uint32_t)V2_LEFT_SLOTS);      // (as in the lean tail)
@@ -976,7 +992,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
 struct V2Roles { uint32_t xgrid, rgrid, tgrid, rsplit, tsplit, bsplit, width; };
 struct V2FinishArgs {
   DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; unsigned long long *counters; V2Lists Q; uint32_t n_regions; V2Roles R;
-  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
+  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem; V2SinkCall S;
 };
 // (every field through a pointer typed for the constant address space, dword by dword: scalar loads by construction — a
 // reference into the segment through a generic pointer left half of the accesses as vector loads inside the hot loops,
@@ -1003,7 +1019,7 @@ template <class T>
 __device__ __forceinline__ T *v2_constant(T *p) { return (T *)(__attribute__((address_space(4))) T *)(uintptr_t)p; }
 struct V2FinishLocals {      // a role's copy of the launch's arguments (what it does not use is never loaded)
   DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; V2Lists Q; uint32_t n_regions; V2Roles R;
-  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem;
+  uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem; V2SinkCall S;
 };
 __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, const uint32_t hi) {
   uint32_t slo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo), shi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
@@ -1013,7 +1029,7 @@ __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, cons
   V2FinishLocals A;
 #define DCRX_KARG(F) A.F = v2_karg<decltype(A.F)>(k, offsetof(V2FinishArgs, F))
   DCRX_KARG(T0); DCRX_KARG(B); DCRX_KARG(cfg); DCRX_KARG(records); DCRX_KARG(Q); DCRX_KARG(R);
-  DCRX_KARG(queue); DCRX_KARG(gqueue); DCRX_KARG(queue_count); DCRX_KARG(Tmem);
+  DCRX_KARG(queue); DCRX_KARG(gqueue); DCRX_KARG(queue_count); DCRX_KARG(Tmem); DCRX_KARG(S);
 #undef DCRX_KARG
   A.n_regions = k[offsetof(V2FinishArgs, n_regions) / 4];
   A.qcap = k[offsetof(V2FinishArgs, qcap) / 4];
@@ -1025,6 +1041,10 @@ __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, cons
   DCRX_GLOBAL(A.B.exc_pos); DCRX_GLOBAL(A.B.exc_chr); DCRX_GLOBAL(A.B.exc_flag); DCRX_GLOBAL(A.T0.image);
 #undef DCRX_GLOBAL
   A.Tmem = v2_constant(A.Tmem); A.Q.counts = v2_constant(A.Q.counts); A.T0.kw_base = v2_constant(A.T0.kw_base);
+  A.S.dev = v2_constant(A.S.dev);      // (the sink's descriptor: nothing of a launch writes it)
+#ifdef DCRX_NO_SINK
+  A.S.dev = nullptr;
+#endif
   return A;
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
@@ -1041,7 +1061,7 @@ DCRX_V2_ROLE void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, c
   const Rescue2Tabs rt = rescue2_tabs(A.T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
   constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
   v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.rsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
-                                       vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid);
+                                       vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid, A.S);
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
 DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
@@ -1054,7 +1074,7 @@ DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, con
   const Tail2Tabs tt = tail2_tabs(A.T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1);
   constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
   v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.tsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
-                                     vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid);
+                                     vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid, A.S);
 }
 template <bool UNIFORM_LEN, int NW, int ORI>
 DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
@@ -1123,6 +1143,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
     for (int k = 0; k < NW; k++) { lg[k] = x[1 + k]; w[k] = x[1 + NW + k]; }
     if (live) {
       v2_general_entry<UNIFORM_LEN, NW, ORI>(T, V, A.B, A.cfg, x[0], lg, w, C, A.records, A.queue, A.gqueue, A.qcap, A.queue_count, tagged);
+      if (A.S.dev) sink_late(A.S, A.records, x[0] & V2_R_MASK);      // tuple sink: the read's tuple, when this form decombined it
       if (polling) valid[i] = 0u;                                      // (re-armed for the next launch)
     }
   }
@@ -1199,7 +1220,7 @@ __global__ __launch_bounds__(DCRX_V2_TBLOCK, DCRX_V2_TWAVES) void tail2_kernel(
   const Tail2Tabs tt = tail2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1);
   __syncthreads();
   v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
-                                     blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_TBLOCK / 64), tid);
+                                     blockIdx.x * (DCRX_V2_TBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_TBLOCK / 64), tid, V2SinkCall{});      // (A/B form: no tuple sink)
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -1219,7 +1240,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
   const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
   __syncthreads();
   v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
-                                       blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_FBLOCK / 64), tid);
+                                       blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_FBLOCK / 64), tid, V2SinkCall{});
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -1297,6 +1318,97 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 
+// ---- the tuple sink's last step (dcrx_sink_device.h) ------------------------------------------------
+// One block per region of the scan, behind the list kernel: the region's bitmap of decombined reads is built in LDS from the
+// items the kernels left, the items are ranked by it, and the message (include/dcrx.h, dcrx_tuple_message_bytes: bitmap |
+// low words | high bytes, in read order) gets the region's words and tuples — at the offset the regions in front of it fill,
+// known from their counts of decombined reads.  The block that reads the counts last re-arms them.
+constexpr int V2_PLACE_BLOCK = 1024;
+__global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCall S, const uint32_t *__restrict__ counts, const uint32_t n_regions,
+                                                                  const uint32_t tcap, const uint32_t ecap, const uint32_t ccap, const uint32_t fused,
+                                                                  const uint64_t n_reads, const uint64_t n_slots, uint8_t *__restrict__ msg,
+                                                                  const uint32_t hi_bytes, uint64_t *__restrict__ d_total) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  __shared__ uint32_t s_part[V2_PLACE_BLOCK];
+  __shared__ uint32_t s_last;
+  const V2SinkDev D = *S.dev;
+  const int tid = threadIdx.x;
+  const uint32_t region = blockIdx.x;
+  const uint32_t wpr = S.per_block >> 5;                 // words of the region's bitmap (a region is a multiple of 512 reads)
+  uint32_t *bm = smem, *pre = smem + wpr;
+  // decombined reads of the regions in front, and of all
+  uint32_t before = 0, all = 0;
+  for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) { const uint32_t h = D.hits[q]; all += h; if (q < region) before += h; }
+  const uint32_t n_late = D.late[region];
+  for (uint32_t i = (uint32_t)tid; i < wpr; i += V2_PLACE_BLOCK) bm[i] = 0u;
+  s_part[tid] = before;
+  __syncthreads();
+  for (int st = V2_PLACE_BLOCK / 2; st > 0; st >>= 1) { if (tid < st) s_part[tid] += s_part[tid + st]; __syncthreads(); }
+  const uint64_t base = s_part[0];
+  __syncthreads();
+  s_part[tid] = all;
+  __syncthreads();
+  for (int st = V2_PLACE_BLOCK / 2; st > 0; st >>= 1) { if (tid < st) s_part[tid] += s_part[tid + st]; __syncthreads(); }
+  const uint64_t total = s_part[0];
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(D.ticket, 1u) == n_regions - 1u ? 1u : 0u;      // (this block has read every count)
+  // the region's sections: (offset, items)
+  const uint32_t n_tail = fused ? counts[V2_L_COUNTS * region + V2_L_RING] : min(counts[V2_L_COUNTS * region + V2_L_TAIL], tcap);
+  const uint32_t n_e = min(counts[V2_L_COUNTS * region + V2_L_E], ecap), n_c = min(counts[V2_L_COUNTS * region + V2_L_C], ccap);
+  const uint32_t sec_off[4] = {0u, S.e_off, S.c_off, S.late_off};
+  const uint32_t sec_n[4] = {n_tail, n_e, n_c, min(n_late, S.late_cap)};
+  const uint64_t blk_lo = (uint64_t)region * S.per_block;
+  const uint2 *items = D.items + (size_t)region * S.stride;
+  const uint8_t *hi = D.hi + (size_t)region * S.stride;
+  for (int sc = 0; sc < 4; sc++)
+    for (uint32_t i = (uint32_t)tid; i < sec_n[sc]; i += V2_PLACE_BLOCK) {
+      const uint32_t r = items[sec_off[sc] + i].x;
+      if (r != V2_SINK_EMPTY) { const uint32_t k = r - (uint32_t)blk_lo; atomicOr(&bm[k >> 5], 1u << (k & 31u)); }
+    }
+  __syncthreads();
+  // exclusive prefix of the words' populations: a run of words per thread, then the runs
+  const uint32_t per = (wpr + V2_PLACE_BLOCK - 1) / V2_PLACE_BLOCK;
+  uint32_t run = 0;
+  for (uint32_t i = (uint32_t)tid * per; i < min(((uint32_t)tid + 1u) * per, wpr); i++) run += (uint32_t)__popc(bm[i]);
+  s_part[tid] = run;
+  __syncthreads();
+  for (int st = 1; st < V2_PLACE_BLOCK; st <<= 1) {
+    const uint32_t v = tid >= st ? s_part[tid - st] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t acc = s_part[tid] - run;
+  for (uint32_t i = (uint32_t)tid * per; i < min(((uint32_t)tid + 1u) * per, wpr); i++) { pre[i] = acc; acc += (uint32_t)__popc(bm[i]); }
+  __syncthreads();
+  // the tuples, in read order
+  const uint64_t bm_bytes = ((n_slots + 63) / 64) * 8;
+  uint32_t *plane_a = reinterpret_cast<uint32_t *>(msg + bm_bytes);
+  uint8_t *plane_b = msg + bm_bytes + total * 4;
+  for (int sc = 0; sc < 4; sc++)
+    for (uint32_t i = (uint32_t)tid; i < sec_n[sc]; i += V2_PLACE_BLOCK) {
+      const uint2 it = items[sec_off[sc] + i];
+      if (it.x == V2_SINK_EMPTY) continue;
+      const uint32_t k = it.x - (uint32_t)blk_lo;
+      const uint64_t at = base + pre[k >> 5] + (uint32_t)__popc(bm[k >> 5] & ((1u << (k & 31u)) - 1u));
+      plane_a[at] = it.y;
+      if (hi_bytes) plane_b[at] = hi[sec_off[sc] + i];
+    }
+  // the region's words of the bitmap (pairs of LDS words), and — the last region's block — the words behind the batch's reads
+  uint64_t *out_bm = reinterpret_cast<uint64_t *>(msg);
+  const uint64_t w_lo = blk_lo >> 6, w_all = bm_bytes / 8;
+  for (uint32_t i = (uint32_t)tid; i < (wpr >> 1); i += V2_PLACE_BLOCK)
+    if (w_lo + i < w_all) out_bm[w_lo + i] = (uint64_t)bm[2 * i] | ((uint64_t)bm[2 * i + 1] << 32);
+  if (region == n_regions - 1u)
+    for (uint64_t w = w_lo + (wpr >> 1) + (uint32_t)tid; w < w_all; w += V2_PLACE_BLOCK) out_bm[w] = 0ull;
+  if (region == 0 && tid == 0) *d_total = total;
+  if (tid == 0) D.late[region] = 0u;
+  if (s_last) {      // every block has its offsets: the counts are zero again for the next call
+    for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) D.hits[q] = 0u;
+    if (tid == 0) *D.ticket = 0u;
+  }
+}
+
 // ---- launcher ------------------------------------------------------------------------------------
 // LDS the scan kernel needs for frame o: the pair table and the block's counters
 static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].trans_bytes + DCRX_N_COUNTERS * 4 + V2_WK_WORDS * 4; }
@@ -1317,7 +1429,7 @@ bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
 template <bool UNIFORM, int NW, int RPL, bool NARROW, bool PREFETCH = true>
 static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                             uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count,
-                            unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry) {
+                            unsigned long long *d_counters, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry, V2SinkLaunch *sink) {
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   // The fused form (the tail inside the scan kernel, through a ring in LDS: scan2_kernel, FUSE) for the 150-nt shape when the
   // frame's pair table leaves room for the side tables, the buckets and a ring of at least four batches; the A/B forms and the
@@ -1405,8 +1517,21 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
   // serves as the fork event as well: one signal on the dispatch, no marker packet)
   const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
+  // The call's tuple sink (dcrx_sink_device.h), when this launch serves it: the shipped shape (one finishing launch), one pass,
+  // no profiling switch, and room: a slab per region with a section per list and one for the late items, a region's bitmap and
+  // its ranks in the place kernel's LDS.
+  V2SinkCall S{};
+  if (sink && P.sink.dev && finish && !separate && !retry && !(cfg.flags & DCRX_F_PROFILE_MASK)) {
+    const uint64_t stride = (uint64_t)Q.tcap + Q.ecap + Q.scap / 2 + pb128;
+    if (n_regions <= P.sink.regions_cap && stride * n_regions <= P.sink.items_cap && stride < (1ull << 32) && per_block / 32 * 8 <= 144u * 1024u) {
+      S.dev = P.sink.dev; S.stride = (uint32_t)stride; S.e_off = Q.tcap; S.c_off = Q.tcap + Q.ecap; S.late_off = Q.tcap + Q.ecap + Q.scap / 2;
+      S.late_cap = (uint32_t)pb128; S.per_block = (uint32_t)per_block; S.wpack = P.sink.wpack;
+      sink->S = S; sink->n_regions = n_regions; sink->tcap = Q.tcap; sink->ecap = Q.ecap; sink->ccap = Q.scap / 2; sink->fused = ring_batches ? 1u : 0u;
+      sink->counts = Q.counts;
+    }
+  }
   hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches);
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches, S);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (finish) {
@@ -1432,7 +1557,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
     V2FinishArgs A;
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
-    A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables;
+    A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables; A.S = S;
     if (!separate) {
       hipLaunchKernelGGL(ring_batches ? kf0 : kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
       e = hipGetLastError();
@@ -1508,15 +1633,32 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   return e;
 }
 
+// the tuple sink's place kernel behind the list kernel (the call's last launch: its stop event rides here)
+hipError_t launch_v2_place(const LaunchPlan &P, const V2SinkLaunch &K, uint64_t n_reads, hipStream_t s, hipEvent_t ev_stop) {
+  static bool seen[64];
+  if (first_use_on_device(seen)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(v2_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    attributes_set_on_device(seen);
+  }
+  const uint32_t lds = (K.S.per_block / 32u) * 8u;
+  hipExtLaunchKernelGGL(v2_place_kernel, dim3(K.n_regions), dim3(V2_PLACE_BLOCK), lds, s, nullptr, ev_stop, 0, K.S, K.counts, K.n_regions, K.tcap, K.ecap,
+                        K.ccap, K.fused, (uint64_t)n_reads, P.sink.n_slots, P.sink.msg, P.sink.bytes - 4u, P.sink.d_total);
+  return hipGetLastError();
+}
+// items of a sink's slabs for batches of up to max_reads reads: per region the three lists' capacities and as many late slots
+// as the region has reads (launch_v2: tcap, ecap, scap / 2 <= pb128 each)
+uint64_t v2_sink_items(uint64_t max_reads, uint32_t n_cu) { return 4 * (max_reads + (uint64_t)n_cu * 1024) + 4096; }
+
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                          uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
-                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry) {
+                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry, V2SinkLaunch *sink) {
   const int o = cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1;
   const bool uniform = B.lens == nullptr, nw10 = B.stride <= 40, narrow = T.v2[o].narrow != 0;
   int shape = (int)((cfg.flags >> 8) & 3u);
   if (shape == 0) shape = nw10 ? 2 : 3;      // two reads per lane (two independent chains per wave) where the registers allow: measured faster than one
-#define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry)
-#define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry)
+#define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
+#define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
   if (nw10) {
     if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);

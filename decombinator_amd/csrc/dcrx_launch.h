@@ -12,6 +12,40 @@
 
 namespace dcrx {
 
+// the narrow tuple (include/dcrx.h, dcrx_tuple_layout) as the kernels take it
+struct TupleLayoutDev {
+  uint32_t w_v, w_j, w_vdel, w_jdel, w_pos, bytes;
+  const uint8_t *j_tag_len;    // len(j_seqs[k])
+  const int32_t *j_jump;       // jump_to_start_j[k]
+};
+// The tuple sink of a handle (dcrx_sink_device.h).  V2SinkDev lives in device memory and stays as it is while the sink is on;
+// V2SinkCall travels with a launch (dev == nullptr: no sink).
+struct V2SinkDev {
+  uint2 *items;                // [regions][stride]: read index (V2_SINK_EMPTY: none) | the tuple's low word
+  uint8_t *hi;                 // [regions][stride]: the tuple's bits 32-39
+  uint32_t *hits;              // [regions] decombined reads (zero between calls)
+  uint32_t *late;              // [regions] items of the late section (zero between calls)
+  uint32_t *ticket;            // blocks of the place kernel that have read the counts (zero between calls)
+  const uint8_t *j_tag_len;
+  const int32_t *j_jump;
+};
+struct V2SinkCall {
+  const V2SinkDev *dev;
+  uint32_t stride;             // items of a region's slab: sections tail (at 0), E, C, late
+  uint32_t e_off, c_off, late_off, late_cap;
+  uint32_t per_block;          // reads of a region
+  uint32_t wpack;              // w_v | w_j << 5 | w_vdel << 10 | w_jdel << 15 | w_pos << 20
+};
+// what a launch is asked to leave in the sink, and whether it did (else the caller compacts the records)
+struct V2SinkJob {
+  const V2SinkDev *dev = nullptr;
+  uint64_t items_cap = 0;      // items allocated
+  uint32_t regions_cap = 0;    // regions the counters hold
+  uint32_t wpack = 0, bytes = 0;
+  uint8_t *msg = nullptr; uint64_t n_slots = 0; uint64_t *d_total = nullptr;
+  bool *done = nullptr;
+};
+
 struct LaunchPlan {
   uint32_t n_cu;
   uint32_t grid;   // fast kernel (upper bound; capped by measured occupancy at launch)
@@ -33,6 +67,7 @@ struct LaunchPlan {
   // optional, set per call (dcrx_set_step_events): start of the first and end of the last kernel of the call.  Attached to
   // those kernels' own dispatches (hipExtLaunchKernelGGL): a separate event record costs the stream ~10 us of gap each
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;
+  V2SinkJob sink;              // set per call while a tuple sink is on (dcrx_set_tuple_sink)
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
@@ -42,12 +77,18 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
 void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *tail_rows, uint64_t *event_rows);
 uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu);
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg);
+// what a v2 launch that serves the call's tuple sink leaves for the list kernel and the place kernel behind it
+struct V2SinkLaunch { V2SinkCall S{}; uint32_t n_regions = 0, tcap = 0, ecap = 0, ccap = 0, fused = 0; const uint32_t *counts = nullptr; };
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                          uint32_t *queue, uint32_t *gqueue, uint32_t qcap, uint32_t *queue_count, unsigned long long *d_counters,
-                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry = 0);
+                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t retry = 0, V2SinkLaunch *sink = nullptr);
+hipError_t launch_v2_place(const LaunchPlan &P, const V2SinkLaunch &K, uint64_t n_reads, hipStream_t s, hipEvent_t ev_stop);
+uint64_t v2_sink_items(uint64_t max_reads, uint32_t n_cu);      // items a handle's sink needs for batches of up to max_reads reads
 hipError_t launch_compact(const dcrx_record_t *rec, uint64_t n, uint64_t first_index, dcrx_record_t *hits,
                           uint64_t *hit_index, uint64_t *ok_bitmap, int packed12, uint64_t *d_total, uint32_t *tile_count,
                           uint64_t *tile_off, hipStream_t s);
+hipError_t launch_compact_narrow(const dcrx_record_t *rec, uint64_t n, uint8_t *msg, uint64_t n_slots, const TupleLayoutDev &L, uint64_t *d_total,
+                                 uint32_t *tile_count, uint64_t *tile_off, hipStream_t s);
 uint32_t compact_tiles(uint64_t n);
 
 }  // namespace dcrx

@@ -117,9 +117,17 @@ class TupleGather:
     TUPLE_BYTES = 12      # (the class default; an instance with v_jumps carries 8)
 
     def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None, v_jumps=None,
-                 n_v: int = None, n_j: int = None):
+                 n_v: int = None, n_j: int = None, tables=None, max_read_len: int = None, use_sink: bool = True):
         from . import _native as nat
         self.nat = nat
+        # `tables` (+ max_read_len): the narrow tuple of include/dcrx.h — widths from the tag tables, neither ins_start nor
+        # ins_len on the wire (5 bytes for human beta at 150 nt); the receiver holds the same tables (nat.TupleCodec)
+        self.tables, self.codec = tables, None
+        if tables is not None:
+            try:
+                self.codec = nat.TupleCodec(tables, int(max_read_len))
+            except nat.DcrxError:
+                self.codec = None             # wider than 64 bits: the fixed forms below
         self.v_jumps = None if v_jumps is None else list(v_jumps)
         # the 8-byte tuple holds v in 11 bits and j in 9 (include/dcrx.h, dcrx_compact_hits_packed8_device) and re-derives
         # ins_start from the V tag's jump: a table it does not describe (n_v / n_j from dcrx_tables_info, when the caller gives
@@ -129,7 +137,7 @@ class TupleGather:
                 raise ValueError(f"TupleGather: {len(self.v_jumps)} V jumps for a table of {n_v} V tags")
             if len(self.v_jumps) >= 2048 or (n_j is not None and n_j >= 512):
                 self.v_jumps = None
-        self.TUPLE_BYTES = 8 if self.v_jumps is not None else 12
+        self.TUPLE_BYTES = self.codec.bytes if self.codec is not None else (8 if self.v_jumps is not None else 12)
         self.world, self.rank, self.n_reads = world, rank, n_reads
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.device = device if self.cuda else torch.device("cpu")
@@ -137,6 +145,9 @@ class TupleGather:
         self.k = 0
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self.compact = compact
+        # the tuple sink (dcrx_set_tuple_sink): the decombine call of a step leaves the step's message itself, on its own
+        # stream — no compaction pass beside the next step's scan; the side stream carries the count exchange and the transfers
+        self.sink = bool(use_sink and self.codec is not None and self.cuda and compact is None)
         self.slots = []
         dev = self.device
         # a rank's message of a step: its bitmap, then its tuples — one buffer, one transfer per peer and step
@@ -177,7 +188,16 @@ class TupleGather:
 
     def before_scan(self) -> None:
         """The current stream waits until the slot's previous compaction has read its records."""
-        ev = self.slots[self.k % len(self.slots)]["compacted"]
+        s = self.slots[self.k % len(self.slots)]
+        if self.sink:
+            # the call about to be queued writes the slot's message: its last transfers must be done (they were posted a step ago)
+            self._post(s)
+            for w in s["work"]:
+                w.wait()
+            s["work"] = []
+            self.nat.set_tuple_sink(self.tables, self.codec, s["msg"].data_ptr(), self.n_reads, s["n"].data_ptr())
+            return
+        ev = s["compacted"]
         if ev is not None and self.cuda:
             torch.cuda.current_stream().wait_event(ev)
 
@@ -213,10 +233,15 @@ class TupleGather:
             for w in s["work"]:          # ... and are done
                 w.wait()
             s["work"] = []
-            if n_reads < self.n_reads:
+            if n_reads < self.n_reads and not self.sink:
                 s["bitmap"].zero_()      # a short batch (the end of a shard): no stale bits beyond its reads
-            if self.compact is not None:
+            if self.sink:
+                pass                     # (the call has left the message and the count on its own stream: nothing to compact)
+            elif self.compact is not None:
                 self.compact(s, n_reads)
+            elif self.codec is not None:
+                nat.compact_hits_narrow_device(self.tables, self.codec, s["rec"].data_ptr(), n_reads, s["msg"].data_ptr(),
+                                               s["n"].data_ptr(), self.side.cuda_stream, n_slots=self.n_reads)
             else:
                 fn = nat.lib().dcrx_compact_hits_packed8_device if self.TUPLE_BYTES == 8 else nat.lib().dcrx_compact_hits_packed_device
                 nat.check(fn(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(), s["bitmap"].data_ptr(), s["n"].data_ptr(),
@@ -237,6 +262,8 @@ class TupleGather:
 
     def finish(self) -> None:
         """Posts what is still to be posted and makes the current stream wait for every transfer."""
+        if self.sink:
+            self.nat.set_tuple_sink(self.tables, None)      # (calls outside the gather's steps leave no message)
         for s in self.slots:
             self._post(s)
         with self._side():
@@ -257,6 +284,10 @@ class TupleGather:
         counts = [int(x) for x in s["counts_host"].tolist()]
         out = []
         for r in range(self.world):
+            if self.codec is not None:
+                rec, idx = self.codec.unpack(s["g_msg"][r][:self.bm_bytes + counts[r] * self.TUPLE_BYTES].cpu().numpy(), self.n_reads, counts[r])
+                out.append((rec, idx, r))
+                continue
             w = s["g_hits"][r][:counts[r] * self.TUPLE_BYTES].cpu().numpy().view(np.uint32).reshape(-1, self.TUPLE_BYTES // 4)
             idx = bitmap_indices(s["g_bitmap"][r].cpu().numpy().view(np.uint64), self.n_reads)
             rec = self.nat.unpack_tuples8(w, self.v_jumps) if self.TUPLE_BYTES == 8 else self.nat.unpack_tuples12(w)

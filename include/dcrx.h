@@ -306,6 +306,50 @@ int dcrx_compact_hits_packed_device(const dcrx_record_t *d_records, uint64_t n_r
 int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_reads, void *d_tuples8,
                                      uint64_t *d_ok_bitmap, uint64_t *d_n_hits, void *hip_stream);
 
+/* The narrow tuple: what a sharded run gathers when the receiver holds the same tag tables.  Field widths come from the
+ * tables (dcrx_tuple_layout), fields are packed least significant first:
+ *   v | j | vdel | jdel | v_start | j_end | short_end | frame
+ * w_v / w_j: bits of n_v - 1 / n_j - 1; w_vdel: bits of max(jump_to_end_v[k] - len(v_seqs[k])) and w_jdel: bits of
+ * max(jump_to_start_j[k]) — a decombined read has passed the filter of decombine.py:560-564, so its deletions fit; w_pos
+ * (v_start and j_end): bits of max_read_len.  Neither ins_start nor ins_len is sent:
+ *   ins_start = v_start + jump_to_end_v[v] - vdel                       (the base after the end of V, :283-285, :547)
+ *   ins_len   = j_end - L - jump_to_start_j[j] + jdel - ins_start       (start of J, :407-409, :447, :506-509, :806)
+ * with L = len(j_seqs[j]), or 2 * j_half_split when short_end is set: the J half1 rescue sets j_seq_end to the half's
+ * start + len(half1) + j_half_split (:450-454), which is not the tag's end when the split is not the tag's middle.
+ * bits = the sum (+ 2); bytes = max(4, ceil(bits / 8)) <= 8.  Human beta, original tags, 150 nt: 39 bits, 5 bytes.
+ * DCRX_E_UNSUPPORTED when bits > 64 (the caller gathers 12-byte tuples instead). */
+typedef struct dcrx_tuple_layout {
+  uint8_t w_v, w_j, w_vdel, w_jdel, w_pos;
+  uint8_t bits, bytes, reserved;
+  uint32_t max_read_len;
+} dcrx_tuple_layout_t;
+int dcrx_tuple_layout(const dcrx_tables_t *tables, uint32_t max_read_len, dcrx_tuple_layout_t *layout);
+
+/* Bytes of the message of a batch over n_reads read slots with n_hits decombined ones (dcrx_compact_hits_narrow_device):
+ *   [ (n_reads + 63) / 64 uint64: bit (i & 63) of word i >> 6 = read i decombined ]
+ *   [ n_hits uint32: the tuples' low 32 bits, in read order ]
+ *   [ n_hits x (bytes - 4) bytes: their high bytes, least significant first ]
+ * The third part starts where the second ends: a sender ships the first dcrx_tuple_message_bytes(...) bytes. */
+uint64_t dcrx_tuple_message_bytes(const dcrx_tuple_layout_t *layout, uint64_t n_reads, uint64_t n_hits);
+
+/* Compacts the status==OK records of a batch into that message (d_message: room for n_hits == n_reads); d_n_hits (one
+ * uint64) gets the count.  n_slots >= n_reads: the read slots the bitmap spans — a sharded run sizes every step's message
+ * for its largest batch, a short last batch leaves the bits beyond its reads zero.  Needs the tables on the current
+ * device (the J tags' lengths and jumps decide short_end). */
+int dcrx_compact_hits_narrow_device(dcrx_tables_t *tables, const dcrx_tuple_layout_t *layout,
+                                    const dcrx_record_t *d_records, uint64_t n_reads, uint64_t n_slots, void *d_message,
+                                    uint64_t *d_n_hits, void *hip_stream);
+
+/* The tuple sink of a handle: while one is set, every dcrx_decombine_device call on the handle ALSO leaves the batch's
+ * message — exactly what dcrx_compact_hits_narrow_device would make of its records, n_slots >= the batch's reads — in
+ * d_message and the count in d_n_hits, on the call's stream.  For the shipped kernels and tuples of up to 40 bits the
+ * kernels that write the records leave the tuples behind as they go and one short launch behind them puts the message in
+ * read order (no pass over the records: the gather of a sharded run costs the step ~2 %, not 12 %); any other launch
+ * shape compacts the records behind the call.  The buffers may change from call to call (a sharded run alternates two
+ * messages); layout == NULL turns the sink off.  The handle's workspace grows by ~36 bytes per read of its largest batch. */
+int dcrx_set_tuple_sink(dcrx_tables_t *tables, const dcrx_tuple_layout_t *layout, void *d_message, uint64_t n_slots,
+                        uint64_t *d_n_hits);
+
 /* ---- the first consumer of the rows: the front half of `collapse` (host, threaded) -------------------------------
  * What read_in_data (src/decombinator/collapse.py:482-565) does to every `.n12` row before it starts grouping rows:
  * get_barcode_positions :367-479 (spacer searches :192-236), set_barcode :278-326, check_umi_quality :343-353 and the

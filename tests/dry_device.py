@@ -15,6 +15,7 @@ class DryDevice:
     def __init__(self, nat, all_tables, tagsets, cfg_synth, batches, n):
         self.nat, self.batches, self.n = nat, batches, n
         self.all_tables = all_tables
+        self.codec = None
         self.records = []          # per batch: the records of the last chain (what the gather carries)
         self.counts = []           # per batch: per chain counters
         for first, cnt in batches:
@@ -39,11 +40,13 @@ class DryDevice:
     def compact(self, slot, n_reads):          # stands in for dcrx_compact_hits_packed_device (same layout, made on the host)
         nat = self.nat
         rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
-        w, bm = sharded.pack_tuples8(rec)      # (the bench gathers 8-byte tuples: TupleGather(v_jumps=...))
-        slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
+        # (the bench gathers narrow tuples: TupleGather(tables=...); one message of bitmap | low words | high bytes)
+        if self.codec is None:
+            self.codec = nat.TupleCodec(self.all_tables[-1], 150)
+        m = self.codec.pack(rec, n_slots=self.n)
         slot["bitmap"].zero_()
-        slot["bitmap"][:len(bm)] = torch.from_numpy(bm.view(np.int64).copy())
-        slot["n"][0] = len(w)
+        slot["msg"][:len(m)] = torch.from_numpy(m.copy())
+        slot["n"][0] = int((rec["status"] == 0).sum())
 
     def name(self):
         return "dry (oracle on the CPU)"

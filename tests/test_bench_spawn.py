@@ -29,7 +29,7 @@ def test_two_ranks_started_by_the_bench_itself_dry():
     d = _line(_run(["--gpus", "2", "--reads", "3000", "--steps", "3", "--warmup", "1"], script=DRY))
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and len(d["config"]["devices"]) == 2
     assert d["dry_run"] is True and d["value"] is None            # a dry run never carries a rate
-    assert d["scaling"] == "weak" and d["gather"]["tuple_bytes"] == 8
+    assert d["scaling"] == "weak" and d["gather"]["tuple_bytes"] == 5
     assert d["gather"]["ms_per_step_without_gather"] is not None
 
 

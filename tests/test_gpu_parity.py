@@ -338,8 +338,10 @@ n = 400_000
 ts = synth.config_tagset(2)
 t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
 dev = torch.device("cuda", 0)
-g = sharded.TupleGather(n, 1, 0, dev, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None)
-assert g.TUPLE_BYTES == (8 if os.environ.get("DCRX_TUPLE8") == "1" else 12)
+mode = os.environ.get("DCRX_TUPLE8")
+g = sharded.TupleGather(n, 1, 0, dev, v_jumps=ts.v_jumps if mode == "1" else None, tables=t if mode in ("narrow", "sink") else None,
+                        max_read_len=150, use_sink=mode == "sink")
+assert g.TUPLE_BYTES == {"0": 12, "1": 8, "narrow": 5, "sink": 5}[mode] and g.sink == (mode == "sink")
 stream = torch.cuda.current_stream()
 d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
 cfg = nat.make_cfg("reverse", False, 130, 0)
@@ -372,7 +374,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("tuple8", ["0", "1"], ids=["12-byte-tuples", "8-byte-tuples"])
+@pytest.mark.parametrize("tuple8", ["0", "1", "narrow", "sink"], ids=["12-byte-tuples", "8-byte-tuples", "narrow-tuples-compacted", "narrow-tuples-sink"])
 def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path, tuple8):
     """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
     transfers) with one rank on this GPU, five steps with different reads: what rank 0 holds for every step equals the
@@ -433,6 +435,17 @@ def test_compact_hits_matches_numpy():
     w8 = d_t8.to_host(np.uint32, 2 * k)
     assert nat.unpack_tuples8(w8, ts.v_jumps).tobytes() == rec[ok].tobytes()
     assert (nat.pack_tuples8(rec).reshape(-1) == w8).all()          # the host-side twin the CPU tests use
+    # narrow tuples (widths from the tables; neither ins_start nor ins_len travels): one message of bitmap, low words, high bytes
+    codec = nat.TupleCodec(t, 150)
+    assert codec.bytes == 5
+    d_msg = nat.DeviceBuffer(codec.message_bytes(n, n))
+    nat.compact_hits_narrow_device(t, codec, d_rec.ptr, n, d_msg.ptr, d_n.ptr)
+    nat.synchronize()
+    assert int(d_n.to_host(np.uint64, 1)[0]) == k
+    msg = d_msg.to_host(np.uint8, codec.message_bytes(n, k))
+    assert msg.tobytes() == codec.pack(rec).tobytes()
+    back, idx = codec.unpack(msg, n, k)
+    assert back.tobytes() == rec[ok].tobytes() and (idx == ok).all()
 
 
 @pytest.mark.parametrize("tag_len", [21, 22], ids=["half15-pair-rescue", "half16-list-rescue"])

@@ -100,12 +100,19 @@ GATHER_WORKER = textwrap.dedent('''
 
     def compact(slot, n_reads):       # stands in for dcrx_compact_hits_packed_device: same layout, made on the host
         rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+        if os.environ.get("DCRX_TUPLE8") == "narrow":      # dcrx_compact_hits_narrow_device: one message, bitmap | low words | high bytes
+            m = g.codec.pack(rec)
+            slot["msg"][:len(m)] = torch.from_numpy(m.copy())
+            slot["n"][0] = int((rec["status"] == 0).sum())
+            return
         w, bm = (sharded.pack_tuples8 if os.environ.get("DCRX_TUPLE8") == "1" else sharded.pack_tuples12)(rec)
         slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
         slot["bitmap"][:] = torch.from_numpy(bm.view(np.int64).copy())
         slot["n"][0] = len(w)
 
-    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None)
+    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None,
+                            tables=t if os.environ.get("DCRX_TUPLE8") == "narrow" else None, max_read_len=150)
+    assert g.TUPLE_BYTES == {"0": 12, "1": 8, "narrow": 5}[os.environ.get("DCRX_TUPLE8")]
     checked = 0
     for step in range(STEPS):
         g.before_scan()
@@ -139,7 +146,7 @@ GATHER_WORKER = textwrap.dedent('''
 import pytest
 
 
-@pytest.mark.parametrize("tuple8", ["0", "1"], ids=["12-byte-tuples", "8-byte-tuples"])
+@pytest.mark.parametrize("tuple8", ["0", "1", "narrow"], ids=["12-byte-tuples", "8-byte-tuples", "narrow-tuples"])
 def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path, tuple8):
     """The gather bench.py runs between ranks (count exchange, exact-size transfers of 12- or 8-byte tuples + bitmap,
     alternating slots), over gloo with two ranks and five steps whose decombined fractions range from 0 to 95 %:
