@@ -101,7 +101,7 @@ struct dcrx_tables {
   dcrx_tuple_layout_t sink_layout{};
   uint8_t *sink_msg = nullptr; uint64_t sink_slots = 0; uint64_t *sink_total = nullptr;
   V2SinkDev *d_sink = nullptr;
-  void *d_sink_items = nullptr, *d_sink_hi = nullptr; uint32_t *d_sink_ctr = nullptr;
+  void *d_sink_items = nullptr; uint32_t *d_sink_ctr = nullptr;
   uint64_t sink_items_cap = 0; uint32_t sink_regions_cap = 0;
 };
 
@@ -113,8 +113,8 @@ static void free_device_state(dcrx_tables *t) {
   (void)hipFree(t->d_dev); t->d_dev = nullptr;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
-  (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_hi); (void)hipFree(t->d_sink_ctr);
-  t->d_sink = nullptr; t->d_sink_items = nullptr; t->d_sink_hi = nullptr; t->d_sink_ctr = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
+  (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_ctr);
+  t->d_sink = nullptr; t->d_sink_items = nullptr; t->d_sink_ctr = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
   if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
   if (t->v2_side2) (void)hipStreamDestroy(t->v2_side2);
   if (t->v2_ev_fork) (void)hipEventDestroy(t->v2_ev_fork);
@@ -342,16 +342,14 @@ static int ensure_sink(dcrx_tables *t, uint64_t max_reads, hipStream_t stream) {
   const uint32_t regions = t->plan.n_cu;
   if (t->d_sink && want <= t->sink_items_cap && regions <= t->sink_regions_cap) return DCRX_OK;
   HIP_TRY(hipStreamSynchronize(stream));
-  (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_hi); (void)hipFree(t->d_sink_ctr); (void)hipFree(t->d_sink);
-  t->d_sink_items = nullptr; t->d_sink_hi = nullptr; t->d_sink_ctr = nullptr; t->d_sink = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
+  (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_ctr); (void)hipFree(t->d_sink);
+  t->d_sink_items = nullptr; t->d_sink_ctr = nullptr; t->d_sink = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
   HIP_TRY(hipMalloc(&t->d_sink_items, want * 8));
-  HIP_TRY(hipMalloc(&t->d_sink_hi, want));
   HIP_TRY(hipMalloc(&t->d_sink_ctr, ((size_t)2 * regions + 16) * 4));
   HIP_TRY(hipMemset(t->d_sink_ctr, 0, ((size_t)2 * regions + 16) * 4));
   HIP_TRY(hipMalloc(&t->d_sink, sizeof(V2SinkDev)));
   V2SinkDev D;
-  D.items = static_cast<uint2 *>(t->d_sink_items); D.hi = static_cast<uint8_t *>(t->d_sink_hi);
-  D.hits = t->d_sink_ctr; D.late = t->d_sink_ctr + regions; D.ticket = t->d_sink_ctr + 2 * regions;
+  D.late = t->d_sink_ctr + regions; D.ticket = t->d_sink_ctr + 2 * regions;      // (the regions' counts of decombined reads in front: V2SinkCall::hits)
   D.j_tag_len = t->dev.g[1].tag_len; D.j_jump = t->dev.g[1].jump;
   HIP_TRY(hipMemcpy(t->d_sink, &D, sizeof D, hipMemcpyHostToDevice));
   t->sink_items_cap = want; t->sink_regions_cap = regions;
@@ -422,7 +420,7 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
       rc = ensure_sink(t, b->n_reads, (hipStream_t)stream);
       if (rc) return rc;
       V2SinkJob &J = t->plan.sink;
-      J.dev = t->d_sink; J.items_cap = t->sink_items_cap; J.regions_cap = t->sink_regions_cap;
+      J.dev = t->d_sink; J.items = static_cast<uint2 *>(t->d_sink_items); J.hits = t->d_sink_ctr; J.items_cap = t->sink_items_cap; J.regions_cap = t->sink_regions_cap;
       J.wpack = LD.w_v | (LD.w_j << 5) | (LD.w_vdel << 10) | (LD.w_jdel << 15) | (LD.w_pos << 20);
       J.bytes = LD.bytes; J.msg = t->sink_msg; J.n_slots = t->sink_slots; J.d_total = t->sink_total; J.done = &sink_done;
     }

@@ -298,15 +298,15 @@ constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
 constexpr int V2_RING_STRIDE = 15;
 constexpr uint32_t V2_RING_MAXBATCHES = 16;
 
-template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, int FUSE = -1>
+// (SINK: the fused form's tail waves also leave the tuple sink's items — an instantiation of its own, so that the kernel of a
+// call without a sink carries none of that code: 0.6 % of the step, measured)
+template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, int FUSE = -1, bool SINK = false>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
     uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S) {
   extern __shared__ __align__(64) uint32_t smem[];
-#ifdef DCRX_NO_SINK
-  S.dev = nullptr;      // (A/B build, tools/: the kernels without the tuple sink's code)
-#endif
+  if constexpr (FUSE >= 0 && !SINK) S.dev = nullptr;      // (the scanning form, FUSE < 0, only flushes a count: one kernel for both)
   const int o = FUSE >= 0 ? FUSE : (cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
   V2Ori V0 = T0.v2[0];
   if (o) V0 = T0.v2[1];
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
         rec.frame = (uint8_t)(o ? 0 : 1);
         if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
-        if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
+        if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, false);      // (a tail read's J tag is whole)
       }
       v2_tally(lds_counts, lane, status, o == 0);
       // tuple sink: the item of every entry of the batch, at the entry's place in the ring's sequence
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     if (tid == V2_L_RING) c = lds_work[V2_WK_HEAD];      // (fused form: entries that went through the ring — the tuple sink's tail section)
     Q.counts[V2_L_COUNTS * region + tid] = c;
   }
-  if (S.dev && tid == 0 && lds_work[V2_WK_SINK]) (void)__hip_atomic_fetch_add(S.dev->hits + region, lds_work[V2_WK_SINK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (S.dev && tid == 0 && lds_work[V2_WK_SINK]) (void)__hip_atomic_fetch_add(S.hits + region, lds_work[V2_WK_SINK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
@@ -835,7 +835,7 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
         status = tail2_fast<ORI == 1>(tt, rw, n, dg, cfg, rec, *Tmem, C);
 #endif
         if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
-        if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
+        if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, false);
       }
       v2_tally(lds_counts, lane, status, o == 0);
       if (S.dev) sink_put(S, region, 0u, first + (uint32_t)lane, first + lane < tn, status == DCRX_S_OK, r, tup, lane, nullptr);      // tuple sink: the entry's item
@@ -946,7 +946,8 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
           else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
-          if (S.dev && status == DCRX_S_OK) tup = sink_tuple(rec, S.wpack, S.dev->j_tag_len, S.dev->j_jump);
+          // (j_end of a J found through its first half is the half's start + 2 * split, decombine.py:450-454: errs bit 3)
+          if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, (errs & 8u) != 0u && 2 * rt.split[1] != (int)rt.t.L[1]);
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
@@ -976,7 +977,7 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
 //               of its lanes' loops, and a short list is better spread over many waves than packed into a few —, `bsplit` blocks
 //               share a region; block `vblock` of n_regions * bsplit;
 //   mode bit 1  then the launch's left list, as it fills, by one wave (block 0 of the launch).
-template <bool UNIFORM_LEN, int NW, int ORI>
+template <bool UNIFORM_LEN, int NW, int ORI, bool SINK>
 DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi);
 
 // ONE launch for everything behind the scan, on the caller's stream — no side streams, no fork and no join (each wait of one
@@ -1042,15 +1043,14 @@ __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, cons
 #undef DCRX_GLOBAL
   A.Tmem = v2_constant(A.Tmem); A.Q.counts = v2_constant(A.Q.counts); A.T0.kw_base = v2_constant(A.T0.kw_base);
   A.S.dev = v2_constant(A.S.dev);      // (the sink's descriptor: nothing of a launch writes it)
-#ifdef DCRX_NO_SINK
-  A.S.dev = nullptr;
-#endif
+  A.S.items = v2_global(A.S.items); A.S.hits = v2_global(A.S.hits);
   return A;
 }
-template <bool UNIFORM_LEN, int NW, int ORI>
+template <bool UNIFORM_LEN, int NW, int ORI, bool SINK>
 DCRX_V2_ROLE void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  if constexpr (!SINK) A.S.dev = nullptr;
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
   const int tid = threadIdx.x;
   const V2Ori V = A.T0.v2[ORI];
@@ -1063,10 +1063,11 @@ DCRX_V2_ROLE void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, c
   v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.rsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
                                        vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid, A.S);
 }
-template <bool UNIFORM_LEN, int NW, int ORI>
+template <bool UNIFORM_LEN, int NW, int ORI, bool SINK>
 DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  if constexpr (!SINK) A.S.dev = nullptr;
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_);
   const int tid = threadIdx.x;
   const V2Ori V = A.T0.v2[ORI];
@@ -1076,10 +1077,11 @@ DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, con
   v2_tail_jobs<UNIFORM_LEN, NW, ORI>(tt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.tsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
                                      vblock * WPB + (uint32_t)(tid >> 6), A.R.tgrid * WPB, tid, A.S);
 }
-template <bool UNIFORM_LEN, int NW, int ORI>
+template <bool UNIFORM_LEN, int NW, int ORI, bool SINK>
 DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
   extern __shared__ __align__(64) uint32_t smem[];
-  const V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  V2FinishLocals A = v2_finish_args(ka_lo, ka_hi);
+  if constexpr (!SINK) A.S.dev = nullptr;
   const uint32_t vblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)vblock_), mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode_);
   const int tid = threadIdx.x, lane = tid & 63;
   V2Ori V = A.T0.v2[ORI];
@@ -1150,7 +1152,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   if (polling && lane == 0) { A.queue_count[V2_QC_LEFT] = 0u; A.queue_count[V2_QC_DONE] = 0u; }
 }
 
-template <bool UNIFORM_LEN, int NW, int ORI, bool TAIL_ROLE = true>
+template <bool UNIFORM_LEN, int NW, int ORI, bool TAIL_ROLE = true, bool SINK = false>
 __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel(const V2FinishArgs A) {
   extern __shared__ __align__(64) uint32_t smem[];
   const int tid = threadIdx.x;
@@ -1179,9 +1181,9 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
   if (staged) {
     L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
     __syncthreads();
-    if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
-    else if (TAIL_ROLE && role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI>(b, (uint32_t)ka, (uint32_t)(ka >> 32));      // (TAIL_ROLE false: the scan kernel has taken the tail, the launch holds no such block)
-    else v2_general_role<UNIFORM_LEN, NW, ORI>(blockIdx.x == 0 ? 3u : 1u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    if (role == 1) v2_rescue_role<UNIFORM_LEN, NW, ORI, SINK>(b, (uint32_t)ka, (uint32_t)(ka >> 32));
+    else if (TAIL_ROLE && role == 2) v2_tail_role<UNIFORM_LEN, NW, ORI, SINK>(b, (uint32_t)ka, (uint32_t)(ka >> 32));      // (TAIL_ROLE false: the scan kernel has taken the tail, the launch holds no such block)
+    else v2_general_role<UNIFORM_LEN, NW, ORI, SINK>(blockIdx.x == 0 ? 3u : 1u, b, (uint32_t)ka, (uint32_t)(ka >> 32));
   }
   __syncthreads();
   if (blockIdx.x != 0 && tid == 0) atomicAdd(A.queue_count + V2_QC_DONE, 1u);
@@ -1201,7 +1203,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void left2_kernel(c
   const V2Ori V = A.T0.v2[ORI];
   const V2FinishLds L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
   __syncthreads();
-  v2_general_role<UNIFORM_LEN, NW, ORI>(2u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
+  v2_general_role<UNIFORM_LEN, NW, ORI, false>(2u, 0u, (uint32_t)ka, (uint32_t)(ka >> 32));
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&A.counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -1324,76 +1326,119 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, 4) void events2_kernel(
 // low words | high bytes, in read order) gets the region's words and tuples — at the offset the regions in front of it fill,
 // known from their counts of decombined reads.  The block that reads the counts last re-arms them.
 constexpr int V2_PLACE_BLOCK = 1024;
+constexpr int V2_PLACE_KEEP = 24;      // items a thread holds in registers between the passes (24 K items per region: a 10 M-read step has 18 K)
+// sums over a block of V2_PLACE_BLOCK threads by wave shuffles (s16: 16 words of LDS; two barriers each)
+__device__ __forceinline__ uint32_t v2_wave_sum(uint32_t x) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d);
+  return x;
+}
+__device__ __forceinline__ uint32_t v2_block_sum(uint32_t x, uint32_t *s16, const int tid) {
+  x = v2_wave_sum(x);
+  __syncthreads();
+  if ((tid & 63) == 0) s16[tid >> 6] = x;
+  __syncthreads();
+  uint32_t t = 0;
+#pragma unroll
+  for (int w = 0; w < V2_PLACE_BLOCK / 64; w++) t += s16[w];
+  return t;
+}
+// exclusive prefix of x over the block's threads
+__device__ __forceinline__ uint32_t v2_block_exclusive(const uint32_t x, uint32_t *s16, const int tid) {
+  uint32_t inc = x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, d); if ((tid & 63) >= d) inc += v; }
+  __syncthreads();
+  if ((tid & 63) == 63) s16[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int w = 0; w < V2_PLACE_BLOCK / 64; w++) off += w < (tid >> 6) ? s16[w] : 0u;
+  return off + inc - x;
+}
 __global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCall S, const uint32_t *__restrict__ counts, const uint32_t n_regions,
                                                                   const uint32_t tcap, const uint32_t ecap, const uint32_t ccap, const uint32_t fused,
                                                                   const uint64_t n_reads, const uint64_t n_slots, uint8_t *__restrict__ msg,
-                                                                  const uint32_t hi_bytes, uint64_t *__restrict__ d_total) {
+                                                                  const uint32_t hi_bytes, uint64_t *__restrict__ d_total, const uint32_t hcap) {
   extern __shared__ __align__(16) uint32_t smem[];
-  __shared__ uint32_t s_part[V2_PLACE_BLOCK];
+  __shared__ uint32_t s16[V2_PLACE_BLOCK / 64];
   __shared__ uint32_t s_last;
   const V2SinkDev D = *S.dev;
   const int tid = threadIdx.x;
   const uint32_t region = blockIdx.x;
   const uint32_t wpr = S.per_block >> 5;                 // words of the region's bitmap (a region is a multiple of 512 reads)
   uint32_t *bm = smem, *pre = smem + wpr;
-  // decombined reads of the regions in front, and of all
-  uint32_t before = 0, all = 0;
-  for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) { const uint32_t h = D.hits[q]; all += h; if (q < region) before += h; }
+  // the region's tuples in read order, staged in LDS when they fit (hcap of them) and copied out in whole lines: a tuple
+  // written straight to its place is a 4-byte and a 1-byte store to an address of its own — 64 lines per wave and store, 17 us
+  // of a 21-us kernel
+  uint32_t *stage_a = smem + 2 * wpr;
+  uint8_t *stage_b = reinterpret_cast<uint8_t *>(stage_a + hcap);
+  // the region's sections as one run of items: item f of the run lies at items[addr(f)]
   const uint32_t n_late = D.late[region];
-  for (uint32_t i = (uint32_t)tid; i < wpr; i += V2_PLACE_BLOCK) bm[i] = 0u;
-  s_part[tid] = before;
-  __syncthreads();
-  for (int st = V2_PLACE_BLOCK / 2; st > 0; st >>= 1) { if (tid < st) s_part[tid] += s_part[tid + st]; __syncthreads(); }
-  const uint64_t base = s_part[0];
-  __syncthreads();
-  s_part[tid] = all;
-  __syncthreads();
-  for (int st = V2_PLACE_BLOCK / 2; st > 0; st >>= 1) { if (tid < st) s_part[tid] += s_part[tid + st]; __syncthreads(); }
-  const uint64_t total = s_part[0];
-  __syncthreads();
-  if (tid == 0) s_last = atomicAdd(D.ticket, 1u) == n_regions - 1u ? 1u : 0u;      // (this block has read every count)
-  // the region's sections: (offset, items)
   const uint32_t n_tail = fused ? counts[V2_L_COUNTS * region + V2_L_RING] : min(counts[V2_L_COUNTS * region + V2_L_TAIL], tcap);
   const uint32_t n_e = min(counts[V2_L_COUNTS * region + V2_L_E], ecap), n_c = min(counts[V2_L_COUNTS * region + V2_L_C], ccap);
-  const uint32_t sec_off[4] = {0u, S.e_off, S.c_off, S.late_off};
-  const uint32_t sec_n[4] = {n_tail, n_e, n_c, min(n_late, S.late_cap)};
+  const uint32_t c0 = n_tail, c1 = c0 + n_e, c2 = c1 + n_c, n_items = c2 + min(n_late, S.late_cap);
   const uint64_t blk_lo = (uint64_t)region * S.per_block;
-  const uint2 *items = D.items + (size_t)region * S.stride;
-  const uint8_t *hi = D.hi + (size_t)region * S.stride;
-  for (int sc = 0; sc < 4; sc++)
-    for (uint32_t i = (uint32_t)tid; i < sec_n[sc]; i += V2_PLACE_BLOCK) {
-      const uint32_t r = items[sec_off[sc] + i].x;
-      if (r != V2_SINK_EMPTY) { const uint32_t k = r - (uint32_t)blk_lo; atomicOr(&bm[k >> 5], 1u << (k & 31u)); }
-    }
+  const uint2 *items = S.items + (size_t)region * S.stride;
+  auto addr = [&](const uint32_t f) -> uint32_t {
+    return f < c0 ? f : (f < c1 ? S.e_off + (f - c0) : (f < c2 ? S.c_off + (f - c1) : S.late_off + (f - c2)));
+  };
+  // A thread's first V2_PLACE_KEEP items stay in registers between the two passes, their loads in flight together (one load at
+  // a time, each behind the one before, cost the kernel 34 us for a 10 M-read step: eighteen round trips to the L2 per pass);
+  // what a larger region holds beyond them is read twice.  The loads go first: the counts' sums below run under them.
+  constexpr int KEEP = V2_PLACE_KEEP;
+  uint2 it[KEEP];
+#pragma unroll
+  for (int k = 0; k < KEEP; k++) {
+    const uint32_t f = (uint32_t)tid + (uint32_t)k * V2_PLACE_BLOCK;
+    it[k] = make_uint2(0u, V2_SINK_EMPTY);
+    if (f < n_items) it[k] = items[addr(f)];
+  }
+  // decombined reads of the regions in front, and of all
+  uint32_t before = 0, all = 0;
+  for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) { const uint32_t h = S.hits[q]; all += h; if (q < region) before += h; }
+  for (uint32_t i = (uint32_t)tid; i < wpr; i += V2_PLACE_BLOCK) bm[i] = 0u;
+  const uint64_t base = v2_block_sum(before, s16, tid);
+  const uint64_t total = v2_block_sum(all, s16, tid);
+  if (tid == 0) s_last = atomicAdd(D.ticket, 1u) == n_regions - 1u ? 1u : 0u;      // (this block has read every count)
+  auto mark = [&](const uint32_t y) { if (y != V2_SINK_EMPTY) { const uint32_t k = y & 0xFFFFFFu; atomicOr(&bm[k >> 5], 1u << (k & 31u)); } };
+#pragma unroll
+  for (int k = 0; k < KEEP; k++) mark(it[k].y);
+  for (uint32_t f = (uint32_t)tid + (uint32_t)KEEP * V2_PLACE_BLOCK; f < n_items; f += V2_PLACE_BLOCK) mark(items[addr(f)].y);
   __syncthreads();
   // exclusive prefix of the words' populations: a run of words per thread, then the runs
   const uint32_t per = (wpr + V2_PLACE_BLOCK - 1) / V2_PLACE_BLOCK;
   uint32_t run = 0;
   for (uint32_t i = (uint32_t)tid * per; i < min(((uint32_t)tid + 1u) * per, wpr); i++) run += (uint32_t)__popc(bm[i]);
-  s_part[tid] = run;
-  __syncthreads();
-  for (int st = 1; st < V2_PLACE_BLOCK; st <<= 1) {
-    const uint32_t v = tid >= st ? s_part[tid - st] : 0u;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t acc = s_part[tid] - run;
+  uint32_t acc = v2_block_exclusive(run, s16, tid);
   for (uint32_t i = (uint32_t)tid * per; i < min(((uint32_t)tid + 1u) * per, wpr); i++) { pre[i] = acc; acc += (uint32_t)__popc(bm[i]); }
   __syncthreads();
   // the tuples, in read order
   const uint64_t bm_bytes = ((n_slots + 63) / 64) * 8;
   uint32_t *plane_a = reinterpret_cast<uint32_t *>(msg + bm_bytes);
   uint8_t *plane_b = msg + bm_bytes + total * 4;
-  for (int sc = 0; sc < 4; sc++)
-    for (uint32_t i = (uint32_t)tid; i < sec_n[sc]; i += V2_PLACE_BLOCK) {
-      const uint2 it = items[sec_off[sc] + i];
-      if (it.x == V2_SINK_EMPTY) continue;
-      const uint32_t k = it.x - (uint32_t)blk_lo;
-      const uint64_t at = base + pre[k >> 5] + (uint32_t)__popc(bm[k >> 5] & ((1u << (k & 31u)) - 1u));
-      plane_a[at] = it.y;
-      if (hi_bytes) plane_b[at] = hi[sec_off[sc] + i];
+  const uint32_t mine = S.hits[region];
+  const bool staged = mine <= hcap;
+  auto place = [&](const uint2 v) {
+    if (v.y == V2_SINK_EMPTY) return;
+    const uint32_t k = v.y & 0xFFFFFFu;
+    const uint32_t rank = pre[k >> 5] + (uint32_t)__popc(bm[k >> 5] & ((1u << (k & 31u)) - 1u));
+    if (staged) {
+      if (rank < hcap) { stage_a[rank] = v.x; stage_b[rank] = (uint8_t)(v.y >> 24); }      // (rank < the region's count by construction)
+    } else {
+      plane_a[base + rank] = v.x;
+      if (hi_bytes) plane_b[base + rank] = (uint8_t)(v.y >> 24);
     }
+  };
+#pragma unroll
+  for (int k = 0; k < KEEP; k++) place(it[k]);
+  for (uint32_t f = (uint32_t)tid + (uint32_t)KEEP * V2_PLACE_BLOCK; f < n_items; f += V2_PLACE_BLOCK) place(items[addr(f)]);
+  if (staged) {
+    __syncthreads();
+    for (uint32_t i = (uint32_t)tid; i < mine; i += V2_PLACE_BLOCK) plane_a[base + i] = stage_a[i];
+    if (hi_bytes)
+      for (uint32_t i = (uint32_t)tid; i < mine; i += V2_PLACE_BLOCK) plane_b[base + i] = stage_b[i];
+  }
   // the region's words of the bitmap (pairs of LDS words), and — the last region's block — the words behind the batch's reads
   uint64_t *out_bm = reinterpret_cast<uint64_t *>(msg);
   const uint64_t w_lo = blk_lo >> 6, w_all = bm_bytes / 8;
@@ -1404,7 +1449,7 @@ __global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCa
   if (region == 0 && tid == 0) *d_total = total;
   if (tid == 0) D.late[region] = 0u;
   if (s_last) {      // every block has its offsets: the counts are zero again for the next call
-    for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) D.hits[q] = 0u;
+    for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) S.hits[q] = 0u;
     if (tid == 0) *D.ticket = 0u;
   }
 }
@@ -1462,6 +1507,17 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   auto kr = o ? rescue2_kernel<UNIFORM, NW, 1> : rescue2_kernel<UNIFORM, NW, 0>;
   auto kf = o ? finish2_kernel<UNIFORM, NW, 1> : finish2_kernel<UNIFORM, NW, 0>;
   auto kf0 = o ? finish2_kernel<UNIFORM, NW, 1, false> : finish2_kernel<UNIFORM, NW, 0, false>;      // ... without the tail role's code
+  // the kernels that also serve a tuple sink (the 150-nt shapes only; other shapes' calls compact their records)
+  constexpr bool CAN_SINK = NW == 10;
+  auto ks_sink = ks;
+  auto kf_sink = kf, kf0_sink = kf0;
+  if constexpr (CAN_SINK) {
+    kf_sink = o ? finish2_kernel<UNIFORM, NW, 1, true, true> : finish2_kernel<UNIFORM, NW, 0, true, true>;
+    kf0_sink = o ? finish2_kernel<UNIFORM, NW, 1, false, true> : finish2_kernel<UNIFORM, NW, 0, false, true>;
+    if constexpr (CAN_FUSE) {
+      if (ring_batches) ks_sink = o ? scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1, true> : scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0, true>;
+    }
+  }
   auto kl = o ? left2_kernel<UNIFORM, NW, 1> : left2_kernel<UNIFORM, NW, 0>;
   static bool seen[64];
   hipError_t e;
@@ -1486,6 +1542,18 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    if constexpr (CAN_SINK) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf_sink), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf0_sink), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      if (e != hipSuccess) return e;
+      if constexpr (CAN_FUSE) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+    }
     attributes_set_on_device(seen);
   }
   if (B.n_reads == 0) return hipSuccess;       // (the tallies stay zero; the list kernel hands them over)
@@ -1521,16 +1589,17 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // no profiling switch, and room: a slab per region with a section per list and one for the late items, a region's bitmap and
   // its ranks in the place kernel's LDS.
   V2SinkCall S{};
-  if (sink && P.sink.dev && finish && !separate && !retry && !(cfg.flags & DCRX_F_PROFILE_MASK)) {
+  if (CAN_SINK && sink && P.sink.dev && finish && !separate && !retry && !(cfg.flags & DCRX_F_PROFILE_MASK)) {
     const uint64_t stride = (uint64_t)Q.tcap + Q.ecap + Q.scap / 2 + pb128;
-    if (n_regions <= P.sink.regions_cap && stride * n_regions <= P.sink.items_cap && stride < (1ull << 32) && per_block / 32 * 8 <= 144u * 1024u) {
-      S.dev = P.sink.dev; S.stride = (uint32_t)stride; S.e_off = Q.tcap; S.c_off = Q.tcap + Q.ecap; S.late_off = Q.tcap + Q.ecap + Q.scap / 2;
+    if (n_regions <= P.sink.regions_cap && stride * n_regions <= P.sink.items_cap && stride < (1ull << 32) && per_block / 32 * 8 <= 144u * 1024u &&
+        per_block < 0xFFFFFFull) {
+      S.dev = P.sink.dev; S.items = P.sink.items; S.hits = P.sink.hits; S.stride = (uint32_t)stride; S.e_off = Q.tcap; S.c_off = Q.tcap + Q.ecap; S.late_off = Q.tcap + Q.ecap + Q.scap / 2;
       S.late_cap = (uint32_t)pb128; S.per_block = (uint32_t)per_block; S.wpack = P.sink.wpack;
       sink->S = S; sink->n_regions = n_regions; sink->tcap = Q.tcap; sink->ecap = Q.ecap; sink->ccap = Q.scap / 2; sink->fused = ring_batches ? 1u : 0u;
       sink->counts = Q.counts;
     }
   }
-  hipExtLaunchKernelGGL(ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
+  hipExtLaunchKernelGGL(S.dev ? ks_sink : ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
                         d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches, S);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -1559,7 +1628,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
     A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables; A.S = S;
     if (!separate) {
-      hipLaunchKernelGGL(ring_batches ? kf0 : kf, dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
+      hipLaunchKernelGGL(S.dev ? (ring_batches ? kf0_sink : kf_sink) : (ring_batches ? kf0 : kf), dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     } else {
@@ -1641,9 +1710,13 @@ hipError_t launch_v2_place(const LaunchPlan &P, const V2SinkLaunch &K, uint64_t 
     if (e != hipSuccess) return e;
     attributes_set_on_device(seen);
   }
-  const uint32_t lds = (K.S.per_block / 32u) * 8u;
+  // LDS: the region's bitmap and its ranks, then room to stage its tuples (5 bytes each) for whole-line stores: as many as fit
+  const uint32_t words = (K.S.per_block / 32u) * 2u;
+  static const int hcap_forced = [] { const char *e = getenv("DCRX_DEBUG_PLACE_HCAP"); return e ? atoi(e) : -1; }();      // (tests: the path of regions whose tuples do not fit)
+  const uint32_t hcap = hcap_forced >= 0 ? ((uint32_t)hcap_forced & ~3u) : (std::min<uint32_t>(K.S.per_block, (150u * 1024u - words * 4u) / 5u) & ~3u);
+  const uint32_t lds = words * 4u + hcap * 5u;
   hipExtLaunchKernelGGL(v2_place_kernel, dim3(K.n_regions), dim3(V2_PLACE_BLOCK), lds, s, nullptr, ev_stop, 0, K.S, K.counts, K.n_regions, K.tcap, K.ecap,
-                        K.ccap, K.fused, (uint64_t)n_reads, P.sink.n_slots, P.sink.msg, P.sink.bytes - 4u, P.sink.d_total);
+                        K.ccap, K.fused, (uint64_t)n_reads, P.sink.n_slots, P.sink.msg, P.sink.bytes - 4u, P.sink.d_total, hcap);
   return hipGetLastError();
 }
 // items of a sink's slabs for batches of up to max_reads reads: per region the three lists' capacities and as many late slots

@@ -21,9 +21,6 @@ struct TupleLayoutDev {
 // The tuple sink of a handle (dcrx_sink_device.h).  V2SinkDev lives in device memory and stays as it is while the sink is on;
 // V2SinkCall travels with a launch (dev == nullptr: no sink).
 struct V2SinkDev {
-  uint2 *items;                // [regions][stride]: read index (V2_SINK_EMPTY: none) | the tuple's low word
-  uint8_t *hi;                 // [regions][stride]: the tuple's bits 32-39
-  uint32_t *hits;              // [regions] decombined reads (zero between calls)
   uint32_t *late;              // [regions] items of the late section (zero between calls)
   uint32_t *ticket;            // blocks of the place kernel that have read the counts (zero between calls)
   const uint8_t *j_tag_len;
@@ -31,6 +28,8 @@ struct V2SinkDev {
 };
 struct V2SinkCall {
   const V2SinkDev *dev;
+  uint2 *items;                // [regions][stride]: the tuple's low word | the read's index inside its region (24 bits; V2_SINK_EMPTY: no tuple) and the tuple's bits 32-39
+  uint32_t *hits;              // [regions] decombined reads (zero between calls)
   uint32_t stride;             // items of a region's slab: sections tail (at 0), E, C, late
   uint32_t e_off, c_off, late_off, late_cap;
   uint32_t per_block;          // reads of a region
@@ -39,6 +38,7 @@ struct V2SinkCall {
 // what a launch is asked to leave in the sink, and whether it did (else the caller compacts the records)
 struct V2SinkJob {
   const V2SinkDev *dev = nullptr;
+  uint2 *items = nullptr; uint32_t *hits = nullptr;
   uint64_t items_cap = 0;      // items allocated
   uint32_t regions_cap = 0;    // regions the counters hold
   uint32_t wpack = 0, bytes = 0;

@@ -3,8 +3,8 @@
 // (bitmap | low words | high bytes, in read order: dcrx_compact_hits_narrow_device's) is put together from ~40 MB of items
 // instead of a second and third pass over the batch's 16-byte records.
 //
-//   items   per region of the scan (a scan block's range of reads) one slab of 8-byte items (read index | tuple's low word) and
-//           a byte per item for the tuple's bits 32-39, in four sections:
+//   items   per region of the scan (a scan block's range of reads) one slab of 8-byte items (the tuple's low word | the read's
+//           index inside the region, 24 bits, and the tuple's bits 32-39), in four sections:
 //             tail   slot = the tail entry's place in the block's ring (fused scan) or in the region's tail list
 //             E, C   slot = the event entry's place in the region's list
 //             late   what the general form, the left list's polling wave and the list kernel decombine: slots drawn with
@@ -22,7 +22,7 @@
 
 namespace dcrx {
 
-constexpr uint32_t V2_SINK_EMPTY = 0xFFFFFFFFu;      // an item's read index when its read did not decombine
+constexpr uint32_t V2_SINK_EMPTY = 0xFFFFFFFFu;      // an item's second word when its read did not decombine (a region holds fewer than 2^24 - 1 reads)
 
 #ifdef __HIPCC__
 // the narrow tuple of include/dcrx.h from a record's fields; wpack: w_v | w_j << 5 | w_vdel << 10 | w_jdel << 15 | w_pos << 20
@@ -43,6 +43,31 @@ __device__ __forceinline__ uint64_t sink_tuple(const dcrx_record_t &r, const uin
   return t;
 }
 
+// the same from what a lean role has in hand: no table is read (short_end: the J half1 rescue found the J gene and the split is
+// not the tag's middle; a tag of the lean forms' classes has the class's length)
+__device__ __forceinline__ uint64_t sink_tuple_lean(const dcrx_record_t &r, const uint32_t wpack, const bool short_end) {
+#ifdef DCRX_EXP_SINK_NOTUPLE
+  return (uint64_t)r.v | ((uint64_t)r.j << 16);
+#endif
+  const uint32_t w_v = wpack & 31u, w_j = (wpack >> 5) & 31u, w_vdel = (wpack >> 10) & 31u, w_jdel = (wpack >> 15) & 31u, w_pos = (wpack >> 20) & 31u;
+  // (the widths are scalars; where everything below j_end fits one word — 29 bits for human beta — one 64-bit shift is all)
+  const uint32_t w_lo = w_v + w_j + w_vdel + w_jdel + w_pos;
+  if (w_lo <= 32u) {
+    const uint32_t lo = (uint32_t)r.v | ((uint32_t)r.j << w_v) | ((uint32_t)r.vdel << (w_v + w_j)) | ((uint32_t)r.jdel << (w_v + w_j + w_vdel)) |
+                        (w_pos ? ((uint32_t)r.v_start << ((w_v + w_j + w_vdel + w_jdel) & 31u)) : 0u);
+    const uint32_t hi = (uint32_t)r.j_end | ((short_end ? 1u : 0u) << w_pos) | ((uint32_t)(r.frame & 1u) << (w_pos + 1u));
+    return (uint64_t)lo | ((uint64_t)hi << w_lo);
+  }
+  uint32_t sh = w_v;
+  uint64_t t = r.v;
+  t |= (uint64_t)r.j << sh; sh += w_j;
+  t |= (uint64_t)r.vdel << sh; sh += w_vdel;
+  t |= (uint64_t)r.jdel << sh; sh += w_jdel;
+  t |= (uint64_t)r.v_start << sh; sh += w_pos;
+  t |= (uint64_t)((uint32_t)r.j_end | ((short_end ? 1u : 0u) << w_pos) | ((uint32_t)(r.frame & 1u) << (w_pos + 1u))) << sh;
+  return t;
+}
+
 // A lean role's item: slot `slot` of the section at `section_off` of `region` (every live lane writes; `hit` lanes the tuple).
 // hits_lds: the block's own tally in LDS (the fused scan: block == region), else the region's count in memory.
 __device__ __forceinline__ void sink_put(const V2SinkCall &S, const uint32_t region, const uint32_t section_off, const uint32_t slot,
@@ -52,12 +77,16 @@ __device__ __forceinline__ void sink_put(const V2SinkCall &S, const uint32_t reg
   if (mh && lane == (int)__builtin_ctzll(mh)) {
     const uint32_t k = (uint32_t)__popcll(mh);
     if (hits_lds) (void)__hip_atomic_fetch_add(hits_lds, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else (void)__hip_atomic_fetch_add(S.dev->hits + region, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else (void)__hip_atomic_fetch_add(S.hits + region, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (live) {
     const size_t at = (size_t)region * S.stride + section_off + slot;
-    S.dev->items[at] = make_uint2(hit ? r : V2_SINK_EMPTY, (uint32_t)tuple);
-    S.dev->hi[at] = (uint8_t)(tuple >> 32);
+    const uint32_t rel = r - region * S.per_block;
+#ifndef DCRX_EXP_SINK_NOSTORE      // (experiment builds, tools/: what the item's store costs a lean loop)
+    S.items[at] = make_uint2((uint32_t)tuple, hit ? (rel | ((uint32_t)(tuple >> 32) << 24)) : V2_SINK_EMPTY);      // (one 8-byte store; the place kernel reads it back out of the L2)
+#else
+    if (at == 0xFFFFFFFFFFFFull) S.items[at] = make_uint2((uint32_t)tuple, rel);
+#endif
   }
 }
 
@@ -75,12 +104,11 @@ __device__ __forceinline__ void sink_late(const V2SinkCall &S, const dcrx_record
   const V2SinkDev *dev = S.dev;
   const uint64_t t = sink_tuple(rec, S.wpack, dev->j_tag_len, dev->j_jump);
   const uint32_t region = r / S.per_block;
-  (void)__hip_atomic_fetch_add(dev->hits + region, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_fetch_add(S.hits + region, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t k = atomicAdd(dev->late + region, 1u);
   if (k >= S.late_cap) return;      // (cannot be: the section holds every read of the region)
   const size_t at = (size_t)region * S.stride + S.late_off + k;
-  dev->items[at] = make_uint2(r, (uint32_t)t);
-  dev->hi[at] = (uint8_t)(t >> 32);
+  S.items[at] = make_uint2((uint32_t)t, (r - region * S.per_block) | ((uint32_t)(t >> 32) << 24));
 }
 #endif
 

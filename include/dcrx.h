@@ -346,7 +346,7 @@ int dcrx_compact_hits_narrow_device(dcrx_tables_t *tables, const dcrx_tuple_layo
  * kernels that write the records leave the tuples behind as they go and one short launch behind them puts the message in
  * read order (no pass over the records: the gather of a sharded run costs the step ~2 %, not 12 %); any other launch
  * shape compacts the records behind the call.  The buffers may change from call to call (a sharded run alternates two
- * messages); layout == NULL turns the sink off.  The handle's workspace grows by ~36 bytes per read of its largest batch. */
+ * messages); layout == NULL turns the sink off.  The handle's workspace grows by ~32 bytes per read of its largest batch. */
 int dcrx_set_tuple_sink(dcrx_tables_t *tables, const dcrx_tuple_layout_t *layout, void *d_message, uint64_t n_slots,
                         uint64_t *d_n_hits);
 

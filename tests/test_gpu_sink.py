@@ -133,3 +133,26 @@ def test_empty_batch_leaves_an_empty_message():
     nat.set_tuple_sink(t, None)
     assert int(d_n.to_host(np.uint64, 1)[0]) == 0
     assert not d_msg.to_host(np.uint8, 16 * 8).any()
+
+
+def test_regions_whose_tuples_do_not_fit_the_place_kernels_lds():
+    """The place kernel stages a region's tuples in LDS for whole-line stores; a region with more tuples than fit (launches of
+    100 M reads) writes each tuple to its place.  Forced here through DCRX_DEBUG_PLACE_HCAP (read once: a process of its own)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+from decombinator_amd import _native as nat, synth
+from tests.test_gpu_sink import _tables, _run
+ts = synth.config_tagset(2)
+t = _tables(ts)
+n = 2_000_000
+db = nat.synth_reads_device(t, nat.synth_cfg(seed=61, p_rearranged=0.9), 0, n)
+rec, msg, k = _run(t, db, n, repeats=2)
+assert k > n // 2
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCRX_DEBUG_PLACE_HCAP="1000", PYTHONPATH=root), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
