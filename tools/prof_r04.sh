@@ -38,6 +38,9 @@ done
 timeout 600 python3 $R/bench.py --no-cpu-baseline --reads 100000000 --steps 5 --warmup 1 2>/dev/null | tail -1 > $S/bench_config2_100M_reads_per_step.log
 timeout 600 python3 $R/bench.py --no-cpu-baseline --config 4 --total-reads 1000000000 --warmup 1 2>/dev/null | tail -1 > $S/bench_config4_one_gpu.log
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29618 DCRX_BENCH_FORCE_GATHER=1 timeout 600 python3 $R/bench.py --no-cpu-baseline > $O/forced_gather.out 2> $O/forced_gather.err; grep "^{" $O/forced_gather.out | tail -1 > $S/bench_forced_gather_one_rank.log; tail -3 $O/forced_gather.err
+bash $R/tools/r04_gather_ab.sh ${TAG}_gather > $S/gather_modes_ab.log 2>&1
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29619 DCRX_BENCH_FORCE_GATHER=1 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/trace_g -- python3 $R/bench.py --no-cpu-baseline --steps 20 --no-gather-ab > /dev/null 2>&1
+python3 $R/tools/timeline.py $O/trace_g | tail -6 > $S/timeline_forced_gather_last_step.txt; rm -rf $O/trace_g
 timeout 300 python3 $R/tools/both_rate.py 2>/dev/null | grep ORIENTATION > $S/orientations.log
 timeout 300 python3 $R/tools/pcie.py 2>/dev/null | grep PCIE > $S/pcie.log
 timeout 900 python3 $R/tools/stage.py --reads 4000000 --py-gzip 2>/dev/null | grep STAGE > $S/stage.log
