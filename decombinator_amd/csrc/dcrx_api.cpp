@@ -81,6 +81,10 @@ struct dcrx_tables {
   uint64_t exc_flag_reads = 0;
   uint32_t *d_queue = nullptr;  // [DCRX_QUEUE_HEADER work counters][exc_flag_reads rescue indices][exc_flag_reads general indices]
   void *d_v2_tail = nullptr, *d_v2_events = nullptr, *d_v2_slow = nullptr;
+  // the tail list (a third of the lists' bytes) exists only for handles whose calls keep the tail a role of the finishing launch:
+  // where the scan takes the tail through its ring in LDS nothing is ever stored in it.  Unknown: decided by the first use
+  // (table sizes), corrected by the first launch that turns out to need the list (dcrx_decombine_device allocates it and launches again)
+  int want_tail = -1;
   void *d_v2_left = nullptr;        // the finishing launch's left list
   uint64_t *d_v2_acc = nullptr;     // the v2 kernels' tallies of the call in flight (zero between calls)  // v2 kernels: the per-wave lists between scan and finishing
   hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
@@ -285,13 +289,20 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     // entries; an entry carries the read's packed words, so the size follows the stride
     uint64_t tr = 0, er = 0;
     v2_list_rows(max_reads, stride, t->plan.n_cu, &tr, &er);
-    if (tr > t->plan.v2_tail_rows || er > t->plan.v2_event_rows || v2_slow_rows(max_reads, stride, t->plan.n_cu) > t->plan.v2_slow_rows) {
-      (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts); (void)hipFree(t->d_v2_slow);
-      t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
-      t->plan.v2_tail = nullptr; t->plan.v2_events = nullptr; t->plan.v2_slow = nullptr;
-      t->plan.v2_tail_rows = t->plan.v2_event_rows = t->plan.v2_slow_rows = 0;
-      const uint64_t sr = v2_slow_rows(max_reads, stride, t->plan.n_cu);
+    // (the fused form: 150-nt shapes, pair tables of up to 64 KB — launch_v2; either frame may be asked for)
+    if (t->want_tail < 0)
+      t->want_tail = (stride <= 40 && std::max(t->host.rel.v2[0].trans_bytes, t->host.rel.v2[1].trans_bytes) <= 64u * 1024u) ? 0 : 1;
+    if (t->want_tail && tr > t->plan.v2_tail_rows) {
+      (void)hipFree(t->d_v2_tail); t->d_v2_tail = nullptr; t->plan.v2_tail = nullptr; t->plan.v2_tail_rows = 0;
       HIP_TRY(hipMalloc(&t->d_v2_tail, tr * 16));
+      t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_tail_rows = tr;
+    }
+    if (er > t->plan.v2_event_rows || v2_slow_rows(max_reads, stride, t->plan.n_cu) > t->plan.v2_slow_rows) {
+      (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts); (void)hipFree(t->d_v2_slow);
+      t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
+      t->plan.v2_events = nullptr; t->plan.v2_slow = nullptr;
+      t->plan.v2_event_rows = t->plan.v2_slow_rows = 0;
+      const uint64_t sr = v2_slow_rows(max_reads, stride, t->plan.n_cu);
       HIP_TRY(hipMalloc(&t->d_v2_events, er * 16));
       HIP_TRY(hipMalloc(&t->d_v2_slow, sr * 16));
       HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 16));
@@ -303,9 +314,9 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
         HIP_TRY(hipMemset(t->d_v2_left, 0, left_bytes));
       }
       t->plan.v2_left = reinterpret_cast<uint4 *>(t->d_v2_left);
-      t->plan.v2_tail = reinterpret_cast<uint4 *>(t->d_v2_tail); t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
+      t->plan.v2_events = reinterpret_cast<uint4 *>(t->d_v2_events);
       t->plan.v2_slow = reinterpret_cast<uint4 *>(t->d_v2_slow);
-      t->plan.v2_counts = t->d_v2_counts; t->plan.v2_tail_rows = tr; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;
+      t->plan.v2_counts = t->d_v2_counts; t->plan.v2_event_rows = er; t->plan.v2_slow_rows = sr;
       if (!t->v2_side) {     // the two side streams (tail kernel; general form over list X) and the events that fork them off the caller's stream and join them back
         if (hipStreamCreateWithFlags(&t->v2_side, hipStreamNonBlocking) != hipSuccess) t->v2_side = nullptr;
         if (t->v2_side && hipStreamCreateWithFlags(&t->v2_side2, hipStreamNonBlocking) != hipSuccess) t->v2_side2 = nullptr;
@@ -425,9 +436,19 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
       J.bytes = LD.bytes; J.msg = t->sink_msg; J.n_slots = t->sink_slots; J.d_total = t->sink_total; J.done = &sink_done;
     }
   }
-  const hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
-                                         t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
-                                         (hipStream_t)stream, t->ev_start, t->ev_stop);
+  hipError_t le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER,
+                                   t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads, t->d_queue, d_counters,
+                                   (hipStream_t)stream, t->ev_start, t->ev_stop);
+  if (le == hipErrorNotReady && !t->want_tail) {
+    // the launch keeps the tail a role of the finishing launch (a frame whose table does not fuse, an A/B switch) and the handle
+    // has no tail list yet: nothing was launched — the list is allocated and the call launched again
+    (void)hipGetLastError();
+    t->want_tail = 1;
+    rc = ensure_device(t, b->n_reads, b->stride, (hipStream_t)stream);
+    if (rc) { t->plan.sink = V2SinkJob{}; return rc; }
+    le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER, t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads,
+                          t->d_queue, d_counters, (hipStream_t)stream, t->ev_start, t->ev_stop);
+  }
   t->plan.sink = V2SinkJob{};
   if (le != hipSuccess) { t->ws_dirty = true; return hip_err(le, "launch_decombine"); }
   if (t->sink_on && !sink_done) {

@@ -1463,7 +1463,7 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // The v2 kernels serve one frame per pass: `reverse` and `forward` are one pass, `both` (decombine.py:1005-1010) the reverse
 // frame and then the forward frame for the reads it did not decombine (both frames' tables must fit).
 bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
-  if (!T.v2_ok || !P.v2_tail || !P.v2_events || !P.v2_slow || !P.v2_acc || !P.v2_left) return false;
+  if (!T.v2_ok || !P.v2_events || !P.v2_slow || !P.v2_acc || !P.v2_left) return false;      // (the tail list: only where a launch needs it, launch_v2)
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
   // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
   auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_block_lds<DCRX_V2_NWLONG>(T, o, DCRX_V2_FBLOCK) <= 64u * 1024u; };
@@ -1572,7 +1572,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   Q.tcap = (uint32_t)std::min<uint64_t>(pb128, P.v2_tail_rows / V2Rows<NW>::T / n_regions) & ~63u;      // (whole chunks of 64 slots)
   Q.ecap = (uint32_t)std::min<uint64_t>(pb128, P.v2_event_rows / V2Rows<NW>::E / n_regions) & ~127u;    // (region `sx`, of the same size, holds two lists of whole chunks)
   Q.scap = (uint32_t)std::min<uint64_t>(Q.ecap, P.v2_slow_rows / V2Rows<NW>::E / n_regions) & ~127u;
-  if (Q.tcap < 64 || Q.ecap < 128 || Q.scap < 128) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
+  // (a launch that keeps the tail a role of the finishing launch needs the tail list, which a handle that has fused so far does
+  // not hold: hipErrorNotReady before anything is launched — dcrx_api.cpp allocates it and comes back)
+  if (!ring_batches && (!P.v2_tail || Q.tcap < 64)) return B.n_reads ? hipErrorNotReady : hipSuccess;
+  if (ring_batches) Q.tcap = (uint32_t)pb128 & ~63u;      // (the fused form: the ring's sequence stands in for the list — the tuple sink's tail section is as long)
+  if (Q.ecap < 128 || Q.scap < 128) return hipErrorInvalidValue;      // the workspace was not sized for this batch (dcrx_api.cpp sizes it)
   // Launch order, all on the caller's stream: scan -> finish2 (the lean rescue over lists E and C, the lean tail and the general
   // form over list X as roles of one launch) -> (dcrx_kernels.hip) the list kernel.  A/B and tests: DCRX_F_V2_SIDE_STREAMS puts the
   // tail kernel and the X pass on two side streams of the handle beside the rescue kernel (round 3's shape: forked from the scan

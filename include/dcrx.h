@@ -267,8 +267,10 @@ int dcrx_set_step_events(dcrx_tables_t *tables, void *start_event, void *stop_ev
 /* Uploads the tables to the current device and sizes the per-launch workspace
  * for batches of up to max_reads reads.  Footprint (device memory, owned by the
  * handle until dcrx_tables_destroy): the entry lists between the kernels of a
- * call, ~163 bytes per read at stride <= 40 (150 nt: 1.63 GB for 10 M reads,
- * 16.3 GB for 100 M) and ~310 bytes per read at stride <= 80 (none beyond stride 128: the long form keeps no lists), plus max_reads / 8
+ * call, ~109 bytes per read at stride <= 40 where the scan kernel takes the tail itself (pair tables of up to 64 KB:
+ * 1.09 GB for 10 M reads of 150 nt, 10.9 GB for 100 M) and ~163 where the tail is a role of the finishing launch (the tail
+ * list is allocated by the first call that needs it), ~310 bytes per read at stride <= 80 (none beyond stride 128: the
+ * long form keeps no lists), plus max_reads / 8
  * bytes of exception bitmap, 8 bytes per read of hand-over queues and a few MB
  * of tables.  A later, larger batch grows it (synchronising the device). */
 int dcrx_reserve_device(dcrx_tables_t *tables, uint64_t max_reads);
