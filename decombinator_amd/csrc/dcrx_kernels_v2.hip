@@ -110,6 +110,7 @@ struct V2Lists {
 template <int NW>
 struct V2Rows {
   static constexpr int T = (2 + NW + 3) / 4, E = (1 + 2 * NW + 3) / 4;
+  static_assert((2 + 2 * NW + 3) / 4 == E, "the digest word of an event entry (put_event) lies in the entry's last row");
 };
 // an event list of a region: its rows (entry i in slot i) and its capacity
 struct V2ListRef { uint4 *rows; uint32_t cap; };
@@ -577,12 +578,13 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // bytes, a flag on the last half pair of an odd read: the general form)
       int lst = 0;
       if (what == V2_EVENTS) lst = (exc || bnd) ? V2_L_X : (shape2(d.vf_n, d.jf_n, d.any) == V2_SHAPE_BOTH ? V2_L_C : V2_L_E);
-      auto put_event = [&](uint4 *rows, const uint32_t at) {
-        uint32_t x[1 + 2 * NW];
+      auto put_event = [&](uint4 *rows, const uint32_t at) {      // (behind the words: the digest of the log, for the lean rescue)
+        uint32_t x[2 + 2 * NW];
         x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
 #pragma unroll
         for (int k = 0; k < NW; k++) { x[1 + k] = lg[q][k]; x[1 + NW + k] = w[q][k]; }
-        v2_put_rows<1 + 2 * NW>(rows, 0u, at, x);
+        x[1 + 2 * NW] = rescue2_digest_pack(d);
+        v2_put_rows<2 + 2 * NW>(rows, 0u, at, x);
       };
       bool to_ev = lst == V2_L_E;
       const unsigned long long me0 = __ballot(to_ev);
@@ -916,16 +918,16 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
     const V2ListRef l = v2_list<NW>(Q, which, region);
     const uint32_t en = min(Q.counts[V2_L_COUNTS * region + which], l.cap);
     constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
-    uint32_t x1[1 + 2 * NW];
-    if constexpr (AHEAD) v2_get_rows<1 + 2 * NW>(l.rows, l.cap, 64 * part + lane, 64 * part + lane < en, x1);
+    uint32_t x1[2 + 2 * NW];
+    if constexpr (AHEAD) v2_get_rows<2 + 2 * NW>(l.rows, l.cap, 64 * part + lane, 64 * part + lane < en, x1);
     for (uint32_t first = 64 * part; first < en; first += STEP) {
-      uint32_t x[1 + 2 * NW];
+      uint32_t x[2 + 2 * NW];
       if constexpr (AHEAD) {
 #pragma unroll
-        for (int k = 0; k < 1 + 2 * NW; k++) x[k] = x1[k];
-        v2_get_rows<1 + 2 * NW>(l.rows, l.cap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
+        for (int k = 0; k < 2 + 2 * NW; k++) x[k] = x1[k];
+        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
       } else {
-        v2_get_rows<1 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x);
+        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x);
       }
       uint32_t lg[NW], w[NW];
 #pragma unroll
@@ -942,8 +944,8 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
           rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
-          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
-          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry);
+          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
+          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
           // (j_end of a J found through its first half is the half's start + 2 * split, decombine.py:450-454: errs bit 3)

@@ -1138,29 +1138,41 @@ DCRX_DEV int shape2(const uint32_t vf_n, const uint32_t jf_n, const uint32_t any
 // C: the block's counters (a full-tag walk that fails is final and counts inside the walk); Cdry: a scratch block of
 // counters nobody reads (a half-tag candidate's walk that fails is not final: the read then takes the general form, and
 // nothing may have been counted).
+// what the scan's digest of a flag log (Digest2) says, in one word of the event entry: the lean rescue then skips its own pass
+// over the log's words (a hundred instructions per batch).  RESCUE2_NO_DIGEST: none given.
+constexpr uint32_t RESCUE2_NO_DIGEST = 0xFFFFFFFFu;
+DCRX_DEV uint32_t rescue2_digest_pack(const Digest2 &d) {
+  return min(d.vf_n, 3u) | (min(d.jf_n, 3u) << 2) | ((d.any & 0xFu) << 4) | ((d.vf_pair & 0xFFu) << 8) | ((d.jf_pair & 0xFFu) << 16);
+}
 template <bool REV, int NW, int SHAPE, class WS>
 DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
-                          dcrx_record_t &rec, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry) {
+                          dcrx_record_t &rec, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry,
+                          const uint32_t dg = RESCUE2_NO_DIGEST) {
   const Tail2Tabs &tt = rt.t;
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
   errs = 0;
   if (n < 32 || Lv > 31 || Lj > 31) return R2S(2);
   // ---- what the flag log holds: pairs with a V tag / a J tag (number and the first), any half-tag flag ----
   uint32_t vfn = 0, jfn = 0, any = 0, vf1 = 0xFFFFFFFFu, jf1 = 0xFFFFFFFFu;
+  if (dg != RESCUE2_NO_DIGEST) {         // (wave-uniform: a list's entries all carry one, or none does)
+    vfn = dg & 3u; jfn = (dg >> 2) & 3u; any = (dg >> 4) & 0xFu;
+    vf1 = ((dg >> 8) & 0xFFu) << 2; jf1 = ((dg >> 16) & 0xFFu) << 2;
+  } else {
 #pragma unroll
-  for (int kk = 0; kk < NW; kk++) {
-    const uint32_t l = lg[kk];
-    any |= l;
-    if (SHAPE != V2_SHAPE_BOTH) {
-      const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
-      const uint32_t kb = (uint32_t)kk << 5;
-      vfn += (uint32_t)dcrx_popc64(tv);
-      vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
-      jfn += (uint32_t)dcrx_popc64(tj);
-      jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
+    for (int kk = 0; kk < NW; kk++) {
+      const uint32_t l = lg[kk];
+      any |= l;
+      if (SHAPE != V2_SHAPE_BOTH) {
+        const uint32_t tv = l & 0x11111111u, tj = l & 0x22222222u;
+        const uint32_t kb = (uint32_t)kk << 5;
+        vfn += (uint32_t)dcrx_popc64(tv);
+        vf1 = min(vf1, (tv ? (uint32_t)dcrx_ctz32(tv) : 0xFFFFFFFFu) | kb);
+        jfn += (uint32_t)dcrx_popc64(tj);
+        jf1 = min(jf1, (tj ? (uint32_t)dcrx_ctz32(tj) : 0xFFFFFFFFu) | kb);
+      }
     }
+    any |= any >> 16; any |= any >> 8; any |= any >> 4; any &= 0xFu;
   }
-  any |= any >> 16; any |= any >> 8; any |= any >> 4; any &= 0xFu;
   if ((n & 1) && log_nibble<NW>(lg, n >> 1)) return R2S(3);       // a flag on the half pair at the end of an odd-length read may not stand
   if (vfn > 1 || (vfn == 0 && !(any & V2_F_VH))) return R2S(4);   // (entries of the scan kernel never look like this)
   const bool vfull = vfn == 1;
