@@ -1078,7 +1078,13 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
   while (nz && res == 0) {
     const int kk = REV ? 31 - dcrx_clz32(nz) : dcrx_ctz32(nz);
     nz &= ~(1u << kk);
+#ifdef DCRX_EXP_SWEEP1      // (experiment build, tools/: one flagged pair per sweep — the records are NOT results; what shorter sweeps would buy)
+    nz = 0;
+#endif
     uint32_t m = log_word<NW>(lg, kk) & mask8;
+#ifdef DCRX_EXP_SWEEP1
+    m &= REV ? (0xFu << (28 - 4 * (dcrx_clz32(m) >> 2))) : (0xFu << (4 * (dcrx_ctz32(m) >> 2)));
+#endif
     while (m && res == 0) {
       const int bit = REV ? 31 - dcrx_clz32(m) : dcrx_ctz32(m);
       m &= ~(1u << bit);
