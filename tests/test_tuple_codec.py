@@ -72,3 +72,23 @@ def test_empty_and_all_failed_batches():
     back, idx = c.unpack(msg, 130, 0)
     assert len(back) == 0 and len(idx) == 0
     assert len(c.pack(rec[:0])) == 0
+
+
+def test_tuple_sink_arguments_are_checked_without_a_gpu():
+    """dcrx_set_tuple_sink validates before anything touches a device: a layout that is not the tables' own, null buffers;
+    layout NULL turns the sink off."""
+    import ctypes as C
+    ts = synth.config_tagset(2)
+    t = pu.native_tables(_tsd(ts))
+    c = nat.TupleCodec(t, 150)
+    lib = nat.lib()
+    assert lib.dcrx_set_tuple_sink(t.handle, None, None, 0, None) == 0                    # off: always fine
+    assert lib.dcrx_set_tuple_sink(t.handle, C.byref(c.layout), None, 100, None) != 0      # no buffers
+    other = nat.TupleCodec(pu.native_tables(_tsd(synth.config5_tagsets()[0])), 150)
+    assert (other.layout.w_v, other.layout.w_j) != (c.layout.w_v, c.layout.w_j)
+    assert lib.dcrx_set_tuple_sink(t.handle, C.byref(other.layout), 8, 100, 8) != 0         # another tag set's layout
+    assert b"layout" in lib.dcrx_last_error()
+    bad = nat.TupleLayoutC.from_buffer_copy(bytes(c.layout))
+    bad.bytes = 8
+    assert lib.dcrx_set_tuple_sink(t.handle, C.byref(bad), 8, 100, 8) != 0
+    assert lib.dcrx_set_tuple_sink(None, C.byref(c.layout), 8, 100, 8) != 0
