@@ -1683,7 +1683,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
       unsigned long long t[V2_L_COUNTS] = {0};
       for (uint32_t r = 0; r < n_regions; r++) for (int k = 0; k < V2_L_COUNTS; k++) t[k] += h[(size_t)V2_L_COUNTS * r + k];
-      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu E %llu C %llu X %llu\n", n_regions, t[V2_L_TAIL], t[V2_L_E], t[V2_L_C], t[V2_L_X]);
+      fprintf(stderr, "dcrx v2 lists: regions %u tail %llu E %llu C %llu X %llu; LDS of a finishing block %u bytes (side tables %u, buckets %u), of a scan block %u\n", n_regions,
+              t[V2_L_TAIL], t[V2_L_E], t[V2_L_C], t[V2_L_X], llds, T.lds_image_bytes - T.dfa_bytes, T.v2[o].bk_bytes, scan_lds);
     }
   }
 #ifdef DCRX_SCAN_STAMPS
