@@ -266,7 +266,8 @@ def run_rank(args, device_factory=None):
     seed = CONFIG_SEED[args.config]
     n_rate = float(os.environ["DCRX_BENCH_N_RATE"]) if os.environ.get("DCRX_BENCH_N_RATE") else 0.0005     # experiments only
     sub_rate = float(os.environ["DCRX_BENCH_SUB_RATE"]) if os.environ.get("DCRX_BENCH_SUB_RATE") else (0.02 if args.config == 5 else 0.005)     # experiments only
-    cfg_synth = nat.synth_cfg(seed=seed, read_len=READ_LEN, sub_rate=sub_rate, n_rate=n_rate)
+    p_rearranged = float(os.environ["DCRX_BENCH_P_REARRANGED"]) if os.environ.get("DCRX_BENCH_P_REARRANGED") else 0.45     # experiments only
+    cfg_synth = nat.synth_cfg(seed=seed, read_len=READ_LEN, p_rearranged=p_rearranged, sub_rate=sub_rate, n_rate=n_rate)
 
     # ---- what a rank works through: `batches` = [(first read index, reads)], one per step of a pass ----
     if args.config == 4:

@@ -306,6 +306,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
       HIP_TRY(hipMalloc(&t->d_v2_events, er * 16));
       HIP_TRY(hipMalloc(&t->d_v2_slow, sr * 16));
       HIP_TRY(hipMalloc(&t->d_v2_counts, (size_t)t->plan.n_cu * 16 * 16));
+      HIP_TRY(hipMemset(t->d_v2_counts, 0, (size_t)t->plan.n_cu * 16 * 16));      // (no hint yet of a region's last share of tail reads: scan2_kernel, V2_L_TWHINT)
       if (!t->d_v2_acc) { HIP_TRY(hipMalloc(&t->d_v2_acc, DCRX_N_COUNTERS * 8)); t->ws_dirty = true; }
       t->plan.v2_acc = t->d_v2_acc;
       if (!t->d_v2_left) {      // V2_LEFT_CAP entries of 32-word reads, and a valid word per entry (zero between launches)

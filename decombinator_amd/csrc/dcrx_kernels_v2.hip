@@ -96,7 +96,7 @@ constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block ca
 //                     last half pair: the general form            (half of the region each)
 // (a list that outgrows its room hands the rest to the list kernel; what a lean kernel does not settle it finishes itself,
 // behind the launch's last block: v2_left_push, v2_general_role)
-enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_RING = 4, V2_L_COUNTS = 8 };      // (V2_L_RING: tail entries that went through the fused scan's ring)
+enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_RING = 4, V2_L_TWHINT = 6, V2_L_COUNTS = 8 };      // (V2_L_RING: tail entries that went through the fused scan's ring)
 constexpr uint32_t V2_LEFT_CAP = 1024;      // entries of the left list (a handful per 10 M reads; more go to the list kernel)
 enum { V2_QC_LEFT = 5, V2_QC_DONE = 6 };    // words of the queue header (DCRX_QUEUE_HEADER): entries of the left list, finishing blocks done
 struct V2Lists {
@@ -280,7 +280,7 @@ __device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restr
 // next item; entries of each list (V2_WK_LIST + V2_L_*)
 enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_SINK = 19, V2_WK_FILLED = 32, V2_WK_GEN = 48,
        V2_WK_WORDS = 64 };      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form; V2_WK_SINK: decombined reads of the tail waves, tuple sink)
-// The fused form (FUSE >= 0 = the frame): the block's last four waves — one per SIMD — do not scan: they take the tail entries
+// The fused form (FUSE >= 0 = the frame): the block's last waves — four of the sixteen, give or take (below) — do not scan: they take the tail entries
 // the scanning waves produce, in batches of 64, out of a ring in LDS, and finish them (tail2_fast) while the scan goes on.  The
 // scan is bound by its LDS look-ups, the tail by instruction issue: on one SIMD the two share what neither uses up, where the
 // tail as a kernel of its own ran behind the scan and beside the rescue (bound by issue as well).  The 168 MB of tail entries
@@ -292,10 +292,17 @@ enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLA
 //   CLAIM    next batch to finish (a tail wave takes batch c when FILLED[c % NB] == 64, or what is left once every scanning
 //            wave has signed off in SCANNED)
 //   GEN      per ring batch: times it has been finished — a scanning wave writes into occurrence k of a ring batch when GEN == k
+//   How many waves take the tail is a block's own choice per launch (the roles differ by wave index only): the share of its
+//   region's reads that were tail reads in the handle's PREVIOUS launch (V2_L_TWHINT in the counts, left there by the block
+//   itself) picks 3 to 6 — config 2 (35 % tail reads) runs 3.7 % faster on 5 than on 4 and 10 % slower on 3, the mouse chains
+//   of config 5 (half the reads are the other chain's: 17 %) 2 % faster on 3 and 3 % slower on 5, a library with 70 % rearranged
+//   reads (54 % tail reads) 5 % faster on 6 than on 5 (profiles/r04/tail_waves_*.log); a handle's first launch takes
+//   DCRX_V2_FUSE_TAILWAVES.
 #ifndef DCRX_V2_FUSE_TAILWAVES
 #define DCRX_V2_FUSE_TAILWAVES 4
 #endif
 constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
+constexpr uint32_t V2_TW6_FRAC256 = 115, V2_TW5_FRAC256 = 69, V2_TW4_FRAC256 = 51;      // 45 % / 27 % / 20 % of a region's reads
 constexpr int V2_RING_STRIDE = 15;
 constexpr uint32_t V2_RING_MAXBATCHES = 16;
 
@@ -305,7 +312,7 @@ template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, 
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S) {
+    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S, uint32_t tail_waves) {
   extern __shared__ __align__(64) uint32_t smem[];
   if constexpr (FUSE >= 0 && !SINK) S.dev = nullptr;      // (the scanning form, FUSE < 0, only flushes a count: one kernel for both)
   const int o = FUSE >= 0 ? FUSE : (cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
@@ -357,7 +364,12 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? (uint32_t)V2_FUSE_TAILWAVES : 0u);
+  uint32_t tw = tail_waves;      // (0: the block's own choice, from what its region held last time)
+  if (FUSE >= 0 && tw == 0u) {
+    const uint32_t h = Q.counts[V2_L_COUNTS * blockIdx.x + V2_L_TWHINT];
+    tw = (h >= 2u && h <= 8u) ? h : (uint32_t)V2_FUSE_TAILWAVES;
+  }
+  const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? tw : 0u);
   const size_t region = blockIdx.x;
   if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
    if constexpr (FUSE >= 0) {
@@ -691,6 +703,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     uint32_t c = tid <= V2_L_X ? lds_work[V2_WK_LIST + tid] : 0u;
     c = min(c, tid == V2_L_TAIL ? Q.tcap : (tid == V2_L_E ? Q.ecap : Q.scap / 2));
     if (tid == V2_L_RING) c = lds_work[V2_WK_HEAD];      // (fused form: entries that went through the ring — the tuple sink's tail section)
+    if (tid == V2_L_TWHINT && FUSE >= 0 && blk_hi > blk_lo) {      // the next launch's tail waves, by this one's share of tail reads
+      const uint32_t frac256 = (uint32_t)(((uint64_t)lds_work[V2_WK_HEAD] << 8) / (blk_hi - blk_lo));
+      c = frac256 >= V2_TW6_FRAC256 ? 6u : (frac256 >= V2_TW5_FRAC256 ? 5u : (frac256 >= V2_TW4_FRAC256 ? 4u : 3u));
+    }
     Q.counts[V2_L_COUNTS * region + tid] = c;
   }
   if (S.dev && tid == 0 && lds_work[V2_WK_SINK]) (void)__hip_atomic_fetch_add(S.hits + region, lds_work[V2_WK_SINK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1591,6 +1607,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
   // serves as the fork event as well: one signal on the dispatch, no marker packet)
   const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
+  static const uint32_t tail_waves_forced = [] { const char *e = getenv("DCRX_DEBUG_TAIL_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 8) ? (uint32_t)v : 0u; }();      // (tests, A/B)
   // The call's tuple sink (dcrx_sink_device.h), when this launch serves it: the shipped shape (one finishing launch), one pass,
   // no profiling switch, and room: a slab per region with a section per list and one for the late items, a region's bitmap and
   // its ranks in the place kernel's LDS.
@@ -1606,7 +1623,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
   }
   hipExtLaunchKernelGGL(S.dev ? ks_sink : ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches, S);
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches, S, tail_waves_forced);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (finish) {
