@@ -366,7 +366,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   }
   uint32_t tw = tail_waves;      // (0: the block's own choice, from what its region held last time)
   if (FUSE >= 0 && tw == 0u) {
-    const uint32_t h = Q.counts[V2_L_COUNTS * blockIdx.x + V2_L_TWHINT];
+    const uint32_t h = Q.counts[V2_L_COUNTS * blockIdx.x + V2_L_TWHINT + (o ? 0 : 1)];      // (a hint per frame: the two passes of orientation `both` meet different shares)
     tw = (h >= 2u && h <= 8u) ? h : (uint32_t)V2_FUSE_TAILWAVES;
   }
   const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? tw : 0u);
@@ -703,7 +703,8 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     uint32_t c = tid <= V2_L_X ? lds_work[V2_WK_LIST + tid] : 0u;
     c = min(c, tid == V2_L_TAIL ? Q.tcap : (tid == V2_L_E ? Q.ecap : Q.scap / 2));
     if (tid == V2_L_RING) c = lds_work[V2_WK_HEAD];      // (fused form: entries that went through the ring — the tuple sink's tail section)
-    if (tid == V2_L_TWHINT && FUSE >= 0 && blk_hi > blk_lo) {      // the next launch's tail waves, by this one's share of tail reads
+    if ((tid == V2_L_TWHINT || tid == V2_L_TWHINT + 1) && FUSE >= 0) c = Q.counts[V2_L_COUNTS * region + tid];      // (the other frame's hint stays)
+    if (tid == V2_L_TWHINT + (o ? 0 : 1) && FUSE >= 0 && blk_hi > blk_lo) {      // the next launch's tail waves in this frame, by this one's share of tail reads
       const uint32_t frac256 = (uint32_t)(((uint64_t)lds_work[V2_WK_HEAD] << 8) / (blk_hi - blk_lo));
       c = frac256 >= V2_TW6_FRAC256 ? 6u : (frac256 >= V2_TW5_FRAC256 ? 5u : (frac256 >= V2_TW4_FRAC256 ? 4u : 3u));
     }
