@@ -96,7 +96,7 @@ constexpr uint32_t DCRX_V2_GROUP_MAX = 64;   // regions an event-kernel block ca
 //                     last half pair: the general form            (half of the region each)
 // (a list that outgrows its room hands the rest to the list kernel; what a lean kernel does not settle it finishes itself,
 // behind the launch's last block: v2_left_push, v2_general_role)
-enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_RING = 4, V2_L_TWHINT = 6, V2_L_COUNTS = 8 };      // (V2_L_RING: tail entries that went through the fused scan's ring)
+enum { V2_L_TAIL = 0, V2_L_E = 1, V2_L_C = 2, V2_L_X = 3, V2_L_RING = 4, V2_L_TICKETS = 5, V2_L_TWHINT = 6, V2_L_COUNTS = 8 };      // (V2_L_TICKETS: the lean rescue's batch tickets of lists E (low half) and C (high half): zero after the scan)      // (V2_L_RING: tail entries that went through the fused scan's ring)
 constexpr uint32_t V2_LEFT_CAP = 1024;      // entries of the left list (a handful per 10 M reads; more go to the list kernel)
 enum { V2_QC_LEFT = 5, V2_QC_DONE = 6 };    // words of the queue header (DCRX_QUEUE_HEADER): entries of the left list, finishing blocks done
 struct V2Lists {
@@ -919,30 +919,50 @@ __device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int 
 // so that the waves in flight at one time run the same code.  Leftovers as in the lean tail.
 template <bool UNIFORM_LEN, int NW, int ORI>
 __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2FinishLds &L, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *__restrict__ records,
-                                               const V2Lists &Q, const uint32_t n_regions, const uint32_t split, uint32_t *__restrict__ queue,
+                                               const V2Lists &Q, const uint32_t n_regions, const uint32_t split_ec, uint32_t *__restrict__ queue,
                                                uint32_t *__restrict__ gqueue, const uint32_t qcap, uint32_t *__restrict__ queue_count,
-                                               const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid, const V2SinkCall &S) {
+                                               const DevTables *__restrict__ Tmem, const uint32_t gwave, const uint32_t n_gwaves, const int tid, const V2SinkCall &S,
+                                               uint32_t *__restrict__ tickets) {
   constexpr int o = ORI;
   const Counters C{L.counts}, Cdry{L.dry};
   const LdsWords lw{dcrx_ldsaddr_of(L.strip)};
   uint32_t *strip = L.strip, *lds_counts = L.counts;
   uint32_t *s_left = L.left;
   const int lane = tid & 63;
-  for (uint32_t job = gwave; job < 2u * n_regions * split && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
-    const int which = job < n_regions * split ? V2_L_E : V2_L_C;
-    const uint32_t region = (job / split) % n_regions, part = job % split;
-    const uint32_t STEP = 64 * split;
+  // (`split_ec`: the waves that share a region's list E in its low byte, list C's in the next)
+  const uint32_t split_e = split_ec & 255u, split_c = (split_ec >> 8) ? (split_ec >> 8) : split_e;
+  for (uint32_t job = gwave; job < n_regions * (split_e + split_c) && !(cfg.flags & DCRX_F_PROFILE_NO_EVENTS); job += n_gwaves) {
+    const int which = job < n_regions * split_e ? V2_L_E : V2_L_C;
+    const uint32_t split = which == V2_L_E ? split_e : split_c, jrel = which == V2_L_E ? job : job - n_regions * split_e;
+    const uint32_t region = jrel / split, part = jrel % split;
     const V2ListRef l = v2_list<NW>(Q, which, region);
     const uint32_t en = min(Q.counts[V2_L_COUNTS * region + which], l.cap);
+    // The `split` waves of a region and list take its batches of 64 as they come: a wave's first batch is its own (`part`), every
+    // further one a ticket from the region's counter (tickets only grow: a wave that draws one beyond the list's end holds none
+    // inside it).  Dealt out in fixed strides, 61 batches over 16 waves made 4 for thirteen of them and 3 for the rest, and the
+    // launch took what the 4 take.  Two tickets are in flight per wave: the batch after next is drawn before this one is worked
+    // on, so that its entries can be requested a batch ahead without a wait for the atomic.
+    auto draw = [&]() -> uint32_t {
+      uint32_t t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(tickets + V2_L_COUNTS * region + V2_L_TICKETS, which == V2_L_E ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      return split + (which == V2_L_E ? (t & 0xFFFFu) : (t >> 16));
+    };
     constexpr bool AHEAD = NW <= 10;       // long reads: no look-ahead (the registers do not hold two entries, and a spill reload waits for the loads in flight)
     uint32_t x1[2 + 2 * NW];
-    if constexpr (AHEAD) v2_get_rows<2 + 2 * NW>(l.rows, l.cap, 64 * part + lane, 64 * part + lane < en, x1);
-    for (uint32_t first = 64 * part; first < en; first += STEP) {
+    uint32_t first = 64 * part, next_first = 64 * part + 64 * en + 64;      // (past the end until a ticket says otherwise)
+    if (first < en) next_first = 64 * draw();
+    if constexpr (AHEAD) v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x1);
+    for (; first < en; ) {
       uint32_t x[2 + 2 * NW];
+      // (the ticket of the batch after next: the atomic is in flight during this batch, its result read behind it)
+      const bool more = next_first < en;
+      uint32_t after_raw = 0;
+      if (more && lane == 0) after_raw = __hip_atomic_fetch_add(tickets + V2_L_COUNTS * region + V2_L_TICKETS, which == V2_L_E ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if constexpr (AHEAD) {
 #pragma unroll
         for (int k = 0; k < 2 + 2 * NW; k++) x[k] = x1[k];
-        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + STEP + lane, first + STEP + lane < en, x1);     // the next batch, in flight during this one
+        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, next_first + lane, next_first + lane < en, x1);     // the next batch, in flight during this one
       } else {
         v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x);
       }
@@ -972,6 +992,11 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
       if (S.dev) sink_put(S, region, which == V2_L_E ? S.e_off : S.c_off, first + (uint32_t)lane, first + lane < en, status == DCRX_S_OK, r, tup, lane, nullptr);      // tuple sink
       if (__builtin_expect(status == RESCUE2_SLOW, 0)) v2_note_left(s_left, first + (uint32_t)lane, B, queue, gqueue, qcap, queue_count, r, (x[0] & V2_R_EXC) != 0u);
+      first = next_first;
+      if (more) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_raw);
+        next_first = 64u * (split + (which == V2_L_E ? (t & 0xFFFFu) : (t >> 16)));
+      }
     }
     const uint32_t n_left = min(s_left[0], (uint32_t)V2_LEFT_SLOTS);      // (as in the lean tail)
     if (__builtin_expect(n_left != 0u, 0)) {
@@ -1040,6 +1065,7 @@ __device__ __forceinline__ T *v2_constant(T *p) { return (T *)(__attribute__((ad
 struct V2FinishLocals {      // a role's copy of the launch's arguments (what it does not use is never loaded)
   DevTables T0; BatchDev B; CfgDev cfg; dcrx_record_t *records; V2Lists Q; uint32_t n_regions; V2Roles R;
   uint32_t *queue, *gqueue; uint32_t qcap; uint32_t *queue_count; const DevTables *Tmem; V2SinkCall S;
+  uint32_t *tickets;      // the lists' counts as plain global memory: the lean rescue draws its batch tickets there (V2_L_TICKETS)
 };
 __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, const uint32_t hi) {
   uint32_t slo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo), shi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
@@ -1060,6 +1086,7 @@ __device__ __forceinline__ V2FinishLocals v2_finish_args(const uint32_t lo, cons
   DCRX_GLOBAL(A.gqueue); DCRX_GLOBAL(A.queue_count); DCRX_GLOBAL(A.B.packed); DCRX_GLOBAL(A.B.lens); DCRX_GLOBAL(A.B.exc_read);
   DCRX_GLOBAL(A.B.exc_pos); DCRX_GLOBAL(A.B.exc_chr); DCRX_GLOBAL(A.B.exc_flag); DCRX_GLOBAL(A.T0.image);
 #undef DCRX_GLOBAL
+  A.tickets = v2_global(A.Q.counts);
   A.Tmem = v2_constant(A.Tmem); A.Q.counts = v2_constant(A.Q.counts); A.T0.kw_base = v2_constant(A.T0.kw_base);
   A.S.dev = v2_constant(A.S.dev);      // (the sink's descriptor: nothing of a launch writes it)
   A.S.items = v2_global(A.S.items); A.S.hits = v2_global(A.S.hits);
@@ -1080,7 +1107,7 @@ DCRX_V2_ROLE void v2_rescue_role(const uint32_t vblock_, const uint32_t ka_lo, c
   const Rescue2Tabs rt = rescue2_tabs(A.T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
   constexpr uint32_t WPB = DCRX_V2_FBLOCK / 64;
   v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, A.B, A.cfg, A.records, A.Q, A.n_regions, A.R.rsplit, A.queue, A.gqueue, A.qcap, A.queue_count, A.Tmem,
-                                       vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid, A.S);
+                                       vblock * WPB + (uint32_t)(tid >> 6), A.R.rgrid * WPB, tid, A.S, A.tickets);
 }
 template <bool UNIFORM_LEN, int NW, int ORI, bool SINK>
 DCRX_V2_ROLE void v2_tail_role(const uint32_t vblock_, const uint32_t ka_lo, const uint32_t ka_hi) {
@@ -1261,7 +1288,7 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void rescue2_kernel
   const Rescue2Tabs rt = rescue2_tabs(T0, V, reinterpret_cast<const uint8_t *>(L.side), reinterpret_cast<const uint8_t *>(L.bk), ORI == 1, kw_base);
   __syncthreads();
   v2_rescue_jobs<UNIFORM_LEN, NW, ORI>(rt, L, B, cfg, records, Q, n_regions, split, queue, gqueue, qcap, queue_count, Tmem,
-                                       blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_FBLOCK / 64), tid, V2SinkCall{});
+                                       blockIdx.x * (DCRX_V2_FBLOCK / 64) + (uint32_t)(tid >> 6), gridDim.x * (DCRX_V2_FBLOCK / 64), tid, V2SinkCall{}, Q.counts);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && L.counts[tid]) atomicAdd(&counters[tid], (unsigned long long)L.counts[tid]);
 }
@@ -1630,8 +1657,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (finish) {
     // waves of the finishing roles that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
     // 4096 on each rescue list of a full-size launch
-    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 4096u / n_regions));
-    const uint32_t fgrid = (2u * n_regions * rsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
+    static const uint32_t rescue_waves = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 4096u; }();      // (A/B)
+    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
+    static const uint32_t rescue_waves_c = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
+    const uint32_t fgrid = (n_regions * (rsplit + csplit) + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
     // blocks of a short list's pass that share a region: as a pass of its own (A/B forms) the list's latency is the launch's, and
     // four blocks per region halve it; as a role under the lean rescue one block per region does (its rounds run hidden)
@@ -1647,7 +1677,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t tgrid = (n_regions * tsplit + DCRX_V2_TBLOCK / 64 - 1) / (DCRX_V2_TBLOCK / 64);
     V2Roles R;
     R.xgrid = sgrid; R.rgrid = fgrid; R.tgrid = ring_batches ? 0u : (n_regions * tsplit + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // (fused: the tail list is empty)
-    R.rsplit = rsplit; R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
+    R.rsplit = rsplit | (csplit << 8); R.tsplit = tsplit; R.bsplit = bsplit; R.width = slow_width;
     V2FinishArgs A;
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
     A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables; A.S = S;
@@ -1677,7 +1707,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       if (cfg.flags & DCRX_F_V2_NO_LEAN_RESCUE) {
         for (int which = V2_L_E; which <= V2_L_C; which++) { e = general(s, which, true, nullptr); if (e != hipSuccess) return e; }
       } else {
-        hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit, queue, gqueue, qcap,
+        hipLaunchKernelGGL(kr, dim3(fgrid), dim3(DCRX_V2_FBLOCK), llds, s, T, B, cfg, rec, d_counters, Q, n_regions, rsplit | (csplit << 8), queue, gqueue, qcap,
                            queue_count, P.dev_tables);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
