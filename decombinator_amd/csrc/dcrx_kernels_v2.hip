@@ -1657,8 +1657,15 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if (finish) {
     // waves of the finishing roles that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
     // 4096 on each rescue list of a full-size launch
-    static const uint32_t rescue_waves = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 4096u; }();      // (A/B)
-    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, 8192u / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
+    // (measured, profiles/r04/rescue_waves_*.log, config3_finish_waves_*.log: where the launch also holds the tail role — the
+    // extended sets — 4 096 tail waves and 3 072 rescue waves per list run config 3's step 6 % faster than 8 192 and 4 096: fewer
+    // blocks wait for a slot; where the scan has taken the tail, config 2 would take 3 072 rescue waves (- 2 %) and config 5 loses
+    // 4 % on them: the 4 096 stay there)
+    static const uint32_t rescue_waves_env = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    const uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? 4096u : 3072u);
+    static const uint32_t tail_role_waves_env = [] { const char *e = getenv("DCRX_DEBUG_TAIL_ROLE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    const uint32_t tail_role_waves = tail_role_waves_env ? tail_role_waves_env : (separate ? 8192u : 4096u);
+    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
     static const uint32_t rescue_waves_c = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
     const uint32_t fgrid = (n_regions * (rsplit + csplit) + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
