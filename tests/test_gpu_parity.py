@@ -727,3 +727,19 @@ def test_clustered_exception_bytes_on_the_gpu(orientation):
         orec, ocnt = pu.oracle_records(ot, reads, orientation, allow, 130)
         pu.assert_records_equal(rec, orec, reads, orientation)
         pu.assert_counters_equal(cnt, ocnt)
+
+
+@pytest.mark.gpu
+def test_tail_waves_follow_the_workload_on_one_handle():
+    """The fused scan's blocks choose their tail waves (3 to 6 of 16) from their region's share of tail reads in the handle's
+    previous launch: batches of very different shares through ONE handle, one after the other — each launch runs on the choice
+    the batch before it left — and every batch bit-exact against the oracle, whatever the choice was."""
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    for k, p in enumerate([1.0, 0.0, 0.6, 0.1, 0.9, 0.3, 0.0, 1.0]):
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=300 + k, p_rearranged=p, sub_rate=0.004, n_rate=0.0003), 0, 150_000)
+        reads = nat.unpack_reads(hb)
+        rec, cnt = nat.decombine(t, hb)
+        orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
+        pu.assert_records_equal(rec, orec, reads, f"batch {k} (p_rearranged {p})")
+        pu.assert_counters_equal(cnt, ocnt, f"batch {k}")
