@@ -100,6 +100,7 @@ struct dcrx_tables {
   bool constants_ready = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // around the dominant kernel
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;  // around every launch of a call
+  V2Tune tune[2];                   // the handle's timing of its own finishing launches (launch_v2), per frame
   // the tuple sink (dcrx_set_tuple_sink): where the next calls leave their message, and the kernels' side of it on the device
   bool sink_on = false;
   dcrx_tuple_layout_t sink_layout{};
@@ -117,6 +118,10 @@ static void free_device_state(dcrx_tables *t) {
   (void)hipFree(t->d_dev); t->d_dev = nullptr;
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
+  for (V2Tune &U : t->tune) {
+    if (U.created) for (auto &pair : U.ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+    U = V2Tune{};
+  }
   (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_ctr);
   t->d_sink = nullptr; t->d_sink_items = nullptr; t->d_sink_ctr = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;
   if (t->v2_side) (void)hipStreamDestroy(t->v2_side);
@@ -272,6 +277,7 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     P.qgrid = (uint32_t)prop.multiProcessorCount * q_per_cu;
     P.reserved_cus = t->reserved_cus;
     P.dev_tables = t->d_dev;
+    P.tune = t->tune;
     t->plan = P;
     t->device = dev;
   }

@@ -1662,7 +1662,45 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // blocks wait for a slot; where the scan has taken the tail, config 2 would take 3 072 rescue waves (- 2 %) and config 5 loses
     // 4 % on them: the 4 096 stay there)
     static const uint32_t rescue_waves_env = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
-    const uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? 4096u : 3072u);
+    uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? 4096u : 3072u);
+    // the fused form: the handle's own choice between 4 096 and 3 072 (V2Tune), timed on its first launches of this batch size
+    hipEvent_t tune_start = nullptr, tune_stop = nullptr;
+    static const bool tune_off = getenv("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
+    if (ring_batches && !separate && !rescue_waves_env && !tune_off && P.tune && !retry && !cfg.flags && B.n_reads >= (1u << 20)) {
+      V2Tune &U = P.tune[o];
+      if (U.n_reads != B.n_reads) { U.n_reads = B.n_reads; U.launches = 0; U.choice = 0; }
+      if (U.choice) rescue_waves = U.choice;
+      else {
+        const int k = U.launches - 1;            // sample index of this launch (the first launch of a size is not timed)
+        if (k >= 0 && k < V2Tune::SAMPLES) {
+          if (!U.created) {
+            bool ok = true;
+            for (int i = 0; i < V2Tune::SAMPLES && ok; i++)
+              ok = hipEventCreate(&U.ev[i][0]) == hipSuccess && hipEventCreate(&U.ev[i][1]) == hipSuccess;
+            U.created = ok;
+            if (!ok) { (void)hipGetLastError(); U.choice = 4096u; }
+          }
+          if (U.created) { rescue_waves = (k & 1) ? 3072u : 4096u; tune_start = U.ev[k][0]; tune_stop = U.ev[k][1]; }
+        } else if (k >= V2Tune::SAMPLES && U.created) {
+          bool ready = true;
+          for (int i = 0; i < V2Tune::SAMPLES && ready; i++) ready = hipEventQuery(U.ev[i][1]) == hipSuccess;
+          (void)hipGetLastError();
+          if (ready) {
+            float ms[2] = {0.f, 0.f};
+            bool ok = true;
+            for (int i = 0; i < V2Tune::SAMPLES && ok; i++) {
+              float t = 0.f;
+              ok = hipEventElapsedTime(&t, U.ev[i][0], U.ev[i][1]) == hipSuccess;
+              ms[i & 1] += t;
+            }
+            (void)hipGetLastError();
+            U.choice = (ok && ms[1] < 0.985f * ms[0]) ? 3072u : 4096u;
+            rescue_waves = U.choice;
+          }
+        }
+        U.launches++;
+      }
+    }
     static const uint32_t tail_role_waves_env = [] { const char *e = getenv("DCRX_DEBUG_TAIL_ROLE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t tail_role_waves = tail_role_waves_env ? tail_role_waves_env : (separate ? 8192u : 4096u);
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
@@ -1689,7 +1727,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     A.T0 = T; A.B = B; A.cfg = cfg; A.records = rec; A.counters = d_counters; A.Q = Q; A.n_regions = n_regions; A.R = R;
     A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables; A.S = S;
     if (!separate) {
-      hipLaunchKernelGGL(S.dev ? (ring_batches ? kf0_sink : kf_sink) : (ring_batches ? kf0 : kf), dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, A);
+      hipExtLaunchKernelGGL(S.dev ? (ring_batches ? kf0_sink : kf_sink) : (ring_batches ? kf0 : kf), dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, tune_start,
+                            tune_stop, 0, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     } else {

@@ -46,6 +46,20 @@ struct V2SinkJob {
   bool *done = nullptr;
 };
 
+// A handle's own choice of the waves that share a region's list E in the finishing launch of the fused form (launch_v2): 16 per
+// region suit some tag sets and 12 others by 1-4 % of the step, whatever the reads are, so a handle
+// times its own launches: behind its first launch of a batch size three finishing launches on 16 and three on 12 in turn carry
+// a pair of events on their dispatch (no marker packets), later launches look (hipEventQuery: no waiting) whether the pairs
+// have completed, and the setting whose launches were at least 1.5 % shorter on average stays; else 16.  One per frame.
+struct V2Tune {
+  static constexpr int SAMPLES = 6;
+  uint32_t choice = 0;               // rescue waves once settled (0: not yet)
+  uint64_t n_reads = 0;              // the batch size the samples belong to
+  int launches = 0;                  // launches seen at that batch size
+  hipEvent_t ev[SAMPLES][2] = {};    // (start, stop) of the finishing launch of sample k
+  bool created = false;
+};
+
 struct LaunchPlan {
   uint32_t n_cu;
   uint32_t grid;   // fast kernel (upper bound; capped by measured occupancy at launch)
@@ -68,6 +82,7 @@ struct LaunchPlan {
   // those kernels' own dispatches (hipExtLaunchKernelGGL): a separate event record costs the stream ~10 us of gap each
   hipEvent_t ev_step_start = nullptr, ev_step_stop = nullptr;
   V2SinkJob sink;              // set per call while a tuple sink is on (dcrx_set_tuple_sink)
+  V2Tune *tune = nullptr;      // [2]: per frame (the handle owns them)
 };
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,
