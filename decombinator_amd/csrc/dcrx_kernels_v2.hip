@@ -1696,6 +1696,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
             (void)hipGetLastError();
             U.choice = (ok && ms[1] < 0.985f * ms[0]) ? 3072u : 4096u;
             rescue_waves = U.choice;
+            static const bool say = getenv("DCRX_DEBUG_TUNE") != nullptr;
+            if (say) fprintf(stderr, "dcrx tune: finishing launches of %llu reads, frame %d: %.1f us on 4096 rescue waves, %.1f on 3072 -> %u (launch %d)\n",
+                             (unsigned long long)B.n_reads, o, 1e3f * ms[0] / (V2Tune::SAMPLES / 2), 1e3f * ms[1] / (V2Tune::SAMPLES / 2), U.choice, U.launches);
           }
         }
         U.launches++;

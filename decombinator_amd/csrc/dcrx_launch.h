@@ -48,11 +48,11 @@ struct V2SinkJob {
 
 // A handle's own choice of the waves that share a region's list E in the finishing launch of the fused form (launch_v2): 16 per
 // region suit some tag sets and 12 others by 1-4 % of the step, whatever the reads are, so a handle
-// times its own launches: behind its first launch of a batch size three finishing launches on 16 and three on 12 in turn carry
+// times its own launches: behind its first launch of a batch size two finishing launches on 16 and two on 12 in turn carry
 // a pair of events on their dispatch (no marker packets), later launches look (hipEventQuery: no waiting) whether the pairs
 // have completed, and the setting whose launches were at least 1.5 % shorter on average stays; else 16.  One per frame.
 struct V2Tune {
-  static constexpr int SAMPLES = 6;
+  static constexpr int SAMPLES = 4;      // (two per setting, in turn: with the first launch they fit the five warm-up launches a caller commonly makes)
   uint32_t choice = 0;               // rescue waves once settled (0: not yet)
   uint64_t n_reads = 0;              // the batch size the samples belong to
   int launches = 0;                  // launches seen at that batch size
