@@ -344,8 +344,11 @@ def run_rank(args, device_factory=None):
     if elapsed_nogather is not None:
         elapsed_nogather = max_over_ranks(elapsed_nogather)
     step_ms, kern_ms = device.event_times(events, timed)
+    if os.environ.get("DCRX_BENCH_DUMP_COUNTERS") == "1" and not dry:      # (instrumented builds of the library, tools/: the raw counter block of the last step)
+        print("counters", [int(x) for x in device.d_cnts[-1].cpu().numpy().astype(np.uint64)], file=sys.stderr)
     n_hits, n_read = device.totals()
-    assert args.cfg_flags or n_read == device.expected_read_count(), (n_read, device.expected_read_count())
+    # (DCRX_BENCH_NO_CHECK=1: experiment builds of the library that leave work out, tools/)
+    assert args.cfg_flags or os.environ.get("DCRX_BENCH_NO_CHECK") == "1" or n_read == device.expected_read_count(), (n_read, device.expected_read_count())
     if gather is not None and os.environ.get("DCRX_BENCH_NO_GATHER_CHECK") != "1":      # (experiment builds of the library: tools/r04_sink_exp.sh)
         gather.check(device.last_step_hits())
     names = [None] * world

@@ -21,6 +21,7 @@ DCRX_DEV void dcrx_atomic_inc(uint32_t *p) { atomicAdd(p, 1u); }
 DCRX_DEV int dcrx_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }
 DCRX_DEV int dcrx_clz64(uint64_t v) { return __clzll((long long)v); }
 DCRX_DEV int dcrx_popc64(uint64_t v) { return __popcll((unsigned long long)v); }
+DCRX_DEV int dcrx_popc32(uint32_t v) { return __popc(v); }
 DCRX_DEV int dcrx_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
 DCRX_DEV int dcrx_clz32(uint32_t v) { return __clz((int)v); }
 // (byte BYTE of w) & mask in one VALU op (SDWA source-byte select)
@@ -80,6 +81,7 @@ inline void dcrx_atomic_inc(uint32_t *p) { ++*p; }
 inline int dcrx_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 inline int dcrx_clz64(uint64_t v) { return __builtin_clzll(v); }
 inline int dcrx_popc64(uint64_t v) { return __builtin_popcountll(v); }
+inline int dcrx_popc32(uint32_t v) { return __builtin_popcount(v); }
 inline int dcrx_ctz32(uint32_t v) { return __builtin_ctz(v); }
 inline int dcrx_clz32(uint32_t v) { return __builtin_clz(v); }
 template <int BYTE>

@@ -70,6 +70,9 @@ constexpr int DCRX_V2_FBLOCK = 256;
 #else
 #define DCRX_STORE_SCAN dcrx_store_record
 #endif
+#ifndef DCRX_V2_LOOP_PRIO
+#define DCRX_V2_LOOP_PRIO 2   /* s_setprio of a scanning wave inside scan2() (0: none; A/B) */
+#endif
 #ifndef DCRX_V2_FULL_LINE_RECORDS
 #define DCRX_V2_FULL_LINE_RECORDS 1   /* the scan kernel writes a record for every read (a placeholder where a later kernel settles it): whole lines leave the wave; A/B: 0.545 against 0.554 ms per step */
 #endif
@@ -502,7 +505,22 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #ifdef DCRX_SCAN_STAMPS
     const unsigned long long st0 = __builtin_readcyclecounter();
 #endif
+    // (the look-up loop is bound by the LDS; what a wave does between two scans — digest, pushes, records — is bound by
+    // issue: a wave inside the loop goes first on its SIMD, so that the block's look-ups stay in flight: - 2 % of the step)
+#if DCRX_V2_LOOP_PRIO
+    __builtin_amdgcn_s_setprio(DCRX_V2_LOOP_PRIO);
+#endif
+#ifdef DCRX_EXP_NOLOOP      // (experiment build, tools/: no look-up at all — what the rest of a scanning wave's work takes; the records are NOT results)
+#pragma unroll
+    for (int q = 0; q < RPL; q++)
+#pragma unroll
+      for (int k = 0; k < NW; k++) lg[q][k] = w[q][k] & (w[q][(k + 1) % NW] >> 3) & (w[q][(k + 2) % NW] << 5) & 0x33333333u;
+#else
     scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
+#endif
+#if DCRX_V2_LOOP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef DCRX_SCAN_STAMPS
     {
       uint32_t keep = 0;
@@ -529,7 +547,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       const bool exc = live && ((xm[q] >> lane) & 1ull);
       const int n = UNIFORM_LEN ? (int)B.read_len : (live ? (int)B.lens[r] : 0);
       if (!UNIFORM_LEN) mask_log2<NW>(lg[q], n);
+#if defined(DCRX_EXP_OLD_DIGEST)
       const Digest2 d = digest2<NW>(lg[q]);
+#else
+      const Digest2 d = digest2_lean<NW>(lg[q]);
+#endif
       if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {        // profiling aid: price the scan alone (records are NOT results)
         if (live) {
           __align__(16) dcrx_record_t rec;
@@ -550,7 +572,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // every lane writes: whole lines of records leave the wave (reads that go on get a placeholder, rewritten by the kernel that
       // settles them) — but for the tail reads of the fused form: a tail wave of this block writes their records, and two stores to
       // one address from two waves have no order
+#ifdef DCRX_EXP_POST_NOREC      // (experiment builds, tools/: parts of a scanning wave's work between two scans left out — the records are NOT results)
+      if (false) {
+#else
       if (live && !(FUSE >= 0 && what == V2_TAIL)) {
+#endif
 #else
       if (vnone || vmulti) {
 #endif
@@ -562,7 +588,11 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         DCRX_STORE_SCAN(records + r, rec);
       }
       const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
+#ifdef DCRX_EXP_POST_NOCNT
+      if (false) {
+#else
       if (lane == 0) {
+#endif
         if (mn) atomicAdd(&lds_counts[DCRX_C_NO_VTAGS_FOUND], (uint32_t)__popcll(mn));
         if (mm) atomicAdd(&lds_counts[DCRX_C_MULTIPLE_V_MATCHES], (uint32_t)__popcll(mm));
         if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
@@ -589,7 +619,9 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // event entries: list E (one gene to rescue: nine in ten), or one of the rare lists C (both genes) and X (exception
       // bytes, a flag on the last half pair of an odd read: the general form)
       int lst = 0;
+#ifndef DCRX_EXP_POST_NOEV
       if (what == V2_EVENTS) lst = (exc || bnd) ? V2_L_X : (shape2(d.vf_n, d.jf_n, d.any) == V2_SHAPE_BOTH ? V2_L_C : V2_L_E);
+#endif
       auto put_event = [&](uint4 *rows, const uint32_t at) {      // (behind the words: the digest of the log, for the lean rescue)
         uint32_t x[2 + 2 * NW];
         x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
@@ -1837,6 +1869,10 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
 #define DCRX_V2A(UN, NW_, RP, NA) launch_v2<UN, NW_, RP, NA>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
+#ifdef DCRX_FAST_BUILD      // (experiment builds, tools/build_variant.sh: the benchmark's launch shape only)
+  if (nw10 && uniform && narrow && shape == 2) return DCRX_V2A(true, 10, 2, true);
+  return hipErrorNotSupported;
+#else
   if (nw10) {
     if (uniform) return narrow ? DCRX_V2(true, 10, true) : DCRX_V2(true, 10, false);
     return narrow ? DCRX_V2(false, 10, true) : DCRX_V2(false, 10, false);
@@ -1848,6 +1884,7 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
   // 321-511 nt: one read per lane, no item in flight beside the one in hand (the registers hold one read and its log)
   if (uniform) return narrow ? DCRX_V2X(true, DCRX_V2_NWLONG, 1, true, false) : DCRX_V2X(true, DCRX_V2_NWLONG, 1, false, false);
   return narrow ? DCRX_V2X(false, DCRX_V2_NWLONG, 1, true, false) : DCRX_V2X(false, DCRX_V2_NWLONG, 1, false, false);
+#endif
 #undef DCRX_V2
 #undef DCRX_V2A
 #undef DCRX_V2X

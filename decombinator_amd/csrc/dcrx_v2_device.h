@@ -148,6 +148,32 @@ DCRX_DEV Digest2 digest2(const uint32_t (&lg)[NW]) {
   return d;
 }
 
+// The digest as the scan kernel takes it (same results where they are read: `any`, the two counts, and a gene's pair when
+// exactly one pair holds its tag — tail2_pack, rescue2_digest_pack and classify2 ask for nothing else; with several such pairs
+// the pair fields hold no meaning).  Per word: the OR, and per gene a masked population count weighted with 1 + (word << 12),
+// so that one sum carries the count (low 12 bits) and — one pair — the word it lies in; the pair inside the word comes out of
+// the OR of all words.  7 vector instructions per word where digest2 takes 17: - 3.7 % of config 2's step.
+template <int NW>
+DCRX_DEV Digest2 digest2_lean(const uint32_t (&lg)[NW]) {
+  uint32_t o = 0, av = 0, aj = 0;
+#pragma unroll
+  for (int kk = 0; kk < NW; kk++) {
+    const uint32_t l = lg[kk];
+    const uint32_t k = 1u + ((uint32_t)kk << 12);
+    o |= l;
+    av += (uint32_t)dcrx_popc32(l & 0x11111111u) * k;
+    aj += (uint32_t)dcrx_popc32(l & 0x22222222u) * k;
+  }
+  Digest2 d;
+  const uint32_t ov = o & 0x11111111u, oj = o & 0x22222222u;
+  o |= o >> 16; o |= o >> 8; o |= o >> 4;
+  d.any = o & 0xFu;
+  d.vf_n = av & 0xFFFu; d.jf_n = aj & 0xFFFu;
+  d.vf_pair = ((av >> 12) << 3) | (ov ? ((uint32_t)dcrx_ctz32(ov) >> 2) : 0u);
+  d.jf_pair = ((aj >> 12) << 3) | (oj ? ((uint32_t)dcrx_ctz32(oj) >> 2) : 0u);
+  return d;
+}
+
 // flags of pair index `pair` (any lane-varying index: a select chain over the words)
 template <int NW>
 DCRX_DEV uint32_t log_nibble(const uint32_t (&lg)[NW], const int pair) {

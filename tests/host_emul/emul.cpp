@@ -47,6 +47,7 @@ static void general_one(bool pair_rescue, const DevTables &T, const BatchDev &B,
   else decombine_general16_one<false, UNIFORM, DCRX_NWMAX>(T, B, C, r, e0, nw, CC, records, slot);
 }
 
+constexpr int FAST_DIGEST_MISMATCH = -77;      // (emul_decombine then returns -100)
 static uint64_t g_v2_lean = 0;    // ... of them settled by the lean tail
 extern "C" uint64_t emul_v2_lean(void) { const uint64_t v = g_v2_lean; g_v2_lean = 0; return v; }
 namespace dcrx { unsigned long long g_r2_reasons[32]; unsigned long long g_walk_steps[2]; }
@@ -79,7 +80,13 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
   const int npairs = UNIFORM ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   if (V.narrow) scan2<NW, 1, true>(tab, w, lg, npairs); else scan2<NW, 1, false>(tab, w, lg, npairs);
   if (!UNIFORM) mask_log2<NW>(lg[0], n);
-  const Digest2 d = digest2<NW>(lg[0]);
+  const Digest2 d = digest2_lean<NW>(lg[0]);      // (the scan kernel's digest; the fields anyone reads must be digest2's)
+  {
+    const Digest2 d0 = digest2<NW>(lg[0]);
+    if (d.any != d0.any || d.vf_n != d0.vf_n || d.jf_n != d0.jf_n || (d0.vf_n == 1 && d.vf_pair != d0.vf_pair) ||
+        (d0.jf_n == 1 && d.jf_pair != d0.jf_pair))
+      return FAST_DIGEST_MISMATCH;
+  }
   const uint32_t bnd = (n & 1) ? log_nibble<NW>(lg[0], n >> 1) : 0u;
   int what = classify2(d, bnd);
   if (exc && what != V2_VNONE) what = V2_EVENTS;
