@@ -122,6 +122,17 @@ def spawn_ranks(args, argv, script=None) -> int:
     return 0
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel and host sources of the library (tools/prof_summary_r05.py holds the same function)."""
+    import hashlib
+    d = os.path.join(ROOT, "decombinator_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def host_cpu_report() -> dict:
     """What the CPU baseline ran on: the cores this process may use, the cgroup's CPU quota, the box's count."""
     rep = {"os_cpu_count": os.cpu_count()}
@@ -317,8 +328,15 @@ def run_rank(args, device_factory=None):
         fence(g)
         return time.perf_counter() - t0
 
+    first_launch_ms = None
     for k in range(args.warmup):
+        if k == 0 and not dry:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
+            torch.cuda.synchronize()
+            t_first = time.perf_counter()
         device.step(k, gather, None)
+        if k == 0 and not dry:
+            torch.cuda.synchronize()
+            first_launch_ms = (time.perf_counter() - t_first) * 1e3
     fence(gather)
     # HIP events around the kernels are not free (a step that carries its four costs ~20 us more): every
     # EVENT_EVERY-th step of the timed region carries them, and the device-side averages below are over those steps
@@ -340,6 +358,12 @@ def run_rank(args, device_factory=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # every rank's own time (the job's is the slowest rank's): a first multi-GPU run then shows at a glance which rank lags
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
+    if use_dist:
+        got = [None] * world
+        dist.all_gather_object(got, per_rank_ms[0])
+        per_rank_ms = got
     elapsed = max_over_ranks(elapsed)
     if elapsed_nogather is not None:
         elapsed_nogather = max_over_ranks(elapsed_nogather)
@@ -347,6 +371,9 @@ def run_rank(args, device_factory=None):
     if os.environ.get("DCRX_BENCH_DUMP_COUNTERS") == "1" and not dry:      # (instrumented builds of the library, tools/: the raw counter block of the last step)
         print("counters", [int(x) for x in device.d_cnts[-1].cpu().numpy().astype(np.uint64)], file=sys.stderr)
     n_hits, n_read = device.totals()
+    if not dry:
+        assert device.device_errors() == 0, "a device-side wait timed out (include/dcrx_codes.h, DCRX_C_DEVICE_ERRORS)"
+
     # (DCRX_BENCH_NO_CHECK=1: experiment builds of the library that leave work out, tools/)
     assert args.cfg_flags or os.environ.get("DCRX_BENCH_NO_CHECK") == "1" or n_read == device.expected_read_count(), (n_read, device.expected_read_count())
     if gather is not None and os.environ.get("DCRX_BENCH_NO_GATHER_CHECK") != "1":      # (experiment builds of the library: tools/r04_sink_exp.sh)
@@ -370,7 +397,7 @@ def run_rank(args, device_factory=None):
             "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic", "world_size": world, "per_rank_ms_per_step": per_rank_ms,
             "config": {
                 "workload": {2: "BASELINE configs[1]: synthetic 10M x 150bp human-beta reads, original-like synthetic "
                                 "tag set (60 V / 13 J), 45% rearranged, 0.5% substitutions, orientation reverse",
@@ -402,15 +429,32 @@ def run_rank(args, device_factory=None):
             traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             v2 = bool(info.get("v2_tables")) and not (args.cfg_flags & 64)
+            roofline_lds = None
             if os.path.exists(tpath) and args.config == 2:
+                # (a constant from a profile: quoted only while the sources it was measured on are the tree's — the digest of
+                # decombinator_amd/csrc that tools/prof_summary_r05.py left in the file — else null, not a stale figure)
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == device.kernels_tag(info):
+                    if (tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == device.kernels_tag(info)
+                            and tj.get("csrc_sha16") == csrc_digest()):
                         traffic = tj.get("hbm_bytes_per_step")
                         traffic_source = ("profiles/traffic.json: rocprofv3 --pmc passes of this command on an earlier run (" +
-                                          tj.get("profile", "?") + "), not measured by this run")
+                                          tj.get("profile", "?") + ") of the same kernel sources (csrc_sha16 " + tj["csrc_sha16"] + "), not measured by this run")
+                        roofline_lds = tj.get("roofline_lds")
+                    else:
+                        traffic_source = "profiles/traffic.json was measured on other kernel sources or another workload: not quoted"
                 except Exception:
                     traffic = None
+            # what the timed steps ran on: the handle's own choice for its finishing launches (dcrx_tune_state: settled inside
+            # the warm-up when that has five steps or more; 0 = not settled, the launches ran on 4096) and the scan blocks' choice
+            # of tail waves (per block, from its region's share of tail reads in the launch before: no host-side state to report)
+            line["tune"] = {
+                "rescue_waves": [tb.tune_state(n)["rescue_waves"] for tb in all_tables],
+                "samples_us": [{k: v for k, v in tb.tune_state(n).items() if k.startswith("us_")} for tb in all_tables],
+                "launches_in_size_class": [tb.tune_state(n)["launches"] for tb in all_tables],
+                "tail_waves": "per scan block: 3-6 by its region's share of tail reads in the previous launch (4 on a handle's first launch)",
+                "first_launch_ms": None if first_launch_ms is None else round(first_launch_ms, 3),
+            }
             line["roofline"] = {
                 "bound": "hbm", "kernel": "all launches of a step (dcrx_decombine_device)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -418,6 +462,7 @@ def run_rank(args, device_factory=None):
                 "step_device_ms_avg": round(step_avg_ms, 5), "step_device_ms_min": round(min(step_ms), 5),
                 "dominant_kernel": ("dcrx::scan2_kernel (scan + lean tail fused: the tail entries go through a ring in LDS)" if v2 else "dcrx::decombine_kernel"), "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
                 "dominant_kernel_ms_min": round(min(kern_ms), 5),
+                "roofline_lds": roofline_lds,
                 "events": f"HIP events on {len(timed)} of the {args.steps} timed steps (every {every}th, in turn the step's pair — on its first and last "
                           "dispatch — and the dominant kernel's pair: a step that carries them runs a few % longer, so the device-side averages can exceed ms_per_step)",
             }
@@ -566,6 +611,10 @@ class HipDevice:
 
     def expected_read_count(self):
         return sum(b[1] for b in self.batches) if self.accumulate else self.n
+
+    def device_errors(self):
+        np, nat = self.np, self.nat
+        return sum(int(c.cpu().numpy().astype(np.uint64)[nat.DEVICE_ERRORS]) for c in self.d_cnts)
 
     def last_step_hits(self):
         np, nat = self.np, self.nat

@@ -33,6 +33,8 @@ COUNTER_NAMES = [
     "read_count", "foundj2notj1", "frame_forward",
 ]
 
+DEVICE_ERRORS = 31      # DCRX_C_DEVICE_ERRORS (not a reference counter)
+
 STATUS_NAMES = [
     "OK", "V_MULTI", "V_WALK_FAIL_AT_END", "V_WALK_FAIL", "V_HALF1_EXHAUSTED", "V_HALF2_EXHAUSTED",
     "V_NONE", "J_MULTI", "J_WALK_FAIL", "J_HALF1_EXHAUSTED", "J_HALF2_EXHAUSTED", "J_NONE",
@@ -178,6 +180,10 @@ def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, q
     return rows[:n], offs, cnt
 
 
+class TuneStateC(C.Structure):
+    _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_4096", C.c_float), ("us_3072", C.c_float)]
+
+
 class SynthCfgC(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_rearranged", C.c_float),
                 ("sub_rate", C.c_float), ("n_rate", C.c_float)]
@@ -188,7 +194,7 @@ EXPORTS = [
     "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
     "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_open_range", "dcrx_fastq_lines", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_set_step_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
-    "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus",
+    "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus", "dcrx_tune_state",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
@@ -242,6 +248,7 @@ def lib():
         "dcrx_collapse_front": (C.c_int64, [vp, u64, C.POINTER(CollapseCfgC), vp, u64, vp, vp, i32]),
         "dcrx_spacer_search": (i32, [C.c_char_p, i32, C.c_char_p, i32, vp, vp, i32, C.POINTER(C.c_int32)]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
+        "dcrx_tune_state": (i32, [vp, i32, u64, C.POINTER(TuneStateC)]),
         "dcrx_gzip_open": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
         "dcrx_gzip_write": (i32, [vp, vp, u64]),
         "dcrx_gzip_close": (i32, [vp]),
@@ -330,6 +337,13 @@ class Tables:
                 "equal_len_per_automaton": bool(inf.equal_len_per_automaton), "pair_scan_bytes": inf.pair_scan_bytes,
                 "v2_tables": bool(inf.v2_tables), "v2_states": list(inf.v2_states), "v2_scan_bytes": max(inf.v2_scan_bytes),
                 "max_read_len": inf.max_read_len}
+
+    def tune_state(self, n_reads: int, orientation: str = "reverse") -> dict:
+        """dcrx_tune_state: what the handle has settled for the finishing launches of batches of n_reads' size class."""
+        st = TuneStateC()
+        check(lib().dcrx_tune_state(self._h, ORIENTATIONS[orientation], int(n_reads), C.byref(st)))
+        return {"rescue_waves": int(st.rescue_waves), "launches": int(st.launches), "us_4096": round(float(st.us_4096), 2),
+                "us_3072": round(float(st.us_3072), 2)}
 
     def close(self):
         if self._h is not None:
@@ -679,6 +693,8 @@ def decombine(tables: Tables, batch: PackedBatch, orientation="reverse", allow_n
     b = batch.as_c()
     check(lib().dcrx_decombine(tables.handle, C.byref(cfg), C.byref(b),
                                rec.ctypes.data if batch.n_reads else None, cnt.ctypes.data))
+    if int(cnt[DEVICE_ERRORS]):      # (include/dcrx_codes.h: a wave gave up waiting for another — the records are not complete)
+        raise RuntimeError(f"dcrx_decombine: {int(cnt[DEVICE_ERRORS])} device-side wait(s) timed out; the records of this call are incomplete")
     return rec, cnt
 
 

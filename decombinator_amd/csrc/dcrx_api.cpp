@@ -119,7 +119,8 @@ static void free_device_state(dcrx_tables *t) {
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
   for (V2Tune &U : t->tune) {
-    if (U.created) for (auto &pair : U.ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+    for (V2TuneSlot &K : U.slot)
+      if (K.created) for (auto &pair : K.ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
     U = V2Tune{};
   }
   (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_ctr);
@@ -434,6 +435,11 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
     if (t->sink_slots < b->n_reads) return set_err(DCRX_E_INVALID, "tuple sink: the message holds fewer read slots than the batch has reads");
     rc = layout_dev(t, &t->sink_layout, &LD);
     if (rc) return rc;
+    // (v_start and j_end travel in w_pos bits each: a batch whose reads can be longer than those bits hold would spill into the
+    // neighbouring fields of every tuple)
+    const uint64_t longest = b->lens ? (uint64_t)b->stride * 4u : (uint64_t)b->read_len;
+    if (LD.w_pos < 32 && (longest >> LD.w_pos) != 0)
+      return set_err(DCRX_E_INVALID, "tuple sink: the batch's reads can be longer than the layout's position fields hold (dcrx_tuple_layout's max_read_len)");
     if (t->sink_layout.bits <= 40 && t->host.rel.v2_ok && b->stride <= DCRX_FAST_MAX_STRIDE) {
       rc = ensure_sink(t, b->n_reads, (hipStream_t)stream);
       if (rc) return rc;
@@ -449,8 +455,11 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
   if (le == hipErrorNotReady && !t->want_tail) {
     // the launch keeps the tail a role of the finishing launch (a frame whose table does not fuse, an A/B switch) and the handle
     // has no tail list yet: nothing was launched — the list is allocated and the call launched again
+    // (orientation `both`: the first pass may have run and tallied before the second found its frame without a tail list — the
+    // workspace is zeroed again, on the same stream behind whatever ran, before the call starts over)
     (void)hipGetLastError();
     t->want_tail = 1;
+    t->ws_dirty = true;
     rc = ensure_device(t, b->n_reads, b->stride, (hipStream_t)stream);
     if (rc) { t->plan.sink = V2SinkJob{}; return rc; }
     le = launch_decombine(t->plan, t->dev, B, C, d_records, t->d_queue + DCRX_QUEUE_HEADER, t->d_queue + DCRX_QUEUE_HEADER + t->exc_flag_reads,
@@ -643,6 +652,9 @@ static int decombine_host(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
     HIP_TRY(hipEventRecord(t->hev_out[set], t->hs_out));
   }
   for (uint64_t k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; k++) { rc = drain(k); if (rc) return rc; }
+  // (include/dcrx_codes.h: a wave that gave up waiting for another says so in the call's counters — the records would not be
+  // complete, and this entry, which has the counters in hand, does not return them as if they were)
+  if (counters[DCRX_C_DEVICE_ERRORS]) return set_err(DCRX_E_HIP, "a device-side wait timed out (the fused scan's ring): the records of this call are incomplete");
   return DCRX_OK;
 }
 
@@ -766,6 +778,16 @@ int dcrx_set_tuple_sink(dcrx_tables_t *t, const dcrx_tuple_layout_t *L, void *d_
   if (std::memcmp(&want, L, sizeof want) != 0) return set_err(DCRX_E_INVALID, "tuple layout does not belong to these tables");
   t->sink_on = true; t->sink_layout = *L;
   t->sink_msg = static_cast<uint8_t *>(d_message); t->sink_slots = n_slots; t->sink_total = d_n_hits;
+  return DCRX_OK;
+}
+
+int dcrx_tune_state(const dcrx_tables_t *t, int orientation, uint64_t n_reads, dcrx_tune_state_t *out) {
+  if (!t || !out) return set_err(DCRX_E_INVALID, "null argument");
+  *out = dcrx_tune_state_t{0u, 0u, 0.f, 0.f};
+  const int k = V2Tune::size_class(n_reads);
+  if (k < 0) return DCRX_OK;
+  const V2TuneSlot &U = t->tune[orientation == DCRX_ORIENT_FORWARD ? 0 : 1].slot[k];
+  out->rescue_waves = U.choice; out->launches = (uint32_t)U.launches; out->us_4096 = U.us[0]; out->us_3072 = U.us[1];
   return DCRX_OK;
 }
 

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   uint32_t *lds_counts = smem + V0.trans_bytes / 4;
   uint32_t *lds_work = lds_counts + DCRX_N_COUNTERS;
   const int tid = threadIdx.x;
-  if (dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans)) != 0u) __builtin_trap();   // v2_entry reads the table at absolute LDS addresses
+  // (v2_entry reads the table at absolute LDS addresses: the dynamic segment starts at 0 because this kernel declares no static
+  // LDS — launch_v2 checks that once per device, hipFuncGetAttributes, and refuses the launch otherwise: nothing traps here)
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   if (tid < V2_WK_WORDS) lds_work[tid] = 0;
   {      // (the block may be launched with fewer threads than it is compiled for: the stride is the block's own size)
@@ -410,7 +411,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
       if (nvalid == V2_RING_EXIT) break;
       if (!nvalid) {
-        if (++spins > (1u << 24)) break;      // (never seen: a scanning wave that does not sign off)
+        if (++spins > (1u << 24)) {           // (never seen: a scanning wave that does not sign off) — said in the call's counters, not passed over in silence
+          if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull);
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
         continue;
       }
@@ -679,13 +683,14 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         bool room = true;
         for (uint32_t g = gb0; g <= gbl; g++) room = room && (uint32_t)__builtin_amdgcn_readlane((int)genv, (int)(g & nb_mask)) >= (g >> nb_shift);
         if (!room && lane == 0) {      // a ring batch's last occupants are still being finished: wait for them
-          for (uint32_t spins = 0; spins < (1u << 24); spins++) {      // (the bound is never reached: a tail wave that does not come back)
-            bool ok = true;
+          bool ok = false;
+          for (uint32_t spins = 0; spins < (1u << 24) && !ok; spins++) {      // (the bound is never reached: a tail wave that does not come back)
+            ok = true;
             for (uint32_t g = gb0; g <= gbl; g++)
               ok = ok && __hip_atomic_load(&lds_work[V2_WK_GEN + (g & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (g >> nb_shift);
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(2);
+            if (!ok) __builtin_amdgcn_s_sleep(2);
           }
+          if (!ok) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull);
         }
         asm volatile("" ::: "memory");
         uint32_t at0 = base;
@@ -1440,7 +1445,7 @@ __global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCa
                                                                   const uint32_t hi_bytes, uint64_t *__restrict__ d_total, const uint32_t hcap) {
   extern __shared__ __align__(16) uint32_t smem[];
   __shared__ uint32_t s16[V2_PLACE_BLOCK / 64];
-  __shared__ uint32_t s_last;
+  __shared__ uint32_t s_last, s_mine;
   const V2SinkDev D = *S.dev;
   const int tid = threadIdx.x;
   const uint32_t region = blockIdx.x;
@@ -1474,7 +1479,9 @@ __global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCa
   }
   // decombined reads of the regions in front, and of all
   uint32_t before = 0, all = 0;
-  for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) { const uint32_t h = S.hits[q]; all += h; if (q < region) before += h; }
+  // (the region's own count is kept from this pass: the block with the last ticket zeroes the counts, and a block that looked
+  // its count up again behind its ticket could find the zero)
+  for (uint32_t q = (uint32_t)tid; q < n_regions; q += V2_PLACE_BLOCK) { const uint32_t h = S.hits[q]; all += h; if (q < region) before += h; if (q == region) s_mine = h; }
   for (uint32_t i = (uint32_t)tid; i < wpr; i += V2_PLACE_BLOCK) bm[i] = 0u;
   const uint64_t base = v2_block_sum(before, s16, tid);
   const uint64_t total = v2_block_sum(all, s16, tid);
@@ -1495,7 +1502,7 @@ __global__ __launch_bounds__(V2_PLACE_BLOCK) void v2_place_kernel(const V2SinkCa
   const uint64_t bm_bytes = ((n_slots + 63) / 64) * 8;
   uint32_t *plane_a = reinterpret_cast<uint32_t *>(msg + bm_bytes);
   uint8_t *plane_b = msg + bm_bytes + total * 4;
-  const uint32_t mine = S.hits[region];
+  const uint32_t mine = s_mine;      // (written before the sums' barriers)
   const bool staged = mine <= hcap;
   auto place = [&](const uint2 v) {
     if (v.y == V2_SINK_EMPTY) return;
@@ -1600,6 +1607,15 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   static bool seen[64];
   hipError_t e;
   if (first_use_on_device(seen)) {
+    {      // the scan kernels address their pair table from LDS address 0: no static LDS may sit in front of the dynamic segment
+      const void *scans[] = {reinterpret_cast<const void *>(ks), reinterpret_cast<const void *>(ks_sink)};
+      for (const void *k : scans) {
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, k);
+        if (e != hipSuccess) return e;
+        if (fa.sharedSizeBytes != 0) return hipErrorNotSupported;      // (dcrx_api.cpp: DCRX_E_HIP with the runtime's text; a toolchain that moves the LDS base)
+      }
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     if constexpr (CAN_FUSE) {
@@ -1698,9 +1714,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // the fused form: the handle's own choice between 4 096 and 3 072 (V2Tune), timed on its first launches of this batch size
     hipEvent_t tune_start = nullptr, tune_stop = nullptr;
     static const bool tune_off = getenv("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
-    if (ring_batches && !separate && !rescue_waves_env && !tune_off && P.tune && !retry && !cfg.flags && B.n_reads >= (1u << 20)) {
-      V2Tune &U = P.tune[o];
-      if (U.n_reads != B.n_reads) { U.n_reads = B.n_reads; U.launches = 0; U.choice = 0; }
+    const int tune_class = V2Tune::size_class(B.n_reads);
+    if (ring_batches && !separate && !rescue_waves_env && !tune_off && P.tune && !retry && !cfg.flags && tune_class >= 0) {
+      V2TuneSlot &U = P.tune[o].slot[tune_class];      // (a size class of its own for every power of two: a short last batch does not unsettle the others')
       if (U.choice) rescue_waves = U.choice;
       else {
         const int k = U.launches - 1;            // sample index of this launch (the first launch of a size is not timed)
@@ -1727,6 +1743,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
             }
             (void)hipGetLastError();
             U.choice = (ok && ms[1] < 0.985f * ms[0]) ? 3072u : 4096u;
+            if (ok) { U.us[0] = 1e3f * ms[0] / (V2Tune::SAMPLES / 2); U.us[1] = 1e3f * ms[1] / (V2Tune::SAMPLES / 2); }
             rescue_waves = U.choice;
             static const bool say = getenv("DCRX_DEBUG_TUNE") != nullptr;
             if (say) fprintf(stderr, "dcrx tune: finishing launches of %llu reads, frame %d: %.1f us on 4096 rescue waves, %.1f on 3072 -> %u (launch %d)\n",

@@ -51,13 +51,26 @@ struct V2SinkJob {
 // times its own launches: behind its first launch of a batch size two finishing launches on 16 and two on 12 in turn carry
 // a pair of events on their dispatch (no marker packets), later launches look (hipEventQuery: no waiting) whether the pairs
 // have completed, and the setting whose launches were at least 1.5 % shorter on average stays; else 16.  One per frame.
-struct V2Tune {
+struct V2TuneSlot {
   static constexpr int SAMPLES = 4;      // (two per setting, in turn: with the first launch they fit the five warm-up launches a caller commonly makes)
   uint32_t choice = 0;               // rescue waves once settled (0: not yet)
-  uint64_t n_reads = 0;              // the batch size the samples belong to
-  int launches = 0;                  // launches seen at that batch size
+  int launches = 0;                  // launches seen in this size class
   hipEvent_t ev[SAMPLES][2] = {};    // (start, stop) of the finishing launch of sample k
   bool created = false;
+  float us[2] = {0.f, 0.f};          // what the samples said: a finishing launch on 4 096 / on 3 072 rescue waves (dcrx_tune_state)
+};
+// ... per size class (batches of 2^(20 + k) .. 2^(21 + k) - 1 reads share a slot): a short last chunk of a host call, or the
+// short last step of a shard, falls into another class and leaves the settled one alone.
+struct V2Tune {
+  static constexpr int SAMPLES = V2TuneSlot::SAMPLES;
+  static constexpr int CLASSES = 12;
+  V2TuneSlot slot[CLASSES];
+  static int size_class(uint64_t n_reads) {      // -1: below a million reads (not tuned)
+    if (n_reads < (1ull << 20)) return -1;
+    int k = 0;
+    while (k + 1 < CLASSES && (n_reads >> (21 + k)) != 0) k++;
+    return k;
+  }
 };
 
 struct LaunchPlan {

@@ -346,7 +346,7 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
     records whose first line starts behind a newline of its range of the FIRST file (line 0: rank 0); the offsets of the cut
     lines are looked up by the ranks whose ranges hold them (a second pass that stops at the line) and all-gathered.
     records_per_unit = 2 keeps the record pairs of bc_read R1 together (reference decombine.py:956-961: zip over one generator
-    consumes two records per iteration).  Every rank must call this (three small collectives)."""
+    consumes two records per iteration).  Every rank must call this (four small collectives)."""
     import os
     from . import _native as nat
     if any(str(p).endswith(".gz") for p in paths):
@@ -419,9 +419,28 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
         begin = 0 if rank == 0 else cuts.get((f, rank))
         end = size if rank == world - 1 else cuts.get((f, rank + 1))
         if begin is None or end is None:
-            return None                   # (cannot happen for consistent counts; be safe)
+            out = None                    # (cannot happen for consistent counts; be safe — and stay for the collective below)
+            break
         out.append((begin, max(begin, end)))
-    return out
+    # The cuts assume four-line records (record k starts at line 4 k).  A file whose sequences run over several lines can have a
+    # multiple of four lines all the same: every rank runs its own shard through the strict reader once (dcrx_fastq_open_range:
+    # parsed by several threads from the page cache, nothing kept) and the verdicts are exchanged; one rank that meets anything
+    # but plain four-line records sends every rank back to the unsharded readers (readfq, which is the definition: reference
+    # decombine.py:228-265) — before a row exists, instead of an error in the middle of one rank's loop.
+    ok = out is not None
+    if ok:
+        try:
+            for p, (begin, end) in zip(paths, out):
+                if end <= begin:
+                    continue
+                with nat.FastqReader(p, False, byte_range=(begin, end)) as rd:
+                    while rd.next(1 << 20).n:
+                        pass
+        except Exception:
+            ok = False
+    oks = [None] * world
+    dist.all_gather_object(oks, ok)
+    return out if all(oks) else None
 
 
 class _NullCtx:

@@ -319,7 +319,10 @@ int dcrx_compact_hits_packed8_device(const dcrx_record_t *d_records, uint64_t n_
  * with L = len(j_seqs[j]), or 2 * j_half_split when short_end is set: the J half1 rescue sets j_seq_end to the half's
  * start + len(half1) + j_half_split (:450-454), which is not the tag's end when the split is not the tag's middle.
  * bits = the sum (+ 2); bytes = max(4, ceil(bits / 8)) <= 8.  Human beta, original tags, 150 nt: 39 bits, 5 bytes.
- * DCRX_E_UNSUPPORTED when bits > 64 (the caller gathers 12-byte tuples instead). */
+ * DCRX_E_UNSUPPORTED when bits > 64 (the caller gathers 12-byte tuples instead).
+ * Contract: every read of a batch whose tuples are packed with a layout is at most 2^w_pos - 1 bases long (max_read_len
+ * fits by construction).  dcrx_decombine_device refuses a batch that can break it while a tuple sink is set (DCRX_E_INVALID:
+ * read_len, or 4 * stride for a batch with lens); dcrx_compact_hits_narrow_device sees records only and trusts its caller. */
 typedef struct dcrx_tuple_layout {
   uint8_t w_v, w_j, w_vdel, w_jdel, w_pos;
   uint8_t bits, bytes, reserved;
@@ -415,6 +418,18 @@ int64_t dcrx_collapse_front(const char *text, uint64_t n_bytes, const dcrx_colla
 int dcrx_gzip_open(const char *path, int level, int n_threads, void **writer);
 int dcrx_gzip_write(void *writer, const void *data, uint64_t n_bytes);
 int dcrx_gzip_close(void *writer);
+
+/* What a handle has settled for its own launches (no counterpart in the reference).  Where the scan kernel takes the tail
+ * itself, a handle times the finishing launches of its first calls of a batch-size class (batches of 2^k .. 2^(k+1) - 1 reads,
+ * k >= 20) and keeps the faster of two settings for the class: rescue_waves = 4096 or 3072 once settled, 0 before (a launch
+ * then runs on the default, 4096, or is one of the four samples); launches = calls seen in the class; us_4096 / us_3072 = what
+ * the samples took (0 before).  orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose
+ * launches are meant).  DCRX_E_INVALID for a null argument. */
+typedef struct dcrx_tune_state {
+  uint32_t rescue_waves, launches;
+  float us_4096, us_3072;
+} dcrx_tune_state_t;
+int dcrx_tune_state(const dcrx_tables_t *tables, int orientation, uint64_t n_reads, dcrx_tune_state_t *out);
 
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */

@@ -36,7 +36,9 @@ enum dcrx_counter {
   DCRX_C_VJ_COUNT = 19,                 /* :1013 */
   DCRX_C_READ_COUNT = 20,               /* :991 */
   DCRX_C_FOUNDJ2NOTJ1 = 21,             /* never incremented by the reference (:526 bumps foundv2notv1); stays 0 */
-  DCRX_C_FRAME_FORWARD = 22             /* not a reference counter: reads decombined in the forward frame */
+  DCRX_C_FRAME_FORWARD = 22,            /* not a reference counter: reads decombined in the forward frame */
+  DCRX_C_DEVICE_ERRORS = 31             /* not a reference counter: waves that gave up waiting for another (the fused scan's ring:
+                                           a bound no run has reached); non-zero = the call's records are NOT complete */
 };
 
 enum dcrx_status {

@@ -41,6 +41,17 @@ def test_config4_fixed_total_sharded_dry():
     assert 0.3 < d["config"]["decombined_fraction"] < 0.5
 
 
+def test_eight_ranks_config4_uneven_total_dry():
+    # BASELINE config 4's world size: 16 001 reads over 8 ranks in steps of 2 000 -> shards of 2 000 and (one) 2 001 reads:
+    # one rank needs a second step for its last read, the other seven run an empty trailing step; every rank's message is
+    # checked against its count on rank 0 (TupleGather.check), the line names the world and every rank's own step time
+    d = _line(_run(["--gpus", "8", "--config", "4", "--total-reads", "16001", "--reads", "2000", "--warmup", "1"], script=DRY))
+    assert d["scaling"] == "strong" and d["steps"] == 2 and d["n_gpus"] == 8 and d["world_size"] == 8
+    assert len(d["per_rank_ms_per_step"]) == 8 and len(d["config"]["devices"]) == 8
+    assert d["gather"]["tuple_bytes"] == 5 and d["gather"]["exposed_ms_per_step"] is not None
+    assert 0.3 < d["config"]["decombined_fraction"] < 0.5
+
+
 def test_a_failing_rank_fails_the_bench():
     p = _run(["--gpus", "2", "--reads", "-5", "--steps", "1", "--warmup", "0"], timeout=300, script=DRY)
     assert p.returncode != 0

@@ -743,3 +743,26 @@ def test_tail_waves_follow_the_workload_on_one_handle():
         orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
         pu.assert_records_equal(rec, orec, reads, f"batch {k} (p_rearranged {p})")
         pu.assert_counters_equal(cnt, ocnt, f"batch {k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,env", [
+    (2, {}),                                                        # the handle's own choice (settles on the sixth call) ...
+    (2, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (2, {"DCRX_DEBUG_RESCUE_WAVES": "4096"}),      # ... and either outcome, forced
+    (2, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "4"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "5"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
+    (2, {"DCRX_DEBUG_NO_TUNE": "1"}),
+    (5, {}), (5, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
+], ids=lambda x: x if isinstance(x, int) else ("own-choice" if not x else "-".join(f"{k[11:].lower()}{v}" for k, v in x.items())))
+def test_timed_launch_shapes_at_size(config, env):
+    """What bench.py times is a launch of >= 2^20 reads on a fused handle whose finishing launch runs on 3 072 or 4 096 rescue
+    waves (the handle's own choice, settled on its sixth launch of a size class) and whose scan blocks run 3 to 6 tail waves:
+    every such shape, forced through the library's A/B switches in a process of its own, on 2.2 M reads of BASELINE configs 2
+    and 5 (mouse gamma), seven launches on one handle, every record and counter of every launch against the oracle."""
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_shape_worker.py"), str(config), "2200000", "7"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "SHAPE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    if not env:      # the handle has settled, on one of the two settings
+        assert "'rescue_waves': 3072" in p.stdout or "'rescue_waves': 4096" in p.stdout, p.stdout

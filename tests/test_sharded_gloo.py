@@ -90,24 +90,41 @@ GATHER_WORKER = textwrap.dedent('''
     ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
                           [r.upper() for r in ts.j_regions], vs, js)
 
+    def step_reads(step, r):
+        """Reads of rank r's batch of `step`: full batches but for the last step of a run of more than two ranks — a shard's
+        short last batch on the odd ranks, and no reads at all on rank 3 (its shard ended a step earlier: an empty step)."""
+        if world > 2 and step == STEPS - 1:
+            return 0 if r == 3 else (N - 1234 if r % 2 else N)
+        return N
+
     def shard_records(step, r):
         """What rank r's device would hold after the scan of `step`: here from the oracle (p_rearranged differs per step
-        and rank, so that the counts do: 5 % .. 95 % decombined, above any fixed fraction)."""
-        p = [0.05, 0.95, 0.5, 0.0, 0.7][step] if r == 0 else [0.9, 0.1, 0.45, 0.6, 0.0][step]
-        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=100 + step, p_rearranged=p), r * N, N)
+        and rank, so that the counts do: 0 % .. 95 % decombined, above any fixed fraction; rank 5 of a larger run never
+        decombines a read: a shard without hits)."""
+        if r == 0:
+            p = [0.05, 0.95, 0.5, 0.0, 0.7][step]
+        elif r == 1:
+            p = [0.9, 0.1, 0.45, 0.6, 0.0][step]
+        else:
+            p = 0.0 if r == 5 else ((0.17 * r + 0.23 * step) % 1.0)
+        n = step_reads(step, r)
+        if n == 0:
+            return np.zeros(0, dtype=nat.RECORD_DTYPE)
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=100 + step, p_rearranged=p), r * N, n)
         rec, _ = pu.oracle_records(ot, nat.unpack_reads(hb), "reverse", False, 130)
         return rec
 
     def compact(slot, n_reads):       # stands in for dcrx_compact_hits_packed_device: same layout, made on the host
-        rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+        rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
         if os.environ.get("DCRX_TUPLE8") == "narrow":      # dcrx_compact_hits_narrow_device: one message, bitmap | low words | high bytes
-            m = g.codec.pack(rec)
+            m = g.codec.pack(rec, n_slots=N)
             slot["msg"][:len(m)] = torch.from_numpy(m.copy())
             slot["n"][0] = int((rec["status"] == 0).sum())
             return
         w, bm = (sharded.pack_tuples8 if os.environ.get("DCRX_TUPLE8") == "1" else sharded.pack_tuples12)(rec)
         slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
-        slot["bitmap"][:] = torch.from_numpy(bm.view(np.int64).copy())
+        slot["bitmap"].zero_()
+        slot["bitmap"][:len(bm)] = torch.from_numpy(bm.view(np.int64).copy())
         slot["n"][0] = len(w)
 
     g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None,
@@ -117,8 +134,9 @@ GATHER_WORKER = textwrap.dedent('''
     for step in range(STEPS):
         g.before_scan()
         rec = shard_records(step, rank)
-        g.records()[:] = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())     # "the scan wrote the records"
-        g.step(N)
+        raw = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+        g.records()[:raw.numel()] = raw                                              # "the scan wrote the records"
+        g.step(len(rec))
         if step >= 1 and rank == 0:
             # the previous step is complete on rank 0 once its transfers are waited for: compare it in full
             g.finish()
@@ -146,11 +164,15 @@ GATHER_WORKER = textwrap.dedent('''
 import pytest
 
 
-@pytest.mark.parametrize("tuple8", ["0", "1", "narrow"], ids=["12-byte-tuples", "8-byte-tuples", "narrow-tuples"])
-def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path, tuple8):
+@pytest.mark.parametrize("tuple8,world", [("0", 2), ("1", 2), ("narrow", 2), ("narrow", 8)],
+                         ids=["12-byte-tuples", "8-byte-tuples", "narrow-tuples", "narrow-tuples-8-ranks"])
+def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path, tuple8, world):
     """The gather bench.py runs between ranks (count exchange, exact-size transfers of 12- or 8-byte tuples + bitmap,
-    alternating slots), over gloo with two ranks and five steps whose decombined fractions range from 0 to 95 %:
-    rank 0 re-expands every rank's tuples and they equal that rank's records."""
+    alternating slots), over gloo with two ranks — and with eight: the world size of BASELINE config 4 — and five steps
+    whose decombined fractions range from 0 to 95 %: rank 0 re-expands every rank's tuples, and they are that rank's
+    decombined records in read order — concatenated in rank order, the order of the reference's outdata.append
+    (decombine.py:1039) over contiguous shards.  The eight-rank run ends as a sharded job does: short last batches, a rank
+    with no reads left in the last step (an empty trailing step), and a rank whose shard never decombines a read."""
     script = tmp_path / "gworker.py"
     script.write_text(GATHER_WORKER)
     s = socket.socket()
@@ -158,8 +180,8 @@ def test_two_rank_tuple_gather_protocol_exact_sizes(tmp_path, tuple8):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    DCRX_ROOT=ROOT, OMP_NUM_THREADS="1", DCRX_TUPLE8=tuple8)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
@@ -210,13 +232,15 @@ STAGE_WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world,run_index,cut", [(2, 0, "shards"), (3, 0, "shards"), (2, 1, "shards"), (3, 2, "shards"), (2, 0, "crlf")])
+@pytest.mark.parametrize("world,run_index,cut", [(2, 0, "shards"), (3, 0, "shards"), (2, 1, "shards"), (3, 2, "shards"), (2, 0, "crlf"),
+                                                 (2, 0, "wrapped"), (3, 1, "wrapped")])
 def test_sharded_stage_equals_single_process(tmp_path, monkeypatch, world, run_index, cut):
     """decombinator_sharded() on two and three gloo ranks (the oracle standing in for the GPUs) against decombinator() in this
     process on the same files: the same rows in the same order, the same counters, one summary log — with the input read in
     shards (every rank its own byte ranges of the FASTQ files: disjoint, in rank order, covering the files, the R1 / R2 files
     of a pair cut at the same record; bc_read R1 keeps its record pairs together), and, for a file that cannot be cut (CRLF
-    line ends), with every rank reading the whole file as before."""
+    line ends; records over more than four lines whose line count is a multiple of four all the same), with every rank reading
+    the whole file as before."""
     import json
     from decombinator_amd import decombine as dec, io as dio, _native as nat
     from tests import golden_util as gu, parity_util as pu
@@ -231,8 +255,23 @@ def test_sharded_stage_equals_single_process(tmp_path, monkeypatch, world, run_i
                  v_names=ts["v_names"], v_regions=ts["v_regions"], j_tags=ts["j_tags"], j_jumps=ts["j_jumps"],
                  j_names=ts["j_names"], j_regions=ts["j_regions"]).write(str(work / "tags"))
     eol = "\r\n" if cut == "crlf" else "\n"
-    (work / "SYNTH_1.fq").write_bytes(stage["fastq_r1"].replace("\n", eol).encode())
-    (work / "SYNTH_2.fq").write_bytes(stage["fastq_r2"].replace("\n", eol).encode())
+
+    def wrapped(text):
+        # two early records with their sequence and quality over two lines each: four lines more, so that the file still
+        # has a multiple of four lines and every later record still starts on a line 4 k — what the newline counts cannot see
+        lines = text.split("\n")
+        out = []
+        for k in range(0, len(lines) - 1, 4):
+            h, sq, plus, ql = lines[k:k + 4]
+            if k in (8, 12):      # (not the first record: fastq_check, as the reference's :126-179, reads the file's first four lines as one)
+                m = len(sq) // 2
+                out += [h, sq[:m], sq[m:], plus, ql[:m], ql[m:]]
+            else:
+                out += [h, sq, plus, ql]
+        return "\n".join(out) + "\n"
+    for name, key in (("SYNTH_1.fq", "fastq_r1"), ("SYNTH_2.fq", "fastq_r2")):
+        text = stage[key]
+        (work / name).write_bytes((wrapped(text) if cut == "wrapped" else text.replace("\n", eol)).encode())
     (work / "single").mkdir()
     (work / "sharded").mkdir()
 
@@ -268,7 +307,7 @@ def test_sharded_stage_equals_single_process(tmp_path, monkeypatch, world, run_i
     # how the ranks read: their own byte ranges only — or, for the file that cannot be cut, the whole file each
     info = got["info"]
     assert [i["rank"] for i in info] == list(range(world))
-    if cut == "crlf":
+    if cut in ("crlf", "wrapped"):
         assert not any(i["sharded_input"] for i in info)
     else:
         assert all(i["sharded_input"] for i in info)
