@@ -181,7 +181,8 @@ def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, q
 
 
 class TuneStateC(C.Structure):
-    _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_4096", C.c_float), ("us_3072", C.c_float)]
+    _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_4096", C.c_float), ("us_3072", C.c_float),
+                ("launch_form", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SynthCfgC(C.Structure):
@@ -343,7 +344,8 @@ class Tables:
         st = TuneStateC()
         check(lib().dcrx_tune_state(self._h, ORIENTATIONS[orientation], int(n_reads), C.byref(st)))
         return {"rescue_waves": int(st.rescue_waves), "launches": int(st.launches), "us_4096": round(float(st.us_4096), 2),
-                "us_3072": round(float(st.us_3072), 2)}
+                "us_3072": round(float(st.us_3072), 2),
+                "launch_form": {0: "none yet", 1: "three-launch form", 2: "v2, tail as a role", 3: "v2, tail inside the scan"}.get(int(st.launch_form), "?")}
 
     def close(self):
         if self._h is not None:

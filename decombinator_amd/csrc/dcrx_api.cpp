@@ -783,10 +783,12 @@ int dcrx_set_tuple_sink(dcrx_tables_t *t, const dcrx_tuple_layout_t *L, void *d_
 
 int dcrx_tune_state(const dcrx_tables_t *t, int orientation, uint64_t n_reads, dcrx_tune_state_t *out) {
   if (!t || !out) return set_err(DCRX_E_INVALID, "null argument");
-  *out = dcrx_tune_state_t{0u, 0u, 0.f, 0.f};
+  *out = dcrx_tune_state_t{0u, 0u, 0.f, 0.f, 0u, 0u};
+  const V2Tune &F = t->tune[orientation == DCRX_ORIENT_FORWARD ? 0 : 1];
+  out->launch_form = F.last_form;
   const int k = V2Tune::size_class(n_reads);
   if (k < 0) return DCRX_OK;
-  const V2TuneSlot &U = t->tune[orientation == DCRX_ORIENT_FORWARD ? 0 : 1].slot[k];
+  const V2TuneSlot &U = F.slot[k];
   out->rescue_waves = U.choice; out->launches = (uint32_t)U.launches; out->us_4096 = U.us[0]; out->us_3072 = U.us[1];
   return DCRX_OK;
 }

@@ -52,19 +52,26 @@ inline uint32_t out_pack(int cls, int len, int kw, bool last) {
 // the filter, the comparison is what decides.
 constexpr uint32_t V2_MAX_STATES = 4095;
 constexpr uint32_t V2_F_VF = 1u, V2_F_JF = 2u, V2_F_VH = 4u, V2_F_JH = 8u;
-constexpr int V2_NB = 64;            // buckets per keyword class
-// bucket of a packed keyword / read window (2 bits per base, first base lowest)
+// The keyword tables: per class a two-choice (cuckoo) hash table of S = 2^k slots — a packed keyword lies in one of the two
+// slots its hash names, so a look-up is two probes side by side and one wait: no chain to walk, no bounds to fetch first (the
+// 64-bucket chains of rounds 2-4 cost a look-up two dependent LDS round trips and a loop over the longest chain of the
+// look-ups in flight).  An empty slot carries the id V2_PH_EMPTY.
+constexpr uint32_t V2_PH_EMPTY = 0xFFFFu;
+constexpr uint32_t V2_PH_MAX_SLOTS = 8192;
+// the two slots of a packed keyword / read window (2 bits per base, first base lowest) in a table of mask + 1 slots
 inline
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-uint32_t v2_hash(uint64_t v) {
+void v2_slots(const uint64_t v, const uint32_t mask, uint32_t &s1, uint32_t &s2) {
   // three 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 run at full rate, v_mul_lo_u32 at a quarter of it): the key's
-  // bits 0-23, 24-47 and 48-63 each times an odd 24-bit constant, summed; the bucket is bits 18-23 of the sum
+  // bits 0-23, 24-47 and 48-63 each times an odd 24-bit constant, summed.  A product's low bits know only the low bits of
+  // the key: both slots are cut from the sum's upper half.
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   const uint32_t a = lo & 0xFFFFFFu, b = ((lo >> 24) | (hi << 8)) & 0xFFFFFFu, c = hi >> 16;
   const uint32_t s = a * 0x9E3779u + b * 0x85EBCBu + c * 0xC2B2AFu;      // (24-bit operands: the device compiles these to the u24 forms)
-  return ((s >> 18) ^ (s >> 7)) & 63u;
+  s1 = (s >> 19) & mask;
+  s2 = ((s >> 12) ^ (s >> 25)) & mask;
 }
 
 struct V2Ori {
@@ -72,15 +79,15 @@ struct V2Ori {
   uint32_t trans_bytes;
   uint32_t n_states;
   uint32_t narrow;                // 1: entries are state << 5 | flags (<= 2047 states: the state bits are the row's byte offset); 0: state << 4 | flags
-  const uint8_t *bk;              // bucket image (staged in LDS behind the side tables)
+  const uint8_t *bk;              // keyword tables' image (staged in LDS behind the side tables)
   uint32_t bk_bytes;
-  // byte offsets inside bk, per keyword class: bucket starts (uint16[V2_NB + 1]), the class-local
-  // keyword index of each slot (uint16[n_kw]) and the slot's packed keyword as the stored read
-  // shows it (uint64[n_kw]); slots are sorted by bucket
-  uint32_t bk_start_off[K_NCLASS];
+  // per keyword class: slots - 1 (a power of two), and byte offsets inside bk of the slots' packed keywords as the stored read
+  // shows them (uint64[slots]), of their class-local keyword indices (uint16[slots]; V2_PH_EMPTY: an empty slot) and of the
+  // first tag that holds each keyword (uint16[slots]: list.index, decombine.py:282 / :406)
+  uint32_t bk_mask[K_NCLASS];
   uint32_t bk_kw_off[K_NCLASS];
   uint32_t bk_pk_off[K_NCLASS];
-  uint32_t bk_tag_off[K_NCLASS];  // uint16[n_kw]: the first tag that holds the slot's keyword (list.index, decombine.py:282 / :406)
+  uint32_t bk_tag_off[K_NCLASS];
 };
 
 struct GeneDevPtrs {

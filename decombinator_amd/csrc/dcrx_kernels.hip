@@ -650,7 +650,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   occ_fast = std::max(occ_fast, 1); occ_list = std::max(occ_list, 1);
   // (the three-launch form holds 320 nt in registers: longer reads all go through its list kernel; the v2 kernels hold 511)
   // (the v2 condition: its entries keep two flags above a 30-bit read index)
-  const bool v2_ok_here = B.stride <= 4 * DCRX_V2_NWLONG && v2_applies(P, T, cfg) && B.n_reads < (1ull << 30);
+  const bool v2_ok_here = B.stride <= 4 * DCRX_V2_NWLONG && v2_applies(P, T, cfg, B.stride) && B.n_reads < (1ull << 30);
   // (`both` as two v2 passes: 0.69 ms per 10 M reads of config 2 against 28 ms through the list kernel)
   const bool v2_both = cfg.orientation == DCRX_ORIENT_BOTH && v2_ok_here;
   const bool all_general = (cfg.orientation == DCRX_ORIENT_BOTH && !v2_both) || (cfg.flags & DCRX_F_FORCE_SLOW_READER) || (B.stride > 4 * DCRX_NWMAX && !v2_ok_here);
@@ -666,6 +666,9 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
   // exception bitmap zeroed for the next batch.  The v2 kernels need no prologue: the scan blocks mark the exception reads of
   // their own ranges, every kernel tallies into the handle's accumulator (zero between calls), and the list kernel — the
   // last launch — hands the counters to the caller and re-arms the accumulator.
+  // (which form this call's launches take, for whoever asks: dcrx_tune_state — a fallback to the three-launch form is then seen,
+  // not inferred from the clock)
+  if (P.tune) P.tune[cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1].last_form = (v2 || v2_both) ? 2u : 1u;
   unsigned long long *acc = (v2 || v2_both) ? reinterpret_cast<unsigned long long *>(P.v2_acc) : d_counters;
   if (!(v2 || v2_both)) {
     const uint64_t items = std::max<uint64_t>(all_general ? B.n_reads : 0, std::max<uint64_t>(B.n_exc, 1));

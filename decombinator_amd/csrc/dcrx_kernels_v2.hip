@@ -49,7 +49,7 @@ bool first_use_on_device(bool (&seen)[64]);
 void attributes_set_on_device(bool (&seen)[64]);
 
 constexpr int DCRX_V2_BLOCK = 1024;
-constexpr int DCRX_V2_FBLOCK = 256;
+constexpr int DCRX_V2_FBLOCK = 256;      // (128: the same step; 512: twice as long — profiles/r05/finish_block_size_ab.log)
 #ifndef DCRX_V2_TBLOCK
 #define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
 #define DCRX_V2_TWAVES 5        /* ... and the waves per SIMD it is compiled for */
@@ -297,7 +297,7 @@ enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLA
 //   GEN      per ring batch: times it has been finished — a scanning wave writes into occurrence k of a ring batch when GEN == k
 //   How many waves take the tail is a block's own choice per launch (the roles differ by wave index only): the share of its
 //   region's reads that were tail reads in the handle's PREVIOUS launch (V2_L_TWHINT in the counts, left there by the block
-//   itself) picks 3 to 6 — config 2 (35 % tail reads) runs 3.7 % faster on 5 than on 4 and 10 % slower on 3, the mouse chains
+//   itself) picks 2 to 6 — (round 4's figures) config 2 (35 % tail reads) runs 3.7 % faster on 5 than on 4 and 10 % slower on 3, the mouse chains
 //   of config 5 (half the reads are the other chain's: 17 %) 2 % faster on 3 and 3 % slower on 5, a library with 70 % rearranged
 //   reads (54 % tail reads) 5 % faster on 6 than on 5 (profiles/r04/tail_waves_*.log); a handle's first launch takes
 //   DCRX_V2_FUSE_TAILWAVES.
@@ -305,7 +305,13 @@ enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLA
 #define DCRX_V2_FUSE_TAILWAVES 4
 #endif
 constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
-constexpr uint32_t V2_TW6_FRAC256 = 115, V2_TW5_FRAC256 = 69, V2_TW4_FRAC256 = 51;      // 45 % / 27 % / 20 % of a region's reads
+// (round 5, with the keyword tables' look-ups at one wait each a tail wave finishes a batch sooner and fewer of them keep up —
+// profiles/r05/tail_waves_by_share.log, ms per step on 2 / 3 / 4 / 5 / 6 tail waves: 12 % tail reads 0.291 / 0.295 / 0.305 / .. ;
+// 23 %: 0.335 / 0.322 / 0.329; 35 % (config 2): 0.423 / 0.362 / 0.356 / 0.363 / 0.374; 47 %: .. 0.426 / 0.389 / 0.391 / 0.400;
+// 58 %: .. 0.443 / 0.417 / 0.426; 70 %: .. 0.502 / 0.462 / 0.450.  Waves that scan AND take tail batches between two items
+// (one loop for both kinds of work, so that no wave slot idles) were built and measured: the loop with both bodies in it runs
+// 8 % slower before the first batch changes hands, and the exchange gives nothing back — profiles/r05/flexible_waves_experiment.log)
+constexpr uint32_t V2_TW6_FRAC256 = 164, V2_TW5_FRAC256 = 133, V2_TW4_FRAC256 = 74, V2_TW3_FRAC256 = 41;      // 64 % / 52 % / 29 % / 16 % of a region's reads
 constexpr int V2_RING_STRIDE = 15;
 constexpr uint32_t V2_RING_MAXBATCHES = 16;
 
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     if ((tid == V2_L_TWHINT || tid == V2_L_TWHINT + 1) && FUSE >= 0) c = Q.counts[V2_L_COUNTS * region + tid];      // (the other frame's hint stays)
     if (tid == V2_L_TWHINT + (o ? 0 : 1) && FUSE >= 0 && blk_hi > blk_lo) {      // the next launch's tail waves in this frame, by this one's share of tail reads
       const uint32_t frac256 = (uint32_t)(((uint64_t)lds_work[V2_WK_HEAD] << 8) / (blk_hi - blk_lo));
-      c = frac256 >= V2_TW6_FRAC256 ? 6u : (frac256 >= V2_TW5_FRAC256 ? 5u : (frac256 >= V2_TW4_FRAC256 ? 4u : 3u));
+      c = frac256 >= V2_TW6_FRAC256 ? 6u : (frac256 >= V2_TW5_FRAC256 ? 5u : (frac256 >= V2_TW4_FRAC256 ? 4u : (frac256 >= V2_TW3_FRAC256 ? 3u : 2u)));
     }
     Q.counts[V2_L_COUNTS * region + tid] = c;
   }
@@ -1018,8 +1024,12 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
           rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
+#ifdef DCRX_EXP_RESCUE_NOOP      // (experiment build, tools/: the entries streamed and records written, nothing resolved — the records are NOT results)
+          status = DCRX_S_J_NONE; rec.v = (uint16_t)(lw.stored64(n - 40) ^ lg[3] ^ x[1 + 2 * NW]);
+#else
           if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
           else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
+#endif
           if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
           else errs = 0;
           // (j_end of a J found through its first half is the half's start + 2 * split, decombine.py:450-454: errs bit 3)
@@ -1178,7 +1188,11 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   // at a time; then — mode bit 1, one wave — the left list as its entries arrive, a lane per entry, in order; every other block
   // signs off in queue_count[V2_QC_DONE] when its role is done (its pushes before that)
   const uint32_t region = vblock / A.R.bsplit, bpart = vblock % A.R.bsplit;
+#ifdef DCRX_EXP_NO_X      // (experiment build, tools/: list X left alone — what the general form's rounds cost the finishing launch; the records are NOT results)
+  const bool do_x = false;
+#else
   const bool do_x = (mode & 1u) && region < A.n_regions && !(A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS);
+#endif
   const V2ListRef lx = v2_list<NW>(A.Q, V2_L_X, do_x ? region : 0u);
   const uint32_t x_total = do_x ? min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], lx.cap) : 0u;
   // (a long list — a run with many N tails — fills its waves: few lanes per wave pay only while the list is a handful per region)
@@ -1547,11 +1561,16 @@ static uint32_t v2_scan_lds_bytes(const DevTables &T, int o) { return T.v2[o].tr
 // reader and orientation `both` keep that form.
 // The v2 kernels serve one frame per pass: `reverse` and `forward` are one pass, `both` (decombine.py:1005-1010) the reverse
 // frame and then the forward frame for the reads it did not decombine (both frames' tables must fit).
-bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg) {
+bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg, const uint32_t stride) {
   if (!T.v2_ok || !P.v2_events || !P.v2_slow || !P.v2_acc || !P.v2_left) return false;      // (the tail list: only where a launch needs it, launch_v2)
   if (cfg.flags & (DCRX_F_V1_KERNELS | DCRX_F_FORCE_SLOW_READER | DCRX_F_ONE_BASE_SCAN | DCRX_F_LIST_RESCUE | DCRX_F_PROFILE_LIST_SCAN_ONLY)) return false;
-  // (the lean kernels add a strip of LDS per lane: priced here at the long-read size)
-  auto fits = [&](int o) { return v2_scan_lds_bytes(T, o) <= 160u * 1024u && v2_finish_block_lds<DCRX_V2_NWLONG>(T, o, DCRX_V2_FBLOCK) <= 64u * 1024u; };
+  // (the lean kernels add a strip of LDS per lane: priced at the register shape the batch's stride takes — at the long reads'
+  // shape whatever the batch, the extended alpha set's larger keyword tables sent its 150-nt batches to the three-launch form)
+  auto fits = [&](int o) {
+    const uint32_t fin = stride <= 40 ? v2_finish_block_lds<10>(T, o, DCRX_V2_FBLOCK)
+                                      : (stride <= 4 * DCRX_NWMAX ? v2_finish_block_lds<DCRX_NWMAX>(T, o, DCRX_V2_FBLOCK) : v2_finish_block_lds<DCRX_V2_NWLONG>(T, o, DCRX_V2_FBLOCK));
+    return v2_scan_lds_bytes(T, o) <= 160u * 1024u && fin <= 64u * 1024u;
+  };
   if (cfg.orientation == DCRX_ORIENT_BOTH) return fits(0) && fits(1) && !(cfg.flags & DCRX_F_PROFILE_MASK);
   return fits(cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
 }
@@ -1586,6 +1605,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if constexpr (CAN_FUSE) {
     if (ring_batches) ks = o ? scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1> : scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0>;
   }
+  if (P.tune && ring_batches) P.tune[o].last_form = 3u;      // (launch_decombine has said 2)
   const uint32_t scan_lds = v2_scan_lds_bytes(T, o) + (ring_batches ? (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + ring_batches * 64u * V2_RING_STRIDE * 4u : 0u);
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
@@ -1758,6 +1778,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
     static const uint32_t rescue_waves_c = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
+    // (list C's jobs behind list E's on the same waves — one round of blocks instead of two — were measured: the step 3 % longer
+    // on config 2, 8 % on config 5: list C's batches are the slow ones, two sweeps each, and want to start with the launch;
+    // profiles/r05/finish_list_c_folded_ab.log)
     const uint32_t fgrid = (n_regions * (rsplit + csplit) + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
     // blocks of a short list's pass that share a region: as a pass of its own (A/B forms) the list's latency is the launch's, and
@@ -1887,7 +1910,7 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
 #define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
 #ifdef DCRX_FAST_BUILD      // (experiment builds, tools/build_variant.sh: the benchmark's launch shape only)
-  if (nw10 && uniform && narrow && shape == 2) return DCRX_V2A(true, 10, 2, true);
+  if (nw10 && uniform && shape == 2) return narrow ? DCRX_V2A(true, 10, 2, true) : DCRX_V2A(true, 10, 2, false);
   return hipErrorNotSupported;
 #else
   if (nw10) {

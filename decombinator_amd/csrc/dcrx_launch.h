@@ -65,6 +65,7 @@ struct V2Tune {
   static constexpr int SAMPLES = V2TuneSlot::SAMPLES;
   static constexpr int CLASSES = 12;
   V2TuneSlot slot[CLASSES];
+  uint32_t last_form = 0;            // the frame's last call: 0 none yet, 1 the three-launch form, 2 the v2 kernels (tail as a role), 3 v2 with the tail inside the scan
   static int size_class(uint64_t n_reads) {      // -1: below a million reads (not tuned)
     if (n_reads < (1ull << 20)) return -1;
     int k = 0;
@@ -104,7 +105,7 @@ hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const Batch
 // dcrx_kernels_v2.hip
 void v2_list_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu, uint64_t *tail_rows, uint64_t *event_rows);
 uint64_t v2_slow_rows(uint64_t max_reads, uint32_t stride, uint32_t n_cu);
-bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg);
+bool v2_applies(const LaunchPlan &P, const DevTables &T, const CfgDev &cfg, uint32_t stride);
 // what a v2 launch that serves the call's tuple sink leaves for the list kernel and the place kernel behind it
 struct V2SinkLaunch { V2SinkCall S{}; uint32_t n_regions = 0, tcap = 0, ecap = 0, ccap = 0, fused = 0; const uint32_t *counts = nullptr; };
 hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,

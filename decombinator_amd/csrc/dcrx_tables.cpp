@@ -484,24 +484,46 @@ int compile_tables(const dcrx_tagset_t *ts, HostTables *out, std::string *err) {
       for (int cls = 0; cls < K_NCLASS; cls++) {
         const size_t nk = kw_str[cls].size();
         std::vector<uint64_t> pk(nk);
-        std::vector<uint32_t> hb(nk);
         for (size_t i = 0; i < nk; i++) {
           const std::string k = shown(kw_str[cls][i]);
           uint64_t v = 0;
           for (size_t x = 0; x < k.size(); x++) v |= (uint64_t)base_code(k[x]) << (2 * x);
-          pk[i] = v; hb[i] = v2_hash(v);
+          pk[i] = v;
         }
-        std::vector<uint16_t> start(V2_NB + 1, 0), slot_kw(nk), slot_tag(nk);
-        std::vector<uint64_t> slot_pk(nk);
-        for (size_t i = 0; i < nk; i++) start[hb[i] + 1]++;
-        for (int b = 0; b < V2_NB; b++) start[b + 1] = (uint16_t)(start[b + 1] + start[b]);
-        std::vector<uint16_t> fill(start.begin(), start.end() - 1);
-        for (size_t i = 0; i < nk; i++) { const uint16_t at = fill[hb[i]]++; slot_kw[at] = (uint16_t)i; slot_pk[at] = pk[i]; slot_tag[at] = (uint16_t)kw_idx[cls][i][0]; }
-        V.bk_start_off[cls] = (uint32_t)K.put(start);
+        // two-choice placement (cuckoo): a table of at least twice the keywords, doubled until every keyword finds a slot
+        uint32_t slots = 8;
+        while (slots < 2 * nk) slots <<= 1;
+        std::vector<int> owner;
+        for (;; slots <<= 1) {
+          if (slots > V2_PH_MAX_SLOTS) { ok = false; break; }      // (two keywords with one hash sum: the three-launch form serves the set)
+          owner.assign(slots, -1);
+          bool placed = true;
+          for (size_t i = 0; i < nk && placed; i++) {
+            int cur = (int)i;
+            uint32_t s1, s2;
+            v2_slots(pk[cur], slots - 1, s1, s2);
+            uint32_t pos = s1;
+            placed = false;
+            for (int kick = 0; kick < 512; kick++) {
+              if (owner[pos] < 0) { owner[pos] = cur; placed = true; break; }
+              std::swap(cur, owner[pos]);
+              v2_slots(pk[cur], slots - 1, s1, s2);
+              pos = pos == s1 ? s2 : s1;
+            }
+          }
+          if (placed) break;
+        }
+        if (!ok) break;
+        std::vector<uint16_t> slot_kw(slots, (uint16_t)V2_PH_EMPTY), slot_tag(slots, (uint16_t)V2_PH_EMPTY);
+        std::vector<uint64_t> slot_pk(slots, ~0ull);
+        for (uint32_t at = 0; at < slots; at++)
+          if (owner[at] >= 0) { const size_t i = (size_t)owner[at]; slot_kw[at] = (uint16_t)i; slot_pk[at] = pk[i]; slot_tag[at] = (uint16_t)kw_idx[cls][i][0]; }
+        V.bk_mask[cls] = slots - 1;
         V.bk_kw_off[cls] = (uint32_t)K.put(slot_kw);
         V.bk_pk_off[cls] = (uint32_t)K.put(slot_pk);
         V.bk_tag_off[cls] = (uint32_t)K.put(slot_tag);
       }
+      if (!ok) break;
       K.reserve(16);
       V.n_states = S2;
       V.narrow = narrow ? 1u : 0u;

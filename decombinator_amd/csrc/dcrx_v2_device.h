@@ -435,13 +435,14 @@ DCRX_DEV uint64_t frame_stored64(const Frame<REV> &F, const int nwords, const in
 // lives in registers would send the struct to scratch memory)
 #define DCRX_V2_PICK(ARR, CLS) ((CLS) == 0 ? (ARR)[0] : (CLS) == 1 ? (ARR)[1] : (CLS) == 2 ? (ARR)[2] : (CLS) == 3 ? (ARR)[3] : (CLS) == 4 ? (ARR)[4] : (ARR)[5])
 DCRX_DEVNI int v2_lookup(const V2Ori &V, const int cls, const uint64_t val) {
-  const uint16_t *st = reinterpret_cast<const uint16_t *>(V.bk + DCRX_V2_PICK(V.bk_start_off, cls));
   const uint16_t *kw = reinterpret_cast<const uint16_t *>(V.bk + DCRX_V2_PICK(V.bk_kw_off, cls));
   const uint64_t *pk = reinterpret_cast<const uint64_t *>(V.bk + DCRX_V2_PICK(V.bk_pk_off, cls));
-  const uint32_t h = v2_hash(val);
-  const uint32_t a = st[h], b = st[h + 1];
-  for (uint32_t i = a; i < b; i++)
-    if (pk[i] == val) return (int)kw[i];
+  uint32_t s1, s2;
+  v2_slots(val, DCRX_V2_PICK(V.bk_mask, cls), s1, s2);
+  const uint64_t p1 = pk[s1], p2 = pk[s2];
+  const uint32_t k1 = kw[s1], k2 = kw[s2];
+  if (p1 == val && k1 != V2_PH_EMPTY) return (int)k1;
+  if (p2 == val && k2 != V2_PH_EMPTY) return (int)k2;
   return -1;
 }
 
@@ -492,16 +493,19 @@ DCRX_DEVNI int dcr_frame3(const DevTables &T, const V2Ori &V, const FR &F, const
   auto sweep = [&](const uint32_t f_full, const uint32_t f_half, const int c_full, const int c_h1, const int c_h2, const int Lf,
                    const int L1, const int L2, Hits2 &hf, Hits2 &h1, Hits2 &h2) {
     // where the three classes' buckets are (picked per lane below between the full tag's and the first half tag's)
-    const uint32_t so_f = V.bk_start_off[c_full], ko_f = V.bk_kw_off[c_full], po_f = V.bk_pk_off[c_full];
-    const uint32_t so_1 = V.bk_start_off[c_h1], ko_1 = V.bk_kw_off[c_h1], po_1 = V.bk_pk_off[c_h1];
-    const uint32_t so_2 = V.bk_start_off[c_h2], ko_2 = V.bk_kw_off[c_h2], po_2 = V.bk_pk_off[c_h2];
-    auto lookup = [&](const uint32_t so, const uint32_t ko, const uint32_t po, const uint64_t val) {
-      const uint16_t *st = reinterpret_cast<const uint16_t *>(V.bk + so);
-      const uint32_t h = v2_hash(val);
-      const uint32_t a = st[h], b = st[h + 1];
+    const uint32_t so_f = V.bk_mask[c_full], ko_f = V.bk_kw_off[c_full], po_f = V.bk_pk_off[c_full];
+    const uint32_t so_1 = V.bk_mask[c_h1], ko_1 = V.bk_kw_off[c_h1], po_1 = V.bk_pk_off[c_h1];
+    const uint32_t so_2 = V.bk_mask[c_h2], ko_2 = V.bk_kw_off[c_h2], po_2 = V.bk_pk_off[c_h2];
+    auto lookup = [&](const uint32_t mask, const uint32_t ko, const uint32_t po, const uint64_t val) {
+      uint32_t s1, s2;
+      v2_slots(val, mask, s1, s2);
+      const uint64_t *pk = reinterpret_cast<const uint64_t *>(V.bk + po);
+      const uint16_t *kws = reinterpret_cast<const uint16_t *>(V.bk + ko);
+      const uint64_t p1 = pk[s1], p2 = pk[s2];
+      const uint32_t k1 = kws[s1], k2 = kws[s2];
       int kw = -1;
-      for (uint32_t i = a; i < b; i++)
-        if (reinterpret_cast<const uint64_t *>(V.bk + po)[i] == val) kw = (int)reinterpret_cast<const uint16_t *>(V.bk + ko)[i];
+      if (p2 == val && k2 != V2_PH_EMPTY) kw = (int)k2;
+      if (p1 == val && k1 != V2_PH_EMPTY) kw = (int)k1;
       return kw;
     };
     for (int x = 0; x < ne; x++) {
@@ -702,7 +706,8 @@ DCRX_DEV bool finish2_words(const DevTables &T, const V2Ori &V, const BatchDev &
 // returns TAIL2_SLOW and takes the general form (dcr_frame3) from the event stack.
 // ------------------------------------------------------------------------------
 struct Tail2Tabs {       // where the lean tail finds its tables (frame in use); index 0 = V, 1 = J
-  dcrx_ldsaddr bk_start[2], bk_tag[2], bk_pk[2];   // full-tag buckets: starts (uint16[V2_NB + 1]), first tag per slot (uint16), packed keyword per slot (uint64)
+  uint32_t bk_mask[2];                             // full-tag tables: slots - 1 ...
+  dcrx_ldsaddr bk_tag[2], bk_pk[2];                // ... the first tag per slot (uint16; V2_PH_EMPTY: an empty slot), the packed keyword per slot (uint64)
   dcrx_ldsaddr jump[2];                            // int32 per tag
   dcrx_ldsaddr w64[2];                             // uint64 per tag: the walk window as the stored read shows it in this frame
   dcrx_ldsaddr w64_ok[2];                          // uint8 per tag
@@ -715,7 +720,7 @@ DCRX_DEV Tail2Tabs tail2_tabs(const DevTables &T0, const V2Ori &V0, const uint8_
   auto at_side = [&](const void *p) { return dcrx_ldsaddr_of(side + ((reinterpret_cast<const uint8_t *>(p) - T0.image) - T0.dfa_bytes)); };
   for (int g = 0; g < 2; g++) {
     const int cls = g == 0 ? K_VFULL : K_JFULL;
-    t.bk_start[g] = dcrx_ldsaddr_of(bk + V0.bk_start_off[cls]);
+    t.bk_mask[g] = V0.bk_mask[cls];
     t.bk_tag[g] = dcrx_ldsaddr_of(bk + V0.bk_tag_off[cls]);
     t.bk_pk[g] = dcrx_ldsaddr_of(bk + V0.bk_pk_off[cls]);
     t.jump[g] = at_side(T0.g[g].jump);
@@ -742,49 +747,38 @@ DCRX_DEV uint64_t tail2_load64(const dcrx_gwords words, const int s) {
 // shift count for a window offset in bases (a look-up that is switched off may carry an offset outside the window)
 DCRX_DEV int v2_sh(const int bases) { return 2 * min(max(bases, 0), 31); }
 struct LookupQ {
-  dcrx_ldsaddr start, ids, pk;   // the class's bucket bounds (uint16[V2_NB + 1]), per slot an id (uint16) and the packed keyword (uint64)
+  uint32_t mask;                 // the class's slots - 1
+  dcrx_ldsaddr ids, pk;          // per slot an id (uint16; V2_PH_EMPTY: an empty slot) and the packed keyword (uint64)
   uint64_t val;                  // the window to find
   bool on;                       // false: no look-up (the result is -1)
 };
+// N look-ups side by side: the two slots of each are fetched together (keyword and id), one wait for all of them
 template <int N>
 DCRX_DEV void lookup_lockstep(const LookupQ (&q)[N], int (&out)[N]) {
-  uint32_t a[N], b[N];
-  uint32_t longest = 0;
+  uint64_t p1[N], p2[N];
+  uint32_t i1[N], i2[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const uint32_t h = v2_hash(q[k].val);
-    a[k] = dcrx_lds_at<uint16_t>(q[k].start, h);
-    b[k] = dcrx_lds_at<uint16_t>(q[k].start, h + 1);
+    uint32_t s1, s2;
+    v2_slots(q[k].val, q[k].mask, s1, s2);
+    p1[k] = dcrx_lds_at<uint64_t>(q[k].pk, s1); p2[k] = dcrx_lds_at<uint64_t>(q[k].pk, s2);
+    i1[k] = dcrx_lds_at<uint16_t>(q[k].ids, s1); i2[k] = dcrx_lds_at<uint16_t>(q[k].ids, s2);
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    if (!q[k].on) b[k] = a[k];
-    longest = max(longest, b[k] - a[k]);
-    out[k] = -1;
-  }
-  for (uint32_t i = 0; i < longest; i++) {
-    uint64_t pv[N];
-    uint32_t id[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      const uint32_t slot = a[k] + i < b[k] ? a[k] + i : a[k];      // (a slot of the class in any case: the bucket table ends with one)
-      pv[k] = dcrx_lds_at<uint64_t>(q[k].pk, slot);
-      id[k] = dcrx_lds_at<uint16_t>(q[k].ids, slot);
-    }
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      if (a[k] + i < b[k] && pv[k] == q[k].val) out[k] = (int)id[k];
+    int r = -1;
+    if (p2[k] == q[k].val && i2[k] != V2_PH_EMPTY) r = (int)i2[k];
+    if (p1[k] == q[k].val && i1[k] != V2_PH_EMPTY) r = (int)i1[k];
+    out[k] = q[k].on ? r : -1;
   }
 }
 
 // first tag holding the full-tag keyword whose packed form is `val`, or -1
 DCRX_DEV int tail2_lookup(const Tail2Tabs &tt, const int g, const uint64_t val) {
-  const uint32_t h = v2_hash(val);
-  const uint32_t a = dcrx_lds_at<uint16_t>(tt.bk_start[g], h), b = dcrx_lds_at<uint16_t>(tt.bk_start[g], h + 1);
-  int tag = -1;
-  for (uint32_t i = a; i < b; i++)
-    if (dcrx_lds_at<uint64_t>(tt.bk_pk[g], i) == val) tag = (int)dcrx_lds_at<uint16_t>(tt.bk_tag[g], i);
-  return tag;
+  const LookupQ q[1] = {{tt.bk_mask[g], tt.bk_tag[g], tt.bk_pk[g], val, true}};
+  int out[1];
+  lookup_lockstep<1>(q, out);
+  return out[0];
 }
 
 // 32 bases of a read held in registers (NW words) from stored base s >= 0: one select chain per
@@ -877,10 +871,10 @@ DCRX_DEV int tail2_fast(const Tail2Tabs &tt, const WS &w, const int n, const uin
   int v, sv, j = 0, sj = 0;
   {   // both candidate ends of the V pair and of the J pair, side by side
     const LookupQ q[4] = {
-        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
-        {tt.bk_start[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva + 1 - wsv)) & mv, sva + 1 + Lv <= n},
-        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, jc == 1 && sja >= 0},
-        {tt.bk_start[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, jc == 1 && sja + 1 + Lj <= n}};
+        {tt.bk_mask[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva - wsv)) & mv, sva >= 0},
+        {tt.bk_mask[0], tt.bk_tag[0], tt.bk_pk[0], (Wv >> v2_sh(sva + 1 - wsv)) & mv, sva + 1 + Lv <= n},
+        {tt.bk_mask[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja - wsj)) & mj, jc == 1 && sja >= 0},
+        {tt.bk_mask[1], tt.bk_tag[1], tt.bk_pk[1], (Wj >> v2_sh(sja + 1 - wsj)) & mj, jc == 1 && sja + 1 + Lj <= n}};
     int t[4];
     lookup_lockstep<4>(q, t);
     slow |= (t[0] >= 0) == (t[1] >= 0);                   // none (cannot be) or two V tags inside the pair
@@ -974,7 +968,8 @@ DCRX_DEV void tail2_count(const Counters &C, const int status, const bool forwar
 // ------------------------------------------------------------------------------
 struct Rescue2Tabs {
   Tail2Tabs t;
-  dcrx_ldsaddr h_start[2][2], h_kw[2][2], h_pk[2][2];   // [gene][half - 1]: buckets of the half-tag classes (starts, class-local keyword, packed keyword)
+  uint32_t h_mask[2][2];                     // [gene][half - 1]: the half-tag classes' tables: slots - 1 ...
+  dcrx_ldsaddr h_kw[2][2], h_pk[2][2];       // ... class-local keyword per slot (uint16; V2_PH_EMPTY: empty), packed keyword per slot (uint64)
   dcrx_ldsaddr kw_begin, kw_tags;                        // keyword -> its tags, ascending (uint32 CSR)
   dcrx_ldsaddr tag_pk[2];                                // uint64 per tag: the tag as the stored read shows it in this frame
   uint32_t kw_base[2][2];                                // first global keyword id of the class
@@ -990,7 +985,7 @@ DCRX_DEV Rescue2Tabs rescue2_tabs(const DevTables &T0, const V2Ori &V0, const ui
   for (int g = 0; g < 2; g++) {
     for (int h = 0; h < 2; h++) {
       const int cls = g == 0 ? (h == 0 ? K_VH1 : K_VH2) : (h == 0 ? K_JH1 : K_JH2);
-      r.h_start[g][h] = dcrx_ldsaddr_of(bk + V0.bk_start_off[cls]);
+      r.h_mask[g][h] = V0.bk_mask[cls];
       r.h_kw[g][h] = dcrx_ldsaddr_of(bk + V0.bk_kw_off[cls]);
       r.h_pk[g][h] = dcrx_ldsaddr_of(bk + V0.bk_pk_off[cls]);
       r.kw_base[g][h] = kw_base[cls];
@@ -1012,16 +1007,6 @@ extern unsigned long long g_r2_reasons[32];
 #define R2S(k) RESCUE2_SLOW
 #endif
 
-// class-local keyword whose packed form is `val`, or -1
-DCRX_DEV int rescue2_lookup(const dcrx_ldsaddr start, const dcrx_ldsaddr kws, const dcrx_ldsaddr pk, const uint64_t val) {
-  const uint32_t h = v2_hash(val);
-  const uint32_t a = dcrx_lds_at<uint16_t>(start, h), b = dcrx_lds_at<uint16_t>(start, h + 1);
-  int kw = -1;
-  for (uint32_t i = a; i < b; i++)
-    if (dcrx_lds_at<uint64_t>(pk, i) == val) kw = (int)dcrx_lds_at<uint16_t>(kws, i);
-  return kw;
-}
-
 // Which gene a half-tag sweep serves: gene G (0 = V, 1 = J) for the whole wave, or (G = -1) picked lane by lane — for an
 // entry whose two genes differ in kind (one has its full tag, the other needs the rescue) one sweep then serves the V
 // rescues and the J rescues of a wave side by side, the same instructions on per-lane tables, instead of one sweep after
@@ -1030,7 +1015,7 @@ template <int G>
 struct GeneOf {
   const Rescue2Tabs &rt;
   bool j;                                       // G = -1: this lane's gene
-  DCRX_DEV dcrx_ldsaddr h_start(int h) const { return G >= 0 ? rt.h_start[G < 0 ? 0 : G][h] : (j ? rt.h_start[1][h] : rt.h_start[0][h]); }
+  DCRX_DEV uint32_t h_mask(int h) const { return G >= 0 ? rt.h_mask[G < 0 ? 0 : G][h] : (j ? rt.h_mask[1][h] : rt.h_mask[0][h]); }
   DCRX_DEV dcrx_ldsaddr h_kw(int h) const { return G >= 0 ? rt.h_kw[G < 0 ? 0 : G][h] : (j ? rt.h_kw[1][h] : rt.h_kw[0][h]); }
   DCRX_DEV dcrx_ldsaddr h_pk(int h) const { return G >= 0 ? rt.h_pk[G < 0 ? 0 : G][h] : (j ? rt.h_pk[1][h] : rt.h_pk[0][h]); }
   DCRX_DEV uint32_t kw_base(int h) const { return G >= 0 ? rt.kw_base[G < 0 ? 0 : G][h] : (j ? rt.kw_base[1][h] : rt.kw_base[0][h]); }
@@ -1122,8 +1107,8 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
         const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
         if (f >= n) continue;
         const int s1 = f - L1 + 1, s2 = f - L2 + 1;
-        const LookupQ q[2] = {{g.h_start(0), g.h_kw(0), g.h_pk(0), (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
-                              {g.h_start(1), g.h_kw(1), g.h_pk(1), (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
+        const LookupQ q[2] = {{g.h_mask(0), g.h_kw(0), g.h_pk(0), (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
+                              {g.h_mask(1), g.h_kw(1), g.h_pk(1), (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
         int kw[2];
         lookup_lockstep<2>(q, kw);
         const int kw1 = kw[0], kw2 = kw[1];
@@ -1223,7 +1208,8 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
     const int sa = 2 * pair - Lf + 1;
     const int ws = min(max(sa, 0), n - 32);
     const uint64_t W = w.stored64(ws);
-    const dcrx_ldsaddr bs = vfull ? tt.bk_start[0] : tt.bk_start[1], bt = vfull ? tt.bk_tag[0] : tt.bk_tag[1], bp = vfull ? tt.bk_pk[0] : tt.bk_pk[1];
+    const uint32_t bs = vfull ? tt.bk_mask[0] : tt.bk_mask[1];
+    const dcrx_ldsaddr bt = vfull ? tt.bk_tag[0] : tt.bk_tag[1], bp = vfull ? tt.bk_pk[0] : tt.bk_pk[1];
     const LookupQ q[2] = {{bs, bt, bp, (W >> v2_sh(sa - ws)) & mf, sa >= 0}, {bs, bt, bp, (W >> v2_sh(sa + 1 - ws)) & mf, sa + 1 + Lf <= n}};
     int t[2];
     lookup_lockstep<2>(q, t);

@@ -428,6 +428,10 @@ int dcrx_gzip_close(void *writer);
 typedef struct dcrx_tune_state {
   uint32_t rescue_waves, launches;
   float us_4096, us_3072;
+  uint32_t launch_form;      /* the frame's last call, whatever its size: 0 none yet, 1 the three-launch form (tag sets or shapes the
+                                v2 kernels do not serve), 2 the v2 kernels with the tail a role of the finishing launch, 3 the v2
+                                kernels with the tail inside the scan kernel */
+  uint32_t reserved;
 } dcrx_tune_state_t;
 int dcrx_tune_state(const dcrx_tables_t *tables, int orientation, uint64_t n_reads, dcrx_tune_state_t *out);
 

@@ -98,6 +98,23 @@ def test_config3_both_chains_bit_exact_vs_oracle():
         orec, ocnt = pu.oracle_records(ot, reads, "reverse", False, 130)
         pu.assert_records_equal(rec, orec, reads, ts.chain)
         pu.assert_counters_equal(cnt, ocnt, ts.chain)
+        # ... through the v2 kernels: the extended sets' tables must not send 150-nt batches to the three-launch form (round 5:
+        # larger keyword tables did, priced at the long reads' register shape — four times the step, and no test said so)
+        assert t.tune_state(n)["launch_form"].startswith("v2"), (ts.chain, t.tune_state(n))
+
+
+def test_every_baseline_tag_set_runs_on_the_v2_kernels():
+    """What bench.py times for BASELINE configs 2, 3 and 5 is the v2 path: every one of their tag sets, 150-nt batches."""
+    sets = [synth.config_tagset(2)] + list(synth.config3_tagsets()) + list(synth.config5_tagsets())
+    for ts in sets:
+        t, _ = _tables(ts)
+        hb = nat.synth_reads_host(t, nat.synth_cfg(seed=1), 0, 5000)
+        nat.decombine(t, hb)
+        form = t.tune_state(5000)["launch_form"]
+        assert form.startswith("v2"), (ts.chain, form)
+    t, _ = _tables(synth.config_tagset(2))
+    nat.decombine(t, nat.synth_reads_host(t, nat.synth_cfg(seed=1), 0, 5000))
+    assert t.tune_state(5000)["launch_form"] == "v2, tail inside the scan"
 
 
 def test_device_generator_equals_host_generator():
@@ -749,13 +766,13 @@ def test_tail_waves_follow_the_workload_on_one_handle():
 @pytest.mark.parametrize("config,env", [
     (2, {}),                                                        # the handle's own choice (settles on the sixth call) ...
     (2, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (2, {"DCRX_DEBUG_RESCUE_WAVES": "4096"}),      # ... and either outcome, forced
-    (2, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "4"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "5"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
+    (2, {"DCRX_DEBUG_TAIL_WAVES": "2"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "4"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "5"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
     (2, {"DCRX_DEBUG_NO_TUNE": "1"}),
-    (5, {}), (5, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
+    (5, {}), (5, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "2"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
 ], ids=lambda x: x if isinstance(x, int) else ("own-choice" if not x else "-".join(f"{k[11:].lower()}{v}" for k, v in x.items())))
 def test_timed_launch_shapes_at_size(config, env):
     """What bench.py times is a launch of >= 2^20 reads on a fused handle whose finishing launch runs on 3 072 or 4 096 rescue
-    waves (the handle's own choice, settled on its sixth launch of a size class) and whose scan blocks run 3 to 6 tail waves:
+    waves (the handle's own choice, settled on its sixth launch of a size class) and whose scan blocks run 2 to 6 tail waves:
     every such shape, forced through the library's A/B switches in a process of its own, on 2.2 M reads of BASELINE configs 2
     and 5 (mouse gamma), seven launches on one handle, every record and counter of every launch against the oracle."""
     import subprocess
