@@ -180,6 +180,58 @@ def collapse_front(text: bytes, oligo: str, allow_ns: bool, lenthreshold: int, q
     return rows[:n], offs, cnt
 
 
+class Cdr3GenesC(C.Structure):
+    _fields_ = [("n_v", C.c_uint32), ("n_j", C.c_uint32),
+                ("v_regions", C.c_void_p), ("v_region_off", C.c_void_p), ("j_regions", C.c_void_p), ("j_region_off", C.c_void_p),
+                ("v_pos", C.c_void_p), ("v_res", C.c_void_p), ("v_res_off", C.c_void_p),
+                ("j_pos", C.c_void_p), ("j_motif", C.c_void_p), ("j_motif_off", C.c_void_p)]
+
+
+CDR3_ROW_DTYPE = np.dtype([("seq_off", "<u8"), ("aa_off", "<u8"), ("seq_len", "<u4"), ("aa_len", "<u4"), ("junction_off", "<u4"),
+                           ("junction_len", "<u4"), ("junction_aa_off", "<u4"), ("junction_aa_len", "<u4"), ("start_cdr3", "<i4"),
+                           ("end_cdr3", "<i4"), ("bad_codon_at", "<u4"), ("status", "u1"), ("productive", "u1"), ("in_frame", "u1"),
+                           ("stop", "u1"), ("conserved_c", "u1"), ("conserved_f", "u1"), ("pad", "u1", (2,)), ("reserved", "<u4")])
+CDR3_OK, CDR3_INDEX_ERROR, CDR3_BAD_CODON = 0, 1, 2
+
+
+class Cdr3Genes:
+    """The gene tables of dcrx_cdr3_batch (the reference's import_gene_information, translate.py:163-254) as texts and offsets."""
+
+    def __init__(self, v_regions, j_regions, v_pos, v_res, j_pos, j_motif):
+        def blob(strings, off_dtype):
+            bs = [str(x).encode("latin-1") for x in strings]
+            off = np.zeros(len(bs) + 1, dtype=off_dtype)
+            off[1:] = np.cumsum([len(b) for b in bs])
+            return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), off
+        self.n_v, self.n_j = len(v_regions), len(j_regions)
+        self._keep = [blob(v_regions, np.uint64), blob(j_regions, np.uint64), blob(v_res, np.uint32), blob(j_motif, np.uint32),
+                      np.ascontiguousarray(v_pos, dtype=np.int32), np.ascontiguousarray(j_pos, dtype=np.int32)]
+        (vr, vo), (jr, jo), (vs, vso), (jm, jmo), vp_, jp_ = self._keep
+        self.c = Cdr3GenesC(self.n_v, self.n_j, vr.ctypes.data, vo.ctypes.data, jr.ctypes.data, jo.ctypes.data,
+                            vp_.ctypes.data, vs.ctypes.data, vso.ctypes.data, jp_.ctypes.data, jm.ctypes.data, jmo.ctypes.data)
+
+
+def cdr3_batch(genes: Cdr3Genes, v, j, vdel, jdel, inserts):
+    """dcrx_cdr3_batch: (rows[CDR3_ROW_DTYPE], text bytes) for the DCRs (v, j, vdel, jdel: integers; inserts: strings)."""
+    n = len(v)
+    v, j, vdel, jdel = (np.ascontiguousarray(x, dtype=np.int32) for x in (v, j, vdel, jdel))
+    ib = [str(x).encode("latin-1") for x in inserts]
+    ioff = np.zeros(n + 1, dtype=np.uint64)
+    ioff[1:] = np.cumsum([len(b) for b in ib])
+    itext = np.frombuffer(b"".join(ib) + b"\0", dtype=np.uint8).copy()
+    rows = np.zeros(n, dtype=CDR3_ROW_DTYPE)
+    assert CDR3_ROW_DTYPE.itemsize == 64
+    args = (C.byref(genes.c), n, v.ctypes.data, j.ctypes.data, vdel.ctypes.data, jdel.ctypes.data, itext.ctypes.data, ioff.ctypes.data, rows.ctypes.data)
+    need = int(lib().dcrx_cdr3_batch(*args, None, 0))
+    if need < 0:
+        check(need)
+    text = np.zeros(max(need, 1), dtype=np.uint8)
+    got = int(lib().dcrx_cdr3_batch(*args, text.ctypes.data, need))
+    if got < 0:
+        check(got)
+    return rows, text.tobytes()
+
+
 class TuneStateC(C.Structure):
     _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_4096", C.c_float), ("us_3072", C.c_float),
                 ("launch_form", C.c_uint32), ("reserved", C.c_uint32)]
@@ -195,7 +247,7 @@ EXPORTS = [
     "dcrx_tables_create", "dcrx_tables_destroy", "dcrx_tables_info", "dcrx_pack_reads", "dcrx_pack_reads_span",
     "dcrx_unpack_reads", "dcrx_fastq_open", "dcrx_fastq_open_range", "dcrx_fastq_lines", "dcrx_fastq_close", "dcrx_fastq_next", "dcrx_count_prefix_byte", "dcrx_assemble_rows",
     "dcrx_decombine", "dcrx_decombine_device", "dcrx_set_timing_events", "dcrx_set_step_events", "dcrx_reserve_device", "dcrx_compact_hits_device",
-    "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus", "dcrx_tune_state",
+    "dcrx_compact_hits_bitmap_device", "dcrx_compact_hits_packed_device", "dcrx_set_reserved_cus", "dcrx_tune_state", "dcrx_cdr3_batch",
     "dcrx_device_count", "dcrx_set_device", "dcrx_device_name", "dcrx_malloc_device", "dcrx_free_device",
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
@@ -250,6 +302,7 @@ def lib():
         "dcrx_spacer_search": (i32, [C.c_char_p, i32, C.c_char_p, i32, vp, vp, i32, C.POINTER(C.c_int32)]),
         "dcrx_set_reserved_cus": (i32, [vp, u32]),
         "dcrx_tune_state": (i32, [vp, i32, u64, C.POINTER(TuneStateC)]),
+        "dcrx_cdr3_batch": (C.c_int64, [C.POINTER(Cdr3GenesC), u64, vp, vp, vp, vp, vp, vp, vp, vp, u64]),
         "dcrx_gzip_open": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
         "dcrx_gzip_write": (i32, [vp, vp, u64]),
         "dcrx_gzip_close": (i32, [vp]),

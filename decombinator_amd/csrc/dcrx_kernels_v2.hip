@@ -1587,7 +1587,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   uint32_t ring_batches = 0;
   // (measured, profiles/r04: config 2's 57 KB table 0.413 ms per step fused against 0.429 with the tail as a role; the extended
   // beta set's 76 KB table 0.752 against 0.726 for config 3's two chains: pair tables of up to 64 KB fuse)
-  if (CAN_FUSE && T.v2[o].trans_bytes <= 64u * 1024u && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
+  static const uint32_t fuse_limit = [] { const char *e = getenv("DCRX_DEBUG_FUSE_LIMIT_KB"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v * 1024u : 64u * 1024u; }();      // (A/B)
+  if (CAN_FUSE && T.v2[o].trans_bytes <= fuse_limit && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
     const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
     static const uint32_t nb_max = [] {      // (tests: DCRX_DEBUG_RING_BATCHES=4 forces the shortest ring)
       const char *e = getenv("DCRX_DEBUG_RING_BATCHES");
@@ -1597,7 +1598,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // (the whole ring or none: with the extended alpha set's 119 KB table only four batches fit, the scanning waves wait for
     // room, and config 3 took 7.26 ms per 100 M reads against 5.91 with the tail as a role of the finishing launch;
     // tests force shorter rings through DCRX_DEBUG_RING_BATCHES)
-    const uint32_t nb_min = getenv("DCRX_DEBUG_RING_BATCHES") ? 4u : V2_RING_MAXBATCHES;
+    // (round 5: a ring of 8 batches serves config 2 as well as one of 16 — 0.366 / 0.373 against 0.374 / 0.377 ms per step —, one
+    // of 4 does not: 0.447; profiles/r05/ring_batches_ab.log)
+    const uint32_t nb_min = getenv("DCRX_DEBUG_RING_BATCHES") ? 4u : 8u;
     for (uint32_t nb = nb_max; nb >= nb_min; nb >>= 1)
       if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches = nb; break; }
   }

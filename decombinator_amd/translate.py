@@ -10,7 +10,6 @@ CDR1/2) are a `GeneInfo` here, set with `set_gene_information` (or passed as `ge
 from __future__ import annotations
 
 import collections as coll
-import re
 from dataclasses import dataclass, field
 from typing import List
 
@@ -96,57 +95,68 @@ def set_gene_information(genes: GeneInfo) -> None:
     _genes = genes
 
 
-def get_cdr3(dcr, headers, inputargs, genes: GeneInfo | None = None):
-    """translate.py:257-357, step for step; returns the dict of output fields."""
+def _native_genes(G: GeneInfo):
+    """The tables of dcrx_cdr3_batch for a GeneInfo, built once per GeneInfo object."""
+    from . import _native as nat
+    cached = getattr(G, "_native", None)
+    if cached is None:
+        cached = nat.Cdr3Genes(G.v_regions, G.j_regions, G.v_translate_position, G.v_translate_residue,
+                               G.j_translate_position, G.j_translate_residue)
+        object.__setattr__(G, "_native", cached)
+    return cached
+
+
+def cdr3_batch(dcrs, headers, inputargs, genes: GeneInfo | None = None):
+    """get_cdr3 for many DCRs at once: one call into libdcrx (dcrx_cdr3_batch, include/dcrx.h — the reference's translate.py:257-357
+    restated natively) and the rows' dictionaries filled from what it returns.  Raises what the reference raises for the first
+    row that would: IndexError (a gene index outside its table, a translation shorter than the V gene's residue position),
+    ValueError (a letter that is no nucleotide code)."""
+    from . import _native as nat
     G = genes if genes is not None else _genes
     if G is None:
         raise RuntimeError("set_gene_information() first (the reference's import_gene_information)")
-    out_data = coll.defaultdict()
-    for f in headers:
-        out_data[f] = ""
-    out_data["decombinator_id"] = (",".join(dcr) if inputargs["command"] == "translate" else ", ".join(dcr))   # :271-274
-    out_data["rev_comp"] = "F"
-    start_cdr3 = 0
-    end_cdr3 = 0
-    v, j, vdel, jdel = int(dcr[0]), int(dcr[1]), int(dcr[2]), int(dcr[3])
-    ins_nt = dcr[4][1:] if inputargs["command"] == "translate" else dcr[4]                                     # :287-290
-    out_data["v_call"] = G.v_names[v].split("*")[0]
-    out_data["j_call"] = G.j_names[j].split("*")[0]
-    v_used = G.v_regions[v] if vdel == 0 else G.v_regions[v][:-vdel]                                            # :296-299
-    j_used = G.j_regions[j][jdel:]
-    out_data["sequence"] = "".join([v_used, ins_nt, j_used])
-    out_data["sequence_aa"] = translate_nt(out_data["sequence"])
-    if (len(out_data["sequence"]) - 1) % 3 == 0:                                                               # :312-317 (the reference's frame test, literally)
-        out_data["productive"] = "T"
-        out_data["vj_in_frame"] = "T"
-    else:
-        out_data["productive"] = "F"
-        out_data["vj_in_frame"] = "F"
-    if "*" in out_data["sequence_aa"]:                                                                         # :320-324
-        out_data["productive"] = "F"
-        out_data["stop_codon"] = "T"
-    else:
-        out_data["stop_codon"] = "F"
-    if out_data["sequence_aa"][G.v_translate_position[v] - 1] == G.v_translate_residue[v]:                      # :327-335 (IndexError like the reference when the sequence is too short)
-        start_cdr3 = G.v_translate_position[v] - 1
-        out_data["conserved_c"] = "T"
-    else:
-        out_data["productive"] = "F"
-        out_data["conserved_c"] = "F"
-    downstream_c = out_data["sequence_aa"][start_cdr3:]
-    site = downstream_c[G.j_translate_position[j]:G.j_translate_position[j] + 4]                                # :341
-    if re.findall(G.j_translate_residue[j], site):
-        end_cdr3 = len(downstream_c) + G.j_translate_position[j] + start_cdr3 + 1
-        out_data["conserved_f"] = "T"
-    else:
-        out_data["productive"] = "F"
-        out_data["conserved_f"] = "F"
-    if out_data["productive"] == "T":                                                                          # :350-355
-        out_data["junction_aa"] = out_data["sequence_aa"][start_cdr3:end_cdr3]
-        out_data["junction"] = out_data["sequence"][start_cdr3 * 3:3 * end_cdr3]
-        out_data["cdr1_aa"] = G.v_cdr1[v]
-        out_data["cdr2_aa"] = G.v_cdr2[v]
-    return out_data
+    from_file = inputargs["command"] == "translate"       # rows of a `.freq` file: fields joined by "," and the insert behind a blank (:271-274, :287-290)
+    ints = [[int(d[k]) for d in dcrs] for k in range(4)]
+    inserts = [(d[4][1:] if from_file else d[4]) for d in dcrs]
+    rows, text = nat.cdr3_batch(_native_genes(G), ints[0], ints[1], ints[2], ints[3], inserts)
+    out = []
+    flag = ("F", "T")
+    for d, r in zip(dcrs, rows):
+        if r["status"] == nat.CDR3_INDEX_ERROR:
+            raise IndexError("string index out of range")
+        if r["status"] == nat.CDR3_BAD_CODON:
+            at = int(r["bad_codon_at"])
+            v, j, vdel, jdel = (int(x) for x in d[:4])
+            seq = "".join([G.v_regions[v] if vdel == 0 else G.v_regions[v][:-vdel], d[4][1:] if from_file else d[4], G.j_regions[j][jdel:]])
+            raise ValueError(f"Codon '{seq[at:at + 3].upper().replace('U', 'T')}' is invalid")
+        rec = coll.defaultdict()
+        for f in headers:
+            rec[f] = ""
+        so, sl, ao, al = int(r["seq_off"]), int(r["seq_len"]), int(r["aa_off"]), int(r["aa_len"])
+        rec["decombinator_id"] = (",".join(d) if from_file else ", ".join(d))
+        rec["rev_comp"] = "F"
+        rec["v_call"] = G.v_names[int(d[0])].split("*")[0]
+        rec["j_call"] = G.j_names[int(d[1])].split("*")[0]
+        rec["sequence"] = text[so:so + sl].decode("latin-1")
+        rec["sequence_aa"] = text[ao:ao + al].decode("latin-1")
+        rec["productive"] = flag[r["productive"]]
+        rec["vj_in_frame"] = flag[r["in_frame"]]
+        rec["stop_codon"] = flag[r["stop"]]
+        rec["conserved_c"] = flag[r["conserved_c"]]
+        rec["conserved_f"] = flag[r["conserved_f"]]
+        if r["productive"]:
+            rec["junction_aa"] = rec["sequence_aa"][int(r["junction_aa_off"]):int(r["junction_aa_off"]) + int(r["junction_aa_len"])]
+            rec["junction"] = rec["sequence"][int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])]
+            rec["cdr1_aa"] = G.v_cdr1[int(d[0])]
+            rec["cdr2_aa"] = G.v_cdr2[int(d[0])]
+        out.append(rec)
+    return out
+
+
+def get_cdr3(dcr, headers, inputargs, genes: GeneInfo | None = None):
+    """The reference's translate.get_cdr3 (translate.py:257-357) for one DCR: same name, arguments and output fields; the work is
+    dcrx_cdr3_batch's (cdr3_batch above, a batch of one)."""
+    return cdr3_batch([dcr], headers, inputargs, genes)[0]
 
 
 # ---- the stage around get_cdr3 (translate.py:163-254 and :388-533), for rows this build or the reference's collapse produced ----
@@ -246,7 +256,7 @@ def cdr3translator(inputargs: dict, data=None) -> list:
                 raise SystemExit
             frequency = tcr[5]
             cluster = tcr[6] if len(tcr) > 6 and isinstance(tcr[6], (int, float)) else ""
-        rec = get_cdr3(tcr[:5], out_headers, inputargs)
+        rec = get_cdr3(tcr[:5], out_headers, inputargs)      # (a batch of one: the rows' own checks above come in the reference's order, row by row)
         rec["sequence_id"] = str(counts["line_count"])
         rec["duplicate_count"] = frequency
         rec["av_UMI_cluster_size"] = cluster

@@ -419,6 +419,47 @@ int dcrx_gzip_open(const char *path, int level, int n_threads, void **writer);
 int dcrx_gzip_write(void *writer, const void *data, uint64_t n_bytes);
 int dcrx_gzip_close(void *writer);
 
+/* ---- translate.get_cdr3 for a batch of DCRs (host only) ----
+ * Replaces the per-row body of the reference's CDR3 step (src/decombinator/translate.py:257-357, called per unique DCR from
+ * cdr3translator :388-533): from the gene tables of import_gene_information (:163-254) and the five fields of each DCR,
+ *   sequence = V region without its last vdel bases + insert + J region from base jdel on (:296-305), its translation
+ *   (standard table; codons with IUPAC ambiguity codes as Bio.Seq.translate resolves them), the in-frame, stop-codon,
+ *   conserved-C and conserved-F calls (:312-347) and, for productive rows, where junction_aa / junction lie (:350-355).
+ * Every index and slice behaves as Python's.  Strings travel as one text and offsets: gene k's region is
+ * v_regions[v_region_off[k] .. v_region_off[k + 1]) (upper case, as the reference stores them), likewise the V genes'
+ * conserved residues (v_translate_residue: compared as a whole string with ONE residue of the translation, :327) and the J
+ * genes' motifs (j_translate_residue: searched with re.findall in four residues, :341-343 — literal characters, '.',
+ * character classes and escaped literals are served; any other regular-expression syntax is DCRX_E_UNSUPPORTED).
+ * The DCRs: v / j / vdel / jdel as integers (int(dcr[k]), :283-286), the insert of row r = ins[ins_off[r] .. ins_off[r + 1])
+ * (the caller has stripped the blank the `translate` command's rows carry, :287-290).
+ * Returns the bytes the rows' text takes — per row its sequence, then its sequence_aa — written into `text` when that fits
+ * text_cap (call with text = NULL to size the buffer); rows[r] says where they lie.  A row the reference would raise on keeps
+ * status != 0 and nothing else: DCRX_CDR3_INDEX_ERROR (a gene index outside its table, or a translation shorter than the V
+ * gene's residue position: IndexError), DCRX_CDR3_BAD_CODON (a letter that is no nucleotide code: Biopython's "Codon '...'
+ * is invalid", bad_codon_at = the codon's first base). */
+enum dcrx_cdr3_status { DCRX_CDR3_OK = 0, DCRX_CDR3_INDEX_ERROR = 1, DCRX_CDR3_BAD_CODON = 2 };
+typedef struct dcrx_cdr3_genes {
+  uint32_t n_v, n_j;
+  const char *v_regions; const uint64_t *v_region_off;      /* n_v + 1 offsets */
+  const char *j_regions; const uint64_t *j_region_off;      /* n_j + 1 */
+  const int32_t *v_pos; const char *v_res; const uint32_t *v_res_off;        /* v_translate_position, v_translate_residue */
+  const int32_t *j_pos; const char *j_motif; const uint32_t *j_motif_off;    /* j_translate_position, j_translate_residue */
+} dcrx_cdr3_genes_t;
+typedef struct dcrx_cdr3_row {
+  uint64_t seq_off, aa_off;              /* into the text: sequence, sequence_aa */
+  uint32_t seq_len, aa_len;
+  uint32_t junction_off, junction_len;          /* inside the row's sequence (productive rows; else 0, 0) */
+  uint32_t junction_aa_off, junction_aa_len;    /* inside the row's sequence_aa */
+  int32_t start_cdr3, end_cdr3;          /* as the reference computes them (residues) */
+  uint32_t bad_codon_at;
+  uint8_t status;                        /* enum dcrx_cdr3_status */
+  uint8_t productive, in_frame, stop, conserved_c, conserved_f;      /* 1 = "T" */
+  uint8_t pad[2];
+  uint32_t reserved;                     /* (64 bytes) */
+} dcrx_cdr3_row_t;
+int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *genes, uint64_t n, const int32_t *v, const int32_t *j, const int32_t *vdel,
+                        const int32_t *jdel, const char *ins, const uint64_t *ins_off, dcrx_cdr3_row_t *rows, char *text, uint64_t text_cap);
+
 /* What a handle has settled for its own launches (no counterpart in the reference).  Where the scan kernel takes the tail
  * itself, a handle times the finishing launches of its first calls of a batch-size class (batches of 2^k .. 2^(k+1) - 1 reads,
  * k >= 20) and keeps the faster of two settings for the class: rescue_waves = 4096 or 3072 once settled, 0 before (a launch

@@ -1,0 +1,104 @@
+"""dcrx_cdr3_batch (include/dcrx.h) — the native restatement of the reference's translate.get_cdr3 (translate.py:257-357) — beyond
+the reference-generated fixtures of test_translate_cdr3.py: its translation against translate_nt (the Python statement of
+Bio.Seq.translate's rules, itself pinned by hand-checked cases) on random sequences with ambiguity codes, the rows the
+reference raises on, Python's index and slice rules at the edges, the motif syntax it serves and the syntax it refuses."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from decombinator_amd import _native as nat
+from decombinator_amd import translate
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "translate_cdr3.json")
+
+
+def _genes(**over):
+    fx = json.load(open(GOLDEN))
+    g = dict(fx["genes"])
+    g.update(over)
+    return translate.GeneInfo(**g)
+
+
+def test_batch_equals_row_by_row_and_the_fixture():
+    fx = json.load(open(GOLDEN))
+    G = translate.GeneInfo(**fx["genes"])
+    for command in ("pipeline", "translate"):
+        cases = [c for c in fx["cases"] if c["command"] == command and c["expect"] != "IndexError"]
+        got = translate.cdr3_batch([c["dcr"] for c in cases], translate.out_headers, {"command": command}, G)
+        assert [dict(x) for x in got] == [c["expect"] for c in cases]
+
+
+def test_translation_equals_translate_nt_with_ambiguity_codes():
+    rnd = random.Random(7)
+    letters = "ACGT" * 6 + "NRYKMSWBDHVXUacgtn"
+    seqs = ["".join(rnd.choice(letters) for _ in range(rnd.randrange(0, 70))) for _ in range(400)]
+    G = translate.GeneInfo(v_regions=seqs, j_regions=[""], v_names=["V*01"] * len(seqs), j_names=["J*01"],
+                           v_translate_position=[1] * len(seqs), v_translate_residue=["C"] * len(seqs),
+                           j_translate_position=[0], j_translate_residue=["FG.G"], v_functionality=["F"] * len(seqs),
+                           j_functionality=["F"], v_cdr1=[""] * len(seqs), v_cdr2=[""] * len(seqs))
+    rows, text = nat.cdr3_batch(translate._native_genes(G), list(range(len(seqs))), [0] * len(seqs), [0] * len(seqs), [0] * len(seqs), [""] * len(seqs))
+    n_checked = 0
+    for s, r in zip(seqs, rows):
+        want = translate.translate_nt(s)
+        if r["status"] == nat.CDR3_INDEX_ERROR:          # fewer than three bases: no residue at position 1
+            assert len(want) == 0
+            continue
+        assert r["status"] == nat.CDR3_OK
+        assert text[int(r["aa_off"]):int(r["aa_off"]) + int(r["aa_len"])].decode() == want, s
+        assert text[int(r["seq_off"]):int(r["seq_off"]) + int(r["seq_len"])].decode() == s       # (the sequence keeps its case: only the translation reads it upper-cased)
+        n_checked += 1
+    assert n_checked > 300
+
+
+def test_rows_the_reference_raises_on():
+    G = _genes()
+    n_v = len(G.v_regions)
+    with pytest.raises(IndexError):
+        translate.get_cdr3([str(n_v), "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)      # v_regions[n_v]
+    with pytest.raises(IndexError):
+        translate.get_cdr3(["0", "0", "400", "400", ""], translate.out_headers, {"command": "pipeline"}, G)          # nothing left to hold the V residue
+    with pytest.raises(ValueError, match="Codon '.*' is invalid"):
+        translate.get_cdr3(["0", "0", "0", "0", "ACJ"], translate.out_headers, {"command": "pipeline"}, G)            # J is no nucleotide code
+    # a negative gene index counts from the end, as a Python list index does
+    a = translate.get_cdr3(["-1", "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
+    b = translate.get_cdr3([str(n_v - 1), "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
+    assert a["sequence"] == b["sequence"] and a["v_call"] == b["v_call"]
+
+
+def test_motif_syntax_served_and_refused():
+    for motif in ("FGXG", "[FW]G.G", "F\\.G", "[^A-D]G", ""):
+        G = _genes(j_translate_residue=[motif] * 5)
+        translate.get_cdr3(["0", "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
+    for motif in ("F(G|A)G", "FG+", "^FG", "FG{2}", "\\w"):
+        G = _genes(j_translate_residue=[motif] * 5)
+        with pytest.raises(nat.DcrxError):
+            translate.get_cdr3(["0", "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
+
+
+def test_motif_search_against_python_re():
+    import re
+    rnd = random.Random(11)
+    aas = "ACDEFGHIKLMNPQRSTVWY*X"
+    for motif in ("FG.G", "[FW]G.G", "G", "[A-F][^G]", "..", "F\\*"):
+        seqs = []
+        for _ in range(300):
+            body = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(30, 90)))
+            seqs.append(body)
+        G = translate.GeneInfo(v_regions=seqs, j_regions=["", ""], v_names=["V*01"] * len(seqs), j_names=["J*01", "J*02"],
+                               v_translate_position=[rnd.randrange(1, 8) for _ in seqs], v_translate_residue=[rnd.choice(aas) for _ in seqs],
+                               j_translate_position=[-6, 2], j_translate_residue=[motif, motif], v_functionality=["F"] * len(seqs),
+                               j_functionality=["F", "F"], v_cdr1=[""] * len(seqs), v_cdr2=[""] * len(seqs))
+        js = [rnd.randrange(2) for _ in seqs]
+        rows, text = nat.cdr3_batch(translate._native_genes(G), list(range(len(seqs))), js, [0] * len(seqs), [0] * len(seqs), [""] * len(seqs))
+        for k, (s, r) in enumerate(zip(seqs, rows)):
+            aa = translate.translate_nt(s)
+            pos = G.v_translate_position[k]
+            start = pos - 1 if aa[pos - 1] == G.v_translate_residue[k] else 0
+            down = aa[start:]
+            jp = G.j_translate_position[js[k]]
+            want = bool(re.findall(motif, down[jp:jp + 4]))
+            assert bool(r["conserved_f"]) == want, (motif, s, js[k])
+            assert bool(r["conserved_c"]) == (start == pos - 1 and aa[pos - 1] == G.v_translate_residue[k])

@@ -11,6 +11,6 @@ O=$R/tools/variants/obj_$NAME
 mkdir -p $O
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -x hip -c $C/dcrx_kernels_v2.hip -o $O/dcrx_kernels_v2.hip.o
 OBJS=""
-for f in dcrx_api.cpp dcrx_tables.cpp dcrx_fastq.cpp dcrx_rows.cpp dcrx_collapse.cpp dcrx_kernels.hip dcrx_synth.hip; do OBJS="$OBJS $C/obj/$f.o"; done
+for f in dcrx_api.cpp dcrx_tables.cpp dcrx_fastq.cpp dcrx_rows.cpp dcrx_collapse.cpp dcrx_translate.cpp dcrx_kernels.hip dcrx_synth.hip; do OBJS="$OBJS $C/obj/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/variants/libdcrx_$NAME.so $O/dcrx_kernels_v2.hip.o $OBJS -lz -lpthread
 echo built tools/variants/libdcrx_$NAME.so
