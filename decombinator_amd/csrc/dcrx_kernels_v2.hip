@@ -1783,7 +1783,8 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
     // (list C's jobs behind list E's on the same waves — one round of blocks instead of two — were measured: the step 3 % longer
     // on config 2, 8 % on config 5: list C's batches are the slow ones, two sweeps each, and want to start with the launch;
-    // profiles/r05/finish_list_c_folded_ab.log)
+    // profiles/r05/finish_list_c_folded_ab.log.  List C's jobs IN FRONT of list E's on the same waves: 1-2 % longer still
+    // than list E's blocks first and list C's in the second round, as shipped; finish_one_round_c_first_ab.log)
     const uint32_t fgrid = (n_regions * (rsplit + csplit) + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
     // blocks of a short list's pass that share a region: as a pass of its own (A/B forms) the list's latency is the launch's, and
