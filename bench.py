@@ -368,6 +368,8 @@ def run_rank(args, device_factory=None):
     if elapsed_nogather is not None:
         elapsed_nogather = max_over_ranks(elapsed_nogather)
     step_ms, kern_ms = device.event_times(events, timed)
+    if os.environ.get("DCRX_BENCH_STEP_TRACE") == "1":      # (does the step time drift over the timed region?  tools/r05_e29.sh)
+        print("step_trace", [round(x, 4) for x in step_ms], "kernel", [round(x, 4) for x in kern_ms], file=sys.stderr)
     if os.environ.get("DCRX_BENCH_DUMP_COUNTERS") == "1" and not dry:      # (instrumented builds of the library, tools/: the raw counter block of the last step)
         print("counters", [int(x) for x in device.d_cnts[-1].cpu().numpy().astype(np.uint64)], file=sys.stderr)
     n_hits, n_read = device.totals()

@@ -302,7 +302,10 @@ enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLA
 //   reads (54 % tail reads) 5 % faster on 6 than on 5 (profiles/r04/tail_waves_*.log); a handle's first launch takes
 //   DCRX_V2_FUSE_TAILWAVES.
 #ifndef DCRX_V2_FUSE_TAILWAVES
-#define DCRX_V2_FUSE_TAILWAVES 4
+#define DCRX_V2_FUSE_TAILWAVES 3
+#endif
+#ifndef DCRX_V2_PRIO_TAIL
+#define DCRX_V2_PRIO_TAIL 1   /* s_setprio of the fused form's tail waves (a scanning wave: DCRX_V2_LOOP_PRIO inside its look-up loop, 0 between two scans) */
 #endif
 constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
 // (round 5, with the keyword tables' look-ups at one wait each a tail wave finishes a batch sooner and fewer of them keep up —
@@ -311,7 +314,12 @@ constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
 // 58 %: .. 0.443 / 0.417 / 0.426; 70 %: .. 0.502 / 0.462 / 0.450.  Waves that scan AND take tail batches between two items
 // (one loop for both kinds of work, so that no wave slot idles) were built and measured: the loop with both bodies in it runs
 // 8 % slower before the first batch changes hands, and the exchange gives nothing back — profiles/r05/flexible_waves_experiment.log)
-constexpr uint32_t V2_TW6_FRAC256 = 164, V2_TW5_FRAC256 = 133, V2_TW4_FRAC256 = 74, V2_TW3_FRAC256 = 41;      // 64 % / 52 % / 29 % / 16 % of a region's reads
+// With the tail waves one priority level above a scanning wave's work between two scans (and one below its look-up loop: DCRX_V2_PRIO_TAIL
+// = 1) a batch finishes sooner again, three waves serve config 2 (0.343-0.345 against 0.347-0.351 ms on four at priority 0, one box:
+// tail_wave_priority_ab.log), and the shares move once more — tail_waves_by_share_tail_priority_1.log, 2 / 3 / 4 / 5 tail waves:
+// 12 %: 0.294 / 0.299; 23 %: 0.323 / 0.326 / 0.336; 35 %: 0.375 / 0.351 / 0.360; 47 %: .. 0.382 / 0.388 / 0.395; 58 %: .. 0.440 /
+// 0.417 / 0.425; 70 %: .. 0.496 / 0.446 / 0.455.
+constexpr uint32_t V2_TW6_FRAC256 = 243, V2_TW5_FRAC256 = 205, V2_TW4_FRAC256 = 136, V2_TW3_FRAC256 = 64;      // 95 % / 80 % / 53 % / 25 % of a region's reads
 constexpr int V2_RING_STRIDE = 15;
 constexpr uint32_t V2_RING_MAXBATCHES = 16;
 
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
    if constexpr (FUSE >= 0) {
     // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
     constexpr bool REV = FUSE == 1;
-#ifdef DCRX_V2_PRIO_TAIL
+#if DCRX_V2_PRIO_TAIL
     __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
 #endif
     const Tail2Tabs tt = tail2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV);

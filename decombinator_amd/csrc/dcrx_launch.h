@@ -52,7 +52,7 @@ struct V2SinkJob {
 // a pair of events on their dispatch (no marker packets), later launches look (hipEventQuery: no waiting) whether the pairs
 // have completed, and the setting whose launches were at least 1.5 % shorter on average stays; else 16.  One per frame.
 struct V2TuneSlot {
-  static constexpr int SAMPLES = 4;      // (two per setting, in turn: with the first launch they fit the five warm-up launches a caller commonly makes)
+  static constexpr int SAMPLES = 2;      // (one per setting — the two differ by a tenth of the launch, samples by a hundredth —: launches 1 and 2 of a size class, so that a caller's third or fourth launch finds them complete and runs on the choice)
   uint32_t choice = 0;               // rescue waves once settled (0: not yet)
   int launches = 0;                  // launches seen in this size class
   hipEvent_t ev[SAMPLES][2] = {};    // (start, stop) of the finishing launch of sample k

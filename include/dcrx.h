@@ -463,7 +463,7 @@ int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *genes, uint64_t n, const int32_
 /* What a handle has settled for its own launches (no counterpart in the reference).  Where the scan kernel takes the tail
  * itself, a handle times the finishing launches of its first calls of a batch-size class (batches of 2^k .. 2^(k+1) - 1 reads,
  * k >= 20) and keeps the faster of two settings for the class: rescue_waves = 4096 or 3072 once settled, 0 before (a launch
- * then runs on the default, 4096, or is one of the four samples); launches = calls seen in the class; us_4096 / us_3072 = what
+ * then runs on the default, 4096, or is one of the two samples); launches = calls seen in the class; us_4096 / us_3072 = what
  * the samples took (0 before).  orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose
  * launches are meant).  DCRX_E_INVALID for a null argument. */
 typedef struct dcrx_tune_state {
