@@ -1028,20 +1028,27 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
         status = RESCUE2_SLOW;
         if (!(x[0] & V2_R_EXC)) {
           const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
-          dcrx_record_t rec;
-          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
 #pragma unroll
           for (int k = 0; k < NW; k++) strip[k] = w[k];
+          // a decombined read's record is stored where its fields are known (and its tuple made there: j_end of a J found through its
+          // first half is the half's start + 2 * split, decombine.py:450-454: errs bit 3); every other settled read's below
+          auto on_ok = [&](dcrx_record_t rec, const uint32_t e) {
+            rec.frame = (uint8_t)(o ? 0 : 1);
+            DCRX_STORE_FINISH(records + r, rec);
+            if (S.dev) tup = sink_tuple_lean(rec, S.wpack, (e & 8u) != 0u && 2 * rt.split[1] != (int)rt.t.L[1]);
+          };
 #ifdef DCRX_EXP_RESCUE_NOOP      // (experiment build, tools/: the entries streamed and records written, nothing resolved — the records are NOT results)
-          status = DCRX_S_J_NONE; rec.v = (uint16_t)(lw.stored64(n - 40) ^ lg[3] ^ x[1 + 2 * NW]);
+          status = DCRX_S_J_NONE; errs = (uint32_t)(lw.stored64(n - 40) ^ lg[3] ^ x[1 + 2 * NW]) & 0u;
 #else
-          if (which == V2_L_E) status = rescue2_fast<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
-          else status = rescue2_fast<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, rec, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
+          if (which == V2_L_E) status = rescue2_fast_to<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
+          else status = rescue2_fast_to<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
 #endif
-          if (status >= 0) { rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1); DCRX_STORE_FINISH(records + r, rec); }
-          else errs = 0;
-          // (j_end of a J found through its first half is the half's start + 2 * split, decombine.py:450-454: errs bit 3)
-          if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, (errs & 8u) != 0u && 2 * rt.split[1] != (int)rt.t.L[1]);
+          if (status > 0) {      // settled, not decombined: the status alone
+            dcrx_record_t rec;
+            rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+            rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1);
+            DCRX_STORE_FINISH(records + r, rec);
+          } else if (status < 0) errs = 0;
         }
       }
       v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
@@ -1283,6 +1290,10 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
   // block 0 — of list X's role — stays to take the left list as it fills and leaves last; every other block signs off when its
   // role is done (its left-list pushes are in memory, each behind a fence of its own)
   const bool staged = work || blockIdx.x == 0;
+#ifdef DCRX_EXP_FINISH_EMPTY      // (experiment builds, tools/: 1 = the launch's blocks leave at once, 2 = they stage their tables and leave — what dispatching and staging cost; the records are NOT results)
+  if (DCRX_EXP_FINISH_EMPTY == 2 && staged) { L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid); __syncthreads(); if (L.counts[tid & 31] == 12345u) A.counters[0] = 1; }
+  return;
+#endif
   if (staged) {
     L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
     __syncthreads();

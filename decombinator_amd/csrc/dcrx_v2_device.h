@@ -1000,6 +1000,14 @@ DCRX_DEV Rescue2Tabs rescue2_tabs(const DevTables &T0, const V2Ori &V0, const ui
 }
 
 constexpr int RESCUE2_SLOW = -1;
+// (host emulation, tools/r2_profile.py: the trips of the lean rescue's loops per entry, from which a wave's trips — the longest
+// of its lanes' — are counted without a GPU)
+#if defined(DCRX_HOST_EMUL) && defined(DCRX_R2_PROFILE)
+void r2_prof(int what, int a);
+#define R2P(what, a) r2_prof(what, a)
+#else
+#define R2P(what, a) ((void)0)
+#endif
 #ifdef DCRX_R2_REASONS
 extern unsigned long long g_r2_reasons[32];
 #define R2S(k) (g_r2_reasons[k]++, RESCUE2_SLOW)
@@ -1048,6 +1056,7 @@ DCRX_DEV int rescue2_candidates(const GeneOf<G> &g, const WS &w, const int n, co
   const dcrx_ldsaddr tpk = g.tag_pk();
   int found = 0;
   for (uint32_t x = x0; x < x1 && !found; x++) {
+    R2P(5, half);
     const int k = (int)dcrx_lds_at<uint32_t>(rt.kw_tags, x);
     const uint64_t y = mismatch_slots(val, dcrx_lds_at<uint64_t>(tpk, (uint32_t)k)) & mask;
     if (dcrx_popc64(y) <= 1) { found = 1; k_out = k; q_out = q; }
@@ -1086,7 +1095,9 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
   int h2n = 0;
   bool any1 = false;
   int res = 0;
+  R2P(1, G);
   while (nz && res == 0) {
+    R2P(2, 0);
     const int kk = REV ? 31 - dcrx_clz32(nz) : dcrx_ctz32(nz);
     nz &= ~(1u << kk);
 #ifdef DCRX_EXP_SWEEP1      // (experiment build, tools/: one flagged pair per sweep — the records are NOT results; what shorter sweeps would buy)
@@ -1097,6 +1108,7 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
     m &= REV ? (0xFu << (28 - 4 * (dcrx_clz32(m) >> 2))) : (0xFu << (4 * (dcrx_ctz32(m) >> 2)));
 #endif
     while (m && res == 0) {
+      R2P(3, 0);
       const int bit = REV ? 31 - dcrx_clz32(m) : dcrx_ctz32(m);
       m &= ~(1u << bit);
       const int pair = 8 * kk + (bit >> 2);
@@ -1106,6 +1118,7 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
       for (int y = 0; y < 2 && res == 0; y++) {
         const int f = REV ? f1 - y : f1 - 1 + y;                   // ascending end position in the frame
         if (f >= n) continue;
+        R2P(4, y);
         const int s1 = f - L1 + 1, s2 = f - L2 + 1;
         const LookupQ q[2] = {{g.h_mask(0), g.h_kw(0), g.h_pk(0), (X >> v2_sh(s1 - xs)) & m1, s1 >= 0},
                               {g.h_mask(1), g.h_kw(1), g.h_pk(1), (X >> v2_sh(s2 - xs)) & m2, s2 >= 0}};
@@ -1118,6 +1131,7 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
           h2n++;
         }
         if (kw1 >= 0) {
+          R2P(8, 0);
           any1 = true;
           const int p = REV ? n - s1 - L1 : s1;
           res = rescue2_candidates<REV, WS, G>(g, w, n, 1, g.kw_base(0) + (uint32_t)kw1, p, k_out, q_out);
@@ -1131,6 +1145,7 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
   if (h2n > 4) return R2S(13);
   half_out = h2n ? 2 : 0;
   for (int i = 0; i < h2n && res == 0; i++) {
+    R2P(6, 0);
     const uint32_t e = (uint32_t)((i < 2 ? h2lo : h2hi) >> (32 * (i & 1)));
     const int f = (int)(e & 0xFFFFu), kw2 = (int)(e >> 16) - 1;
     const int s2 = f - L2 + 1;
@@ -1161,10 +1176,14 @@ constexpr uint32_t RESCUE2_NO_DIGEST = 0xFFFFFFFFu;
 DCRX_DEV uint32_t rescue2_digest_pack(const Digest2 &d) {
   return min(d.vf_n, 3u) | (min(d.jf_n, 3u) << 2) | ((d.any & 0xFu) << 4) | ((d.vf_pair & 0xFFu) << 8) | ((d.jf_pair & 0xFFu) << 16);
 }
-template <bool REV, int NW, int SHAPE, class WS>
-DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
-                          dcrx_record_t &rec, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry,
-                          const uint32_t dg = RESCUE2_NO_DIGEST) {
+// rescue2_fast_to: the fields of a decombined read go to `on_ok` where they are known (the kernel stores the record there): a
+// caller that took them back as results paid for it at every early exit — the function has two dozen, and each nesting level
+// set all eight fields, the rescue bits and the tuple to their defaults again (15 moves a level: a fifth of the lean rescue's
+// vector instructions were such moves).
+template <bool REV, int NW, int SHAPE, class WS, class OnOk>
+DCRX_DEV int rescue2_fast_to(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
+                             OnOk &&on_ok, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry,
+                             const uint32_t dg = RESCUE2_NO_DIGEST) {
   const Tail2Tabs &tt = rt.t;
   const int Lv = (int)tt.L[0], Lj = (int)tt.L[1];
   errs = 0;
@@ -1303,11 +1322,23 @@ DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&l
   if (vp + Lv > jend + Lj) return DCRX_S_F_OVERLAP;
   int lo, hi;
   pyslice(n, end_v + 1, start_j, lo, hi);                                             // read[vdat[1]+1 : jdat[1]] :577
+  dcrx_record_t rec;
   rec.v = (uint16_t)v; rec.j = (uint16_t)j;
   rec.v_start = (uint16_t)vp; rec.j_end = (uint16_t)jend;
   rec.ins_start = (uint16_t)lo; rec.ins_len = (uint16_t)(hi - lo);
   rec.vdel = (uint8_t)kv; rec.jdel = (uint8_t)kj;
+  rec.status = (uint8_t)DCRX_S_OK; rec.frame = 0;
+  on_ok(rec, errs);
   return DCRX_S_OK;
+}
+// ... and with the fields handed back in `rec` (untouched unless the read decombined)
+template <bool REV, int NW, int SHAPE, class WS>
+DCRX_DEV int rescue2_fast(const Rescue2Tabs &rt, const WS &w, const uint32_t (&lg)[NW], const int n, const CfgDev &cfg,
+                          dcrx_record_t &rec, uint32_t &errs, const DevTables &T, const Counters &C, const Counters &Cdry,
+                          const uint32_t dg = RESCUE2_NO_DIGEST) {
+  return rescue2_fast_to<REV, NW, SHAPE>(rt, w, lg, n, cfg, [&](const dcrx_record_t &r, const uint32_t) {
+    rec.v = r.v; rec.j = r.j; rec.v_start = r.v_start; rec.j_end = r.j_end; rec.ins_start = r.ins_start; rec.ins_len = r.ins_len;
+    rec.vdel = r.vdel; rec.jdel = r.jdel; }, errs, T, C, Cdry, dg);
 }
 
 // the counters a status of the lean rescue stands for (besides read_count); errs as rescue2_fast leaves them

@@ -56,6 +56,17 @@ extern "C" void emul_walk_hist(uint64_t *out) { for (int i = 0; i < 32; i++) { o
 extern "C" void emul_r2_reasons(uint64_t *out) { for (int i = 0; i < 32; i++) { out[i] = dcrx::g_r2_reasons[i]; dcrx::g_r2_reasons[i] = 0; } }
 static uint64_t g_v2_stats[64];  // [what] ; 8 + min(#events, 15) ; 24 + kind of event entry; 32 + status of event entries
 extern "C" void emul_v2_stats(uint64_t *out) { for (int i = 0; i < 64; i++) { out[i] = g_v2_stats[i]; g_v2_stats[i] = 0; } }
+#ifdef DCRX_R2_PROFILE
+// tools/r2_profile.py: (what, a) per loop trip of the lean rescue, an entry's events behind a (0, read) marker; every clean event
+// entry then takes the form compiled for its shape, as the kernel's do
+static std::vector<int32_t> g_r2_trace;
+namespace dcrx { void r2_prof(int what, int a) { g_r2_trace.push_back(what); g_r2_trace.push_back(a); } }
+extern "C" uint64_t emul_r2_trace(int32_t *out, uint64_t cap) {
+  const uint64_t n = g_r2_trace.size();
+  if (out) { for (uint64_t i = 0; i < n && i < cap; i++) out[i] = g_r2_trace[i]; g_r2_trace.clear(); }
+  return n;
+}
+#endif
 static uint64_t g_v2_reads = 0;   // reads that took the v2 form since the last emul_v2_reads() call
 extern "C" uint64_t emul_v2_reads(void) { const uint64_t v = g_v2_reads; g_v2_reads = 0; return v; }
 
@@ -144,10 +155,18 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
     const int shp = shape2(d.vf_n, d.jf_n, d.any);
     int st;
 #define DCRX_EMUL_R2(SH) (o ? rescue2_fast<true, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry) : rescue2_fast<false, NW, SH>(rt, rw, lg[0], n, C, rec, errs, T, CC, Cdry))
+#ifdef DCRX_R2_PROFILE
+    dcrx::r2_prof(0, (int)r); dcrx::r2_prof(9, shp);
+    if (bnd) st = DCRX_EMUL_R2(V2_SHAPE_ANY);
+#else
     if ((r & 1) || bnd) st = DCRX_EMUL_R2(V2_SHAPE_ANY);
+#endif
     else if (shp == V2_SHAPE_ONE) st = DCRX_EMUL_R2(V2_SHAPE_ONE);
     else st = DCRX_EMUL_R2(V2_SHAPE_BOTH);
 #undef DCRX_EMUL_R2
+#ifdef DCRX_R2_PROFILE
+    dcrx::r2_prof(7, st);
+#endif
     if (st >= 0) {
       rec.status = (uint8_t)st; rec.frame = (uint8_t)(o ? 0 : 1);
       records[r] = rec;

@@ -11,6 +11,10 @@
 //   3  every row twice (64-byte lines), copy (lane & 1): no compare                                     [113 KB]
 //   4  the 85 rows of depth <= 3 thirty-two times, lane l reads bank l % 32 of its copy: no two lanes of a group meet there;
 //      the rest once                                                                                    [85 x 1 KB + 1 684 x 32 = 139 KB]
+//   5  the split look-up: a shallow state (trie depth <= 4) is a function of the last bases and needs no
+//      row; a "goes deep" bitmap over the 6-mer, 32 copies with lane l at bank l % 32 (ds_read_b32, no two lanes of a group meet),
+//      is probed on every step, and only the lanes that are deep (14 %) or go deep (12 %) read a 16-bit entry — the deep rows'
+//      table or a 6-mer -> state table, one masked ds_read_u16 with the address picked per lane                [56.6 + 16 + 8 KB]
 // Prints cycles (s_memtime) and ns per wave-look-up per CU, and what a 10 M x 150-nt step would need of the LDS at that cost.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,6 +32,7 @@ __global__ __launch_bounds__(1024) void gather_kernel(uint32_t *out, unsigned lo
   constexpr uint32_t NSYM = LAYOUT == 1 ? 64u : 16u;
   constexpr uint32_t NROWS = LAYOUT == 1 ? 990u : ROWS;
   constexpr uint32_t NHOT = LAYOUT == 4 ? HOT3 : HOT;
+  constexpr uint32_t SHALLOW = 0xFFFFu, BITMAP_AT = ROWS * 16u, SIX_AT = BITMAP_AT + 8192u;      // (uint16 units: the bitmap's 4 096 dwords, then the 6-mer table)
   // a row's first cell (32-byte units) in the layout
   auto cell = [](uint32_t row) -> uint32_t {
     if (LAYOUT == 1) return row * 4u;
@@ -41,18 +46,30 @@ __global__ __launch_bounds__(1024) void gather_kernel(uint32_t *out, unsigned lo
     const uint32_t row = i / NSYM, sym = i % NSYM;
     const uint32_t x = mix(i * 2654435761u + seed);
     const uint32_t nxt = (x & 1023u) < p_hot_1024 ? (x >> 10) % NHOT : NHOT + (x >> 10) % (NROWS - NHOT);
-    const uint16_t ent = (uint16_t)cell(nxt);
+    uint16_t ent = (uint16_t)cell(nxt);
+    if (LAYOUT == 5) ent = (x & 1023u) < 154u ? (uint16_t)(NHOT + (x >> 10) % (NROWS - NHOT)) : (uint16_t)SHALLOW;      // a deep state stays deep on 15 % of its steps
     if (LAYOUT == 2 && row < HOT) { for (uint32_t c = 0; c < 4; c++) tab[(cell(row) + c) * 16u + sym] = ent; }
     else if (LAYOUT == 3) { tab[cell(row) * 16u + sym] = ent; tab[(cell(row) + 1u) * 16u + sym] = ent; }
     else if (LAYOUT == 4 && row < HOT3) { for (uint32_t c = 0; c < 32; c++) tab[(cell(row) * 16u) + (sym >> 1) * 64u + c * 2u + (sym & 1u)] = ent; }   // dword (sym / 2) of copy c at bank c
     else if (LAYOUT == 1) tab[cell(row) * 16u + sym] = ent;
     else tab[cell(row) * 16u + sym] = ent;
   }
+  if (LAYOUT == 5) {
+    uint32_t *bm = reinterpret_cast<uint32_t *>(tab + BITMAP_AT);
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) {      // dword (i / 32) of copy (i % 32): 13.8 % of the 6-mers go deep
+      uint32_t v = 0;
+      for (uint32_t b = 0; b < 32; b++) v |= (mix((i >> 5) * 32u + b + seed * 7919u) % 1000u < 138u ? 1u : 0u) << b;
+      bm[i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) tab[SIX_AT + i] = (uint16_t)(NHOT + mix(i ^ seed) % (NROWS - NHOT));
+  }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t e[2], w[2];
   for (int c = 0; c < 2; c++) { e[c] = cell((threadIdx.x * 7u + c * 13u) % NHOT); w[c] = mix(threadIdx.x * 2654435761u ^ (c * 40503u) ^ seed); }
+  if (LAYOUT == 5) e[0] = e[1] = SHALLOW;
   typedef __attribute__((address_space(3))) uint16_t lds_u16;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < ITER; i++) {
@@ -61,6 +78,16 @@ __global__ __launch_bounds__(1024) void gather_kernel(uint32_t *out, unsigned lo
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         uint32_t off;
+        if (LAYOUT == 5) {
+          const uint32_t k6 = (w[c] >> (4 * s)) & 0xFFFu;
+          const uint32_t probe = *reinterpret_cast<const lds_u32 *>(static_cast<uintptr_t>(2u * BITMAP_AT + (((k6 >> 5) << 5) + (lane & 31u)) * 4u));
+          const bool deep = e[c] != SHALLOW, go = ((probe >> (k6 & 31u)) & 1u) != 0u;
+          const uint32_t at = deep ? ((e[c] << 5) | ((k6 & 0xFu) << 1)) : 2u * (SIX_AT + k6);
+          uint32_t nx = SHALLOW;
+          if (deep || go) nx = *reinterpret_cast<const lds_u16 *>(static_cast<uintptr_t>(at));
+          e[c] = nx;
+          continue;
+        }
         if (LAYOUT == 0) off = (e[c] << 5) | (((w[c] >> (4 * s)) & 0xFu) << 1);
         else if (LAYOUT == 1) off = (e[c] << 5) | (((w[c] >> (6 * s)) & 0x3Fu) << 1);
         else if (LAYOUT == 2) off = (e[c] << 5) | (((w[c] >> (4 * s)) & 0xFu) << 1) | (e[c] < HOT * 4u ? (lane & 3u) << 5 : 0u);
@@ -115,5 +142,7 @@ int main() {
     if (run<3>("3 every row x 2 (copy = lane & 1)", ROWS * 64, cus, d_out, d_cyc, d_rt, p_hot, 75)) return 1;
     if (run<4>("4 rows of depth <= 3 x 32 (a bank per lane), the rest once", HOT3 * 1024 + (ROWS - HOT3) * 32, cus, d_out, d_cyc, d_rt, p_hot, 75)) return 1;
   }
+  printf("-- the split look-up (14 %% of the lanes deep, 12 %% going deep: its own draw)\n");
+  if (run<5>("5 split: a bitmap probe per step (a bank per lane), a masked 16-bit read for the deep lanes", ROWS * 32 + 16384 + 8192, cus, d_out, d_cyc, d_rt, 880u, 75)) return 1;
   return 0;
 }

@@ -31,6 +31,8 @@ for spec in tail_as_a_role:131072 side_streams:65536 separate_launches:32768 thr
   timeout 600 python3 $R/bench.py --no-cpu-baseline --cfg-flags $fl 2>/dev/null | tail -1 > $S/bench_config2_$name.log
 done
 timeout 600 python3 $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $S/bench_config2_again_same_box.log
+timeout 600 python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $S/bench_config2_steps20_warmup5.log
+DCRX_BENCH_STEP_TRACE=1 timeout 600 python3 $R/bench.py --no-cpu-baseline --steps 200 --warmup 5 2>&1 | grep step_trace > $S/step_time_over_200_steps.log
 for c in 3 5; do
   timeout 600 python3 $R/bench.py --no-cpu-baseline --config $c --steps 20 2>/dev/null | tail -1 > $S/bench_config${c}.log
   timeout 600 python3 $R/bench.py --no-cpu-baseline --config $c --reads 100000000 --steps 5 --warmup 1 2>/dev/null | tail -1 > $S/bench_config${c}_100M_reads.log

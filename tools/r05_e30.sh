@@ -1,0 +1,16 @@
+# The lean rescue with list E's several-pair entries put back for batches of their own (DCRX_V2_DEFER_PAIRS) against the same build without:
+# parity of the new form against the oracle at 2 M reads first (fast build: config 2's launch shape only), then A/B, interleaved.
+R=$GRAFT_REPO_ROOT; cd $R; export DCRX_DEBUG_FLAGS=1
+DCRX_LIB_PATH=$R/tools/variants/libdcrx_defer.so python3 tests/forced_shape_worker.py 2 2097152 3 2>&1 | tail -3
+cd /tmp
+run() { n=$1; lib=$2; shift 2
+  DCRX_LIB_PATH=$R/tools/variants/libdcrx_$lib.so python3 $R/bench.py --no-cpu-baseline --steps 40 --warmup 30 "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', d['ms_per_step'], 'scan', d['roofline']['dominant_kernel_ms_avg'], 'rest', round(d['roofline']['step_device_ms_avg']-d['roofline']['dominant_kernel_ms_avg'],4))"
+}
+for rep in 1 2 3; do
+run "nodefer cfg2" nodefer
+run "defer   cfg2" defer
+done
+for rep in 1 2; do
+DCRX_BENCH_SUB_RATE=0.02 run "nodefer cfg2 sub 0.02" nodefer
+DCRX_BENCH_SUB_RATE=0.02 run "defer   cfg2 sub 0.02" defer
+done
