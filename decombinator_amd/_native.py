@@ -233,8 +233,8 @@ def cdr3_batch(genes: Cdr3Genes, v, j, vdel, jdel, inserts):
 
 
 class TuneStateC(C.Structure):
-    _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_4096", C.c_float), ("us_3072", C.c_float),
-                ("launch_form", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("rescue_waves", C.c_uint32), ("launches", C.c_uint32), ("us_first", C.c_float), ("us_second", C.c_float),
+                ("launch_form", C.c_uint32), ("candidates", C.c_uint32)]
 
 
 class SynthCfgC(C.Structure):
@@ -396,8 +396,9 @@ class Tables:
         """dcrx_tune_state: what the handle has settled for the finishing launches of batches of n_reads' size class."""
         st = TuneStateC()
         check(lib().dcrx_tune_state(self._h, ORIENTATIONS[orientation], int(n_reads), C.byref(st)))
-        return {"rescue_waves": int(st.rescue_waves), "launches": int(st.launches), "us_4096": round(float(st.us_4096), 2),
-                "us_3072": round(float(st.us_3072), 2),
+        first, second = int(st.candidates) & 0xFFFF, int(st.candidates) >> 16
+        return {"rescue_waves": int(st.rescue_waves), "launches": int(st.launches), f"us_{first}": round(float(st.us_first), 2),
+                f"us_{second}": round(float(st.us_second), 2),
                 "launch_form": {0: "none yet", 1: "three-launch form", 2: "v2, tail as a role", 3: "v2, tail inside the scan"}.get(int(st.launch_form), "?")}
 
     def close(self):

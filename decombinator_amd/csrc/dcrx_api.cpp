@@ -786,10 +786,11 @@ int dcrx_tune_state(const dcrx_tables_t *t, int orientation, uint64_t n_reads, d
   *out = dcrx_tune_state_t{0u, 0u, 0.f, 0.f, 0u, 0u};
   const V2Tune &F = t->tune[orientation == DCRX_ORIENT_FORWARD ? 0 : 1];
   out->launch_form = F.last_form;
+  out->candidates = n_reads >= V2Tune::BIG_BATCH ? (8192u | (4096u << 16)) : (4096u | (3072u << 16));
   const int k = V2Tune::size_class(n_reads);
   if (k < 0) return DCRX_OK;
   const V2TuneSlot &U = F.slot[k];
-  out->rescue_waves = U.choice; out->launches = (uint32_t)U.launches; out->us_4096 = U.us[0]; out->us_3072 = U.us[1];
+  out->rescue_waves = U.choice; out->launches = (uint32_t)U.launches; out->us_first = U.us[0]; out->us_second = U.us[1];
   return DCRX_OK;
 }
 

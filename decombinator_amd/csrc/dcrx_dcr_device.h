@@ -1674,13 +1674,15 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
 // ------------------------------------------------------------------------------
 // Reads beyond the register shapes and the packed hit lists (512 .. 65 535 nt: merged pairs, long amplicons — the
 // reference has no length limit, decombine.py:228-265, :534-585): one read per lane in the plainest form there is.
-// One scan per frame over the packed words in memory with the one-base table in global memory — OR of the entry flags,
+// One scan per frame over the packed words in memory with the one-base table — in LDS where the tables' image fits beside the
+// block's counters (every BASELINE tag set's does: 28 KB of rows for config 2, 59 KB for the extended alpha set), else in
+// global memory — OR of the entry flags,
 // and per full-tag class the count and the first hit's state and end, all in plain integers (the accumulators and hit
 // lists of the forms above pack a position into nine bits) —, then dcr_frame with the rescue by re-scanning.
 // Slow by design: such reads are rare, and everything else of their batch stays on the fast shapes.
 // ------------------------------------------------------------------------------
-template <bool REV>
-DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const ReadView &rv) {
+template <bool REV, bool TABLE_LDS = false>
+DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv) {
   const Frame<REV> F(rv);
   ScanOut so;
   so.acc = 0; so.vcount = so.jcount = 0; so.vstate = so.jstate = 0; so.vend = so.jend = 0;
@@ -1700,7 +1702,7 @@ DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const ReadView &rv) {
       const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
       wv = REV ? (wv << 2) : (wv >> 2);
       if (xc.hit(i)) { e = T.row0; continue; }                // unknown byte: machine back to the root
-      e = trans_at<false>(nullptr, T, (e & TE_ROW_MASK) + (code << 2));
+      e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
       const uint32_t fl = e & ~TE_ROW_MASK;
       if (!fl) continue;
       so.acc |= fl;
@@ -1714,9 +1716,9 @@ DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const ReadView &rv) {
   return so;
 }
 
-template <bool UNIFORM_LEN>
-DCRX_DEV void decombine_long_one(const DevTables &T, const BatchDev &B, const CfgDev &cfg, const uint64_t r, const Counters &C,
-                                 dcrx_record_t *records) {
+template <bool UNIFORM_LEN, bool TABLE_LDS = false>
+DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
+                                 const Counters &C, dcrx_record_t *records) {
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
@@ -1737,12 +1739,12 @@ DCRX_DEV void decombine_long_one(const DevTables &T, const BatchDev &B, const Cf
   int status = DCRX_S_V_NONE, frame = 0;
   for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
     if (attempt == 0) {
-      const ScanOut so = scan_plain<true>(T, rv);
-      status = dcr_frame<true, false, false>(T, nullptr, rv, so, cfg, C, rec, nullptr); frame = 0;
+      const ScanOut so = scan_plain<true, TABLE_LDS>(T, lds_trans, rv);
+      status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, nullptr); frame = 0;
       if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
     } else {
-      const ScanOut so = scan_plain<false>(T, rv);
-      status = dcr_frame<false, false, false>(T, nullptr, rv, so, cfg, C, rec, nullptr); frame = 1;
+      const ScanOut so = scan_plain<false, TABLE_LDS>(T, lds_trans, rv);
+      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, nullptr); frame = 1;
     }
   }
   C.add(DCRX_C_READ_COUNT);                                           // :991

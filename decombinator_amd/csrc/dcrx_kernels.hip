@@ -766,28 +766,69 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
 __global__ void zero_counters_kernel(unsigned long long *__restrict__ counters) {
   if (threadIdx.x < DCRX_N_COUNTERS) counters[threadIdx.x] = 0;
 }
-template <bool UNIFORM_LEN>
-__global__ __launch_bounds__(256) void decombine_long_kernel(DevTables T, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records,
-                                                             unsigned long long *__restrict__ counters) {
-  __shared__ uint32_t lds_counts[DCRX_N_COUNTERS];
+// TABLE_LDS: the tables' image (the one-base rows, then the side tables) staged in the block's LDS as the list kernel stages it.
+// A step of the scan is a dependent look-up with 64 different addresses per wave: out of the L2 that is 64 requests through
+// one texture-address unit (the launch ran at 0.18 T bases/s), out of LDS a gather over 32 banks.
+template <bool UNIFORM_LEN, bool TABLE_LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void decombine_long_kernel(DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records,
+                                                               unsigned long long *__restrict__ counters) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  uint32_t *lds_counts = smem;
+  uint32_t *lds_trans = smem + DCRX_N_COUNTERS;
+  static_assert(DCRX_N_COUNTERS % 4 == 0, "the rows stay 16-byte aligned");
   const int tid = threadIdx.x;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
+  DevTables T = T0;
+  if (TABLE_LDS) {
+    const uint32_t lds_addr = dcrx_lds_address(reinterpret_cast<const uint8_t *>(lds_trans));
+    stage_lds<BLOCK>(T0.image, lds_trans, T0.lds_image_bytes / 16, T0.dfa_bytes / 16, lds_addr, tid);
+    T = tables_in_lds(T0, reinterpret_cast<const uint8_t *>(lds_trans), 0);
+    T.row0 = lds_addr;
+  }
   __syncthreads();
   const Counters C{lds_counts};
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + tid; r < B.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
-    decombine_long_one<UNIFORM_LEN>(T, B, cfg, r, C, records);
+    decombine_long_one<UNIFORM_LEN, TABLE_LDS>(T, lds_trans, B, cfg, r, C, records);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
+}
+template <bool TABLE_LDS, int BLOCK>
+static hipError_t launch_long_as(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
+                                 unsigned long long *d_counters, hipStream_t s, const uint32_t grid, const uint32_t lds) {
+  auto ku = decombine_long_kernel<true, TABLE_LDS, BLOCK>;
+  auto kr = decombine_long_kernel<false, TABLE_LDS, BLOCK>;
+  static bool attr_seen[64];
+  if (TABLE_LDS && first_use_on_device(attr_seen)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ku), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attributes_set_on_device(attr_seen);
+  }
+  if (B.lens) hipExtLaunchKernelGGL(kr, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
+  else hipExtLaunchKernelGGL(ku, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
+  return hipGetLastError();
 }
 static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                               unsigned long long *d_counters, hipStream_t s) {
   hipExtLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, s, P.ev_step_start, nullptr, 0, d_counters);
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
+  // the tables in LDS where a block's image leaves room for two blocks of 512 threads per compute unit or one of 1 024 (long
+  // dependent chains: the waves of a unit hide one another's look-ups); a batch of a few reads keeps the form without staging
+  const uint32_t lds = DCRX_N_COUNTERS * 4u + T.lds_image_bytes;
+  static const bool no_lds = getenv("DCRX_DEBUG_LONG_GLOBAL_TABLES") != nullptr;      // (A/B)
+  if (!no_lds && T.lds_image_bytes && lds <= 156u * 1024u && B.n_reads >= 4096u) {
+    if (lds <= 78u * 1024u) {
+      const uint32_t per_cu = std::min<uint32_t>(4u, (160u * 1024u) / lds);
+      const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, (B.n_reads + 511) / 512));
+      return launch_long_as<true, 512>(P, T, B, cfg, rec, d_counters, s, grid, lds);
+    }
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 1023) / 1024));
+    return launch_long_as<true, 1024>(P, T, B, cfg, rec, d_counters, s, grid, lds);
+  }
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, (B.n_reads + 63) / 64));      // (a wave per block where the batch is small: long chains, few reads)
-  const uint32_t block = B.n_reads > (uint64_t)grid * 64 ? 256u : 64u;
-  if (B.lens) hipExtLaunchKernelGGL(decombine_long_kernel<false>, dim3(grid), dim3(block), 0, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
-  else hipExtLaunchKernelGGL(decombine_long_kernel<true>, dim3(grid), dim3(block), 0, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
-  return hipGetLastError();
+  if (B.n_reads > (uint64_t)grid * 64) return launch_long_as<false, 256>(P, T, B, cfg, rec, d_counters, s, grid, DCRX_N_COUNTERS * 4u);
+  return launch_long_as<false, 64>(P, T, B, cfg, rec, d_counters, s, grid, DCRX_N_COUNTERS * 4u);
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,

@@ -1752,7 +1752,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // blocks wait for a slot; where the scan has taken the tail, config 2 would take 3 072 rescue waves (- 2 %) and config 5 loses
     // 4 % on them: the 4 096 stay there)
     static const uint32_t rescue_waves_env = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
-    uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? 4096u : 3072u);
+    // (batches of 2^25 reads and more, fused form: 8 192 — config 5 at 100 M reads per launch 18.4 against 17.4 G reads/s, config 2
+    // 32.0 against 31.4; at 30 M + 2 % / none: profiles/r05/rescue_waves_by_batch_size.log)
+    const bool big = B.n_reads >= V2Tune::BIG_BATCH;
+    const uint32_t waves_first = (ring_batches && !separate && big) ? 8192u : 4096u, waves_second = (ring_batches && !separate && big) ? 4096u : 3072u;
+    uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? waves_first : 3072u);
     // the fused form: the handle's own choice between 4 096 and 3 072 (V2Tune), timed on its first launches of this batch size
     hipEvent_t tune_start = nullptr, tune_stop = nullptr;
     static const bool tune_off = getenv("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
@@ -1768,10 +1772,13 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
             for (int i = 0; i < V2Tune::SAMPLES && ok; i++)
               ok = hipEventCreate(&U.ev[i][0]) == hipSuccess && hipEventCreate(&U.ev[i][1]) == hipSuccess;
             U.created = ok;
-            if (!ok) { (void)hipGetLastError(); U.choice = 4096u; }
+            if (!ok) { (void)hipGetLastError(); U.choice = waves_first; }
           }
-          if (U.created) { rescue_waves = (k & 1) ? 3072u : 4096u; tune_start = U.ev[k][0]; tune_stop = U.ev[k][1]; }
+          if (U.created) { rescue_waves = (k & 1) ? waves_second : waves_first; tune_start = U.ev[k][0]; tune_stop = U.ev[k][1]; }
         } else if (k >= V2Tune::SAMPLES && U.created) {
+          // (a big batch's samples are waited for, once: a caller that queues such launches ahead of the device — each takes
+          // milliseconds — would otherwise never find them complete, and the wait is one launch's time at most)
+          if (big && k == V2Tune::SAMPLES) (void)hipEventSynchronize(U.ev[V2Tune::SAMPLES - 1][1]);
           bool ready = true;
           for (int i = 0; i < V2Tune::SAMPLES && ready; i++) ready = hipEventQuery(U.ev[i][1]) == hipSuccess;
           (void)hipGetLastError();
@@ -1784,12 +1791,12 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
               ms[i & 1] += t;
             }
             (void)hipGetLastError();
-            U.choice = (ok && ms[1] < 0.985f * ms[0]) ? 3072u : 4096u;
+            U.choice = (ok && ms[1] < 0.985f * ms[0]) ? waves_second : waves_first;
             if (ok) { U.us[0] = 1e3f * ms[0] / (V2Tune::SAMPLES / 2); U.us[1] = 1e3f * ms[1] / (V2Tune::SAMPLES / 2); }
             rescue_waves = U.choice;
             static const bool say = getenv("DCRX_DEBUG_TUNE") != nullptr;
-            if (say) fprintf(stderr, "dcrx tune: finishing launches of %llu reads, frame %d: %.1f us on 4096 rescue waves, %.1f on 3072 -> %u (launch %d)\n",
-                             (unsigned long long)B.n_reads, o, 1e3f * ms[0] / (V2Tune::SAMPLES / 2), 1e3f * ms[1] / (V2Tune::SAMPLES / 2), U.choice, U.launches);
+            if (say) fprintf(stderr, "dcrx tune: finishing launches of %llu reads, frame %d: %.1f us on %u rescue waves, %.1f on %u -> %u (launch %d)\n",
+                             (unsigned long long)B.n_reads, o, 1e3f * ms[0] / (V2Tune::SAMPLES / 2), waves_first, 1e3f * ms[1] / (V2Tune::SAMPLES / 2), waves_second, U.choice, U.launches);
           }
         }
         U.launches++;

@@ -462,17 +462,21 @@ int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *genes, uint64_t n, const int32_
 
 /* What a handle has settled for its own launches (no counterpart in the reference).  Where the scan kernel takes the tail
  * itself, a handle times the finishing launches of its first calls of a batch-size class (batches of 2^k .. 2^(k+1) - 1 reads,
- * k >= 20) and keeps the faster of two settings for the class: rescue_waves = 4096 or 3072 once settled, 0 before (a launch
- * then runs on the default, 4096, or is one of the two samples); launches = calls seen in the class; us_4096 / us_3072 = what
- * the samples took (0 before).  orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose
- * launches are meant).  DCRX_E_INVALID for a null argument. */
+ * k >= 20) on two settings and keeps the faster for the class: 4096 or 3072 rescue waves for batches below 2^25 reads, 8192 or
+ * 4096 from there (`candidates`: the first setting | the second << 16).  rescue_waves = the choice once settled, 0 before (a
+ * launch then runs on the first setting or is one of the two samples); launches = calls seen in the class; us_first / us_second =
+ * what the samples took (0 before).  The samples are read without waiting, so a caller that queues launches ahead of the device
+ * keeps the first setting until they are complete — except for batches of 2^25 reads and more, where the fourth call of a class
+ * waits for the third's finishing launch once (milliseconds; such batches gain up to 6 % from the choice).
+ * orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose launches are meant).
+ * DCRX_E_INVALID for a null argument. */
 typedef struct dcrx_tune_state {
   uint32_t rescue_waves, launches;
-  float us_4096, us_3072;
+  float us_first, us_second;
   uint32_t launch_form;      /* the frame's last call, whatever its size: 0 none yet, 1 the three-launch form (tag sets or shapes the
                                 v2 kernels do not serve), 2 the v2 kernels with the tail a role of the finishing launch, 3 the v2
                                 kernels with the tail inside the scan kernel */
-  uint32_t reserved;
+  uint32_t candidates;
 } dcrx_tune_state_t;
 int dcrx_tune_state(const dcrx_tables_t *tables, int orientation, uint64_t n_reads, dcrx_tune_state_t *out);
 

@@ -13,7 +13,7 @@ from decombinator_amd import _native as nat, synth
 ts = synth.config_tagset(2)
 t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
 for L in [int(x) for x in sys.argv[1:]] or [150, 250, 300, 400, 500, 600, 2000]:
-    n = 4_000_000 if L <= 511 else 200_000
+    n = 4_000_000 if L <= 511 else (2_000_000 if L <= 1000 else 500_000)      # (the long form: every lane of the chip a read, and a few rounds of them)
     db = nat.synth_reads_device(t, nat.synth_cfg(seed=2, read_len=L), 0, n)
     d_rec = nat.DeviceBuffer(n * 16)
     d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
