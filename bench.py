@@ -455,7 +455,7 @@ def run_rank(args, device_factory=None):
                 "samples_us": [{k: v for k, v in tb.tune_state(n).items() if k.startswith("us_")} for tb in all_tables],
                 "launches_in_size_class": [tb.tune_state(n)["launches"] for tb in all_tables],
                 "launch_form": [tb.tune_state(n)["launch_form"] for tb in all_tables],      # (what really ran: a tag set the v2 kernels do not serve shows here)
-                "tail_waves": "per scan block: 2-6 by its region's share of tail reads in the previous launch (4 on a handle's first launch)",
+                "tail_waves": "per scan block: 2-6 by its region's share of tail reads in the previous launch (3 on a handle's first launch)",
                 "first_launch_ms": None if first_launch_ms is None else round(first_launch_ms, 3),
             }
             line["roofline"] = {

@@ -684,6 +684,8 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // every ring batch's GEN (lane l reads GEN[l % NB]: a value read a moment early only errs towards waiting); the entries;
       // the batches' FILLED counts behind them (LDS keeps a wave's order: nothing to wait for).  Per read of the item the same
       // cost 43 us of a 10 M-read step: three dependent LDS round trips behind the look-ups of fifteen other waves, twice per item.
+      // (List E's draw — one round trip per read of the item, above — moved into this transaction as well: the scan 4-6 us LONGER,
+      // the masks and digests of both reads kept alive for it; profiles/r05/list_e_draw_in_the_ring_transaction_ab.log.)
       uint32_t cnts[RPL], total = 0;
 #pragma unroll
       for (int q = 0; q < RPL; q++) { cnts[q] = (uint32_t)__popcll(tmask[q]); total += cnts[q]; }
@@ -1756,7 +1758,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // 32.0 against 31.4; at 30 M + 2 % / none: profiles/r05/rescue_waves_by_batch_size.log)
     const bool big = B.n_reads >= V2Tune::BIG_BATCH;
     const uint32_t waves_first = (ring_batches && !separate && big) ? 8192u : 4096u, waves_second = (ring_batches && !separate && big) ? 4096u : 3072u;
-    uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? waves_first : 3072u);
+    // (the tail as a role of this launch — the extended sets of config 3 —: 3 072, and 4 096 for big batches: 19.3 against 18.8 G reads/s
+    // at 100 M reads, 16.3 against 16.6 at 10 M; profiles/r05/config3_waves_by_batch_size.log)
+    uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? waves_first : (big ? 4096u : 3072u));
     // the fused form: the handle's own choice between 4 096 and 3 072 (V2Tune), timed on its first launches of this batch size
     hipEvent_t tune_start = nullptr, tune_stop = nullptr;
     static const bool tune_off = getenv("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
