@@ -344,11 +344,14 @@ class _Spans:
 
 
 def _clip(off, length, lo, hi=None):
-    """Span of python's s[lo:hi] (0 <= lo <= hi) inside the span (off, length)."""
-    length = length.astype(np.int64)
-    a = np.minimum(lo, length)
-    b = length if hi is None else np.minimum(hi, length)
-    return (off + a.astype(np.uint64)), (b - a).astype(np.uint32)
+    """Span of python's s[lo:hi] (0 <= lo <= hi) inside the span (off, length): uint64 offsets, uint32 lengths (a million of
+    each per batch: no temporaries in other types — the first form spent 16 ms of a batch's 80 here)."""
+    length = np.asarray(length, dtype=np.uint32)
+    b = length if hi is None else np.minimum(length, np.uint32(hi))
+    if lo == 0:
+        return off, b
+    a = np.minimum(length, np.uint32(lo))
+    return off + a, b - a
 
 
 def _next_spans(rd1, rd2, bclength, sampling):
