@@ -24,3 +24,11 @@
 /* the switches after which records are not results */
 #define DCRX_F_PROFILE_MASK (DCRX_F_PROFILE_SCAN_ONLY | DCRX_F_PROFILE_LIST_SCAN_ONLY | DCRX_F_PROFILE_RESCUE_HITS_ONLY | DCRX_F_PROFILE_NO_FINISH | \
                              DCRX_F_PROFILE_NO_EVENTS | DCRX_F_PROFILE_NO_TAIL | DCRX_F_PROFILE_TAIL_STREAM_ONLY)
+
+// The A/B and developer switches the library reads from the environment (DCRX_DEBUG_*, DCRX_STAMPS_DUMP) are honoured only while
+// DCRX_DEBUG_FLAGS=1 is set, like the cfg flags above: a production process cannot be steered by a stray variable.
+#include <cstdlib>
+static inline const char *dcrx_debug_env(const char *name) {
+  static const bool on = [] { const char *e = std::getenv("DCRX_DEBUG_FLAGS"); return e && e[0] == '1'; }();
+  return on ? std::getenv(name) : nullptr;
+}

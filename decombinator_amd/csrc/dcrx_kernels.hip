@@ -710,7 +710,7 @@ static hipError_t launch_all(const LaunchPlan &P, const DevTables &T, const Batc
     e = launch_v2_any(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, acc, s, scan_start, ev_stop, 0u, P.sink.dev ? &K : nullptr);
     if (e != hipSuccess) return e;
   }
-  if (v2 && getenv("DCRX_DEBUG_HANDOVER")) {      // developer aid: how many reads the v2 kernels handed over
+  if (v2 && dcrx_debug_env("DCRX_DEBUG_HANDOVER")) {      // developer aid: how many reads the v2 kernels handed over
     uint32_t qc[2] = {0, 0};
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(qc, queue_count, sizeof qc, hipMemcpyDeviceToHost);
@@ -816,7 +816,7 @@ static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const Bat
   // the tables in LDS where a block's image leaves room for two blocks of 512 threads per compute unit or one of 1 024 (long
   // dependent chains: the waves of a unit hide one another's look-ups); a batch of a few reads keeps the form without staging
   const uint32_t lds = DCRX_N_COUNTERS * 4u + T.lds_image_bytes;
-  static const bool no_lds = getenv("DCRX_DEBUG_LONG_GLOBAL_TABLES") != nullptr;      // (A/B)
+  static const bool no_lds = dcrx_debug_env("DCRX_DEBUG_LONG_GLOBAL_TABLES") != nullptr;      // (A/B)
   if (!no_lds && T.lds_image_bytes && lds <= 156u * 1024u && B.n_reads >= 4096u) {
     if (lds <= 78u * 1024u) {
       const uint32_t per_cu = std::min<uint32_t>(4u, (160u * 1024u) / lds);

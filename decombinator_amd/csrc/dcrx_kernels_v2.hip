@@ -1608,11 +1608,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   uint32_t ring_batches = 0;
   // (measured, profiles/r04: config 2's 57 KB table 0.413 ms per step fused against 0.429 with the tail as a role; the extended
   // beta set's 76 KB table 0.752 against 0.726 for config 3's two chains: pair tables of up to 64 KB fuse)
-  static const uint32_t fuse_limit = [] { const char *e = getenv("DCRX_DEBUG_FUSE_LIMIT_KB"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v * 1024u : 64u * 1024u; }();      // (A/B)
+  static const uint32_t fuse_limit = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_FUSE_LIMIT_KB"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v * 1024u : 64u * 1024u; }();      // (A/B)
   if (CAN_FUSE && T.v2[o].trans_bytes <= fuse_limit && !(cfg.flags & (DCRX_F_V2_NO_FUSE | DCRX_F_V2_SIDE_STREAMS | DCRX_F_V2_LEAN_SERIAL | DCRX_F_V2_NO_LEAN_RESCUE | (DCRX_F_PROFILE_MASK & ~DCRX_F_PROFILE_TAIL_STREAM_ONLY)))) {
     const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes;
     static const uint32_t nb_max = [] {      // (tests: DCRX_DEBUG_RING_BATCHES=4 forces the shortest ring)
-      const char *e = getenv("DCRX_DEBUG_RING_BATCHES");
+      const char *e = dcrx_debug_env("DCRX_DEBUG_RING_BATCHES");
       const uint32_t v = e ? (uint32_t)atoi(e) : V2_RING_MAXBATCHES;
       return (v == 4u || v == 8u || v == 16u) ? v : V2_RING_MAXBATCHES;
     }();
@@ -1621,7 +1621,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // tests force shorter rings through DCRX_DEBUG_RING_BATCHES)
     // (round 5: a ring of 8 batches serves config 2 as well as one of 16 — 0.366 / 0.373 against 0.374 / 0.377 ms per step —, one
     // of 4 does not: 0.447; profiles/r05/ring_batches_ab.log)
-    const uint32_t nb_min = getenv("DCRX_DEBUG_RING_BATCHES") ? 4u : 8u;
+    const uint32_t nb_min = dcrx_debug_env("DCRX_DEBUG_RING_BATCHES") ? 4u : 8u;
     for (uint32_t nb = nb_max; nb >= nb_min; nb >>= 1)
       if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches = nb; break; }
   }
@@ -1727,7 +1727,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // (the caller's stop event for the scan, when there is one — timing, or a caller that orders other work behind the scan —
   // serves as the fork event as well: one signal on the dispatch, no marker packet)
   const hipEvent_t fork_ev = ev_stop ? ev_stop : P.v2_ev_fork;
-  static const uint32_t tail_waves_forced = [] { const char *e = getenv("DCRX_DEBUG_TAIL_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 8) ? (uint32_t)v : 0u; }();      // (tests, A/B)
+  static const uint32_t tail_waves_forced = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_TAIL_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 8) ? (uint32_t)v : 0u; }();      // (tests, A/B)
   // The call's tuple sink (dcrx_sink_device.h), when this launch serves it: the shipped shape (one finishing launch), one pass,
   // no profiling switch, and room: a slab per region with a section per list and one for the late items, a region's bitmap and
   // its ranks in the place kernel's LDS.
@@ -1753,7 +1753,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     // extended sets — 4 096 tail waves and 3 072 rescue waves per list run config 3's step 6 % faster than 8 192 and 4 096: fewer
     // blocks wait for a slot; where the scan has taken the tail, config 2 would take 3 072 rescue waves (- 2 %) and config 5 loses
     // 4 % on them: the 4 096 stay there)
-    static const uint32_t rescue_waves_env = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    static const uint32_t rescue_waves_env = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_RESCUE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     // (batches of 2^25 reads and more, fused form: 8 192 — config 5 at 100 M reads per launch 18.4 against 17.4 G reads/s, config 2
     // 32.0 against 31.4; at 30 M + 2 % / none: profiles/r05/rescue_waves_by_batch_size.log)
     const bool big = B.n_reads >= V2Tune::BIG_BATCH;
@@ -1763,7 +1763,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     uint32_t rescue_waves = rescue_waves_env ? rescue_waves_env : ((ring_batches || separate) ? waves_first : (big ? 4096u : 3072u));
     // the fused form: the handle's own choice between 4 096 and 3 072 (V2Tune), timed on its first launches of this batch size
     hipEvent_t tune_start = nullptr, tune_stop = nullptr;
-    static const bool tune_off = getenv("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
+    static const bool tune_off = dcrx_debug_env("DCRX_DEBUG_NO_TUNE") != nullptr;      // (tests, A/B)
     const int tune_class = V2Tune::size_class(B.n_reads);
     if (ring_batches && !separate && !rescue_waves_env && !tune_off && P.tune && !retry && !cfg.flags && tune_class >= 0) {
       V2TuneSlot &U = P.tune[o].slot[tune_class];      // (a size class of its own for every power of two: a short last batch does not unsettle the others')
@@ -1798,7 +1798,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
             U.choice = (ok && ms[1] < 0.985f * ms[0]) ? waves_second : waves_first;
             if (ok) { U.us[0] = 1e3f * ms[0] / (V2Tune::SAMPLES / 2); U.us[1] = 1e3f * ms[1] / (V2Tune::SAMPLES / 2); }
             rescue_waves = U.choice;
-            static const bool say = getenv("DCRX_DEBUG_TUNE") != nullptr;
+            static const bool say = dcrx_debug_env("DCRX_DEBUG_TUNE") != nullptr;
             if (say) fprintf(stderr, "dcrx tune: finishing launches of %llu reads, frame %d: %.1f us on %u rescue waves, %.1f on %u -> %u (launch %d)\n",
                              (unsigned long long)B.n_reads, o, 1e3f * ms[0] / (V2Tune::SAMPLES / 2), waves_first, 1e3f * ms[1] / (V2Tune::SAMPLES / 2), waves_second, U.choice, U.launches);
           }
@@ -1806,10 +1806,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
         U.launches++;
       }
     }
-    static const uint32_t tail_role_waves_env = [] { const char *e = getenv("DCRX_DEBUG_TAIL_ROLE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    static const uint32_t tail_role_waves_env = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_TAIL_ROLE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t tail_role_waves = tail_role_waves_env ? tail_role_waves_env : (separate ? 8192u : 4096u);
     const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
-    static const uint32_t rescue_waves_c = [] { const char *e = getenv("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
+    static const uint32_t rescue_waves_c = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
     // (list C's jobs behind list E's on the same waves — one round of blocks instead of two — were measured: the step 3 % longer
     // on config 2, 8 % on config 5: list C's batches are the slow ones, two sweeps each, and want to start with the launch;
@@ -1879,7 +1879,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       hipLaunchKernelGGL(kl, dim3(1), dim3(DCRX_V2_FBLOCK), llds, s, A);      // what the lean kernels left
       e = hipGetLastError(); if (e != hipSuccess) return e;
     }
-    static const bool dbg = getenv("DCRX_DEBUG_V2_COUNTS") != nullptr;
+    static const bool dbg = dcrx_debug_env("DCRX_DEBUG_V2_COUNTS") != nullptr;
     if (dbg && e == hipSuccess) {          // debugging aid: the lists' populations (synchronises)
       std::vector<uint32_t> h((size_t)V2_L_COUNTS * n_regions);
       (void)hipStreamSynchronize(s);
@@ -1895,7 +1895,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     std::vector<uint32_t> h(4 * (size_t)n_regions);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
-    if (const char *dump = getenv("DCRX_STAMPS_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); } }
+    if (const char *dump = dcrx_debug_env("DCRX_STAMPS_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); } }
     double a = 0, b = 0, life = 0;
     uint32_t t_first = 0xFFFFFFFFu;
     for (uint32_t r = 0; r < n_regions; r++) t_first = std::min(t_first, h[4 * r]);
@@ -1922,7 +1922,7 @@ hipError_t launch_v2_place(const LaunchPlan &P, const V2SinkLaunch &K, uint64_t 
   }
   // LDS: the region's bitmap and its ranks, then room to stage its tuples (5 bytes each) for whole-line stores: as many as fit
   const uint32_t words = (K.S.per_block / 32u) * 2u;
-  static const int hcap_forced = [] { const char *e = getenv("DCRX_DEBUG_PLACE_HCAP"); return e ? atoi(e) : -1; }();      // (tests: the path of regions whose tuples do not fit)
+  static const int hcap_forced = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_PLACE_HCAP"); return e ? atoi(e) : -1; }();      // (tests: the path of regions whose tuples do not fit)
   const uint32_t hcap = hcap_forced >= 0 ? ((uint32_t)hcap_forced & ~3u) : (std::min<uint32_t>(K.S.per_block, (150u * 1024u - words * 4u) / 5u) & ~3u);
   const uint32_t lds = words * 4u + hcap * 5u;
   hipExtLaunchKernelGGL(v2_place_kernel, dim3(K.n_regions), dim3(V2_PLACE_BLOCK), lds, s, nullptr, ev_stop, 0, K.S, K.counts, K.n_regions, K.tcap, K.ecap,

@@ -661,7 +661,7 @@ for orientation in ("reverse", "forward"):
 print("ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DCRX_DEBUG_RING_BATCHES=ring, PYTHONPATH=root)
+    env = dict(os.environ, DCRX_DEBUG_FLAGS="1", DCRX_DEBUG_RING_BATCHES=ring, PYTHONPATH=root)
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
 
@@ -777,7 +777,7 @@ def test_timed_launch_shapes_at_size(config, env):
     and 5 (mouse gamma), seven launches on one handle, every record and counter of every launch against the oracle."""
     import subprocess
     import sys
-    e = dict(os.environ, **env)
+    e = dict(os.environ, DCRX_DEBUG_FLAGS="1", **env)      # (the library honours its DCRX_DEBUG_* switches only with this set)
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_shape_worker.py"), str(config), "2200000", "7"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "SHAPE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])

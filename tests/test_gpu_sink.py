@@ -153,6 +153,6 @@ assert k > n // 2
 print("ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCRX_DEBUG_PLACE_HCAP="1000", PYTHONPATH=root), cwd=root,
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCRX_DEBUG_FLAGS="1", DCRX_DEBUG_PLACE_HCAP="1000", PYTHONPATH=root), cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])

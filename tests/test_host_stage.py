@@ -274,3 +274,54 @@ def test_n12rows_behaves_like_the_reference_list():
     rows.write_text(text, ", ")
     text.flush()
     assert buf.getvalue().decode() == "".join(", ".join(r) + "\n" for r in expect)
+
+
+def test_clip_is_pythons_slice_on_spans():
+    """_clip(off, len, lo, hi): the span of s[lo:hi] inside every span of a batch, in the arrays' own types."""
+    from decombinator_amd.decombine import _clip
+    rng = np.random.default_rng(5)
+    off = rng.integers(0, 1 << 40, 500, dtype=np.uint64)
+    ln = rng.integers(0, 80, 500).astype(np.uint32)
+    for lo, hi in [(0, None), (0, 42), (42, None), (42, 73), (6, 6), (0, 0), (79, 200)]:
+        o, l = _clip(off, ln, lo, hi)
+        assert o.dtype == np.uint64 and l.dtype == np.uint32
+        for k in range(len(ln)):
+            want = range(int(ln[k]))[lo:hi]
+            assert int(l[k]) == len(want)
+            if len(want):
+                assert int(o[k]) == int(off[k]) + want[0]
+
+
+def test_rows_blob_is_bytes_filled_by_the_library():
+    """assemble_rows_blob hands back a bytes object (not zeroed first by Python: the library's writers touch its pages) whose
+    content is the rows' text, byte for byte what the per-row Python assembly gives."""
+    n = 3000
+    rng = np.random.default_rng(9)
+    rec = np.zeros(n, dtype=nat.RECORD_DTYPE)
+    ok = rng.random(n) < 0.5
+    rec["status"] = np.where(ok, 0, 3)
+    rec["v"], rec["j"] = rng.integers(0, 60, n), rng.integers(0, 13, n)
+    rec["v_start"] = rng.integers(0, 30, n)
+    rec["j_end"] = rec["v_start"] + rng.integers(20, 60, n)
+    rec["ins_start"] = rec["v_start"] + 5
+    rec["ins_len"] = rng.integers(0, 10, n)
+    rec["vdel"], rec["jdel"], rec["frame"] = 2, 3, 1
+
+    def spans(length):
+        text = bytes(rng.integers(65, 90, n * length, dtype=np.uint8))
+        return text, np.arange(n, dtype=np.uint64) * length, np.full(n, length, dtype=np.uint32)
+    vdj, qual, ident, bc, bcq = spans(100), spans(100), spans(20), spans(12), spans(12)
+    blob, rows = nat.assemble_rows_blob(rec, vdj, qual, ident, bc, bcq)
+    assert isinstance(blob, bytes) and rows == int(ok.sum())
+    want = []
+    for k in np.nonzero(ok)[0]:
+        s = vdj[0][int(vdj[1][k]):int(vdj[1][k]) + 100].decode()
+        q = qual[0][int(qual[1][k]):int(qual[1][k]) + 100].decode()
+        r = rec[k]
+        ins = s[int(r["ins_start"]):int(r["ins_start"]) + int(r["ins_len"])]
+        a, b = int(r["v_start"]), int(r["j_end"])
+        fields = [str(int(r["v"])), str(int(r["j"])), str(int(r["vdel"])), str(int(r["jdel"])), ins,
+                  ident[0][int(ident[1][k]):int(ident[1][k]) + 20].decode(), s[a:b], q[a:b],
+                  bc[0][int(bc[1][k]):int(bc[1][k]) + 12].decode(), bcq[0][int(bcq[1][k]):int(bcq[1][k]) + 12].decode()]
+        want.append(", ".join(fields) + "\n")
+    assert blob.decode() == "".join(want)

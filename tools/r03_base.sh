@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/r03_base.sh TAG — micro-benchmark, bench line, list populations and kernel trace of the current build
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 TAG=${1:-r03_base}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-kernel durations at several shares of reads with an N (the slow list's population)
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03_nrate
 mkdir -p $O

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/r04_finish_params3.sh — config 3 (extended sets: the tail a role of the finishing launch) by the waves that share a
 # region's tail list (DCRX_DEBUG_TAIL_ROLE_WAVES) and its list E (DCRX_DEBUG_RESCUE_WAVES)
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 R=$GRAFT_REPO_ROOT
 cd /tmp
 run() { local label=$1; shift; timeout 300 python3 $R/bench.py --no-cpu-baseline --steps 30 --warmup 8 "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label ms_per_step', d['ms_per_step'], 'scan', d['roofline']['dominant_kernel_ms_avg'])"; }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/r04_tail_waves.sh TAG — the fused scan with 3 / 4 / 5 tail waves forced (DCRX_DEBUG_TAIL_WAVES) and with the
 # blocks' own choice (unset), on configs 2 and 5 at 10 M reads per step and on config 2 with 15 % and 70 % rearranged reads
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 TAG=${1:-r04_tw}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/r04_tune_ab.sh — the handle's own choice of the waves on list E (V2Tune) against the fixed 16 (DCRX_DEBUG_NO_TUNE=1), one box
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 R=$GRAFT_REPO_ROOT
 cd /tmp
 run() { local label=$1; shift; timeout 300 python3 $R/bench.py --no-cpu-baseline --steps 40 --warmup 12 "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label ms_per_step', d['ms_per_step'], 'scan', d['roofline']['dominant_kernel_ms_avg'])"; }

@@ -1,5 +1,6 @@
 # Tune with one sample per setting: does the choice land inside the driver's five warm-up launches, and what does
 # `--steps 20 --warmup 5` read then?  Then the GPU suite on the same library.
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 R=$GRAFT_REPO_ROOT; cd $R
 for i in 1 2 3; do
   DCRX_DEBUG_TUNE=1 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 2>&1 | grep -E "tune|ms_per_step" | python3 -c "

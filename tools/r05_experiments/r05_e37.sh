@@ -1,4 +1,5 @@
 # After the tuner learnt 8 192 | 4 096 for big batches: the three configs at 100 M reads per step with a warm-up that lets it settle, then the GPU suite.
+export DCRX_DEBUG_FLAGS=1      # (the library honours its DCRX_DEBUG_* switches only with this set)
 R=$GRAFT_REPO_ROOT; cd /tmp
 run() { n=$1; shift
   DCRX_DEBUG_TUNE=1 python3 $R/bench.py --no-cpu-baseline --reads 100000000 --steps 5 --warmup 5 "$@" 2>&1 | grep -E "^dcrx tune|^\{" | python3 -c "
