@@ -122,13 +122,18 @@ def spawn_ranks(args, argv, script=None) -> int:
     return 0
 
 
+# (what the decombine call never runs: the FASTQ reader, row assembly, the collapse front, CDR3 translation)
+HOST_ONLY_SOURCES = ("dcrx_fastq.cpp", "dcrx_rows.cpp", "dcrx_collapse.cpp", "dcrx_translate.cpp")
+
+
 def csrc_digest() -> str:
-    """sha256 over the kernel and host sources of the library (tools/prof_summary_r05.py holds the same function)."""
+    """sha256 over the sources of the library that the decombine call runs — kernels, device headers, tables, launch code
+    (tools/prof_summary_r05.py holds the same function)."""
     import hashlib
     d = os.path.join(ROOT, "decombinator_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h", ".cpp")) and name not in HOST_ONLY_SOURCES:
             h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

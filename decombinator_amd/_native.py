@@ -520,7 +520,7 @@ class FastqBatch:
 
     __slots__ = ("n", "text", "name_off", "name_len", "seq_off", "seq_len", "qual_off", "qual_len")
 
-    def __init__(self, c: FastqBatchC):
+    def __init__(self, c: FastqBatchC, copy: bool = True):
         n = self.n = int(c.n_records)
         # zero-copy window on the reader's buffer: valid until the next call of next() on that reader
         self.text = (C.c_char * int(c.text_bytes)).from_address(c.text) if c.text_bytes else b""
@@ -528,7 +528,10 @@ class FastqBatch:
         def arr(ptr, ct, dt):
             if n == 0:
                 return np.zeros(0, dtype=dt)
-            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).astype(dt, copy=True)
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+            # copy=False: the offset and length arrays are windows on the reader's store as well (36 MB per million records not
+            # copied) — valid, like the text, until the next call of next() on that reader
+            return a.astype(dt, copy=True) if copy else a
         self.name_off, self.name_len = arr(c.name_off, C.c_uint64, np.uint64), arr(c.name_len, C.c_uint32, np.uint32)
         self.seq_off, self.seq_len = arr(c.seq_off, C.c_uint64, np.uint64), arr(c.seq_len, C.c_uint32, np.uint32)
         self.qual_off, self.qual_len = arr(c.qual_off, C.c_uint64, np.uint64), arr(c.qual_len, C.c_uint32, np.uint32)
@@ -570,10 +573,10 @@ class FastqReader:
         else:
             check(lib().dcrx_fastq_open(os.fsencode(path), int(bool(gzipped)), C.byref(self._h)))
 
-    def next(self, max_records: int) -> FastqBatch:
+    def next(self, max_records: int, copy: bool = True) -> FastqBatch:
         c = FastqBatchC()
         check(lib().dcrx_fastq_next(self._h, int(max_records), C.byref(c)))
-        return FastqBatch(c)
+        return FastqBatch(c, copy)
 
     def close(self) -> None:
         if self._h:

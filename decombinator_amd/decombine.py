@@ -361,10 +361,10 @@ def _next_spans(rd1, rd2, bclength, sampling):
     none_qual = "'NoneType' object is not subscriptable"      # what record[2][...] raises on a FASTA record
     sp = _Spans()
     if rd2 is not None:
-        b1 = rd1.next(BATCH_READS)
+        b1 = rd1.next(BATCH_READS, copy=False)      # (windows on the readers' stores: a batch is done with before the next is asked for)
         if b1.n == 0:
             return None
-        b2 = rd2.next(b1.n)
+        b2 = rd2.next(b1.n, copy=False)
         sp.last = b2.n < b1.n          # zip() stops with the shorter file
         if sp.last:
             b1.truncate(b2.n)
@@ -381,7 +381,7 @@ def _next_spans(rd1, rd2, bclength, sampling):
         sp.id_start, sp.id_len = b1.name_off, b1.name_len
         r2_off, r2_len = b2.seq_off, b2.seq_len
     else:
-        b = rd1.next(2 * BATCH_READS)
+        b = rd1.next(2 * BATCH_READS, copy=False)
         sp.last = b.n < 2 * BATCH_READS
         n = b.n // 2                   # an unpaired last record is consumed and dropped by zip()
         if n == 0:
