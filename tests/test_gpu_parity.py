@@ -667,6 +667,38 @@ print("ok")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["original-like beta (blocks of 512 threads)", "extended-like alpha (one block of 1 024 per unit)"])
+def test_long_form_with_its_tables_in_lds(which):
+    """Batches of 4 096 reads and more of 512 nt and longer take the long form with the tables' image staged in LDS (round 5:
+    dcrx_kernels.hip, launch_long) — two launch shapes by the image's size; 6 000 reads of 600 nt and a ragged batch of
+    512-3 000 nt, real rearrangements in random flanks with substitutions and exception bytes, reverse and `both`, against
+    the oracle (smaller batches keep the form without staging: the test below)."""
+    import random
+    ts = synth.config_tagset(2) if which.startswith("original") else synth.config3_tagsets()[0]
+    t, ot = _tables(ts)
+    rng = random.Random(7)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=77, p_rearranged=0.8, sub_rate=0.01, n_rate=0.002), 0, 12000)
+    cores = nat.unpack_reads(hb)
+    rnd = lambda k: "".join(rng.choice("ACGT") for _ in range(k))
+
+    def lengthen(r, n):
+        a = rng.randrange(0, n - len(r) + 1)
+        s = rnd(a) + r + rnd(n - len(r) - a)
+        return orc.revcomp(s) if rng.random() < 0.3 else s
+    uniform = [lengthen(r, 600) for r in cores[:6000]]
+    ragged = [lengthen(r, rng.choice([512, 513, 600, 777, 1500, 3000])) for r in cores[6000:12000]]
+    for reads in (uniform, ragged):
+        b = nat.pack_reads(reads)
+        assert b.stride > 128 and b.n_reads >= 4096
+        for orientation in ("reverse", "both"):
+            rec, cnt = nat.decombine(t, b, orientation=orientation)
+            orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+            pu.assert_records_equal(rec, orec, reads, "long, tables in LDS, " + orientation)
+            assert (cnt == ocnt).all()
+        assert int((rec["status"] == 0).sum()) > len(reads) // 2
+
+
+@pytest.mark.gpu
 def test_reads_of_512_nt_and_more_decombine_in_all_orientations(tmp_path):
     """VERDICT r3 "missing" 1: the reference has no read-length limit (decombine.py:228-265, :534-585).  Reads of 600 and
     2 000 nt (and some of 513, 5 000 and 20 000 nt) — real rearrangements embedded in random flanks, with substitutions and
