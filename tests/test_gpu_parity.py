@@ -262,6 +262,41 @@ def test_full_size_10M_properties_and_sampled_blocks():
     pu.assert_counters_equal(cnt, tot_o, "all 10 M reads")
 
 
+def test_big_batches_settle_between_8192_and_4096_rescue_waves():
+    """A handle's launches of 2^25 reads and more (round 5): the first on 8 192 rescue waves, then one timed sample on each
+    of 8 192 and 4 096, the fourth call waits for the samples once and keeps the faster — every launch's records and counters
+    the same bytes (40 M reads of config 2 on one handle, five calls; the first call's records are what the sampled-block
+    tests of this file pin against the oracle at such sizes)."""
+    n = 40_000_000
+    ts = synth.config_tagset(2)
+    t, _ = _tables(ts)
+    db = nat.synth_reads_device(t, nat.synth_cfg(seed=12), 0, n)
+    d_rec = nat.DeviceBuffer(n * 16)
+    d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    first_rec = first_cnt = None
+    rng = np.random.default_rng(12)
+    blocks = [int(b) * 65_536 for b in rng.integers(0, n // 65_536, size=8)]
+    for call in range(5):
+        nat.check(nat.lib().dcrx_memset_device(d_rec.ptr, 0xEE, n * 16))
+        nat.decombine_device(t, db, d_rec, d_cnt)
+        nat.synchronize()
+        cnt = d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+        parts = []
+        for first in blocks:
+            part = np.zeros(65_536, dtype=nat.RECORD_DTYPE)
+            nat.check(nat.lib().dcrx_memcpy_d2h(part.ctypes.data, d_rec.ptr + first * 16, 65_536 * 16))
+            parts.append(part.tobytes())
+        if call == 0:
+            first_rec, first_cnt = parts, cnt
+            assert int(cnt[20]) == n
+        else:
+            assert parts == first_rec, f"call {call}"
+            assert (cnt == first_cnt).all(), f"call {call}"
+    st = t.tune_state(n)
+    assert st["rescue_waves"] in (8192, 4096) and st["launch_form"] == "v2, tail inside the scan", st
+    assert "us_8192" in st and "us_4096" in st and st["us_8192"] > 0 and st["us_4096"] > 0, st
+
+
 @pytest.mark.parametrize("which", ["config3_alpha", "config3_beta", "config5_mouse_g", "config5_mouse_d"])
 def test_100M_reads_sampled_blocks(which):
     """BASELINE configs 3 and 5 at their full 100 M reads, device-resident: status histogram vs
