@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libdcrx.so")
 
 N_COUNTERS = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum dcrx_counter order; the strings are the reference's Counter keys
 # (reference decombine.py:598 and the increments cited in include/dcrx_codes.h)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DCRX_ABI_VERSION 2
+#define DCRX_ABI_VERSION 3
 
 enum dcrx_error {
   DCRX_OK = 0,
