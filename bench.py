@@ -333,13 +333,28 @@ def run_rank(args, device_factory=None):
         fence(g)
         return time.perf_counter() - t0
 
+    # The chip's clocks come up over the first ~60 steps behind an idle gap (profiles/r05_final/step_time_over_200_steps.log: 0.361 ->
+    # 0.334 ms), and the set-up above ends in seconds of host work (the exception lists) with the device idle: the device is kept
+    # busy with PREROLL_STEPS untimed steps of the same call (320: a tenth of a second) before the W warm-up steps, so that `--steps 20 --warmup 5` times
+    # what `--steps 200` times.  The line says how many (`preroll_steps`); the warm-up and the timed region are untouched.
     first_launch_ms = None
-    for k in range(args.warmup):
-        if k == 0 and not dry:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
+    preroll_steps = int(os.environ.get("DCRX_BENCH_PREROLL_STEPS", "320")) if (not dry and args.warmup > 0) else 0      # (every rank the same count: the steps of a sharded run hold collectives)
+    for k in range(preroll_steps):
+        if k == 0:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
             torch.cuda.synchronize()
             t_first = time.perf_counter()
         device.step(k, gather, None)
-        if k == 0 and not dry:
+        if k == 0:
+            torch.cuda.synchronize()
+            first_launch_ms = (time.perf_counter() - t_first) * 1e3
+        elif k % 32 == 31:
+            torch.cuda.synchronize()      # (the host does not run hundreds of launches ahead of the device)
+    for k in range(args.warmup):
+        if k == 0 and not dry and first_launch_ms is None:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
+            torch.cuda.synchronize()
+            t_first = time.perf_counter()
+        device.step(k, gather, None)
+        if k == 0 and not dry and first_launch_ms is None:
             torch.cuda.synchronize()
             first_launch_ms = (time.perf_counter() - t_first) * 1e3
     fence(gather)
@@ -351,6 +366,11 @@ def run_rank(args, device_factory=None):
     timed = [k for k in range(args.steps) if k % every == every - 1 or args.steps < every]
     events = device.make_events(args.steps, timed)
     elapsed = timed_loop(gather, args.steps, events, set(timed))
+    # the same steps once more, 200 of them, behind the timed region: the steady-state figure beside the headline (an extra key)
+    elapsed_steady = None
+    steady_steps = int(os.environ.get("DCRX_BENCH_STEADY_STEPS", "200"))
+    if not dry and steady_steps > 0 and args.config != 4:
+        elapsed_steady = timed_loop(gather, steady_steps)
     elapsed_nogather = None
     if gather is not None and not args.no_gather_ab:
         # the same steps without the gather: the difference is the gather time the steps do not hide
@@ -370,6 +390,8 @@ def run_rank(args, device_factory=None):
         dist.all_gather_object(got, per_rank_ms[0])
         per_rank_ms = got
     elapsed = max_over_ranks(elapsed)
+    if elapsed_steady is not None:
+        elapsed_steady = max_over_ranks(elapsed_steady)
     if elapsed_nogather is not None:
         elapsed_nogather = max_over_ranks(elapsed_nogather)
     step_ms, kern_ms = device.event_times(events, timed)
@@ -403,6 +425,8 @@ def run_rank(args, device_factory=None):
             "metric": "Mreads/s decombined (150 bp human-beta)" if args.config in (2, 4) else f"Mreads/s decombined (150 bp, BASELINE config {args.config})",
             "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_steady": None if elapsed_steady is None else round(elapsed_steady / steady_steps * 1e3, 4),
+            "preroll_steps": preroll_steps,
             "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic", "world_size": world, "per_rank_ms_per_step": per_rank_ms,
             "config": {

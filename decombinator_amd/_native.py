@@ -191,7 +191,7 @@ CDR3_ROW_DTYPE = np.dtype([("seq_off", "<u8"), ("aa_off", "<u8"), ("seq_len", "<
                            ("junction_len", "<u4"), ("junction_aa_off", "<u4"), ("junction_aa_len", "<u4"), ("start_cdr3", "<i4"),
                            ("end_cdr3", "<i4"), ("bad_codon_at", "<u4"), ("status", "u1"), ("productive", "u1"), ("in_frame", "u1"),
                            ("stop", "u1"), ("conserved_c", "u1"), ("conserved_f", "u1"), ("pad", "u1", (2,)), ("reserved", "<u4")])
-CDR3_OK, CDR3_INDEX_ERROR, CDR3_BAD_CODON = 0, 1, 2
+CDR3_OK, CDR3_INDEX_ERROR, CDR3_BAD_CODON, CDR3_MOTIF_LEFT = 0, 1, 2, 3
 
 
 class Cdr3Genes:

@@ -439,7 +439,9 @@ int dcrx_decombine_device(dcrx_tables_t *t, const dcrx_cfg_t *cfg, const dcrx_ba
     // neighbouring fields of every tuple)
     const uint64_t longest = b->lens ? (uint64_t)b->stride * 4u : (uint64_t)b->read_len;
     if (LD.w_pos < 32 && (longest >> LD.w_pos) != 0)
-      return set_err(DCRX_E_INVALID, "tuple sink: the batch's reads can be longer than the layout's position fields hold (dcrx_tuple_layout's max_read_len)");
+      return set_err(DCRX_E_INVALID, b->lens ? "tuple sink: a batch with per-read lengths is priced at the longest read its stride holds (4 * stride bases: the lengths "
+                                                "live in device memory); give dcrx_tuple_layout a max_read_len of 4 * stride for such batches"
+                                              : "tuple sink: the batch's reads are longer than the layout's position fields hold (dcrx_tuple_layout's max_read_len)");
     if (t->sink_layout.bits <= 40 && t->host.rel.v2_ok && b->stride <= DCRX_FAST_MAX_STRIDE) {
       rc = ensure_sink(t, b->n_reads, (hipStream_t)stream);
       if (rc) return rc;

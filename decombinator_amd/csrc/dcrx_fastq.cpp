@@ -660,16 +660,24 @@ uint64_t dcrx_count_prefix_byte(const char *text, const uint64_t *start, const u
   unsigned nt = n >= (1u << 17) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
   if (const char *e = std::getenv("DCRX_HOST_THREADS")) nt = std::max(1, std::min(8, std::atoi(e)));
   if (nt == 1) return range(0, n);
+  // (threads that have started are always joined: a std::thread that is destroyed while joinable ends the process before any
+  // handler runs; a range whose thread could not be had is counted here)
+  std::vector<uint64_t> part(nt, 0);
+  std::vector<std::thread> th;
+  unsigned started = 1;                       // ranges [1, started) run on threads of their own
   try {
-    std::vector<uint64_t> part(nt, 0);
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back([&, t] { part[t] = range(n * t / nt, n * (t + 1) / nt); });
-    part[0] = range(0, n / nt);
-    for (auto &x : th) x.join();
-    uint64_t k = 0;
-    for (unsigned t = 0; t < nt; t++) k += part[t];
-    return k;
-  } catch (...) { return range(0, n); }      // (no thread to be had: the plain loop)
+    th.reserve(nt);
+    for (; started < nt; started++) {
+      const unsigned t = started;
+      th.emplace_back([&part, &range, n, nt, t] { part[t] = range(n * t / nt, n * (t + 1) / nt); });
+    }
+  } catch (...) {}                            // (no thread to be had: the rest of the ranges in this one)
+  part[0] = range(0, n / nt);
+  for (unsigned t = started; t < nt; t++) part[t] = range(n * t / nt, n * (t + 1) / nt);
+  for (auto &x : th) x.join();
+  uint64_t k = 0;
+  for (unsigned t = 0; t < nt; t++) k += part[t];
+  return k;
 }
 
 }  // extern "C"

@@ -49,6 +49,9 @@ bool first_use_on_device(bool (&seen)[64]);
 void attributes_set_on_device(bool (&seen)[64]);
 
 constexpr int DCRX_V2_BLOCK = 1024;
+#ifdef DCRX_SCAN_STAMPS
+__device__ uint32_t *g_scan_stamps;      // instrumented build (tools/): four 100 MHz stamps per wave of the scan kernel
+#endif
 constexpr int DCRX_V2_FBLOCK = 256;      // (128: the same step; 512: twice as long — profiles/r05/finish_block_size_ab.log)
 #ifndef DCRX_V2_TBLOCK
 #define DCRX_V2_TBLOCK 256      /* threads of a tail-kernel block ... */
@@ -149,6 +152,20 @@ __device__ __forceinline__ void v2_get_rows(const uint4 *rows, const uint32_t ca
     if (4 * k + 2 < N) x[4 * k + 2] = v.z;
     if (4 * k + 3 < N) x[4 * k + 3] = v.w;
   }
+}
+
+// The batch in hand has landed, and the compiler knows: an empty statement takes and gives back each of its registers, and the
+// index the next batch's loads are addressed with goes through the last of them, so that no load of the next batch can be
+// scheduled in front.  Without this the compiler renames the copy `x = x1` away, the batch in hand IS the destination of loads
+// issued one trip earlier, and its first use gets `s_waitcnt vmcnt(0)` — behind the loads of the NEXT batch, issued a moment
+// before (they are conditional: the pass has no count to wait for): the look-ahead then hides nothing, every wave sits out one
+// memory round trip per batch with nothing in flight (round 6: found in the ISA of the scan loop and of both lean roles).
+template <int N>
+__device__ __forceinline__ uint32_t v2_landed(uint32_t (&x)[N], uint32_t next_index) {
+#pragma unroll
+  for (int k = 0; k < N; k++) asm volatile("" : "+v"(x[k]));
+  asm volatile("" : "+v"(next_index) : "v"(x[N - 1]));
+  return next_index;
 }
 
 // a read the v2 kernels hand to the three-launch form: clean reads to its rescue queue, reads
@@ -339,6 +356,10 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   uint32_t *lds_counts = smem + V0.trans_bytes / 4;
   uint32_t *lds_work = lds_counts + DCRX_N_COUNTERS;
   const int tid = threadIdx.x;
+#ifdef DCRX_SCAN_STAMPS
+  const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime();      // instrumented build (tools/): per wave, 100 MHz ticks
+  unsigned long long stamp_setup = 0, stamp_loop_end = 0;
+#endif
   // (v2_entry reads the table at absolute LDS addresses: the dynamic segment starts at 0 because this kernel declares no static
   // LDS — launch_v2 checks that once per device, hipFuncGetAttributes, and refuses the launch otherwise: nothing traps here)
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
@@ -389,6 +410,9 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   }
   const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? tw : 0u);
   const size_t region = blockIdx.x;
+#ifdef DCRX_SCAN_STAMPS
+  stamp_setup = __builtin_amdgcn_s_memrealtime();
+#endif
   if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
    if constexpr (FUSE >= 0) {
     // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
@@ -506,23 +530,40 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   const int npairs = UNIFORM_LEN ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   uint32_t w[RPL][NW];
   unsigned long long xm[RPL];
-#ifdef DCRX_SCAN_STAMPS
-  unsigned long long stamp_scan = 0, stamp_rest = 0, stamp_prev = 0;      // clocks inside scan2() / between two scan2() calls, per wave
-  const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   uint32_t item = draw();
   if (PREFETCH && item < n_items) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)item * WT, blk_hi, lane, w, xm);
+  if (PREFETCH) {
+    // The first item's words are waited for HERE, and the compiler is told so (an empty statement that takes and gives back each
+    // register).  Without it the loop below saw "w may still be in flight" on its entry edge and put `s_waitcnt vmcnt(0)` in front
+    // of the first look-up of EVERY item — behind the loads of the next item, issued a moment before: each wave then sat out a whole
+    // memory round trip per item with nothing in flight, and the item "in flight during the scan" was in flight during nothing
+    // (round 6; the counter counts loads in order and the conditional loads in between leave the pass no count to wait for).
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+#pragma unroll
+      for (int k = 0; k < NW; k++) asm volatile("" : "+v"(w[q][k]));
+      asm volatile("" : "+v"(xm[q]));
+    }
+  }
   while (item < n_items) {
     uint32_t wn[RPL][NW];
     unsigned long long xn[RPL];
     const uint32_t next = draw();
     const bool more = next < n_items;
     if (!PREFETCH) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)item * WT, blk_hi, lane, w, xm);
+#ifdef DCRX_EXP_WARM
+    // (experiment: no item in registers ahead — the next item's lines are asked for instead, one dword per 128-byte line, so that
+    // its loads meet them in the L2; the value is kept alive to the end of this item so that the load is really issued)
+    uint32_t warm = 0;
+    if (!PREFETCH && more) {
+      const uint64_t b0 = (blk_lo + (uint64_t)next * WT) * B.stride, b1 = min(blk_hi, blk_lo + (uint64_t)(next + 1) * WT) * B.stride;
+      const uint64_t a = (b0 & ~127ull) + (uint64_t)lane * 128u;
+      if (a < b1) warm = *reinterpret_cast<const uint32_t *>(B.packed + a);
+      if (WT * 40u > 64u * 128u && a + 64u * 128u < b1) warm ^= *reinterpret_cast<const uint32_t *>(B.packed + a + 64u * 128u);
+    }
+#endif
     if (PREFETCH) { if (more) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)next * WT, blk_hi, lane, wn, xn); }     // in flight while this item is scanned
     uint32_t lg[RPL][NW];
-#ifdef DCRX_SCAN_STAMPS
-    const unsigned long long st0 = __builtin_readcyclecounter();
-#endif
     // (the look-up loop is bound by the LDS; what a wave does between two scans — digest, pushes, records — is bound by
     // issue: a wave inside the loop goes first on its SIMD, so that the block's look-ups stay in flight: - 2 % of the step)
 #if DCRX_V2_LOOP_PRIO
@@ -538,18 +579,6 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #endif
 #if DCRX_V2_LOOP_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef DCRX_SCAN_STAMPS
-    {
-      uint32_t keep = 0;
-#pragma unroll
-      for (int q = 0; q < RPL; q++) keep ^= lg[q][NW - 1];
-      asm volatile("" :: "v"(keep));
-    }
-    const unsigned long long st1 = __builtin_readcyclecounter();
-    stamp_scan += st1 - st0;
-    if (stamp_prev) stamp_rest += st0 - stamp_prev;
-    stamp_prev = st1;
 #endif
     unsigned long long tmask[RPL];      // (fused form) the tail lanes of each of the item's reads, and their digests
     uint32_t tdg[RPL];
@@ -737,6 +766,9 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         xm[q] = xn[q];
       }
     }
+#ifdef DCRX_EXP_WARM
+    asm volatile("" :: "v"(warm));
+#endif
     item = next;
   }
   if (FUSE >= 0 && lane == 0) {      // this wave's last entries are in the ring
@@ -744,12 +776,15 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     atomicAdd(&lds_work[V2_WK_SCANNED], 1u);
   }
   }
+#ifdef DCRX_SCAN_STAMPS
+  stamp_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();
   if (B.n_exc) v2_exc_marks(B, e_lo, e_hi, false, tid);      // the marks have served (an entry carries V2_R_EXC from here on)
 #ifdef DCRX_SCAN_STAMPS
-  if (lane == 0) {      // instrumented build (tools/): per wave (not per region; its runs finish nothing) start and end in the 100 MHz counter, clocks inside / between scans
-    uint32_t *c = Q.counts + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));      // (the counts array holds 8 words per compute unit's 16 waves: room for these)
-    c[0] = (uint32_t)stamp_r0; c[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); c[2] = (uint32_t)(stamp_scan >> 6); c[3] = (uint32_t)(stamp_rest >> 6);
+  if (lane == 0) {      // instrumented build (tools/): per wave start, set-up done, main loop left, end — 100 MHz ticks — into a buffer of the build's own
+    uint32_t *c = g_scan_stamps + 4 * ((size_t)blockIdx.x * (DCRX_V2_BLOCK / 64) + (size_t)(tid >> 6));
+    c[0] = (uint32_t)stamp_r0; c[1] = (uint32_t)stamp_setup; c[2] = (uint32_t)stamp_loop_end; c[3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
   }
 #else
   if (tid < V2_L_COUNTS) {      // (entries beyond a list's capacity were handed over, not stored; L starts empty)
@@ -882,7 +917,8 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
       if constexpr (AHEAD) {
 #pragma unroll
         for (int k = 0; k < 2 + NW; k++) x[k] = x1[k];
-        v2_get_rows<2 + NW>(tq, Q.tcap, first + STEP + lane, first + STEP + lane < tn, x1);     // the next batch, in flight during this one
+        const uint32_t nf = v2_landed(x, first + STEP);
+        v2_get_rows<2 + NW>(tq, Q.tcap, nf + lane, nf + lane < tn, x1);     // the next batch, in flight during this one
       } else {
         v2_get_rows<2 + NW>(tq, Q.tcap, first + lane, first + lane < tn, x);
       }
@@ -1011,11 +1047,15 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
       // (the ticket of the batch after next: the atomic is in flight during this batch, its result read behind it)
       const bool more = next_first < en;
       uint32_t after_raw = 0;
-      if (more && lane == 0) after_raw = __hip_atomic_fetch_add(tickets + V2_L_COUNTS * region + V2_L_TICKETS, which == V2_L_E ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if constexpr (AHEAD) {
+      uint32_t nf = next_first;
+      if constexpr (AHEAD) {      // (the batch in hand lands first: the ticket's atomic below is then in flight beside the next batch's loads, not waited for here)
 #pragma unroll
         for (int k = 0; k < 2 + 2 * NW; k++) x[k] = x1[k];
-        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, next_first + lane, next_first + lane < en, x1);     // the next batch, in flight during this one
+        nf = v2_landed(x, next_first);
+      }
+      if (more && lane == 0) after_raw = __hip_atomic_fetch_add(tickets + V2_L_COUNTS * region + V2_L_TICKETS, which == V2_L_E ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (AHEAD) {
+        v2_get_rows<2 + 2 * NW>(l.rows, l.cap, nf + lane, nf + lane < en, x1);     // the next batch, in flight during this one
       } else {
         v2_get_rows<2 + 2 * NW>(l.rows, l.cap, first + lane, first + lane < en, x);
       }
@@ -1604,7 +1644,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   // The fused form (the tail inside the scan kernel, through a ring in LDS: scan2_kernel, FUSE) for the 150-nt shape when the
   // frame's pair table leaves room for the side tables, the buckets and a ring of at least four batches; the A/B forms and the
   // profiling switches keep the tail a launch of its own.
-  constexpr bool CAN_FUSE = NW == 10 && RPL == 2 && PREFETCH;
+  constexpr bool CAN_FUSE = NW == 10 && ((RPL == 2 && PREFETCH) || (RPL == 3 && !PREFETCH));
   uint32_t ring_batches = 0;
   // (measured, profiles/r04: config 2's 57 KB table 0.413 ms per step fused against 0.429 with the tail as a role; the extended
   // beta set's 76 KB table 0.752 against 0.726 for config 3's two chains: pair tables of up to 64 KB fuse)
@@ -1694,6 +1734,12 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
     attributes_set_on_device(seen);
   }
+#ifdef DCRX_SCAN_STAMPS
+  {
+    static uint32_t *stamps = nullptr;
+    if (!stamps) { (void)hipMalloc(&stamps, (size_t)4096 * 16 * 16); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stamps), &stamps, sizeof(stamps)); }
+  }
+#endif
   if (B.n_reads == 0) return hipSuccess;       // (the tallies stay zero; the list kernel hands them over)
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
   // One scan block per compute unit, each with a contiguous range of the reads — a multiple of 512: whole items of its waves and
@@ -1891,22 +1937,41 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
   }
 #ifdef DCRX_SCAN_STAMPS
-  if ((cfg.flags & DCRX_F_PROFILE_NO_FINISH) && e == hipSuccess) {      // instrumented build (tools/): where a scan wave's clocks go
-    std::vector<uint32_t> h(4 * (size_t)n_regions);
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h.data(), Q.counts, h.size() * 4, hipMemcpyDeviceToHost);
-    if (const char *dump = dcrx_debug_env("DCRX_STAMPS_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); } }
-    double a = 0, b = 0, life = 0;
-    uint32_t t_first = 0xFFFFFFFFu;
-    for (uint32_t r = 0; r < n_regions; r++) t_first = std::min(t_first, h[4 * r]);
-    std::vector<uint32_t> starts, ends;
-    for (uint32_t r = 0; r < n_regions; r++) { a += h[4 * r + 2]; b += h[4 * r + 3]; life += h[4 * r + 1] - h[4 * r]; starts.push_back(h[4 * r] - t_first); ends.push_back(h[4 * r + 1] - t_first); }
-    std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
-    auto pc = [&](const std::vector<uint32_t> &v, double q) { return v[(size_t)(q * (v.size() - 1))] / 100.0; };
-    fprintf(stderr, "dcrx scan stamps: per wave, mean ticks inside scan2() %.0f, between scans %.0f; mean wave lifetime %.1f us; wave starts (us after the first) p50 %.1f p90 %.1f max %.1f; "
-            "wave ends min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
-            64.0 * a / n_regions, 64.0 * b / n_regions, life / n_regions / 100.0, pc(starts, 0.5), pc(starts, 0.9), pc(starts, 1.0),
-            pc(ends, 0.0), pc(ends, 0.1), pc(ends, 0.5), pc(ends, 0.9), pc(ends, 0.99), pc(ends, 1.0));
+  {      // instrumented build (tools/): when do a scan block's waves start, leave their loops and end?  (synchronises; launch DCRX_STAMPS_LAUNCH of the process, default 30)
+    static int launches = 0;
+    static const int want = [] { const char *e = dcrx_debug_env("DCRX_STAMPS_LAUNCH"); return e ? atoi(e) : 30; }();
+    if (launches++ == want && e == hipSuccess) {
+      const size_t nw = (size_t)n_regions * (DCRX_V2_BLOCK / 64);
+      std::vector<uint32_t> h(4 * nw);
+      (void)hipStreamSynchronize(s);
+      uint32_t *dptr = nullptr;
+      (void)hipMemcpyFromSymbol(&dptr, HIP_SYMBOL(g_scan_stamps), sizeof(dptr));
+      (void)hipMemcpy(h.data(), dptr, h.size() * 4, hipMemcpyDeviceToHost);
+      if (const char *dump = dcrx_debug_env("DCRX_STAMPS_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); } }
+      uint32_t t0 = 0xFFFFFFFFu;
+      for (size_t i = 0; i < nw; i++) t0 = std::min(t0, h[4 * i]);
+      auto pcs = [&](const char *what, std::vector<double> v) {
+        std::sort(v.begin(), v.end());
+        auto pc = [&](double q) { return v[(size_t)(q * (v.size() - 1))]; };
+        fprintf(stderr, "dcrx scan stamps: %-44s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f p99 %6.1f max %6.1f us\n", what, pc(0), pc(0.1), pc(0.5), pc(0.9), pc(0.99), pc(1.0));
+      };
+      std::vector<double> st, su, le_scan, le_tail, en, blk_scan_end, blk_end;
+      for (uint32_t r = 0; r < n_regions; r++) {
+        double last_scan = 0, last = 0;
+        for (int wv = 0; wv < DCRX_V2_BLOCK / 64; wv++) {
+          const uint32_t *c = &h[4 * ((size_t)r * (DCRX_V2_BLOCK / 64) + wv)];
+          st.push_back((c[0] - t0) / 100.0); su.push_back((c[1] - t0) / 100.0); en.push_back((c[3] - t0) / 100.0);
+          const bool tailw = ring_batches && wv >= (DCRX_V2_BLOCK / 64) - 3;      // (a guess at three tail waves: the block's own choice is not known here)
+          (tailw ? le_tail : le_scan).push_back((c[2] - t0) / 100.0);
+          if (!tailw) last_scan = std::max(last_scan, (c[2] - t0) / 100.0);
+          last = std::max(last, (c[3] - t0) / 100.0);
+        }
+        blk_scan_end.push_back(last_scan); blk_end.push_back(last);
+      }
+      pcs("wave start", st); pcs("wave set-up done (tables staged)", su); pcs("scanning wave leaves its loop", le_scan);
+      if (!le_tail.empty()) pcs("tail wave leaves its loop (last three waves)", le_tail);
+      pcs("wave end", en); pcs("per block: last scanning wave leaves", blk_scan_end); pcs("per block: end", blk_end);
+    }
   }
 #endif
   return e;
@@ -1944,7 +2009,11 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
 #define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
 #ifdef DCRX_FAST_BUILD      // (experiment builds, tools/build_variant.sh: the benchmark's launch shape only)
+#ifdef DCRX_EXP_RPL3
+  if (nw10 && uniform && shape == 2) return narrow ? DCRX_V2X(true, 10, 3, true, false) : DCRX_V2X(true, 10, 3, false, false);
+#else
   if (nw10 && uniform && shape == 2) return narrow ? DCRX_V2A(true, 10, 2, true) : DCRX_V2A(true, 10, 2, false);
+#endif
   return hipErrorNotSupported;
 #else
   if (nw10) {

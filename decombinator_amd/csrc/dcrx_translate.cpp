@@ -11,6 +11,7 @@
 //   productive   = all four hold; junction_aa / junction are cut only then                              (:350-355)
 // Every index and slice behaves as Python's (negative positions count from the end, slices clamp, an index outside the
 // string is the reference's IndexError: status 1 here).
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -61,6 +62,7 @@ inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 // one codon (upper case, U already T); 0 when a letter is no nucleotide code (Biopython raises: "Codon '...' is invalid")
 char translate_codon(char a, char b, char c) {
   const Codons &K = g_codons;
+  if (a == '-' && b == '-' && c == '-') return '-';      // (Seq.translate's gap = '-': a codon of gaps is a gap, a partial one raises)
   const uint8_t ia = K.code[(uint8_t)a], ib = K.code[(uint8_t)b], ic = K.code[(uint8_t)c];
   if (ia < 4 && ib < 4 && ic < 4) return K.aa[16 * ia + 4 * ib + ic];
   const uint8_t oa = K.opts[(uint8_t)a], ob = K.opts[(uint8_t)b], oc = K.opts[(uint8_t)c];
@@ -88,22 +90,29 @@ char translate_codon(char a, char b, char c) {
 // ---- the J motif: the subset of Python's `re` the `.translate` files use — literal characters, '.', character classes
 // (ranges, a leading '^'), a backslash in front of a literal; anything else (groups, alternation, repetition, anchors) is
 // said, not guessed at (DCRX_E_UNSUPPORTED) ----
+struct ByteSet {                             // the bytes a position accepts
+  std::array<uint64_t, 4> w{{0, 0, 0, 0}};
+  void set(int k) { w[(size_t)(k >> 6)] |= 1ull << (k & 63); }
+  bool test(uint8_t k) const { return (w[k >> 6] >> (k & 63)) & 1ull; }
+  void flip() { for (auto &x : w) x = ~x; }
+};
 struct Motif {
-  std::vector<std::vector<bool>> tok;      // per position: the bytes it accepts
+  std::vector<ByteSet> tok;
   bool ok = true;
+  bool parsed = false;                       // (motifs are parsed when a row first asks for them)
 };
 Motif parse_motif(const char *p, size_t n) {
   Motif m;
   size_t i = 0;
   while (i < n) {
-    std::vector<bool> set(256, false);
+    ByteSet set;
     const char c = p[i];
-    if (c == '.') { for (int k = 0; k < 256; k++) set[k] = k != '\n'; i++; }
+    if (c == '.') { for (int k = 0; k < 256; k++) if (k != '\n') set.set(k); i++; }
     else if (c == '\\') {
       if (i + 1 >= n) { m.ok = false; return m; }
       const char d = p[i + 1];
       if ((d >= 'a' && d <= 'z') || (d >= 'A' && d <= 'Z') || (d >= '0' && d <= '9')) { m.ok = false; return m; }      // (\d, \w, \1 ...: classes and references)
-      set[(uint8_t)d] = true; i += 2;
+      set.set((uint8_t)d); i += 2;
     } else if (c == '[') {
       size_t k = i + 1;
       bool neg = false;
@@ -115,19 +124,19 @@ Motif parse_motif(const char *p, size_t n) {
         if (k + 2 < n && p[k + 1] == '-' && p[k + 2] != ']') {
           const uint8_t lo = (uint8_t)p[k], hi = (uint8_t)p[k + 2];
           if (lo > hi) { m.ok = false; return m; }
-          for (int x = lo; x <= hi; x++) set[x] = true;
+          for (int x = lo; x <= hi; x++) set.set(x);
           k += 3;
-        } else { set[(uint8_t)p[k]] = true; k++; }
+        } else { set.set((uint8_t)p[k]); k++; }
         first = false;
       }
       if (!closed) { m.ok = false; return m; }
-      if (neg) for (int x = 0; x < 256; x++) set[x] = !set[x];
+      if (neg) set.flip();
       i = k;
     } else if (std::strchr("()|*+?{}^$", c)) { m.ok = false; return m; }
-    else { set[(uint8_t)c] = true; i++; }
+    else { set.set((uint8_t)c); i++; }
     // a repetition behind the token
     if (i < n && std::strchr("*+?{", p[i])) { m.ok = false; return m; }
-    m.tok.push_back(std::move(set));
+    m.tok.push_back(set);
   }
   return m;
 }
@@ -135,7 +144,7 @@ bool motif_search(const Motif &m, const char *s, int64_t n) {      // re.findall
   const int64_t k = (int64_t)m.tok.size();
   for (int64_t o = 0; o + k <= n; o++) {
     bool hit = true;
-    for (int64_t x = 0; x < k && hit; x++) hit = m.tok[(size_t)x][(uint8_t)s[o + x]];
+    for (int64_t x = 0; x < k && hit; x++) hit = m.tok[(size_t)x].test((uint8_t)s[o + x]);
     if (hit) return true;
   }
   return false;
@@ -151,15 +160,9 @@ extern "C" int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *G, uint64_t n, const
       (G->n_j && (!G->j_regions || !G->j_region_off || !G->j_pos || !G->j_motif || !G->j_motif_off)))
     return set_err(DCRX_E_INVALID, "dcrx_cdr3_batch: a gene table is null");
   try {
+    // a J gene's motif is parsed when a row first uses that gene (the reference compiles only the motif it searches with,
+    // translate.py:341-343): a motif this parser does not serve costs the rows of that gene their last step, nobody else's
     std::vector<Motif> motifs(G->n_j);
-    for (uint32_t k = 0; k < G->n_j; k++) {
-      motifs[k] = parse_motif(G->j_motif + G->j_motif_off[k], G->j_motif_off[k + 1] - G->j_motif_off[k]);
-      if (!motifs[k].ok) {
-        const std::string msg = "dcrx_cdr3_batch: the J motif '" + std::string(G->j_motif + G->j_motif_off[k], G->j_motif_off[k + 1] - G->j_motif_off[k]) +
-                                "' uses regular-expression syntax beyond literals, '.' and character classes";
-        return set_err(DCRX_E_UNSUPPORTED, msg.c_str());
-      }
-    }
     uint64_t at = 0;
     std::string seq, aa;
     for (uint64_t r = 0; r < n; r++) {
@@ -219,13 +222,21 @@ extern "C" int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *G, uint64_t n, const
       int64_t slo, shi;
       pyslice64(dn, jp, jp + 4, slo, shi);
       int64_t end = 0;
-      if (motif_search(motifs[(size_t)ji], aa.data() + dlo + slo, shi - slo)) { end = dn + jp + start + 1; R.conserved_f = 1; }
+      Motif &M = motifs[(size_t)ji];
+      if (!M.parsed) { M = parse_motif(G->j_motif + G->j_motif_off[ji], G->j_motif_off[ji + 1] - G->j_motif_off[ji]); M.parsed = true; }
+      if (!M.ok) {
+        // regular-expression syntax beyond literals, '.' and classes: the row keeps everything up to here — its text, the
+        // in-frame / stop / conserved-C calls, where the search would look (motif_lo, motif_len inside sequence_aa) — and the
+        // caller finishes it with its own regular-expression engine (conserved_f, end_cdr3, productive, the junctions)
+        R.status = DCRX_CDR3_MOTIF_LEFT;
+        R.junction_aa_off = (uint32_t)(dlo + slo); R.junction_aa_len = (uint32_t)(shi - slo);
+      } else if (motif_search(M, aa.data() + dlo + slo, shi - slo)) { end = dn + jp + start + 1; R.conserved_f = 1; }
       else R.productive = 0;
       R.start_cdr3 = (int32_t)start; R.end_cdr3 = (int32_t)end;
       // the row's text: sequence, then sequence_aa; the junctions are slices of them
       R.seq_off = at; R.seq_len = (uint32_t)sn;
       R.aa_off = at + (uint64_t)sn; R.aa_len = (uint32_t)an;
-      if (R.productive) {
+      if (R.productive && R.status == DCRX_CDR3_OK) {
         pyslice64(an, start, end, lo, hi);
         R.junction_aa_off = (uint32_t)lo; R.junction_aa_len = (uint32_t)(hi - lo);
         pyslice64(sn, start * 3, 3 * end, lo, hi);

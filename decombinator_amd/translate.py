@@ -10,6 +10,7 @@ CDR1/2) are a `GeneInfo` here, set with `set_gene_information` (or passed as `ge
 from __future__ import annotations
 
 import collections as coll
+import re
 from dataclasses import dataclass, field
 from typing import List
 
@@ -139,18 +140,39 @@ def cdr3_batch(dcrs, headers, inputargs, genes: GeneInfo | None = None):
         rec["j_call"] = G.j_names[int(d[1])].split("*")[0]
         rec["sequence"] = text[so:so + sl].decode("latin-1")
         rec["sequence_aa"] = text[ao:ao + al].decode("latin-1")
-        rec["productive"] = flag[r["productive"]]
+        productive, conserved_f = bool(r["productive"]), bool(r["conserved_f"])
+        ja = (int(r["junction_aa_off"]), int(r["junction_aa_len"]))
+        jn = (int(r["junction_off"]), int(r["junction_len"]))
+        if r["status"] == nat.CDR3_MOTIF_LEFT:
+            # the J gene's motif uses regular-expression syntax the library's matcher does not serve (alternation, groups,
+            # repetition): the row's last step with Python's engine, as the reference runs it (translate.py:338-355)
+            aa, start = rec["sequence_aa"], int(r["start_cdr3"])
+            j = int(d[1])
+            conserved_f = bool(re.findall(G.j_translate_residue[j], aa[ja[0]:ja[0] + ja[1]]))
+            if conserved_f:
+                end = len(aa[start:]) + G.j_translate_position[j] + start + 1
+                ja = tuple(_span(len(aa), start, end))
+                jn = tuple(_span(len(rec["sequence"]), start * 3, 3 * end))
+            else:
+                productive = False
+        rec["productive"] = flag[productive]
         rec["vj_in_frame"] = flag[r["in_frame"]]
         rec["stop_codon"] = flag[r["stop"]]
         rec["conserved_c"] = flag[r["conserved_c"]]
-        rec["conserved_f"] = flag[r["conserved_f"]]
-        if r["productive"]:
-            rec["junction_aa"] = rec["sequence_aa"][int(r["junction_aa_off"]):int(r["junction_aa_off"]) + int(r["junction_aa_len"])]
-            rec["junction"] = rec["sequence"][int(r["junction_off"]):int(r["junction_off"]) + int(r["junction_len"])]
+        rec["conserved_f"] = flag[conserved_f]
+        if productive:
+            rec["junction_aa"] = rec["sequence_aa"][ja[0]:ja[0] + ja[1]]
+            rec["junction"] = rec["sequence"][jn[0]:jn[0] + jn[1]]
             rec["cdr1_aa"] = G.v_cdr1[int(d[0])]
             rec["cdr2_aa"] = G.v_cdr2[int(d[0])]
         out.append(rec)
     return out
+
+
+def _span(n, start, stop):
+    """(offset, length) of Python's s[start:stop] on a string of n characters."""
+    lo, hi, _ = slice(start, stop).indices(n)
+    return lo, max(0, hi - lo)
 
 
 def get_cdr3(dcr, headers, inputargs, genes: GeneInfo | None = None):
@@ -239,7 +261,10 @@ def cdr3translator(inputargs: dict, data=None) -> list:
         fh.close()
     else:
         rows = data
-    out = []
+    # The rows' own checks come row by row in the reference, each in front of that row's get_cdr3 (:430-470): the rows up to
+    # the first one that fails a check are translated in ONE call of the batch entry (an error inside get_cdr3 of an earlier
+    # row is then raised first, as there), and only then the check's own exit.
+    pending, meta, stop = [], [], None
     for line in rows:
         counts["line_count"] += 1
         if inputargs["command"] == "translate":
@@ -251,13 +276,17 @@ def cdr3translator(inputargs: dict, data=None) -> list:
             frequency, cluster = 1, ""
         else:
             if not isinstance(tcr[5], int):
-                print("TCR frequency could not be detected. If using non-barcoded data, please include the additional '-nbc' "
-                      "argument when running CDR3translator.")
-                raise SystemExit
+                stop = ("TCR frequency could not be detected. If using non-barcoded data, please include the additional '-nbc' "
+                        "argument when running CDR3translator.")
+                break
             frequency = tcr[5]
             cluster = tcr[6] if len(tcr) > 6 and isinstance(tcr[6], (int, float)) else ""
-        rec = get_cdr3(tcr[:5], out_headers, inputargs)      # (a batch of one: the rows' own checks above come in the reference's order, row by row)
-        rec["sequence_id"] = str(counts["line_count"])
+        pending.append(tcr[:5])
+        meta.append((str(counts["line_count"]), frequency, cluster))
+    out = []
+    recs = cdr3_batch(pending, out_headers, inputargs) if pending else []
+    for rec, (sid, frequency, cluster) in zip(recs, meta):
+        rec["sequence_id"] = sid
         rec["duplicate_count"] = frequency
         rec["av_UMI_cluster_size"] = cluster
         if rec["productive"] == "T":
@@ -267,4 +296,7 @@ def cdr3translator(inputargs: dict, data=None) -> list:
             counts["NP_count"] += 1
             if not inputargs.get("nonproductivefilter"):
                 out.append([rec[x] for x in out_headers])
+    if stop is not None:
+        print(stop)
+        raise SystemExit
     return out

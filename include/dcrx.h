@@ -429,15 +429,19 @@ int dcrx_gzip_close(void *writer);
  * v_regions[v_region_off[k] .. v_region_off[k + 1]) (upper case, as the reference stores them), likewise the V genes'
  * conserved residues (v_translate_residue: compared as a whole string with ONE residue of the translation, :327) and the J
  * genes' motifs (j_translate_residue: searched with re.findall in four residues, :341-343 — literal characters, '.',
- * character classes and escaped literals are served; any other regular-expression syntax is DCRX_E_UNSUPPORTED).
+ * character classes and escaped literals are served here; a motif with any other regular-expression syntax is parsed only when a
+ * row uses its gene, as the reference compiles only the motif it searches with, and such a row comes back DCRX_CDR3_MOTIF_LEFT:
+ * text, in_frame, stop, conserved_c, start_cdr3 are set, productive holds the calls so far, junction_aa_off / junction_aa_len
+ * say which residues of sequence_aa the search looks at, and the caller finishes the row with its own engine — conserved_f,
+ * end_cdr3 = len(sequence_aa[start_cdr3:]) + j_pos + start_cdr3 + 1 on a match, the junctions; decombinator_amd/translate.py does).
  * The DCRs: v / j / vdel / jdel as integers (int(dcr[k]), :283-286), the insert of row r = ins[ins_off[r] .. ins_off[r + 1])
  * (the caller has stripped the blank the `translate` command's rows carry, :287-290).
  * Returns the bytes the rows' text takes — per row its sequence, then its sequence_aa — written into `text` when that fits
  * text_cap (call with text = NULL to size the buffer); rows[r] says where they lie.  A row the reference would raise on keeps
  * status != 0 and nothing else: DCRX_CDR3_INDEX_ERROR (a gene index outside its table, or a translation shorter than the V
  * gene's residue position: IndexError), DCRX_CDR3_BAD_CODON (a letter that is no nucleotide code: Biopython's "Codon '...'
- * is invalid", bad_codon_at = the codon's first base). */
-enum dcrx_cdr3_status { DCRX_CDR3_OK = 0, DCRX_CDR3_INDEX_ERROR = 1, DCRX_CDR3_BAD_CODON = 2 };
+ * is invalid", bad_codon_at = the codon's first base; a codon of three gaps '---' is the gap '-', as Seq.translate has it). */
+enum dcrx_cdr3_status { DCRX_CDR3_OK = 0, DCRX_CDR3_INDEX_ERROR = 1, DCRX_CDR3_BAD_CODON = 2, DCRX_CDR3_MOTIF_LEFT = 3 };
 typedef struct dcrx_cdr3_genes {
   uint32_t n_v, n_j;
   const char *v_regions; const uint64_t *v_region_off;      /* n_v + 1 offsets */

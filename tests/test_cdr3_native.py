@@ -68,14 +68,64 @@ def test_rows_the_reference_raises_on():
     assert a["sequence"] == b["sequence"] and a["v_call"] == b["v_call"]
 
 
-def test_motif_syntax_served_and_refused():
+def test_motif_syntax_served_natively_or_finished_with_re():
+    """Literals, '.', classes and escaped literals are matched inside the library; a motif with any other regular-expression
+    syntax is parsed only when a row uses its gene (the reference compiles only the motif it searches with, translate.py:341-343)
+    and such a row is finished with Python's `re` — same fields as the equivalent motif the library serves itself."""
     for motif in ("FGXG", "[FW]G.G", "F\\.G", "[^A-D]G", ""):
         G = _genes(j_translate_residue=[motif] * 5)
         translate.get_cdr3(["0", "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
-    for motif in ("F(G|A)G", "FG+", "^FG", "FG{2}", "\\w"):
-        G = _genes(j_translate_residue=[motif] * 5)
-        with pytest.raises(nat.DcrxError):
-            translate.get_cdr3(["0", "0", "0", "0", "ACG"], translate.out_headers, {"command": "pipeline"}, G)
+    fx = json.load(open(GOLDEN))
+    cases = [c for c in fx["cases"] if c["command"] == "pipeline" and c["expect"] != "IndexError"]
+    dcrs = [c["dcr"] for c in cases]
+    n_j = len(fx["genes"]["j_regions"])
+    pairs = [("(F|W)G.G", "[FW]G.G"), ("FG.G?", "FG."), ("^FG", None), ("F(?=G)", None), ("\\w", None)]
+    n_left = 0
+    for motif, same_as in pairs:
+        G = _genes(j_translate_residue=[motif] * n_j)
+        rows, _ = nat.cdr3_batch(translate._native_genes(G), [int(d[0]) for d in dcrs], [int(d[1]) for d in dcrs], [int(d[2]) for d in dcrs],
+                                 [int(d[3]) for d in dcrs], [d[4] for d in dcrs])
+        assert all(r["status"] == nat.CDR3_MOTIF_LEFT for r in rows)
+        n_left += len(rows)
+        got = translate.cdr3_batch(dcrs, translate.out_headers, {"command": "pipeline"}, G)
+        if same_as is not None:
+            want = translate.cdr3_batch(dcrs, translate.out_headers, {"command": "pipeline"}, _genes(j_translate_residue=[same_as] * n_j))
+            assert [dict(x) for x in got] == [dict(x) for x in want], motif
+        else:                     # no equivalent in the served syntax: the search itself, by hand
+            import re
+            for d, g in zip(dcrs, got):
+                aa = g["sequence_aa"]
+                pos = G.v_translate_position[int(d[0])]
+                start = pos - 1 if aa[pos - 1] == G.v_translate_residue[int(d[0])] else 0
+                jp = G.j_translate_position[int(d[1])]
+                assert g["conserved_f"] == ("T" if re.findall(motif, aa[start:][jp:jp + 4]) else "F"), (motif, d)
+                assert (g["junction_aa"] != "") == (g["productive"] == "T") or g["productive"] == "T"
+    assert n_left > 20
+
+
+def test_an_unsupported_motif_of_an_unused_gene_costs_nothing():
+    """(round 5's advisor finding) One J gene with alternation in its motif made every call fail, whichever genes the rows used."""
+    fx = json.load(open(GOLDEN))
+    n_j = len(fx["genes"]["j_regions"])
+    base = _genes()
+    odd = _genes(j_translate_residue=[base.j_translate_residue[0]] + ["(F|W)G.G"] * (n_j - 1))
+    dcr = ["0", "0", "0", "0", "ACG"]
+    a = translate.get_cdr3(dcr, translate.out_headers, {"command": "pipeline"}, base)
+    b = translate.get_cdr3(dcr, translate.out_headers, {"command": "pipeline"}, odd)
+    assert dict(a) == dict(b)
+    rows, _ = nat.cdr3_batch(translate._native_genes(odd), [0], [0], [0], [0], ["ACG"])
+    assert rows[0]["status"] == nat.CDR3_OK
+
+
+def test_a_codon_of_gaps_is_a_gap():
+    """Bio.Seq.translate's gap defaults to '-': '---' gives '-', a partial gap raises (biopython 1.84, Bio/Seq.py _translate_str)."""
+    G = translate.GeneInfo(v_regions=["TGT---GCA", "TGT-A-GCA"], j_regions=[""], v_names=["V*01"] * 2, j_names=["J*01"],
+                           v_translate_position=[1] * 2, v_translate_residue=["C"] * 2, j_translate_position=[0], j_translate_residue=["A"],
+                           v_functionality=["F"] * 2, j_functionality=["F"], v_cdr1=[""] * 2, v_cdr2=[""] * 2)
+    rows, text = nat.cdr3_batch(translate._native_genes(G), [0, 1], [0, 0], [0, 0], [0, 0], ["", ""])
+    assert rows[0]["status"] == nat.CDR3_OK
+    assert text[int(rows[0]["aa_off"]):int(rows[0]["aa_off"]) + int(rows[0]["aa_len"])].decode() == "C-A"
+    assert rows[1]["status"] == nat.CDR3_BAD_CODON and rows[1]["bad_codon_at"] == 3
 
 
 def test_motif_search_against_python_re():
