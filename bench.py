@@ -10,11 +10,13 @@ against the original-like synthetic tag set, generated ON the GPU from
 resident in HBM.  A step is one pass of the hot path (dcrx_decombine_device:
 automaton scan + half-tag rescue + walks + filters -> 16-byte records + counters)
 over the rank's 10 M-read batch; with N > 1 every rank takes its own 10 M reads
-(weak scaling), compacts its DCR tuples and the tuples are gathered on rank 0 over
-RCCL inside the same step.
+(weak scaling), leaves its DCR tuples in a message and the messages are gathered on rank 0 over
+RCCL inside the same step — through libdcrx's own RCCL binding (include/dcrx.h dcrx_comm_*): this
+file imports no torch; the ranks find each other through a file of the node's temporary directory
+(decombinator_amd/_native.py comm_from_env).
 
 `--gpus N` without a launcher (WORLD_SIZE unset): this process — before it
-imports torch or touches HIP — starts N child processes of this same file, one
+touches HIP — starts N child processes of this same file, one
 per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
 their environment), waits for them, relays rank 0's JSON line and exits non-zero
 if any of them did.  Under torch.distributed.run the ranks are the launcher's.
@@ -229,42 +231,37 @@ def cpu_baseline(nat, tables, ts, cfg_synth, sample_reads: int):
     }
 
 
-def run_rank(args, device_factory=None):
-    """One rank.  `device_factory` is given only by tests/bench_dry.py: a CPU stand-in for the device over the gloo backend
-    (the line then says "dry_run": true and carries no rate); the command line of this file cannot set it."""
+def run_rank(args, device_factory=None, comm_factory=None):
+    """One rank.  `device_factory` / `comm_factory` are given only by tests/bench_dry.py: a CPU stand-in for the device and a
+    gloo communicator + host-memory backend (the line then says "dry_run": true and carries no rate); the command line of this
+    file cannot set them."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     dry = device_factory is not None
 
-    # torch first: its bundled HIP runtime (same soname as /opt/rocm's) must be the one
-    # libdcrx binds to, so that torch/RCCL and the kernels share one runtime.
-    import torch
-    import torch.distributed as dist
     import numpy as np
 
     from decombinator_amd import _native as nat
     from decombinator_amd import synth
     from decombinator_amd import sharded
 
-    if dry:
-        dev = torch.device("cpu")
-    else:
-        if not torch.cuda.is_available():
+    if not dry:
+        if nat.device_count() < 1:
             sys.exit("bench.py needs a GPU: the decombine hot path has no CPU fallback")
-        torch.cuda.set_device(local_rank)
         nat.check(nat.lib().dcrx_set_device(local_rank))
-        dev = torch.device("cuda", local_rank)
     # DCRX_BENCH_FORCE_GATHER=1 with one rank exercises the gather path on one GPU
     use_dist = world > 1 or (os.environ.get("DCRX_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ)
-    if use_dist:
+    comm, backend = None, None
+    main_stream = None if dry else nat.Stream()      # the stream of the decombine calls (one handle = one stream)
+    sptr = None if dry else main_stream.ptr
+    if dry:
+        comm, backend = comm_factory(use_dist)
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    sptr = 0 if dry else torch.cuda.current_stream().cuda_stream
+        comm = nat.comm_from_env()                   # RCCL through libdcrx; rank 0's id travels through a file of this node
+        backend = sharded.RcclBackend(nat, comm, sptr)
 
     # the chains a step resolves: one table set each (the reference resolves one chain per call, decombine.py:593-661)
     if args.config in (2, 4):
@@ -301,12 +298,12 @@ def run_rank(args, device_factory=None):
     if dry:
         device = device_factory(nat, all_tables, tagsets, cfg_synth, batches, n)
     else:
-        device = HipDevice(nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
+        device = HipDevice(nat, np, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
     # what travels: the narrow tuple of the tag set (5 bytes here) left by the decombine call itself (the handle's tuple sink);
     # A/B (DCRX_BENCH_GATHER_MODE): "narrow" = the same tuples compacted from the records on a side stream, "tuple8" = round 3's
     # 8-byte tuples, compacted
     gmode = os.environ.get("DCRX_BENCH_GATHER_MODE", "sink")
-    gather = sharded.TupleGather(n, world, rank, None if dry else dev, compact=device.compact, v_jumps=ts.v_jumps,
+    gather = sharded.TupleGather(n, backend, compact=device.compact, v_jumps=ts.v_jumps,
                                  n_v=info["n_v"], n_j=info["n_j"], tables=tables if gmode in ("sink", "narrow") else None,
                                  max_read_len=READ_LEN, use_sink=gmode == "sink") if use_dist else None
     if use_dist and not dry and (world > 1 or os.environ.get("DCRX_BENCH_RESERVED_CUS")):
@@ -321,9 +318,9 @@ def run_rank(args, device_factory=None):
         if g is not None:
             g.finish()
         if use_dist:
-            dist.barrier()
+            comm.barrier(sptr)
         if not dry:
-            torch.cuda.synchronize()
+            nat.synchronize()
 
     def timed_loop(g, steps, events=None, timed=()):
         fence(g)
@@ -341,21 +338,21 @@ def run_rank(args, device_factory=None):
     preroll_steps = int(os.environ.get("DCRX_BENCH_PREROLL_STEPS", "320")) if (not dry and args.warmup > 0) else 0      # (every rank the same count: the steps of a sharded run hold collectives)
     for k in range(preroll_steps):
         if k == 0:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
-            torch.cuda.synchronize()
+            nat.synchronize()
             t_first = time.perf_counter()
         device.step(k, gather, None)
         if k == 0:
-            torch.cuda.synchronize()
+            nat.synchronize()
             first_launch_ms = (time.perf_counter() - t_first) * 1e3
         elif k % 32 == 31:
-            torch.cuda.synchronize()      # (the host does not run hundreds of launches ahead of the device)
+            nat.synchronize()      # (the host does not run hundreds of launches ahead of the device)
     for k in range(args.warmup):
         if k == 0 and not dry and first_launch_ms is None:      # what a cold handle's first step takes (workspace allocation, code load, untuned launch shape)
-            torch.cuda.synchronize()
+            nat.synchronize()
             t_first = time.perf_counter()
         device.step(k, gather, None)
         if k == 0 and not dry and first_launch_ms is None:
-            torch.cuda.synchronize()
+            nat.synchronize()
             first_launch_ms = (time.perf_counter() - t_first) * 1e3
     fence(gather)
     # HIP events around the kernels are not free (a step that carries its four costs ~20 us more): every
@@ -376,19 +373,15 @@ def run_rank(args, device_factory=None):
         # the same steps without the gather: the difference is the gather time the steps do not hide
         elapsed_nogather = timed_loop(None, args.steps)
 
-    def max_over_ranks(x):
+    def max_over_ranks(x):      # (seconds, exchanged as whole nanoseconds)
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(comm.allreduce_host_u64(np.array([int(round(x * 1e9))], dtype=np.uint64), 1)[0]) / 1e9
 
     # every rank's own time (the job's is the slowest rank's): a first multi-GPU run then shows at a glance which rank lags
     per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
     if use_dist:
-        got = [None] * world
-        dist.all_gather_object(got, per_rank_ms[0])
-        per_rank_ms = got
+        per_rank_ms = comm.allgather_object(per_rank_ms[0])
     elapsed = max_over_ranks(elapsed)
     if elapsed_steady is not None:
         elapsed_steady = max_over_ranks(elapsed_steady)
@@ -398,7 +391,7 @@ def run_rank(args, device_factory=None):
     if os.environ.get("DCRX_BENCH_STEP_TRACE") == "1":      # (does the step time drift over the timed region?  tools/r05_e29.sh)
         print("step_trace", [round(x, 4) for x in step_ms], "kernel", [round(x, 4) for x in kern_ms], file=sys.stderr)
     if os.environ.get("DCRX_BENCH_DUMP_COUNTERS") == "1" and not dry:      # (instrumented builds of the library, tools/: the raw counter block of the last step)
-        print("counters", [int(x) for x in device.d_cnts[-1].cpu().numpy().astype(np.uint64)], file=sys.stderr)
+        print("counters", [int(x) for x in device.counters_host(-1)], file=sys.stderr)
     n_hits, n_read = device.totals()
     if not dry:
         assert device.device_errors() == 0, "a device-side wait timed out (include/dcrx_codes.h, DCRX_C_DEVICE_ERRORS)"
@@ -407,16 +400,10 @@ def run_rank(args, device_factory=None):
     assert args.cfg_flags or os.environ.get("DCRX_BENCH_NO_CHECK") == "1" or n_read == device.expected_read_count(), (n_read, device.expected_read_count())
     if gather is not None and os.environ.get("DCRX_BENCH_NO_GATHER_CHECK") != "1":      # (experiment builds of the library: tools/r04_sink_exp.sh)
         gather.check(device.last_step_hits())
-    names = [None] * world
-    if use_dist:
-        dist.all_gather_object(names, device.name())
-    else:
-        names = [device.name()]
+    names = comm.allgather_object(device.name()) if use_dist else [device.name()]
     hits_all = n_hits
     if use_dist:
-        t = torch.tensor([n_hits], dtype=torch.int64, device=dev)
-        dist.all_reduce(t)
-        hits_all = int(t.item())
+        hits_all = int(comm.allreduce_host_u64(np.array([n_hits], dtype=np.uint64))[0])
 
     if rank == 0:
         total_reads = args.total_reads if args.config == 4 else n * world * args.steps
@@ -446,7 +433,8 @@ def run_rank(args, device_factory=None):
                 "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if info.get("v2_tables") else info["dfa_bytes"],
                 "decombined_fraction": round(hits_all / max(1, device.expected_read_count() * world if args.config != 4 else args.total_reads), 4),
                 "parallelism": f"reads sharded x{world}, gather of DCR tuples to rank 0 ({'gloo' if dry else 'RCCL'})" if world > 1 else "single GPU",
-                "world_size": dist.get_world_size() if use_dist else 1, "devices": names,
+                "world_size": comm.world if use_dist else 1, "devices": names,
+                "collectives": ("gloo (dry run)" if dry else "RCCL through libdcrx (dcrx_comm_*: no torch in this process)") if use_dist else None,
             },
         }
         if dry:
@@ -516,21 +504,22 @@ def run_rank(args, device_factory=None):
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.barrier(sptr)
+        comm.close()
 
 
 class HipDevice:
-    """The rank's GPU: resident reads of every batch, the record planes and one dcrx_decombine_device per chain and step."""
+    """The rank's GPU: resident reads of every batch, the record planes and one dcrx_decombine_device per chain and step.
+    Device memory, streams and events through the library's own entries (nat.DeviceBuffer / Stream / Event): no torch."""
 
-    def __init__(self, nat, torch, np, dev, sptr, all_tables, cfg_synth, batches, n, stride, cfg_flags):
-        self.nat, self.torch, self.np, self.dev, self.sptr = nat, torch, np, dev, sptr
+    def __init__(self, nat, np, sptr, all_tables, cfg_synth, batches, n, stride, cfg_flags):
+        self.nat, self.np, self.sptr = nat, np, sptr
         self.all_tables, self.batches, self.n, self.stride = all_tables, batches, n, stride
         self.cfg_flags = cfg_flags
         total = sum(b[1] for b in batches)
         # inputs resident in HBM before the timed region
         # (several chains: a batch is drawn in equal parts from each chain's germlines, part k from chain k)
-        self.d_packed = torch.empty(max(1, total) * stride + 16, dtype=torch.uint8, device=dev)
+        self.d_packed = nat.DeviceBuffer(max(1, total) * stride + 16)
         self.bc = []
         self._keep = []
         at = 0
@@ -540,7 +529,7 @@ class HipDevice:
                 lo, hi = cnt * k // len(all_tables), cnt * (k + 1) // len(all_tables)
                 if hi > lo:
                     nat.check(nat.lib().dcrx_synth_reads_device(tb.handle, nat.C.byref(cfg_synth), first + lo, hi - lo, stride,
-                                                                self.d_packed.data_ptr() + (at + lo) * stride, sptr))
+                                                                self.d_packed.ptr + (at + lo) * stride, sptr))
                 e_r, e_p, e_c = nat.synth_exceptions_host(tb, cfg_synth, first + lo, hi - lo)
                 ers.append(e_r.astype(np.int64) + lo); eps.append(e_p); ecs.append(e_c)
             er, ep, ec = np.concatenate(ers), np.concatenate(eps), np.concatenate(ecs)
@@ -555,33 +544,38 @@ class HipDevice:
                 key, idx = np.unique(key, return_index=True)      # sorted by (read, position), one entry per place
                 er, ep = key // 65536, key % 65536
                 ec = np.concatenate([ec, np.full(len(cr), ord("N"), dtype=ec.dtype)])[idx]
-                # ... packed as the packer packs such bytes: zero bits (dcrx_pack_reads; the device generator leaves the drawn base)
-                rows2d = self.d_packed[at * stride:(at + cnt) * stride].view(cnt, stride)
-                tp = torch.from_numpy(pick).to(dev)
+                # ... packed as the packer packs such bytes: zero bits (dcrx_pack_reads; the device generator leaves the drawn base):
+                # the batch's rows through the host, once, before anything is timed
+                nat.synchronize()
+                rows2d = np.zeros((cnt, stride), dtype=np.uint8)
+                nat.check(nat.lib().dcrx_memcpy_d2h(rows2d.ctypes.data, self.d_packed.ptr + at * stride, rows2d.nbytes))
                 lo_b, hi_b = int(span[0]) // 4, (READ_LEN + 3) // 4
                 if int(span[0]) % 4:
-                    rows2d[tp, lo_b] &= (1 << (2 * (int(span[0]) % 4))) - 1
+                    rows2d[pick, lo_b] &= (1 << (2 * (int(span[0]) % 4))) - 1
                     lo_b += 1
-                rows2d[tp, lo_b:hi_b] = 0
-            d_er = torch.from_numpy(er.astype(np.int64)).to(dev).to(torch.int32)  # same bits as uint32
-            d_ep = torch.from_numpy(ep.astype(np.int32)).to(dev).to(torch.int16)
-            d_ec = torch.from_numpy(ec).to(dev)
+                rows2d[pick, lo_b:hi_b] = 0
+                nat.check(nat.lib().dcrx_memcpy_h2d(self.d_packed.ptr + at * stride, rows2d.ctypes.data, rows2d.nbytes))
+            d_er = nat.DeviceBuffer.from_host(er.astype(np.uint32))
+            d_ep = nat.DeviceBuffer.from_host(ep.astype(np.uint16))
+            d_ec = nat.DeviceBuffer.from_host(ec.astype(np.uint8))
             self._keep.append((d_er, d_ep, d_ec))
             b = nat.BatchC()
-            b.n_reads, b.packed, b.stride, b.read_len, b.lens = cnt, self.d_packed.data_ptr() + at * stride, stride, READ_LEN, None
+            b.n_reads, b.packed, b.stride, b.read_len, b.lens = cnt, self.d_packed.ptr + at * stride, stride, READ_LEN, None
             b.n_exc = len(er)
-            b.exc_read, b.exc_pos, b.exc_chr = (d_er.data_ptr(), d_ep.data_ptr(), d_ec.data_ptr()) if len(er) else (None, None, None)
+            b.exc_read, b.exc_pos, b.exc_chr = (d_er.ptr, d_ep.ptr, d_ec.ptr) if len(er) else (None, None, None)
             self.bc.append(b)
             at += cnt
-        self.d_recs = [torch.empty(n * 16, dtype=torch.uint8, device=dev) for _ in all_tables]      # one record plane per chain
-        self.d_cnts = [torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev) for _ in all_tables]
-        self.d_sum = [torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev) for _ in all_tables]   # config 4: over the steps of a pass
+        self.d_recs = [nat.DeviceBuffer(n * 16) for _ in all_tables]      # one record plane per chain
+        # a counter block per chain and batch of a pass (every call overwrites its own block): config 4's pass is summed on the host
+        self.d_cnts = [[nat.DeviceBuffer.from_host(np.zeros(nat.N_COUNTERS, dtype=np.uint64)) for _ in self.bc] for _ in all_tables]
         self.cfg = nat.make_cfg("reverse", False, 130, cfg_flags)
         for tb in all_tables:
             nat.check(nat.lib().dcrx_reserve_device(tb.handle, n))
         self.accumulate = len(batches) > 1
+        self.last_batch = 0
         self.event_every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
         self.compact = None            # TupleGather then compacts with dcrx_compact_hits_packed_device
+        nat.synchronize()
 
     def name(self):
         return self.nat.device_name()
@@ -600,7 +594,9 @@ class HipDevice:
 
     def step(self, k, gather, ev):
         nat = self.nat
-        b = self.bc[k % len(self.bc)]
+        kb = k % len(self.bc)
+        b = self.bc[kb]
+        self.last_batch = kb
         rec = self.d_recs[-1]
         if gather is not None:           # alternating record buffers: the previous step's tuples are still being compacted
             gather.before_scan()
@@ -614,14 +610,10 @@ class HipDevice:
                 if kind in (1, 2):
                     nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[c][2].ptr, ev[c][3].ptr))
             nat.check(nat.lib().dcrx_decombine_device(tb.handle, nat.C.byref(self.cfg), nat.C.byref(b),
-                                                      (rec if last else self.d_recs[c]).data_ptr(), self.d_cnts[c].data_ptr(), self.sptr))
+                                                      (rec if last else self.d_recs[c]).ptr, self.d_cnts[c][kb].ptr, self.sptr))
             if ev is not None:
                 nat.check(nat.lib().dcrx_set_step_events(tb.handle, None, None))
                 nat.check(nat.lib().dcrx_set_timing_events(tb.handle, None, None))
-            if self.accumulate:          # a pass over several batches: the pass's counters (every call zeroes its own block)
-                if k % len(self.bc) == 0:
-                    self.d_sum[c].zero_()
-                self.d_sum[c] += self.d_cnts[c]
         if gather is not None:
             gather.step(b.n_reads)
 
@@ -632,11 +624,16 @@ class HipDevice:
         kern_ms = [sum(e[2].elapsed_ms(e[3]) for e in events[k]) for k in kt]         # the dominant kernel(s) alone
         return step_ms, kern_ms
 
-    def _counter(self, name):
+    def counters_host(self, chain):
+        """The counters of `chain`: of the last step, or — a pass over several batches (config 4) — summed over the pass."""
         np, nat = self.np, self.nat
-        src = self.d_sum if self.accumulate else self.d_cnts
-        i = nat.COUNTER_NAMES.index(name)
-        return [int(c.cpu().numpy().astype(np.uint64)[i]) for c in src]
+        nat.synchronize()
+        blocks = self.d_cnts[chain] if self.accumulate else [self.d_cnts[chain][self.last_batch]]
+        return sum(blk.to_host(np.uint64, nat.N_COUNTERS) for blk in blocks)
+
+    def _counter(self, name):
+        i = self.nat.COUNTER_NAMES.index(name)
+        return [int(self.counters_host(c)[i]) for c in range(len(self.all_tables))]
 
     def totals(self):
         return sum(self._counter("vj_count")), min(self._counter("read_count"))
@@ -645,12 +642,13 @@ class HipDevice:
         return sum(b[1] for b in self.batches) if self.accumulate else self.n
 
     def device_errors(self):
-        np, nat = self.np, self.nat
-        return sum(int(c.cpu().numpy().astype(np.uint64)[nat.DEVICE_ERRORS]) for c in self.d_cnts)
+        nat = self.nat
+        return sum(int(self.counters_host(c)[nat.DEVICE_ERRORS]) for c in range(len(self.all_tables)))
 
     def last_step_hits(self):
         np, nat = self.np, self.nat
-        return int(self.d_cnts[-1].cpu().numpy().astype(np.uint64)[nat.COUNTER_NAMES.index("vj_count")])
+        nat.synchronize()
+        return int(self.d_cnts[-1][self.last_batch].to_host(np.uint64, nat.N_COUNTERS)[nat.COUNTER_NAMES.index("vj_count")])
 
 
 def main():
@@ -658,7 +656,7 @@ def main():
     args = parse_args(argv)
     if args.cfg_flags:
         os.environ.setdefault("DCRX_DEBUG_FLAGS", "1")      # profiling switches are refused by the library without this
-    # HIP maps its streams onto 4 hardware queues by default; with the gather's streams (torch's side stream, RCCL's) beside
+    # HIP maps its streams onto 4 hardware queues by default; with the gather's streams (the side stream, RCCL's) beside
     # the three of a decombine call, two of those would share a queue and run their kernels one after the other.  Only then:
     # without the gather the default is right (the two-chain configs, two handles with three streams each, lose a third of
     # their rate on 8 queues: 0.81 -> 1.12 ms per step).

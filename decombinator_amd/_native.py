@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCRX_LIB_PATH") or os.path.join(_HERE, "csrc", "libdcrx.so")
 
 N_COUNTERS = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enum dcrx_counter order; the strings are the reference's Counter keys
 # (reference decombine.py:598 and the increments cited in include/dcrx_codes.h)
@@ -252,6 +252,10 @@ EXPORTS = [
     "dcrx_malloc_host", "dcrx_free_host", "dcrx_memcpy_h2d", "dcrx_memcpy_d2h", "dcrx_memset_device", "dcrx_synchronize", "dcrx_event_create",
     "dcrx_event_destroy", "dcrx_event_record", "dcrx_event_elapsed_ms", "dcrx_abi_version", "dcrx_last_error",
     "dcrx_compact_hits_packed8_device", "dcrx_tuple_layout", "dcrx_tuple_message_bytes", "dcrx_compact_hits_narrow_device", "dcrx_set_tuple_sink", "dcrx_collapse_front", "dcrx_spacer_search", "dcrx_gzip_open", "dcrx_gzip_write", "dcrx_gzip_close", "dcrx_build_info", "dcrx_synth_reads_host", "dcrx_synth_reads_device", "dcrx_synth_exceptions_host",
+    "dcrx_set_tune_wait", "dcrx_comm_available", "dcrx_comm_unique_id", "dcrx_comm_create", "dcrx_comm_create_all", "dcrx_comm_destroy", "dcrx_comm_info",
+    "dcrx_comm_allreduce_u64", "dcrx_comm_allreduce_f64", "dcrx_comm_allgather", "dcrx_comm_gather_v", "dcrx_comm_barrier", "dcrx_comm_allgather_host",
+    "dcrx_comm_allreduce_host_u64", "dcrx_decombine_sharded", "dcrx_event_synchronize", "dcrx_event_create_ordering", "dcrx_stream_create", "dcrx_stream_destroy", "dcrx_stream_synchronize",
+    "dcrx_stream_wait_event", "dcrx_memcpy_d2h_async", "dcrx_memcpy_d2d_async", "dcrx_memset_device_async",
 ]
 
 _lib = None
@@ -327,6 +331,30 @@ def lib():
         "dcrx_synth_reads_host": (i32, [vp, C.POINTER(SynthCfgC), u64, u64, u32, vp]),
         "dcrx_synth_reads_device": (i32, [vp, C.POINTER(SynthCfgC), u64, u64, u32, vp, vp]),
         "dcrx_synth_exceptions_host": (C.c_int64, [vp, C.POINTER(SynthCfgC), u64, u64, vp, vp, vp, u64]),
+        "dcrx_set_tune_wait": (i32, [vp, i32]),
+        "dcrx_comm_available": (i32, []),
+        "dcrx_comm_unique_id": (i32, [vp]),
+        "dcrx_comm_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "dcrx_comm_create_all": (i32, [i32, vp, C.POINTER(vp)]),
+        "dcrx_comm_destroy": (None, [vp]),
+        "dcrx_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "dcrx_comm_allreduce_u64": (i32, [vp, vp, vp, u64, i32, vp]),
+        "dcrx_comm_allreduce_f64": (i32, [vp, vp, vp, u64, i32, vp]),
+        "dcrx_comm_allgather": (i32, [vp, vp, vp, u64, vp]),
+        "dcrx_comm_gather_v": (i32, [vp, vp, u64, vp, vp, i32, vp]),
+        "dcrx_comm_barrier": (i32, [vp, vp]),
+        "dcrx_comm_allgather_host": (i32, [vp, vp, vp, u64]),
+        "dcrx_comm_allreduce_host_u64": (i32, [vp, vp, u64, i32]),
+        "dcrx_decombine_sharded": (i32, [vp, vp, C.POINTER(CfgC), C.POINTER(BatchC), vp, vp, C.POINTER(TupleLayoutC), vp, u64, vp, vp, vp]),
+        "dcrx_event_synchronize": (i32, [vp]),
+        "dcrx_event_create_ordering": (i32, [C.POINTER(vp)]),
+        "dcrx_stream_create": (i32, [C.POINTER(vp)]),
+        "dcrx_stream_destroy": (i32, [vp]),
+        "dcrx_stream_synchronize": (i32, [vp]),
+        "dcrx_stream_wait_event": (i32, [vp, vp]),
+        "dcrx_memcpy_d2h_async": (i32, [vp, vp, C.c_size_t, vp]),
+        "dcrx_memcpy_d2d_async": (i32, [vp, vp, C.c_size_t, vp]),
+        "dcrx_memset_device_async": (i32, [vp, i32, C.c_size_t, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not match include/dcrx.h
@@ -911,13 +939,16 @@ def synchronize():
 
 
 class Event:
-    def __init__(self):
+    def __init__(self, timing: bool = True):
         p = C.c_void_p()
-        check(lib().dcrx_event_create(C.byref(p)))
+        check((lib().dcrx_event_create if timing else lib().dcrx_event_create_ordering)(C.byref(p)))      # (timing=False: for ordering streams only, cheaper to record)
         self.ptr = p.value
 
     def record(self, stream=None):
         check(lib().dcrx_event_record(self.ptr, stream))
+
+    def synchronize(self):
+        check(lib().dcrx_event_synchronize(self.ptr))
 
     def elapsed_ms(self, later: "Event") -> float:
         ms = C.c_float()
@@ -930,6 +961,175 @@ class Event:
                 lib().dcrx_event_destroy(self.ptr)
         except Exception:
             pass
+
+
+class Stream:
+    """A HIP stream of the caller's own (dcrx_stream_create): a sharded run's side stream for the exchange."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().dcrx_stream_create(C.byref(p)))
+        self.ptr = p.value
+
+    def synchronize(self):
+        check(lib().dcrx_stream_synchronize(self.ptr))
+
+    def wait_event(self, ev: "Event"):
+        check(lib().dcrx_stream_wait_event(self.ptr, ev.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dcrx_stream_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+# ---- multi-GPU: RCCL bound by the library itself (include/dcrx.h, "multi-GPU") ----
+COMM_ID_BYTES = 128
+COMM_SUM, COMM_MAX = 0, 1
+
+
+class Comm:
+    """An RCCL communicator through the C ABI: one process per GPU (`Comm(uid, world, rank)` after dcrx_set_device), the id drawn
+    by rank 0 (`Comm.unique_id()`) and carried to the others by the caller — `comm_from_env()` does that for ranks started on one
+    node by torch.distributed.run or by bench.py's own spawn.  No torch anywhere."""
+
+    def __init__(self, uid: bytes, world: int, rank: int):
+        assert len(uid) == COMM_ID_BYTES
+        self._uid = np.frombuffer(uid, dtype=np.uint8).copy()
+        h = C.c_void_p()
+        check(lib().dcrx_comm_create(self._uid.ctypes.data, int(world), int(rank), C.byref(h)))
+        self.handle, self.world, self.rank = h.value, int(world), int(rank)
+
+    @staticmethod
+    def available() -> bool:
+        return bool(lib().dcrx_comm_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        check(lib().dcrx_comm_unique_id(buf.ctypes.data))
+        return buf.tobytes()
+
+    # --- device memory, asynchronous on `stream` (a pointer or None) ---
+    def allreduce_u64(self, d_in: int, d_out: int, n: int, op: int = COMM_SUM, stream=None):
+        check(lib().dcrx_comm_allreduce_u64(self.handle, d_in, d_out, int(n), op, stream))
+
+    def allreduce_f64(self, d_in: int, d_out: int, n: int, op: int = COMM_MAX, stream=None):
+        check(lib().dcrx_comm_allreduce_f64(self.handle, d_in, d_out, int(n), op, stream))
+
+    def allgather(self, d_in: int, d_out: int, bytes_per_rank: int, stream=None):
+        check(lib().dcrx_comm_allgather(self.handle, d_in, d_out, int(bytes_per_rank), stream))
+
+    def gather_v(self, d_send: int, send_bytes: int, d_recv=None, recv_bytes=None, root: int = 0, stream=None):
+        """Every rank but `root` sends send_bytes from d_send; the root receives recv_bytes[r] into d_recv[r] (one group)."""
+        ptrs = sizes = None
+        if self.rank == root and self.world > 1:
+            ptrs = (C.c_void_p * self.world)(*[int(p) if p else None for p in d_recv])
+            sizes = (C.c_uint64 * self.world)(*[int(b) for b in recv_bytes])
+        check(lib().dcrx_comm_gather_v(self.handle, d_send, int(send_bytes), ptrs, sizes, int(root), stream))
+
+    def barrier(self, stream=None):
+        check(lib().dcrx_comm_barrier(self.handle, stream))
+
+    # --- host memory, synchronous: the control plane of a sharded run ---
+    def allgather_host(self, arr: np.ndarray) -> np.ndarray:
+        """Every rank's array (same shape and dtype on all ranks), stacked in rank order."""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + a.shape, dtype=a.dtype)
+        check(lib().dcrx_comm_allgather_host(self.handle, a.ctypes.data if a.nbytes else None, out.ctypes.data if out.nbytes else None, a.nbytes))
+        return out
+
+    def allreduce_host_u64(self, values, op: int = COMM_SUM) -> np.ndarray:
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        check(lib().dcrx_comm_allreduce_host_u64(self.handle, a.ctypes.data if a.size else None, a.size, op))
+        return a
+
+    def allgather_bytes(self, blob: bytes) -> list:
+        """Every rank's bytes, in rank order (sizes first, then one padded all-gather)."""
+        sizes = self.allgather_host(np.array([len(blob)], dtype=np.uint64)).reshape(-1)
+        kmax = int(sizes.max()) if sizes.size else 0
+        if kmax == 0:
+            return [b"" for _ in range(self.world)]
+        pad = np.zeros(kmax, dtype=np.uint8)
+        pad[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+        got = self.allgather_host(pad)
+        return [got[r, :int(sizes[r])].tobytes() for r in range(self.world)]
+
+    def allgather_object(self, obj) -> list:
+        import pickle
+        return [pickle.loads(b) for b in self.allgather_bytes(pickle.dumps(obj))]
+
+    def gather_bytes(self, blob: bytes, dst: int = 0):
+        """Every rank's bytes on `dst`, in rank order (a list there, None elsewhere): the sizes (an all-gather), then one exact-size
+        transfer per peer from device memory into device memory (dcrx_comm_gather_v), waited for before this returns."""
+        sizes = [int(x) for x in self.allgather_host(np.array([len(blob)], dtype=np.uint64)).reshape(-1)]
+        if self.world == 1:
+            return [blob]
+        mine = DeviceBuffer.from_host(np.frombuffer(blob, dtype=np.uint8)) if len(blob) else DeviceBuffer(16)
+        recv = None
+        if self.rank == dst:
+            recv = [DeviceBuffer(max(n, 16)) if r != dst else None for r, n in enumerate(sizes)]
+        self.gather_v(mine.ptr, len(blob), [b.ptr if b is not None else None for b in recv] if recv else None, sizes if recv else None, dst, None)
+        synchronize()
+        if self.rank != dst:
+            return None
+        return [blob if r == dst else recv[r].to_host(np.uint8, sizes[r]).tobytes() for r in range(self.world)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().dcrx_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_from_env(timeout_s: float = 300.0) -> Comm:
+    """The communicator of a rank started with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in its environment (one node:
+    torch.distributed.run, bench.py's spawn).  Rank 0 draws the id and leaves it in a file of the node's temporary directory —
+    named for the launcher's port and the launcher's process, which every rank of one launch shares and no other launch does —
+    written under another name and renamed, so that a reader never sees half of it; the others wait for the file.  Rank 0
+    removes it once every rank has joined (the communicator exists).  DCRX_COMM_ID_FILE overrides the path (a shared file
+    system carries the id between nodes the same way)."""
+    import tempfile
+    import time
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    path = os.environ.get("DCRX_COMM_ID_FILE")
+    if not path:
+        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+        path = os.path.join(tempfile.gettempdir(), f"dcrx_comm_id_{key}")
+    if rank == 0:
+        uid = Comm.unique_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+    else:
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) == COMM_ID_BYTES:
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout_s:.0f} s (did rank 0 start?)")
+            time.sleep(0.01)
+    comm = Comm(uid, world, rank)
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return comm
 
 
 def compact_hits_bitmap_device(d_records: DeviceBuffer, n_reads: int, d_hits: DeviceBuffer, d_ok_bitmap: DeviceBuffer,

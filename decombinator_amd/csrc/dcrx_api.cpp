@@ -796,6 +796,12 @@ int dcrx_tune_state(const dcrx_tables_t *t, int orientation, uint64_t n_reads, d
   return DCRX_OK;
 }
 
+int dcrx_set_tune_wait(dcrx_tables_t *t, int allow) {
+  if (!t) return set_err(DCRX_E_INVALID, "tables is null");
+  for (V2Tune &U : t->tune) U.may_wait = allow != 0;
+  return DCRX_OK;
+}
+
 int dcrx_set_reserved_cus(dcrx_tables_t *t, uint32_t n_cus) {
   if (!t) return set_err(DCRX_E_INVALID, "tables is null");
   t->reserved_cus = n_cus;

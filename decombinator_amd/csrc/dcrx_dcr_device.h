@@ -705,20 +705,13 @@ DCRX_DEV ScanOut finish4(const DevTables &T, const ScanAcc &a) {
   return so;
 }
 
-// developer experiment switches (timing only; results are wrong when set)
-#ifdef DCRX_EXPERIMENT_NO_J
-#define DCRX_EXP_JACC(x)
-#else
-#define DCRX_EXP_JACC(x) x
-#endif
-
 #define DCRX_STEP(CODE)                                                                         \
   do {                                                                                          \
     e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) | ((uint32_t)(CODE) << 2));         \
     acc |= e;                                                                                   \
     const uint32_t t_ = ((e & TE_ROW_MASK) << 5) | it;                                          \
     vacc += (uint32_t)dcrx_sbfe((int)e, TE_VFULL_BIT, 1) & t_;                                  \
-    DCRX_EXP_JACC(jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;)                   \
+    jacc += (uint32_t)dcrx_sbfe((int)e, TE_JFULL_BIT, 1) & t_;                                  \
     it += (1u << ACC_POS_SHIFT);                                                                \
   } while (0)
 

@@ -238,6 +238,25 @@ __device__ __forceinline__ void v2_load_item(const BatchDev &B, const uint32_t n
 // multiple of 512 reads, so its bits fill whole 64-byte lines that no other block reads or writes: neither a vector nor a
 // scalar cache can hold a line of them from before the marks.  s: 6 words of LDS.
 __device__ __forceinline__ void v2_exc_slice(const BatchDev &B, const uint64_t blk_lo, const uint64_t blk_hi, uint32_t *s, const int tid) {
+  // A short list (the usual case: one read in two thousand carries such a byte, 5 000 entries for 10 M reads) in ONE pass: the
+  // list is sorted, so a bound is the number of entries below it — every thread counts its share against both keys, one LDS
+  // atomic per wave and key, one barrier.  The k-ary search below took three rounds of a dependent load between barriers:
+  // 4-5 of the 7.5 us a scan block spent before its first look-up (round 6, profiles/r06/scan_wave_stamps.log).
+  if (B.n_exc <= 16u * blockDim.x) {
+    if (tid < 4) s[tid] = 0u;
+    __syncthreads();
+    uint32_t below_lo = 0, below_hi = 0;
+    for (uint64_t i = (uint32_t)tid; i < B.n_exc; i += blockDim.x) {
+      const uint64_t r = B.exc_read[i];
+      below_lo += r < blk_lo ? 1u : 0u;
+      below_hi += r < blk_hi ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { below_lo += __shfl_xor(below_lo, o); below_hi += __shfl_xor(below_hi, o); }
+    if ((tid & 63) == 0) { if (below_lo) atomicAdd(&s[0], below_lo); if (below_hi) atomicAdd(&s[2], below_hi); }
+    __syncthreads();
+    return;      // s[0] = the slice's first entry, s[2] = one behind its last (what the caller reads)
+  }
   const uint32_t half = blockDim.x >> 1;
   const int which = (uint32_t)tid >= half ? 1 : 0;
   const uint32_t j = (uint32_t)tid - (which ? half : 0u);
@@ -457,15 +476,6 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         continue;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries were written before FILLED said so: nothing is read early)
-#ifdef DCRX_EXP_TAIL_NOOP
-      if (lane == 0) {
-        __hip_atomic_store(&lds_work[V2_WK_FILLED + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        atomicAdd(&lds_work[V2_WK_GEN + (c & nb_mask)], 1u);
-      }
-      spins = 0;
-      continue;
-#endif
       uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
       int status = -2;
       uint32_t r = 0, dg = 0;
@@ -551,17 +561,6 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     const uint32_t next = draw();
     const bool more = next < n_items;
     if (!PREFETCH) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)item * WT, blk_hi, lane, w, xm);
-#ifdef DCRX_EXP_WARM
-    // (experiment: no item in registers ahead — the next item's lines are asked for instead, one dword per 128-byte line, so that
-    // its loads meet them in the L2; the value is kept alive to the end of this item so that the load is really issued)
-    uint32_t warm = 0;
-    if (!PREFETCH && more) {
-      const uint64_t b0 = (blk_lo + (uint64_t)next * WT) * B.stride, b1 = min(blk_hi, blk_lo + (uint64_t)(next + 1) * WT) * B.stride;
-      const uint64_t a = (b0 & ~127ull) + (uint64_t)lane * 128u;
-      if (a < b1) warm = *reinterpret_cast<const uint32_t *>(B.packed + a);
-      if (WT * 40u > 64u * 128u && a + 64u * 128u < b1) warm ^= *reinterpret_cast<const uint32_t *>(B.packed + a + 64u * 128u);
-    }
-#endif
     if (PREFETCH) { if (more) v2_load_item<NW, RPL>(B, nw, blk_lo + (uint64_t)next * WT, blk_hi, lane, wn, xn); }     // in flight while this item is scanned
     uint32_t lg[RPL][NW];
     // (the look-up loop is bound by the LDS; what a wave does between two scans — digest, pushes, records — is bound by
@@ -569,17 +568,14 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #if DCRX_V2_LOOP_PRIO
     __builtin_amdgcn_s_setprio(DCRX_V2_LOOP_PRIO);
 #endif
-#ifdef DCRX_EXP_NOLOOP      // (experiment build, tools/: no look-up at all — what the rest of a scanning wave's work takes; the records are NOT results)
-#pragma unroll
-    for (int q = 0; q < RPL; q++)
-#pragma unroll
-      for (int k = 0; k < NW; k++) lg[q][k] = w[q][k] & (w[q][(k + 1) % NW] >> 3) & (w[q][(k + 2) % NW] << 5) & 0x33333333u;
-#else
-    scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
-#endif
+    if (UNIFORM_LEN && NW == 10 && npairs == 75) scan2<NW, RPL, NARROW, (UNIFORM_LEN && NW == 10) ? 75 : 0>(tab, w, lg, npairs);      // (150 nt: the count known to the compiler)
+    else scan2<NW, RPL, NARROW>(tab, w, lg, npairs);
 #if DCRX_V2_LOOP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+    // (round 6: the next item's words landed HERE instead — a whole scan behind their loads, in front of this item's stores, so
+    // that the copy w = wn at the loop's end does not sit behind the stores' acknowledgements — measured 0.6 % slower, one register
+    // more: profiles/r06/scan_early_landing_ab.log)
     unsigned long long tmask[RPL];      // (fused form) the tail lanes of each of the item's reads, and their digests
     uint32_t tdg[RPL];
 #pragma unroll
@@ -594,11 +590,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       const bool exc = live && ((xm[q] >> lane) & 1ull);
       const int n = UNIFORM_LEN ? (int)B.read_len : (live ? (int)B.lens[r] : 0);
       if (!UNIFORM_LEN) mask_log2<NW>(lg[q], n);
-#if defined(DCRX_EXP_OLD_DIGEST)
-      const Digest2 d = digest2<NW>(lg[q]);
-#else
-      const Digest2 d = digest2_lean<NW>(lg[q]);
-#endif
+      const Digest2 d = digest2_scan<NW>(lg[q]);
       if (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) {        // profiling aid: price the scan alone (records are NOT results)
         if (live) {
           __align__(16) dcrx_record_t rec;
@@ -619,11 +611,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // every lane writes: whole lines of records leave the wave (reads that go on get a placeholder, rewritten by the kernel that
       // settles them) — but for the tail reads of the fused form: a tail wave of this block writes their records, and two stores to
       // one address from two waves have no order
-#ifdef DCRX_EXP_POST_NOREC      // (experiment builds, tools/: parts of a scanning wave's work between two scans left out — the records are NOT results)
-      if (false) {
-#else
       if (live && !(FUSE >= 0 && what == V2_TAIL)) {
-#endif
 #else
       if (vnone || vmulti) {
 #endif
@@ -635,11 +623,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         DCRX_STORE_SCAN(records + r, rec);
       }
       const unsigned long long mn = __ballot(vnone), mm = __ballot(vmulti);
-#ifdef DCRX_EXP_POST_NOCNT
-      if (false) {
-#else
       if (lane == 0) {
-#endif
         if (mn) atomicAdd(&lds_counts[DCRX_C_NO_VTAGS_FOUND], (uint32_t)__popcll(mn));
         if (mm) atomicAdd(&lds_counts[DCRX_C_MULTIPLE_V_MATCHES], (uint32_t)__popcll(mm));
         if (mn | mm) atomicAdd(&lds_counts[DCRX_C_READ_COUNT], (uint32_t)__popcll(mn | mm));
@@ -666,9 +650,7 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       // event entries: list E (one gene to rescue: nine in ten), or one of the rare lists C (both genes) and X (exception
       // bytes, a flag on the last half pair of an odd read: the general form)
       int lst = 0;
-#ifndef DCRX_EXP_POST_NOEV
       if (what == V2_EVENTS) lst = (exc || bnd) ? V2_L_X : (shape2(d.vf_n, d.jf_n, d.any) == V2_SHAPE_BOTH ? V2_L_C : V2_L_E);
-#endif
       auto put_event = [&](uint4 *rows, const uint32_t at) {      // (behind the words: the digest of the log, for the lean rescue)
         uint32_t x[2 + 2 * NW];
         x[0] = (uint32_t)r | (exc ? V2_R_EXC : 0u);
@@ -766,9 +748,6 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
         xm[q] = xn[q];
       }
     }
-#ifdef DCRX_EXP_WARM
-    asm volatile("" :: "v"(warm));
-#endif
     item = next;
   }
   if (FUSE >= 0 && lane == 0) {      // this wave's last entries are in the ring
@@ -1079,12 +1058,8 @@ __device__ __forceinline__ void v2_rescue_jobs(const Rescue2Tabs &rt, const V2Fi
             DCRX_STORE_FINISH(records + r, rec);
             if (S.dev) tup = sink_tuple_lean(rec, S.wpack, (e & 8u) != 0u && 2 * rt.split[1] != (int)rt.t.L[1]);
           };
-#ifdef DCRX_EXP_RESCUE_NOOP      // (experiment build, tools/: the entries streamed and records written, nothing resolved — the records are NOT results)
-          status = DCRX_S_J_NONE; errs = (uint32_t)(lw.stored64(n - 40) ^ lg[3] ^ x[1 + 2 * NW]) & 0u;
-#else
           if (which == V2_L_E) status = rescue2_fast_to<ORI == 1, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
           else status = rescue2_fast_to<ORI == 1, NW, V2_SHAPE_BOTH>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, x[1 + 2 * NW]);
-#endif
           if (status > 0) {      // settled, not decombined: the status alone
             dcrx_record_t rec;
             rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
@@ -1245,11 +1220,7 @@ DCRX_V2_ROLE void v2_general_role(const uint32_t mode_, const uint32_t vblock_, 
   // at a time; then — mode bit 1, one wave — the left list as its entries arrive, a lane per entry, in order; every other block
   // signs off in queue_count[V2_QC_DONE] when its role is done (its pushes before that)
   const uint32_t region = vblock / A.R.bsplit, bpart = vblock % A.R.bsplit;
-#ifdef DCRX_EXP_NO_X      // (experiment build, tools/: list X left alone — what the general form's rounds cost the finishing launch; the records are NOT results)
-  const bool do_x = false;
-#else
   const bool do_x = (mode & 1u) && region < A.n_regions && !(A.cfg.flags & DCRX_F_PROFILE_NO_EVENTS);
-#endif
   const V2ListRef lx = v2_list<NW>(A.Q, V2_L_X, do_x ? region : 0u);
   const uint32_t x_total = do_x ? min(A.Q.counts[V2_L_COUNTS * region + V2_L_X], lx.cap) : 0u;
   // (a long list — a run with many N tails — fills its waves: few lanes per wave pay only while the list is a handful per region)
@@ -1332,10 +1303,6 @@ __global__ __launch_bounds__(DCRX_V2_FBLOCK, DCRX_V2_RWAVES) void finish2_kernel
   // block 0 — of list X's role — stays to take the left list as it fills and leaves last; every other block signs off when its
   // role is done (its left-list pushes are in memory, each behind a fence of its own)
   const bool staged = work || blockIdx.x == 0;
-#ifdef DCRX_EXP_FINISH_EMPTY      // (experiment builds, tools/: 1 = the launch's blocks leave at once, 2 = they stage their tables and leave — what dispatching and staging cost; the records are NOT results)
-  if (DCRX_EXP_FINISH_EMPTY == 2 && staged) { L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid); __syncthreads(); if (L.counts[tid & 31] == 12345u) A.counters[0] = 1; }
-  return;
-#endif
   if (staged) {
     L = v2_finish_stage<NW, DCRX_V2_FBLOCK>(A.T0, V, smem, tid);
     __syncthreads();
@@ -1826,9 +1793,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
           }
           if (U.created) { rescue_waves = (k & 1) ? waves_second : waves_first; tune_start = U.ev[k][0]; tune_stop = U.ev[k][1]; }
         } else if (k >= V2Tune::SAMPLES && U.created) {
-          // (a big batch's samples are waited for, once: a caller that queues such launches ahead of the device — each takes
-          // milliseconds — would otherwise never find them complete, and the wait is one launch's time at most)
-          if (big && k == V2Tune::SAMPLES) (void)hipEventSynchronize(U.ev[V2Tune::SAMPLES - 1][1]);
+          // (a big batch's samples may be waited for, once, where the caller has said so — dcrx_set_tune_wait —: a caller that queues
+          // such launches ahead of the device — each takes milliseconds — would otherwise never find them complete; without that
+          // permission the call keeps its contract of never waiting and the handle stays on the first setting until a query succeeds)
+          if (big && k == V2Tune::SAMPLES && P.tune[o].may_wait) (void)hipEventSynchronize(U.ev[V2Tune::SAMPLES - 1][1]);      // (only where the caller allowed it: dcrx_set_tune_wait)
           bool ready = true;
           for (int i = 0; i < V2Tune::SAMPLES && ready; i++) ready = hipEventQuery(U.ev[i][1]) == hipSuccess;
           (void)hipGetLastError();
@@ -2009,11 +1977,7 @@ hipError_t launch_v2_any(const LaunchPlan &P, const DevTables &T, const BatchDev
 #define DCRX_V2X(UN, NW_, RP, NA, PF) launch_v2<UN, NW_, RP, NA, PF>(P, T, B, cfg, rec, queue, gqueue, qcap, queue_count, d_counters, s, ev_start, ev_stop, retry, sink)
 #define DCRX_V2(UN, NW_, NA) (shape == 3 ? DCRX_V2A(UN, NW_, 1, NA) : (shape == 1 && UN && NW_ == 10 && NA) ? DCRX_V2X(true, 10, 4, true, false) : DCRX_V2A(UN, NW_, 2, NA))
 #ifdef DCRX_FAST_BUILD      // (experiment builds, tools/build_variant.sh: the benchmark's launch shape only)
-#ifdef DCRX_EXP_RPL3
-  if (nw10 && uniform && shape == 2) return narrow ? DCRX_V2X(true, 10, 3, true, false) : DCRX_V2X(true, 10, 3, false, false);
-#else
   if (nw10 && uniform && shape == 2) return narrow ? DCRX_V2A(true, 10, 2, true) : DCRX_V2A(true, 10, 2, false);
-#endif
   return hipErrorNotSupported;
 #else
   if (nw10) {

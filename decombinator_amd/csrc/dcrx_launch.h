@@ -66,6 +66,7 @@ struct V2Tune {
   static constexpr int CLASSES = 12;
   static constexpr uint64_t BIG_BATCH = 1ull << 25;      // reads: from here a handle chooses between 8 192 and 4 096 rescue waves (below: 4 096 and 3 072)
   V2TuneSlot slot[CLASSES];
+  bool may_wait = false;             // dcrx_set_tune_wait: the fourth call of a big-batch size class may wait for the third's finishing launch, once
   uint32_t last_form = 0;            // the frame's last call: 0 none yet, 1 the three-launch form, 2 the v2 kernels (tail as a role), 3 v2 with the tail inside the scan
   static int size_class(uint64_t n_reads) {      // -1: below a million reads (not tuned)
     if (n_reads < (1ull << 20)) return -1;

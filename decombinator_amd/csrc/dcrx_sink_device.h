@@ -46,9 +46,6 @@ __device__ __forceinline__ uint64_t sink_tuple(const dcrx_record_t &r, const uin
 // the same from what a lean role has in hand: no table is read (short_end: the J half1 rescue found the J gene and the split is
 // not the tag's middle; a tag of the lean forms' classes has the class's length)
 __device__ __forceinline__ uint64_t sink_tuple_lean(const dcrx_record_t &r, const uint32_t wpack, const bool short_end) {
-#ifdef DCRX_EXP_SINK_NOTUPLE
-  return (uint64_t)r.v | ((uint64_t)r.j << 16);
-#endif
   const uint32_t w_v = wpack & 31u, w_j = (wpack >> 5) & 31u, w_vdel = (wpack >> 10) & 31u, w_jdel = (wpack >> 15) & 31u, w_pos = (wpack >> 20) & 31u;
   // (the widths are scalars; where everything below j_end fits one word — 29 bits for human beta — one 64-bit shift is all)
   const uint32_t w_lo = w_v + w_j + w_vdel + w_jdel + w_pos;
@@ -82,11 +79,7 @@ __device__ __forceinline__ void sink_put(const V2SinkCall &S, const uint32_t reg
   if (live) {
     const size_t at = (size_t)region * S.stride + section_off + slot;
     const uint32_t rel = r - region * S.per_block;
-#ifndef DCRX_EXP_SINK_NOSTORE      // (experiment builds, tools/: what the item's store costs a lean loop)
     S.items[at] = make_uint2((uint32_t)tuple, hit ? (rel | ((uint32_t)(tuple >> 32) << 24)) : V2_SINK_EMPTY);      // (one 8-byte store; the place kernel reads it back out of the L2)
-#else
-    if (at == 0xFFFFFFFFFFFFull) S.items[at] = make_uint2((uint32_t)tuple, rel);
-#endif
   }
 }
 

@@ -69,8 +69,11 @@ inline dcrx_gwords dcrx_gwords_of(const uint8_t *p) { return reinterpret_cast<co
 // The scan of RPL reads side by side (independent chains in one instruction stream).
 // w[q][kk]: word kk of read q.  lg[q][kk]: nibble j = flags of the pair at bases 16kk+2j, 16kk+2j+1.
 // npairs: pairs to scan (wave-uniform): (n + 1) / 2 for a batch of one length, 8 * words otherwise.
-template <int NW, int RPL, bool NARROW>
-DCRX_DEV void scan2(const V2Tab &tab, const uint32_t (&w)[RPL][NW], uint32_t (&lg)[RPL][NW], const int npairs) {
+// NPAIRS_CT > 0: the number of pairs is known where the kernel is compiled (the 150-nt batches: 75) — no test per word, no
+// counted loop for a partial word, and the chains of the two reads never drain at a word's end: one straight run of look-ups.
+template <int NW, int RPL, bool NARROW, int NPAIRS_CT = 0>
+DCRX_DEV void scan2(const V2Tab &tab, const uint32_t (&w)[RPL][NW], uint32_t (&lg)[RPL][NW], const int npairs_rt) {
+  const int npairs = NPAIRS_CT > 0 ? NPAIRS_CT : npairs_rt;
   uint32_t e[RPL];
 #pragma unroll
   for (int q = 0; q < RPL; q++) e[q] = 0;      // root
@@ -93,9 +96,18 @@ DCRX_DEV void scan2(const V2Tab &tab, const uint32_t (&w)[RPL][NW], uint32_t (&l
       uint32_t wv[RPL], l[RPL];
 #pragma unroll
       for (int q = 0; q < RPL; q++) { wv[q] = w[q][kk]; l[q] = 0; }
-      for (int j = 0; j < cnt; j++) {
+      if constexpr (NPAIRS_CT > 0) {      // (a count the compiler knows: straight-line)
 #pragma unroll
-        for (int q = 0; q < RPL; q++) { DCRX_V2_STEP(NARROW, e[q], l[q], (wv[q] & 15u) << 1); wv[q] >>= 4; }
+        for (int j = 0; j < 8; j++)
+          if (j < cnt) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { DCRX_V2_STEP(NARROW, e[q], l[q], (wv[q] & 15u) << 1); wv[q] >>= 4; }
+          }
+      } else {
+        for (int j = 0; j < cnt; j++) {
+#pragma unroll
+          for (int q = 0; q < RPL; q++) { DCRX_V2_STEP(NARROW, e[q], l[q], (wv[q] & 15u) << 1); wv[q] >>= 4; }
+        }
       }
 #pragma unroll
       for (int q = 0; q < RPL; q++) lg[q][kk] = l[q] >> (4 * (8 - cnt));
@@ -172,6 +184,43 @@ DCRX_DEV Digest2 digest2_lean(const uint32_t (&lg)[NW]) {
   d.vf_pair = ((av >> 12) << 3) | (ov ? ((uint32_t)dcrx_ctz32(ov) >> 2) : 0u);
   d.jf_pair = ((aj >> 12) << 3) | (oj ? ((uint32_t)dcrx_ctz32(oj) >> 2) : 0u);
   return d;
+}
+
+// The ten-word shape's digest on MERGED words (round 6): the two full-tag flags of two words share one word (bit-field insert:
+// a shift and one v_bfi), then each gene's flags of four words share one — bit i of a nibble: words 0, 2, 1, 3 of the four —,
+// so that counts and positions are taken on three words per gene instead of ten: ~65 vector instructions where digest2_lean takes
+// ~100.  Same contract: `any`, the two counts, and a gene's pair when exactly one pair holds its tag.
+DCRX_DEV uint32_t dcrx_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+DCRX_DEV Digest2 digest2_packed10(const uint32_t (&lg)[10]) {
+  uint32_t o = lg[0];
+#pragma unroll
+  for (int kk = 1; kk < 10; kk++) o |= lg[kk];
+  uint32_t M[5];      // nibble bits: V tag of word 2 j, J tag of word 2 j, V tag of word 2 j + 1, J tag of word 2 j + 1
+#pragma unroll
+  for (int j = 0; j < 5; j++) M[j] = dcrx_bfi(0x33333333u, lg[2 * j], lg[2 * j + 1] << 2);
+  const uint32_t e = 0x55555555u;
+  const uint32_t q0 = dcrx_bfi(e, M[0], M[1] << 1), q1 = dcrx_bfi(e, M[2], M[3] << 1), q2 = M[4] & e;                // V tags: words 0-3, 4-7, 8-9
+  const uint32_t r0 = dcrx_bfi(e, M[0] >> 1, M[1]), r1 = dcrx_bfi(e, M[2] >> 1, M[3]), r2 = (M[4] >> 1) & e;          // J tags, the same places
+  const uint32_t av = (uint32_t)dcrx_popc32(q0) + (uint32_t)dcrx_popc32(q1) * 0x1001u + (uint32_t)dcrx_popc32(q2) * 0x2001u;
+  const uint32_t aj = (uint32_t)dcrx_popc32(r0) + (uint32_t)dcrx_popc32(r1) * 0x1001u + (uint32_t)dcrx_popc32(r2) * 0x2001u;
+  auto place = [](const uint32_t a, const uint32_t any3) -> uint32_t {      // the pair of a gene's one flag: 8 * word + nibble
+    const uint32_t tb = any3 ? (uint32_t)dcrx_ctz32(any3) : 0u;
+    const uint32_t i = tb & 3u, word = 4u * (a >> 12) + (((i & 1u) << 1) | (i >> 1));
+    return (word << 3) | (tb >> 2);
+  };
+  Digest2 d;
+  o |= o >> 16; o |= o >> 8; o |= o >> 4;
+  d.any = o & 0xFu;
+  d.vf_n = av & 0xFFFu; d.jf_n = aj & 0xFFFu;
+  d.vf_pair = place(av, q0 | q1 | q2);
+  d.jf_pair = place(aj, r0 | r1 | r2);
+  return d;
+}
+// what the scan kernel (and its host emulation) takes
+template <int NW>
+DCRX_DEV Digest2 digest2_scan(const uint32_t (&lg)[NW]) {
+  if constexpr (NW == 10) return digest2_packed10(lg);
+  else return digest2_lean<NW>(lg);
 }
 
 // flags of pair index `pair` (any lane-varying index: a select chain over the words)
@@ -1100,13 +1149,7 @@ DCRX_DEV int rescue2_half(const GeneOf<G> &g, const WS &w, const uint32_t (&lg)[
     R2P(2, 0);
     const int kk = REV ? 31 - dcrx_clz32(nz) : dcrx_ctz32(nz);
     nz &= ~(1u << kk);
-#ifdef DCRX_EXP_SWEEP1      // (experiment build, tools/: one flagged pair per sweep — the records are NOT results; what shorter sweeps would buy)
-    nz = 0;
-#endif
     uint32_t m = log_word<NW>(lg, kk) & mask8;
-#ifdef DCRX_EXP_SWEEP1
-    m &= REV ? (0xFu << (28 - 4 * (dcrx_clz32(m) >> 2))) : (0xFu << (4 * (dcrx_ctz32(m) >> 2)));
-#endif
     while (m && res == 0) {
       R2P(3, 0);
       const int bit = REV ? 31 - dcrx_clz32(m) : dcrx_ctz32(m);

@@ -1,24 +1,31 @@
-"""Multi-GPU sharding of the decombine hot path: one process per GPU, reads split
-into contiguous ranges by rank, a final gather of the DCR tuples on rank 0 and a
-sum of the counters (torch.distributed; backend "nccl" is RCCL over xGMI on
-ROCm, "gloo" in the CPU tests).
+"""Multi-GPU sharding of the decombine hot path: one process per GPU, reads split into contiguous ranges by rank, a final
+gather of the DCR tuples on rank 0 and a sum of the counters — over RCCL / xGMI through the library's own binding
+(include/dcrx.h "multi-GPU": dcrx_comm_*, dcrx_decombine_sharded; decombinator_amd._native.Comm).  No other framework is on
+this path: nothing here imports torch.
 
-The reference is single-process: nothing here mirrors reference
-code.  decombinator_sharded() is the product entry (the whole stage over the ranks);
-TupleGather is what bench.py times (device-resident shards, tuples gathered per step).  Each read's result depends only on that read and the replicated tables
-(reference decombine.py:534-585 has no cross-read state but the additive
-Counter, :598), so the only exchange is the final one:
+The reference is single-process: nothing here mirrors reference code.  decombinator_sharded() is the product
+entry (the whole stage over the ranks); TupleGather is what bench.py times (device-resident shards, tuples gathered per step);
+decombine_sharded_step() is one synchronous step through the C entry dcrx_decombine_sharded.  Each read's result depends only
+on that read and the replicated tables (reference decombine.py:534-585 has no cross-read state but the additive Counter,
+:598), so the only exchange is the final one:
 
-  * contiguous shards, so that concatenating the ranks' outputs in rank order
-    reproduces the reference's input-order `.n12` (outdata.append, :1039);
-  * DCR tuples = the status-OK 16-byte records + their global read indices,
-    compacted on the device (dcrx_compact_hits_device);
-  * counters: all_reduce(sum) of the uint64[32] block.
+  * contiguous shards, so that concatenating the ranks' outputs in rank order reproduces the reference's input-order `.n12`
+    (outdata.append, :1039);
+  * DCR tuples = the narrow tuples of the status-OK records + one bit per read, left by the decombine call itself (the
+    handle's tuple sink) or compacted from the records;
+  * counters: all-reduce (sum) of the uint64[32] block.
+
+Two small interfaces keep the protocol testable without a GPU (tests/gloo_backend.py implements both over gloo on host
+memory; the product's implementations are _native.Comm and RcclBackend below):
+
+  communicator   world, rank, allgather_host(array), allreduce_host_u64(values), allgather_bytes(blob),
+                 allgather_object(obj), gather_bytes(blob, dst), barrier()            — host memory, synchronous
+  backend        what TupleGather needs of a device: buffers, a side stream's ordering, the count exchange and the
+                 exact-size transfers (class RcclBackend documents the methods)
 """
 from __future__ import annotations
 
-import torch
-import torch.distributed as dist
+import numpy as np
 
 
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
@@ -26,49 +33,42 @@ def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
 
 
-def reduce_counters(counters: torch.Tensor) -> torch.Tensor:
-    """Sum of every rank's int64[32] counter block, on every rank."""
-    out = counters.clone()
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+def reduce_counters(comm, counters) -> np.ndarray:
+    """Sum of every rank's uint64[32] counter block, on every rank."""
+    out = np.ascontiguousarray(counters, dtype=np.uint64).copy()
+    if comm is not None and comm.world > 1:
+        out = comm.allreduce_host_u64(out)
     return out
 
 
-def gather_exact(hits: torch.Tensor, index: torch.Tensor, dst: int = 0):
-    """Gathers each rank's (k_r, 16) uint8 tuple block and (k_r,) int64 index block on
-    `dst`, concatenated in rank order.  Sizes are exchanged first (one small
-    all_gather), then one padded gather per array.  Returns (hits, index) on dst and
-    (None, None) elsewhere."""
-    assert hits.dtype == torch.uint8 and hits.dim() == 2 and hits.shape[1] == 16
-    assert index.dtype == torch.int64 and index.shape[0] == hits.shape[0]
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_bytes(comm, blob: bytes, dst: int = 0):
+    """Every rank's bytes on `dst`, in rank order (a list of bytes objects there, None elsewhere).  What the sharded stage
+    sends to rank 0: the rows' text, assembled on the rank that holds the reads."""
+    return comm.gather_bytes(blob, dst)
+
+
+def gather_exact(comm, hits, index, dst: int = 0):
+    """Gathers each rank's (k_r, 16) uint8 tuple block and (k_r,) int64 index block on `dst`, concatenated in rank order.
+    Returns (hits, index) on dst and (None, None) elsewhere."""
+    hits = np.ascontiguousarray(hits, dtype=np.uint8)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    assert hits.ndim == 2 and hits.shape[1] == 16 and index.shape[0] == hits.shape[0]
+    if comm is None or comm.world == 1:
         return hits, index
-    world, rank = dist.get_world_size(), dist.get_rank()
-    k = torch.tensor([hits.shape[0]], dtype=torch.int64, device=hits.device)
-    ks = [torch.zeros_like(k) for _ in range(world)]
-    dist.all_gather(ks, k)
-    counts = [int(x.item()) for x in ks]
-    kmax = max(counts) if counts else 0
-    pad_h = torch.zeros((kmax, 16), dtype=torch.uint8, device=hits.device)
-    pad_i = torch.zeros((kmax,), dtype=torch.int64, device=hits.device)
-    pad_h[:hits.shape[0]] = hits
-    pad_i[:index.shape[0]] = index
-    if rank == dst:
-        gh = [torch.empty_like(pad_h) for _ in range(world)]
-        gi = [torch.empty_like(pad_i) for _ in range(world)]
-        dist.gather(pad_h, gh, dst=dst)
-        dist.gather(pad_i, gi, dst=dst)
-        return (torch.cat([g[:c] for g, c in zip(gh, counts)]),
-                torch.cat([g[:c] for g, c in zip(gi, counts)]))
-    dist.gather(pad_h, None, dst=dst)
-    dist.gather(pad_i, None, dst=dst)
-    return None, None
+    parts = comm.gather_bytes(hits.tobytes() + index.tobytes(), dst)
+    if comm.rank != dst:
+        return None, None
+    hs, ix = [], []
+    for p in parts:
+        k = len(p) // 24
+        hs.append(np.frombuffer(p[:16 * k], dtype=np.uint8).reshape(-1, 16))
+        ix.append(np.frombuffer(p[16 * k:], dtype=np.int64))
+    return np.concatenate(hs), np.concatenate(ix)
 
 
 def pack_tuples12(rec):
     """Host-side twin of dcrx_compact_hits_packed_device: the status-OK records of `rec` (RECORD_DTYPE) as
     (k, 3) uint32 tuples in read order, and the bitmap of the reads they belong to ((n + 63) // 64 uint64)."""
-    import numpy as np
     ok = rec["status"] == 0
     r = rec[ok]
     w = np.zeros((len(r), 3), dtype=np.uint32)
@@ -83,7 +83,6 @@ def pack_tuples12(rec):
 
 def bitmap_indices(bitmap, n_reads: int):
     """Read indices (ascending) whose bit is set."""
-    import numpy as np
     bits = np.unpackbits(np.ascontiguousarray(bitmap, dtype=np.uint64).view(np.uint8), bitorder="little")[:n_reads]
     return np.nonzero(bits)[0]
 
@@ -95,31 +94,119 @@ def pack_tuples8(rec):
     return nat.pack_tuples8(rec), bitmap
 
 
+class _Event:
+    """An event of the side or the main stream, re-recorded in place (no allocation per step)."""
+
+    def __init__(self, nat):
+        self.ev = nat.Event(timing=False)
+
+    def record(self, stream_ptr):
+        self.ev.record(stream_ptr)
+        return self
+
+    def synchronize(self):
+        self.ev.synchronize()
+
+
+class RcclBackend:
+    """What TupleGather needs of a device, on a GPU: device buffers, a side stream ordered against the stream the decombine
+    calls run on (`main_stream`: a hipStream_t pointer, None = the default stream), the count exchange and the exact-size
+    transfers over RCCL (nat.Comm; comm None = one rank, nothing travels).
+
+      buffer(nbytes) -> object with .ptr (.np on host backends: the same bytes as an array)
+      host_counts(world) -> uint64 array the counts are copied into (pinned here)
+      side_wait_main() / main_wait_side()        stream ordering
+      new_event() -> an event the calls below record; main_wait(event) / side_wait(event); event.synchronize() for the host
+      side_ptr                                   the pointer compaction launches take
+      zero(buf, offset, nbytes)                  on the side stream
+      exchange_counts(n_buf, counts_buf, host)   all-gather of the ranks' counts and their copy to the host -> event
+      post(slot_bufs, counts)                    the exact-size transfers of one slot (rank 0: one grouped receive) -> event
+    """
+    cuda = True
+
+    def __init__(self, nat, comm=None, main_stream=None):
+        self.nat, self.comm = nat, comm
+        self.world = comm.world if comm is not None else 1
+        self.rank = comm.rank if comm is not None else 0
+        self.main = main_stream
+        self.side = nat.Stream()
+        self.side_ptr = self.side.ptr
+        self._tmp = _Event(nat)
+
+    def buffer(self, nbytes: int):
+        buf = self.nat.DeviceBuffer(max(int(nbytes), 16))
+        self.nat.check(self.nat.lib().dcrx_memset_device(buf.ptr, 0, buf.nbytes))
+        return buf
+
+    def host_counts(self, world: int):
+        return self.nat.pinned_empty((world,), np.uint64)
+
+    def side_wait_main(self):
+        self.side.wait_event(self._tmp.record(self.main).ev)
+
+    def main_wait_side(self):
+        self.main_wait(self._tmp.record(self.side_ptr))
+
+    def new_event(self):
+        return _Event(self.nat)
+
+    def main_wait(self, event):
+        self.nat.check(self.nat.lib().dcrx_stream_wait_event(self.main, event.ev.ptr))
+
+    def side_wait(self, event):
+        pass      # (the transfers ran on the side stream: what follows on it is behind them)
+
+    def zero(self, buf, offset: int, nbytes: int):
+        self.nat.check(self.nat.lib().dcrx_memset_device_async(buf.ptr + offset, 0, nbytes, self.side_ptr))
+
+    def exchange_counts(self, n_buf, counts_buf, host, event):
+        nat = self.nat
+        if self.world > 1:
+            self.comm.allgather(n_buf.ptr, counts_buf.ptr, 8, self.side_ptr)
+        else:
+            nat.check(nat.lib().dcrx_memcpy_d2d_async(counts_buf.ptr, n_buf.ptr, 8, self.side_ptr))
+        nat.check(nat.lib().dcrx_memcpy_d2h_async(host.ctypes.data, counts_buf.ptr, 8 * self.world, self.side_ptr))
+        return event.record(self.side_ptr)
+
+    def post(self, own_msg, peer_msgs, nbytes, event):
+        """nbytes[r]: the exact size of rank r's message.  Rank 0 receives every peer's into peer_msgs[r]; the others send."""
+        if self.world > 1:
+            self.comm.gather_v(own_msg.ptr, nbytes[self.rank], [m.ptr if m is not None else None for m in peer_msgs] if self.rank == 0 else None,
+                               nbytes if self.rank == 0 else None, 0, self.side_ptr)
+        return event.record(self.side_ptr)
+
+    def to_host(self, buf, nbytes: int) -> np.ndarray:
+        return buf.to_host(np.uint8, nbytes)
+
+    def synchronize(self):
+        self.nat.synchronize()
+
+
 class TupleGather:
     """Per-step gather of the DCR tuples on rank 0, exact sizes, nothing truncated.
 
-    A tuple travels as 8 bytes when the V tags' jumps are given (`v_jumps`; dcrx_compact_hits_packed8_device: every field of
-    the record but ins_start, which rank 0 re-derives from the tag file's jump — tag sets of < 2048 V and < 512 J tags) and
-    as 12 bytes otherwise (dcrx_compact_hits_packed_device), in read order, plus one bit per read saying which reads
+    A tuple travels as the tag set's narrow tuple when `tables` is given (include/dcrx.h dcrx_tuple_layout: 5 bytes for
+    human beta at 150 nt; the receiver holds the same tables), as 8 bytes when only the V tags' jumps are given (`v_jumps`;
+    dcrx_compact_hits_packed8_device) and as 12 bytes otherwise, in read order, plus one bit per read saying which reads
     decombined: at eight ranks and 20 G reads/s per rank the tuples are what the xGMI links into rank 0 carry.  Per step, on a
     side stream beside the scan of the following step:
 
-      1. compaction of the step's records -> tuples, bitmap, count (on the device);
-      2. count exchange: all_gather of the ranks' counts, copied to pinned host memory;
+      1. the step's message: left by the decombine call itself (tuple sink) or compacted from its records -> tuples, bitmap, count;
+      2. count exchange: all-gather of the ranks' counts, copied to pinned host memory;
       3. one step later, when the counts have arrived: exact-size point-to-point transfers
          (rank r sends one message: its bitmap, then count_r tuples; rank 0 posts the receives from all peers as one group).
 
-    The caller alternates between `depth` record buffers (`records()`), the scan of step k + depth waits for
-    the compaction of step k (`before_scan`), and a buffer set is reused only after its transfers completed.
-    `compact` replaces step 1 (tests feed tuples made on the host); device None or CPU runs without streams
-    (gloo), else on a CUDA side stream (RCCL)."""
+    The caller alternates between `depth` record buffers (`records()`), the scan of step k + depth waits for the compaction
+    of step k (`before_scan`), and a buffer set is reused only after its transfers completed.  `compact` replaces step 1
+    (tests feed tuples made on the host).  `backend`: RcclBackend on a GPU; tests/gloo_backend.GlooBackend on host memory."""
 
     TUPLE_BYTES = 12      # (the class default; an instance with v_jumps carries 8)
 
-    def __init__(self, n_reads: int, world: int, rank: int, device: torch.device, depth: int = 2, compact=None, v_jumps=None,
+    def __init__(self, n_reads: int, backend, depth: int = 2, compact=None, v_jumps=None,
                  n_v: int = None, n_j: int = None, tables=None, max_read_len: int = None, use_sink: bool = True):
         from . import _native as nat
-        self.nat = nat
+        self.nat, self.be = nat, backend
+        world, rank = backend.world, backend.rank
         # `tables` (+ max_read_len): the narrow tuple of include/dcrx.h — widths from the tag tables, neither ins_start nor
         # ins_len on the wire (5 bytes for human beta at 150 nt); the receiver holds the same tables (nat.TupleCodec)
         self.tables, self.codec = tables, None
@@ -139,157 +226,127 @@ class TupleGather:
                 self.v_jumps = None
         self.TUPLE_BYTES = self.codec.bytes if self.codec is not None else (8 if self.v_jumps is not None else 12)
         self.world, self.rank, self.n_reads = world, rank, n_reads
-        self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.device = device if self.cuda else torch.device("cpu")
+        self.cuda = bool(backend.cuda)
         self.words = (n_reads + 63) // 64
         self.k = 0
-        self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self.compact = compact
         # the tuple sink (dcrx_set_tuple_sink): the decombine call of a step leaves the step's message itself, on its own
         # stream — no compaction pass beside the next step's scan; the side stream carries the count exchange and the transfers
         self.sink = bool(use_sink and self.codec is not None and self.cuda and compact is None)
         self.slots = []
-        dev = self.device
         # a rank's message of a step: its bitmap, then its tuples — one buffer, one transfer per peer and step
-        bm_bytes = self.words * 8
-        msg_bytes = bm_bytes + n_reads * self.TUPLE_BYTES
-
-        def message():
-            m = torch.zeros(msg_bytes, dtype=torch.uint8, device=dev)
-            return m, m[:bm_bytes].view(torch.int64), m[bm_bytes:]
-
-        self.bm_bytes = bm_bytes
+        self.bm_bytes = self.words * 8
+        msg_bytes = self.bm_bytes + n_reads * self.TUPLE_BYTES
         for _ in range(depth):
-            msg, bitmap, hits = message()
+            msg = backend.buffer(msg_bytes)
             slot = {
-                "rec": torch.empty(n_reads * 16, dtype=torch.uint8, device=dev),
+                "rec": backend.buffer(n_reads * 16),
                 "msg": msg,
-                "hits": hits,
-                "bitmap": bitmap,
-                "n": torch.zeros(1, dtype=torch.int64, device=dev),
-                "counts": [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)],
-                "counts_host": torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda),
-                "counted": None,       # event: counts_host is filled
-                "compacted": None,     # event: the compaction that read this slot's records is done
+                "n": backend.buffer(8),
+                "counts": backend.buffer(8 * world),
+                "counts_host": backend.host_counts(world),
+                "counted": backend.new_event(), "has_counts": False,      # event: counts_host is filled
+                "compacted": backend.new_event(), "has_compacted": False,  # event: the compaction that read this slot's records is done
+                "moved": backend.new_event(), "in_flight": False,          # event: the slot's last transfers are done
                 "posted": True,        # the transfers of the slot's last use have been posted
-                "work": [],
                 "step": -1,
             }
+            if not self.cuda:           # host memory: the hooks of the tests write the message through these views
+                slot["bitmap"] = msg.np[:self.bm_bytes].view(np.int64)
+                slot["hits"] = msg.np[self.bm_bytes:]
             if rank == 0:
-                peers = [(slot["msg"], slot["bitmap"], slot["hits"]) if r == 0 else message() for r in range(world)]
-                slot["g_msg"] = [p[0] for p in peers]
-                slot["g_bitmap"] = [p[1] for p in peers]
-                slot["g_hits"] = [p[2] for p in peers]
+                slot["g_msg"] = [msg if r == 0 else backend.buffer(msg_bytes) for r in range(world)]
             self.slots.append(slot)
 
-    def records(self) -> torch.Tensor:
-        """The record buffer the next scan writes (call before_scan() first)."""
+    def records(self):
+        """The record buffer the next scan writes (call before_scan() first): an object with .ptr (and .np on host memory)."""
         return self.slots[self.k % len(self.slots)]["rec"]
 
     def before_scan(self) -> None:
-        """The current stream waits until the slot's previous compaction has read its records."""
+        """The stream of the decombine calls waits until the slot's previous compaction has read its records."""
         s = self.slots[self.k % len(self.slots)]
         if self.sink:
             # the call about to be queued writes the slot's message: its last transfers must be done (they were posted a step ago)
             self._post(s)
-            for w in s["work"]:
-                w.wait()
-            s["work"] = []
-            self.nat.set_tuple_sink(self.tables, self.codec, s["msg"].data_ptr(), self.n_reads, s["n"].data_ptr())
+            if s["in_flight"]:
+                self.be.main_wait(s["moved"])
+                s["in_flight"] = False
+            self.nat.set_tuple_sink(self.tables, self.codec, s["msg"].ptr, self.n_reads, s["n"].ptr)
             return
-        ev = s["compacted"]
-        if ev is not None and self.cuda:
-            torch.cuda.current_stream().wait_event(ev)
+        if s["has_compacted"] and self.cuda:
+            self.be.main_wait(s["compacted"])
 
-    def _side(self):
-        return torch.cuda.stream(self.side) if self.cuda else _NullCtx()
+    def _sizes(self, counts):
+        return [self.bm_bytes + int(c) * self.TUPLE_BYTES for c in counts]
 
     def _post(self, s) -> None:
         """Exact-size transfers of a slot whose counts have arrived."""
         if s["posted"]:
             return
-        if s["counted"] is not None:
+        if s["has_counts"]:
             s["counted"].synchronize()       # the host waits for the counts (a few bytes, one step old)
         counts = [int(x) for x in s["counts_host"].tolist()]
         s["posted"] = True
-        with self._side():
-            if self.rank == 0:
-                # one grouped call for the receives from every peer (one launch on RCCL, not one per peer)
-                ops = [dist.P2POp(dist.irecv, s["g_msg"][r][:self.bm_bytes + counts[r] * self.TUPLE_BYTES], r) for r in range(1, self.world)]
-                if ops:
-                    s["work"].extend(dist.batch_isend_irecv(ops))
-            else:
-                s["work"].append(dist.isend(s["msg"][:self.bm_bytes + counts[self.rank] * self.TUPLE_BYTES], dst=0))
+        self.be.post(s["msg"], s.get("g_msg"), self._sizes(counts), s["moved"])
+        s["in_flight"] = True
 
     def step(self, n_reads: int) -> None:
-        """After the scan of this step has been queued on the current stream."""
-        nat = self.nat
+        """After the scan of this step has been queued on the main stream."""
+        nat, be = self.nat, self.be
         s = self.slots[self.k % len(self.slots)]
         prev = self.slots[(self.k - 1) % len(self.slots)] if self.k else None
+        be.side_wait_main()
+        self._post(s)                # (a slot is reused only when its last transfers were posted ...
+        if s["in_flight"]:
+            be.side_wait(s["moved"])     # ... and are done: on a device the side stream's own order, on host memory a wait)
+        if n_reads < self.n_reads and not self.sink:
+            be.zero(s["msg"], 0, self.bm_bytes)      # a short batch (the end of a shard): no stale bits beyond its reads
+        if self.sink:
+            pass                     # (the call has left the message and the count on its own stream: nothing to compact)
+        elif self.compact is not None:
+            self.compact(s, n_reads)
+        elif self.codec is not None:
+            nat.compact_hits_narrow_device(self.tables, self.codec, s["rec"].ptr, n_reads, s["msg"].ptr, s["n"].ptr, be.side_ptr, n_slots=self.n_reads)
+        else:
+            fn = nat.lib().dcrx_compact_hits_packed8_device if self.TUPLE_BYTES == 8 else nat.lib().dcrx_compact_hits_packed_device
+            nat.check(fn(s["rec"].ptr, n_reads, s["msg"].ptr + self.bm_bytes, s["msg"].ptr, s["n"].ptr, be.side_ptr))
         if self.cuda:
-            self.side.wait_stream(torch.cuda.current_stream())
-        with self._side():
-            self._post(s)                # (a slot is reused only when its last transfers were posted ...)
-            for w in s["work"]:          # ... and are done
-                w.wait()
-            s["work"] = []
-            if n_reads < self.n_reads and not self.sink:
-                s["bitmap"].zero_()      # a short batch (the end of a shard): no stale bits beyond its reads
-            if self.sink:
-                pass                     # (the call has left the message and the count on its own stream: nothing to compact)
-            elif self.compact is not None:
-                self.compact(s, n_reads)
-            elif self.codec is not None:
-                nat.compact_hits_narrow_device(self.tables, self.codec, s["rec"].data_ptr(), n_reads, s["msg"].data_ptr(),
-                                               s["n"].data_ptr(), self.side.cuda_stream, n_slots=self.n_reads)
-            else:
-                fn = nat.lib().dcrx_compact_hits_packed8_device if self.TUPLE_BYTES == 8 else nat.lib().dcrx_compact_hits_packed_device
-                nat.check(fn(s["rec"].data_ptr(), n_reads, s["hits"].data_ptr(), s["bitmap"].data_ptr(), s["n"].data_ptr(),
-                             self.side.cuda_stream))
-            if self.cuda:
-                s["compacted"] = self.side.record_event()
-            if self.world > 1:
-                dist.all_gather(s["counts"], s["n"])
-            else:
-                s["counts"][0].copy_(s["n"])
-            s["counts_host"].copy_(torch.cat(s["counts"]), non_blocking=True)
-            s["counted"] = self.side.record_event() if self.cuda else None
-            s["posted"] = False
-            s["step"] = self.k
+            s["compacted"].record(be.side_ptr)
+            s["has_compacted"] = True
+        be.exchange_counts(s["n"], s["counts"], s["counts_host"], s["counted"])
+        s["has_counts"] = True
+        s["posted"] = False
+        s["step"] = self.k
         self.k += 1
         if prev is not None and prev is not s:
             self._post(prev)             # the previous step's counts are one step old by now
 
     def finish(self) -> None:
-        """Posts what is still to be posted and makes the current stream wait for every transfer."""
+        """Posts what is still to be posted and makes the main stream wait for every transfer."""
         if self.sink:
             self.nat.set_tuple_sink(self.tables, None)      # (calls outside the gather's steps leave no message)
         for s in self.slots:
             self._post(s)
-        with self._side():
-            for s in self.slots:
-                for w in s["work"]:
-                    w.wait()
-                s["work"] = []
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+        self.be.main_wait_side()
+        for s in self.slots:
+            s["in_flight"] = False
 
     def gathered(self, step: int):
         """On rank 0, after finish(): the tuples of `step` (one of the last `depth` steps) as (records, read index
-        within the rank, rank) per rank, re-expanded from the 12-byte form and the bitmaps."""
-        import numpy as np
+        within the rank, rank) per rank, re-expanded from the wire form and the bitmaps."""
         s = next(x for x in self.slots if x["step"] == step)
-        if self.cuda:
-            torch.cuda.synchronize()
+        self.be.synchronize()
         counts = [int(x) for x in s["counts_host"].tolist()]
+        sizes = self._sizes(counts)
         out = []
         for r in range(self.world):
+            raw = self.be.to_host(s["g_msg"][r], sizes[r])
             if self.codec is not None:
-                rec, idx = self.codec.unpack(s["g_msg"][r][:self.bm_bytes + counts[r] * self.TUPLE_BYTES].cpu().numpy(), self.n_reads, counts[r])
+                rec, idx = self.codec.unpack(raw, self.n_reads, counts[r])
                 out.append((rec, idx, r))
                 continue
-            w = s["g_hits"][r][:counts[r] * self.TUPLE_BYTES].cpu().numpy().view(np.uint32).reshape(-1, self.TUPLE_BYTES // 4)
-            idx = bitmap_indices(s["g_bitmap"][r].cpu().numpy().view(np.uint64), self.n_reads)
+            w = raw[self.bm_bytes:].view(np.uint32).reshape(-1, self.TUPLE_BYTES // 4)
+            idx = bitmap_indices(raw[:self.bm_bytes].view(np.uint64), self.n_reads)
             rec = self.nat.unpack_tuples8(w, self.v_jumps) if self.TUPLE_BYTES == 8 else self.nat.unpack_tuples12(w)
             out.append((rec, idx, r))
         return out
@@ -297,8 +354,7 @@ class TupleGather:
     def check(self, n_hits_local: int) -> None:
         """After the run: the last step's counts and bitmaps are consistent on rank 0."""
         self.finish()
-        if self.cuda:
-            torch.cuda.synchronize()
+        self.be.synchronize()
         last = self.slots[(self.k - 1) % len(self.slots)]
         counts = [int(x) for x in last["counts_host"].tolist()]
         if counts[self.rank] != n_hits_local:
@@ -309,34 +365,24 @@ class TupleGather:
                     raise RuntimeError(f"rank {r}: {len(rec)} tuples, {len(idx)} bitmap bits, {counts[r]} announced")
 
 
-def _backend_device():
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+def decombine_sharded_step(tables, comm, codec, batch_c, d_records_ptr: int, d_counters_ptr: int, d_message_ptr: int, n_slots: int,
+                           d_gathered_ptrs=None, orientation="reverse", allow_ns=False, lenthreshold=130, stream=None):
+    """One step of a sharded run through the C entry dcrx_decombine_sharded (include/dcrx.h): the hot path on this rank's
+    shard, the counts all-gathered, the tuple messages on rank 0 in exact sizes, the counters summed — all inside the library.
+    Returns the ranks' counts of decombined reads; the transfers and the all-reduce are on `stream`, not yet waited for."""
+    from . import _native as nat
+    C = nat.C
+    cfg = nat.make_cfg(orientation, allow_ns, lenthreshold, 0)
+    counts = (C.c_uint64 * comm.world)()
+    ptrs = None
+    if comm.rank == 0 and comm.world > 1:
+        ptrs = (C.c_void_p * comm.world)(*[int(p) if p else None for p in d_gathered_ptrs])
+    nat.check(nat.lib().dcrx_decombine_sharded(tables.handle, comm.handle, C.byref(cfg), C.byref(batch_c), d_records_ptr, d_counters_ptr,
+                                               C.byref(codec.layout), d_message_ptr, int(n_slots), ptrs, counts, stream))
+    return [int(x) for x in counts]
 
 
-def gather_bytes(blob: bytes, dst: int = 0):
-    """Every rank's bytes on `dst`, in rank order (a list of bytes objects there, None elsewhere): the sizes first (one small
-    all_gather), then one padded gather of uint8 tensors — over RCCL from device memory on the GPU box, over gloo in the CPU
-    tests.  What the sharded stage sends to rank 0: the rows' text, assembled on the rank that holds the reads."""
-    import numpy as np
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = _backend_device()
-    k = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
-    ks = [torch.zeros_like(k) for _ in range(world)]
-    dist.all_gather(ks, k)
-    sizes = [int(x.item()) for x in ks]
-    kmax = max(max(sizes), 1)
-    pad = torch.zeros(kmax, dtype=torch.uint8, device=dev)
-    if len(blob):
-        pad[:len(blob)] = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
-    if rank == dst:
-        got = [torch.empty_like(pad) for _ in range(world)]
-        dist.gather(pad, got, dst=dst)
-        return [g[:n].cpu().numpy().tobytes() for g, n in zip(got, sizes)]
-    dist.gather(pad, None, dst=dst)
-    return None
-
-
-def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
+def plan_fastq_shards(comm, paths, records_per_unit: int = 1):
     """Byte ranges [(begin, end) per file] of the records this rank reads — contiguous shards in rank order, whole records, the
     files of a pair cut at the same record — or None when the files cannot be read in shards (gzipped, carriage returns, not
     whole four-line records, pairs of different length): the caller then reads unsharded.
@@ -349,6 +395,7 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
     consumes two records per iteration).  Every rank must call this (four small collectives)."""
     import os
     from . import _native as nat
+    world, rank = comm.world, comm.rank
     if any(str(p).endswith(".gz") for p in paths):
         return None
     # (whatever goes wrong on one rank — a file it cannot open — is part of what is exchanged: no rank leaves before the
@@ -368,8 +415,7 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
             mine.append((n, cr, last_nl, size))
     except Exception:
         mine = "ERR"
-    every = [None] * world
-    dist.all_gather_object(every, mine)
+    every = comm.allgather_object(mine)
     if any(x == "ERR" for x in every):
         return None
     counts = [[every[r][f][0] for r in range(world)] for f in range(len(paths))]
@@ -409,8 +455,7 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
                 except Exception:
                     off = None
                 found[(f, r)] = off
-    allfound = [None] * world
-    dist.all_gather_object(allfound, found)
+    allfound = comm.allgather_object(found)
     cuts = {}
     for d in allfound:
         cuts.update(d)
@@ -438,80 +483,59 @@ def plan_fastq_shards(paths, world: int, rank: int, records_per_unit: int = 1):
                         pass
         except Exception:
             ok = False
-    oks = [None] * world
-    dist.all_gather_object(oks, ok)
+    oks = comm.allgather_object(ok)
     return out if all(oks) else None
 
 
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-
-def decombinator_sharded(inputargs: dict, device_index: int | None = None):
-    """The decombine stage over all ranks of the initialised process group (one process per GPU): the multi-GPU form
-    of decombinator_amd.decombine.decombinator().
+def decombinator_sharded(inputargs: dict, comm, device_index: int | None = None):
+    """The decombine stage over all ranks of `comm` (one process per GPU; a communicator as the module's head describes:
+    _native.Comm over RCCL): the multi-GPU form of decombinator_amd.decombine.decombinator().
 
     The input is read in shards: rank r reads the records of its contiguous share of the FASTQ bytes and nothing else of the
     files (plan_fastq_shards: plain four-line files; the R1 / R2 files of a pair are cut at the same record), decombines them
-    on its own GPU and assembles their rows; the rows' bytes are gathered on rank 0 (gather_bytes: one padded gather, RCCL on
-    the GPU box) and concatenated in rank order — contiguous shards, so that this is the input order the reference's
-    outdata.append keeps (decombine.py:1039); the counters are summed over the ranks before rank 0 prints the totals and
-    writes the summary log.  Files that cannot be cut (gzipped, multi-line records, carriage returns) are read whole by
-    every rank, batches dealt round-robin, as before.  Returns the rows (an N12Rows, as decombinator() does) on rank 0 and
-    None on the other ranks.  No data-path collective: the gather of the rows at the end and one all-reduce of 64 integers."""
-    import numpy as np
-
+    on its own GPU and assembles their rows; the rows' bytes are gathered on rank 0 (gather_bytes) and concatenated in rank
+    order — contiguous shards, so that this is the input order the reference's outdata.append keeps (decombine.py:1039); the
+    counters are summed over the ranks before rank 0 prints the totals and writes the summary log.  Files that cannot be cut
+    (gzipped, multi-line records, carriage returns) are read whole by every rank, batches dealt round-robin, as before.
+    Returns the rows (an N12Rows, as decombinator() does) on rank 0 and None on the other ranks.  No data-path collective:
+    the gather of the rows at the end and one all-reduce of 64 integers."""
     from decombinator_amd import _native as nat
     from decombinator_amd import decombine as dec
 
-    if not dist.is_initialized():
-        raise RuntimeError("decombinator_sharded needs an initialised torch.distributed process group")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    if comm is None:
+        raise RuntimeError("decombinator_sharded needs a communicator (decombinator_amd._native.comm_from_env())")
+    rank, world = comm.rank, comm.world
     if device_index is not None:
         nat.check(nat.lib().dcrx_set_device(int(device_index)))
-
-    keys_holder = {}
 
     def reduce_counts(counts):
         # the Counter's keys differ between ranks (a key appears with its first increment): agree on the union first
         mine = sorted(k for k in counts if k not in ("start_time", "end_time"))
-        every = [None] * world
-        dist.all_gather_object(every, mine)
+        every = comm.allgather_object(mine)
         keys = sorted(set(k for ks in every for k in ks))
-        keys_holder["keys"] = keys
-        t = torch.tensor([int(counts.get(k, 0)) for k in keys], dtype=torch.int64)
-        if t.numel():
-            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-            t = t.to(dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            for k, v in zip(keys, t.cpu().tolist()):
+        if keys:
+            sums = comm.allreduce_host_u64(np.array([int(counts.get(k, 0)) for k in keys], dtype=np.uint64))
+            for k, v in zip(keys, sums.tolist()):
                 counts[k] = int(v)
 
     def exchange_error(err):
         # every rank reports whether its part raised; if any did, every rank raises here, before the first collective of
-        # the results (a rank that stopped alone would leave the others waiting in all_gather_object for ever)
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
-        if int(flag.item()) == 0:
+        # the results (a rank that stopped alone would leave the others waiting for ever)
+        flag = comm.allreduce_host_u64(np.array([1 if err is not None else 0], dtype=np.uint64))
+        if int(flag[0]) == 0:
             return
-        said = [None] * world
-        dist.all_gather_object(said, None if err is None else f"{type(err).__name__}: {err}")
+        said = comm.allgather_object(None if err is None else f"{type(err).__name__}: {err}")
         if err is not None:
             raise err
         raise RuntimeError("decombinator_sharded: " + "; ".join(f"rank {r}: {m}" for r, m in enumerate(said) if m))
 
     rows = dec.decombinator(inputargs, shard=(rank, world), reduce_counts=reduce_counts, exchange_error=exchange_error,
-                            plan_shards=plan_fastq_shards)
+                            plan_shards=lambda paths, w, r, unit: plan_fastq_shards(comm, paths, unit))
     chunks = rows._tagged_chunks()
     # a rank's message: per chunk (tag, rows, bytes) — three int64 — then the chunks' text
     head = np.array([[t, n, len(b)] for t, b, n in chunks], dtype=np.int64).reshape(-1, 3)
     msg = np.int64(len(chunks)).tobytes() + head.tobytes() + b"".join(b for _, b, _ in chunks)
-    parts = gather_bytes(msg, dst=0)
+    parts = gather_bytes(comm, msg, dst=0)
     if rank != 0:
         return None
     tagged = []

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DCRX_ABI_VERSION 3
+#define DCRX_ABI_VERSION 4
 
 enum dcrx_error {
   DCRX_OK = 0,
@@ -249,7 +249,10 @@ int dcrx_decombine(dcrx_tables_t *tables, const dcrx_cfg_t *cfg, const dcrx_batc
  * d_records and d_counters (DCRX_N_COUNTERS uint64, overwritten) are device
  * memory.  No allocation and no synchronisation happens inside once the tables
  * have been used on this device with a batch at least this large
- * (dcrx_reserve_device does that up front). */
+ * (dcrx_reserve_device does that up front) — with ONE exception, and only where the caller has asked for it
+ * (dcrx_set_tune_wait, below): the fourth call of a size class of 2^25 reads and more may then wait for the third
+ * call's finishing launch, once per class.  Without that call nothing in here ever waits for the device, so the
+ * stream may be captured or run arbitrarily far ahead of the host. */
 int dcrx_decombine_device(dcrx_tables_t *tables, const dcrx_cfg_t *cfg,
                           const dcrx_batch_t *device_batch, dcrx_record_t *d_records,
                           uint64_t *d_counters, void *hip_stream);
@@ -470,8 +473,9 @@ int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *genes, uint64_t n, const int32_
  * 4096 from there (`candidates`: the first setting | the second << 16).  rescue_waves = the choice once settled, 0 before (a
  * launch then runs on the first setting or is one of the two samples); launches = calls seen in the class; us_first / us_second =
  * what the samples took (0 before).  The samples are read without waiting, so a caller that queues launches ahead of the device
- * keeps the first setting until they are complete — except for batches of 2^25 reads and more, where the fourth call of a class
- * waits for the third's finishing launch once (milliseconds; such batches gain up to 6 % from the choice).
+ * keeps the first setting until they are complete — except, where the caller has allowed it with dcrx_set_tune_wait(tables, 1),
+ * for batches of 2^25 reads and more: the fourth call of such a class then waits for the third's finishing launch, once
+ * (milliseconds; such batches gain up to 6 % from the choice).  The default is never to wait.
  * orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose launches are meant).
  * DCRX_E_INVALID for a null argument. */
 typedef struct dcrx_tune_state {
@@ -483,10 +487,59 @@ typedef struct dcrx_tune_state {
   uint32_t candidates;
 } dcrx_tune_state_t;
 int dcrx_tune_state(const dcrx_tables_t *tables, int orientation, uint64_t n_reads, dcrx_tune_state_t *out);
+/* allow != 0: dcrx_decombine_device may wait once per big-batch size class as described above (0, the default: never). */
+int dcrx_set_tune_wait(dcrx_tables_t *tables, int allow);
 
 /* The persistent kernels of dcrx_decombine_device normally fill every compute unit; n_cus of
  * them are left free from the next call on (for a collective running on another stream). */
 int dcrx_set_reserved_cus(dcrx_tables_t *tables, uint32_t n_cus);
+
+/* ---- multi-GPU: RCCL over xGMI, bound directly (SURVEY.md 8(b) dcrx_decombine_sharded, 8(e)) -----------------------
+ * The reference has no counterpart (one process, one Counter: decombine.py:598, README.md:370-376 "submit many jobs").
+ * Reads are sharded over the ranks in contiguous ranges (rank r of W owns reads [r N / W, (r + 1) N / W): concatenating the
+ * ranks' outputs in rank order is the reference's input order, outdata.append :1039), every rank runs the hot path on its own
+ * GPU, and ONE exchange follows: the ranks' counts of decombined reads (all-gather), their tuple messages — the
+ * dcrx_set_tuple_sink message: a bitmap of the shard's reads and the narrow tuples of the decombined ones — to rank 0 in
+ * exact sizes (grouped send / receive), the uint64[DCRX_N_COUNTERS] summed over the ranks (all-reduce).
+ * librccl is opened on the first call of this section (by soname: a process that already holds an RCCL shares it); a caller
+ * that never comes here never loads it.  DCRX_E_UNSUPPORTED when it cannot be opened.
+ *
+ * A communicator: one process per GPU — rank 0 draws an id (dcrx_comm_unique_id), carries its DCRX_COMM_ID_BYTES bytes to the
+ * other ranks by whatever means it has (a file, a socket, an environment variable of the launcher), and every rank calls
+ * dcrx_comm_create on its own device (dcrx_set_device first) — or one process for all GPUs: dcrx_comm_create_all fills
+ * out[0 .. world) (ncclCommInitAll; devices == NULL: 0 .. world - 1). */
+#define DCRX_COMM_ID_BYTES 128
+enum dcrx_comm_op { DCRX_COMM_SUM = 0, DCRX_COMM_MAX = 1 };
+typedef struct dcrx_comm dcrx_comm_t;
+int dcrx_comm_available(void);                        /* 1 when librccl could be opened */
+int dcrx_comm_unique_id(uint8_t *id /* DCRX_COMM_ID_BYTES */);
+int dcrx_comm_create(const uint8_t *id, int world, int rank, dcrx_comm_t **out);
+int dcrx_comm_create_all(int world, const int *devices, dcrx_comm_t **out /* [world] */);
+void dcrx_comm_destroy(dcrx_comm_t *comm);
+int dcrx_comm_info(const dcrx_comm_t *comm, int *world, int *rank, int *device);
+/* The pieces, asynchronous on `hip_stream`, device memory throughout — for a caller that pipelines steps (bench.py:
+ * the transfers of step k beside the scan of step k + 1).  gather_v: every rank but `root` sends send_bytes from d_send;
+ * the root receives recv_bytes[r] into d_recv[r] from every r != root, all in one group (its own message stays where it
+ * is; d_recv and recv_bytes are read on the root only). */
+int dcrx_comm_allreduce_u64(dcrx_comm_t *comm, const uint64_t *d_in, uint64_t *d_out, uint64_t n, int op, void *hip_stream);
+int dcrx_comm_allreduce_f64(dcrx_comm_t *comm, const double *d_in, double *d_out, uint64_t n, int op, void *hip_stream);
+int dcrx_comm_allgather(dcrx_comm_t *comm, const void *d_in, void *d_out /* world x bytes_per_rank */, uint64_t bytes_per_rank, void *hip_stream);
+int dcrx_comm_gather_v(dcrx_comm_t *comm, const void *d_send, uint64_t send_bytes, void *const *d_recv, const uint64_t *recv_bytes,
+                       int root, void *hip_stream);
+int dcrx_comm_barrier(dcrx_comm_t *comm, void *hip_stream);      /* an all-reduce of one word, then the stream is waited for */
+/* Host memory in and out, synchronous (staged through device memory): sizes, error flags, a Counter's keys. */
+int dcrx_comm_allgather_host(dcrx_comm_t *comm, const void *h_in, void *h_out /* world x bytes_per_rank */, uint64_t bytes_per_rank);
+int dcrx_comm_allreduce_host_u64(dcrx_comm_t *comm, uint64_t *h_inout, uint64_t n, int op);
+/* One step of a sharded run in one call, on every rank: dcrx_decombine_device on this rank's shard (device memory, as
+ * there) with the tuple sink on d_message (room for dcrx_tuple_message_bytes(layout, n_slots, n_slots); n_slots >= the
+ * shard's reads); then the exchange above.  On return the stream holds — not yet waited for — the transfers and the
+ * all-reduce: d_counters will be the JOB's counters on every rank, and on rank 0 d_gathered[r] rank r's message for r > 0
+ * (d_gathered[0] is not touched: rank 0's own message is d_message; d_gathered is read on rank 0 only).  n_hits_by_rank
+ * (host, [world]) is filled before the call returns: the one wait inside (the counts decide the transfers' sizes).
+ * Unpacking a message: bitmap of n_slots bits, then the tuples in read order (dcrx_tuple_layout_t above). */
+int dcrx_decombine_sharded(dcrx_tables_t *tables, dcrx_comm_t *comm, const dcrx_cfg_t *cfg, const dcrx_batch_t *device_shard,
+                           dcrx_record_t *d_records, uint64_t *d_counters, const dcrx_tuple_layout_t *layout, void *d_message,
+                           uint64_t n_slots, void *const *d_gathered, uint64_t *n_hits_by_rank, void *hip_stream);
 
 /* ---- device plumbing for callers without a HIP binding of their own ---- */
 int dcrx_device_count(void);
@@ -507,6 +560,16 @@ int dcrx_event_create(void **event);
 int dcrx_event_destroy(void *event);
 int dcrx_event_record(void *event, void *hip_stream);
 int dcrx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+int dcrx_event_synchronize(void *event);
+int dcrx_event_create_ordering(void **event);      /* an event without timestamps (hipEventDisableTiming): for ordering streams, cheaper to record */
+/* streams of the caller's own, and copies on them (a sharded caller's side stream for the exchange) */
+int dcrx_stream_create(void **hip_stream);
+int dcrx_stream_destroy(void *hip_stream);
+int dcrx_stream_synchronize(void *hip_stream);
+int dcrx_stream_wait_event(void *hip_stream, void *event);
+int dcrx_memcpy_d2h_async(void *dst_host, const void *src_device, size_t bytes, void *hip_stream);
+int dcrx_memcpy_d2d_async(void *dst_device, const void *src_device, size_t bytes, void *hip_stream);
+int dcrx_memset_device_async(void *dst_device, int value, size_t bytes, void *hip_stream);
 
 int dcrx_abi_version(void);
 const char *dcrx_last_error(void);

@@ -20,7 +20,17 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(bench.spawn_ranks(args, argv, script=os.path.abspath(__file__)))
     from tests import dry_device
-    bench.run_rank(args, device_factory=dry_device.DryDevice)
+
+    def comm_factory(use_dist):      # gloo on host memory in place of RCCL on device memory (tests/gloo_backend.py)
+        if not use_dist:
+            return None, None
+        import torch.distributed as dist
+        from tests.gloo_backend import GlooBackend, GlooComm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")))
+        comm = GlooComm()
+        return comm, GlooBackend(comm)
+    bench.run_rank(args, device_factory=dry_device.DryDevice, comm_factory=comm_factory)
 
 
 if __name__ == "__main__":

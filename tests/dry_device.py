@@ -4,7 +4,6 @@ device would.  Nothing here is a measurement; the line is marked "dry_run": true
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 from decombinator_amd import sharded
 from oracle import oracle as orc
@@ -39,14 +38,14 @@ class DryDevice:
 
     def compact(self, slot, n_reads):          # stands in for dcrx_compact_hits_packed_device (same layout, made on the host)
         nat = self.nat
-        rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
+        rec = np.frombuffer(slot["rec"].np.tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
         # (the bench gathers narrow tuples: TupleGather(tables=...); one message of bitmap | low words | high bytes)
         if self.codec is None:
             self.codec = nat.TupleCodec(self.all_tables[-1], 150)
         m = self.codec.pack(rec, n_slots=self.n)
-        slot["bitmap"].zero_()
-        slot["msg"][:len(m)] = torch.from_numpy(m.copy())
-        slot["n"][0] = int((rec["status"] == 0).sum())
+        slot["bitmap"][:] = 0
+        slot["msg"].np[:len(m)] = m
+        slot["n"].np.view(np.int64)[0] = int((rec["status"] == 0).sum())
 
     def name(self):
         return "dry (oracle on the CPU)"
@@ -75,8 +74,8 @@ class DryDevice:
         if gather is not None:
             gather.before_scan()
             buf = gather.records()
-            raw = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
-            buf[:raw.numel()] = raw
+            raw = rec.view(np.uint8).reshape(-1)
+            buf.np[:raw.size] = raw
             gather.step(len(rec))
 
     def event_times(self, events, timed):

@@ -91,7 +91,7 @@ static int v2_one(const DevTables &T, const BatchDev &B, const CfgDev &C, uint64
   const int npairs = UNIFORM ? (int)((B.read_len + 1u) >> 1) : 8 * (int)(nw < (uint32_t)NW ? nw : (uint32_t)NW);
   if (V.narrow) scan2<NW, 1, true>(tab, w, lg, npairs); else scan2<NW, 1, false>(tab, w, lg, npairs);
   if (!UNIFORM) mask_log2<NW>(lg[0], n);
-  const Digest2 d = digest2_lean<NW>(lg[0]);      // (the scan kernel's digest; the fields anyone reads must be digest2's)
+  const Digest2 d = digest2_scan<NW>(lg[0]);      // (the scan kernel's digest; the fields anyone reads must be digest2's)
   {
     const Digest2 d0 = digest2<NW>(lg[0]);
     if (d.any != d0.any || d.vf_n != d0.vf_n || d.jf_n != d0.jf_n || (d0.vf_n == 1 && d.vf_pair != d0.vf_pair) ||

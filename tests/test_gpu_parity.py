@@ -375,27 +375,22 @@ def test_config4_one_rank_shard_of_the_billion_reads():
 
 RCCL_GATHER_WORKER = '''
 import os, sys
-import torch                      # first: its bundled HIP runtime must be the one libdcrx binds to
-import torch.distributed as dist
 import numpy as np
 sys.path.insert(0, os.environ["DCRX_ROOT"])
 from decombinator_amd import _native as nat, sharded, synth
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
-torch.cuda.set_device(0)
+assert "torch" not in sys.modules      # RCCL through libdcrx's own binding: nothing else in this process
 nat.check(nat.lib().dcrx_set_device(0))
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+comm = nat.Comm(nat.Comm.unique_id(), 1, 0)      # one rank, through RCCL proper (ncclCommInitRank, ncclAllGather of the counts)
 n = 400_000
 ts = synth.config_tagset(2)
 t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
-dev = torch.device("cuda", 0)
 mode = os.environ.get("DCRX_TUPLE8")
-g = sharded.TupleGather(n, 1, 0, dev, v_jumps=ts.v_jumps if mode == "1" else None, tables=t if mode in ("narrow", "sink") else None,
-                        max_read_len=150, use_sink=mode == "sink")
+stream = nat.Stream()
+g = sharded.TupleGather(n, sharded.RcclBackend(nat, comm, stream.ptr), v_jumps=ts.v_jumps if mode == "1" else None,
+                        tables=t if mode in ("narrow", "sink") else None, max_read_len=150, use_sink=mode == "sink")
 assert g.TUPLE_BYTES == {"0": 12, "1": 8, "narrow": 5, "sink": 5}[mode] and g.sink == (mode == "sink")
-stream = torch.cuda.current_stream()
-d_cnt = torch.zeros(nat.N_COUNTERS, dtype=torch.int64, device=dev)
+d_cnt = nat.DeviceBuffer(nat.N_COUNTERS * 8)
 cfg = nat.make_cfg("reverse", False, 130, 0)
 want = []
 for step in range(5):
@@ -404,11 +399,10 @@ for step in range(5):
     g.before_scan()
     rec = g.records()
     b = db.as_c()
-    nat.check(nat.lib().dcrx_decombine_device(t.handle, nat.C.byref(cfg), nat.C.byref(b), rec.data_ptr(),
-                                              d_cnt.data_ptr(), stream.cuda_stream))
+    nat.check(nat.lib().dcrx_decombine_device(t.handle, nat.C.byref(cfg), nat.C.byref(b), rec.ptr, d_cnt.ptr, stream.ptr))
     g.step(n)
-    torch.cuda.synchronize()      # the same records through the host, for comparison
-    r = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=nat.RECORD_DTYPE)
+    nat.synchronize()      # the same records through the host, for comparison
+    r = rec.to_host(nat.RECORD_DTYPE, n)
     ok = np.nonzero(r["status"] == 0)[0]
     want.append((r[ok].copy(), ok))
     if step >= 1:
@@ -421,17 +415,76 @@ g.finish()
 assert grec.tobytes() == want[4][0].tobytes() and (gidx == want[4][1]).all()
 g.check(len(want[4][0]))
 assert len(want[1][0]) > 0.8 * n and len(want[2][0]) < 0.05 * n       # far above and far below any fixed fraction
+# the host-side exchanges of the sharded stage, one rank
+assert comm.allgather_object({"rank": 0}) == [{"rank": 0}]
+assert comm.gather_bytes(b"rows of rank 0") == [b"rows of rank 0"]
+assert list(comm.allreduce_host_u64([3, 4])) == [3, 4]
+comm.barrier(stream.ptr)
 print("RCCL_GATHER_OK", [len(w[0]) for w in want])
-dist.destroy_process_group()
+comm.close()
 '''
+
+
+SHARDED_ENTRY_WORKER = '''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["DCRX_ROOT"])
+from decombinator_amd import _native as nat, sharded, synth
+
+assert "torch" not in sys.modules
+nat.check(nat.lib().dcrx_set_device(0))
+comm = nat.Comm(nat.Comm.unique_id(), 1, 0)
+n = 300_000
+ts = synth.config_tagset(2)
+t = nat.Tables(ts.v_tags, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, *ts.half_splits)
+codec = nat.TupleCodec(t, 150)
+stream = nat.Stream()
+d_rec, d_cnt = nat.DeviceBuffer(n * 16), nat.DeviceBuffer(nat.N_COUNTERS * 8)
+d_msg = nat.DeviceBuffer(codec.message_bytes(n, n))
+for step in range(3):
+    db = nat.synth_reads_device(t, nat.synth_cfg(seed=70 + step, p_rearranged=[0.45, 0.9, 0.05][step]), step * n, n)
+    b = db.as_c()
+    counts = sharded.decombine_sharded_step(t, comm, codec, b, d_rec.ptr, d_cnt.ptr, d_msg.ptr, n, stream=stream.ptr)
+    stream.synchronize()
+    rec = d_rec.to_host(nat.RECORD_DTYPE, n)
+    cnt = d_cnt.to_host(np.uint64, nat.N_COUNTERS)
+    ok = np.nonzero(rec["status"] == 0)[0]
+    assert counts == [len(ok)], (counts, len(ok))
+    assert int(cnt[nat.COUNTER_NAMES.index("vj_count")]) == len(ok) and int(cnt[nat.COUNTER_NAMES.index("read_count")]) == n
+    grec, gidx = codec.unpack(d_msg.to_host(np.uint8, codec.message_bytes(n, len(ok))), n, len(ok))
+    assert (gidx == ok).all() and grec.tobytes() == rec[ok].tobytes(), f"step {step}"
+    # the same call without the exchange: the same records and counters
+    d_rec2, d_cnt2 = nat.DeviceBuffer(n * 16), nat.DeviceBuffer(nat.N_COUNTERS * 8)
+    nat.decombine_device(t, db, d_rec2, d_cnt2, stream=stream.ptr)
+    stream.synchronize()
+    assert d_rec2.to_host(nat.RECORD_DTYPE, n).tobytes() == rec.tobytes() and (d_cnt2.to_host(np.uint64, nat.N_COUNTERS) == cnt).all()
+print("SHARDED_ENTRY_OK")
+comm.close()
+'''
+
+
+def test_c_entry_decombine_sharded_on_one_rank(tmp_path):
+    """dcrx_decombine_sharded (include/dcrx.h: the hot path, the all-gather of the counts, the exact-size gather of the tuple
+    messages and the all-reduce of the counters inside ONE call of the library, RCCL bound by the library itself) as the only
+    rank of a communicator on this GPU: the message equals the decombined records tuple for tuple, the counts and the counters
+    those of the plain call.  More ranks run the same protocol over gloo in tests/test_sharded_gloo.py (the oracle as device)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "entry_worker.py"
+    script.write_text(SHARDED_ENTRY_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, DCRX_ROOT=root), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "SHARDED_ENTRY_OK" in out.stdout, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("tuple8", ["0", "1", "narrow", "sink"], ids=["12-byte-tuples", "8-byte-tuples", "narrow-tuples-compacted", "narrow-tuples-sink"])
 def test_rccl_tuple_gather_single_rank_tuple_for_tuple(tmp_path, tuple8):
     """The gather bench.py runs (TupleGather: side stream, alternating slots, count exchange over RCCL, exact-size
     transfers) with one rank on this GPU, five steps with different reads: what rank 0 holds for every step equals the
-    decombined records of that step, tuple for tuple and bit for bit of the bitmap.  In a child process: torch has to
-    be imported before libdcrx there."""
+    decombined records of that step, tuple for tuple and bit for bit of the bitmap.  In a child process of its own (a
+    communicator, streams): RCCL through the binding of libdcrx, no torch in that process."""
     import os
     import subprocess
     import sys
@@ -560,21 +613,19 @@ def test_rescue_forms_on_both_strands(chain, flags):
 
 SHARDED_STAGE_WORKER = '''
 import json, os, sys
-import torch                      # first: its bundled HIP runtime must be the one libdcrx binds to
-import torch.distributed as dist
 sys.path.insert(0, os.environ["DCRX_ROOT"])
-from decombinator_amd import sharded, decombine as dec
+from decombinator_amd import sharded, decombine as dec, _native as nat
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29547")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert "torch" not in sys.modules
+os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_PORT="29547")
+nat.check(nat.lib().dcrx_set_device(0))
+comm = nat.comm_from_env()            # (the id through the node's temporary directory, as a launcher's ranks find it)
 dec.BATCH_READS = 9
 args = json.load(open(os.path.join(os.environ["DCRX_WORK"], "args.json")))
-rows = sharded.decombinator_sharded(args, device_index=0)
+rows = sharded.decombinator_sharded(args, comm, device_index=0)
 json.dump([list(r) for r in rows], open(os.path.join(os.environ["DCRX_WORK"], "rows.json"), "w"))
 print("SHARDED_STAGE_OK", len(rows))
-dist.destroy_process_group()
+comm.close()
 '''
 
 

@@ -21,9 +21,11 @@ WORKER = textwrap.dedent('''
     from decombinator_amd import sharded, synth, _native as nat
     from oracle import oracle as orc
     from tests import parity_util as pu
+    from tests.gloo_backend import GlooComm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = GlooComm()
     N = 6001
     ts = synth.config_tagset(2)
     vs, js = ts.half_splits
@@ -34,17 +36,17 @@ WORKER = textwrap.dedent('''
     hb = nat.synth_reads_host(t, nat.synth_cfg(seed=4), lo, hi - lo)   # any shard from (seed, index)
     rec, cnt = pu.oracle_records(ot, nat.unpack_reads(hb), "reverse", False, 130)
     ok = np.nonzero(rec["status"] == 0)[0]
-    hits = torch.from_numpy(rec[ok].view(np.uint8).reshape(-1, 16).copy())
-    index = torch.from_numpy((ok + lo).astype(np.int64))
-    gh, gi = sharded.gather_exact(hits, index, dst=0)
-    total = sharded.reduce_counters(torch.from_numpy(cnt.astype(np.int64)))
+    hits = rec[ok].view(np.uint8).reshape(-1, 16).copy()
+    index = (ok + lo).astype(np.int64)
+    gh, gi = sharded.gather_exact(comm, hits, index, dst=0)
+    total = sharded.reduce_counters(comm, cnt)
     if rank == 0:
         whole = nat.synth_reads_host(t, nat.synth_cfg(seed=4), 0, N)
         wrec, wcnt = pu.oracle_records(ot, nat.unpack_reads(whole), "reverse", False, 130)
         wok = np.nonzero(wrec["status"] == 0)[0]
-        assert gh.numpy().tobytes() == wrec[wok].tobytes(), "tuples differ from the unsharded run"
-        assert (gi.numpy() == wok).all(), "indices differ"
-        assert (total.numpy().astype(np.uint64) == wcnt).all(), "counters differ"
+        assert gh.tobytes() == wrec[wok].tobytes(), "tuples differ from the unsharded run"
+        assert (gi == wok).all(), "indices differ"
+        assert (total == wcnt).all(), "counters differ"
         print("SHARDED_OK", len(wok))
     else:
         assert gh is None and gi is None
@@ -80,6 +82,7 @@ GATHER_WORKER = textwrap.dedent('''
     from decombinator_amd import sharded, synth, _native as nat
     from oracle import oracle as orc
     from tests import parity_util as pu
+    from tests.gloo_backend import GlooComm, GlooBackend
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -115,27 +118,27 @@ GATHER_WORKER = textwrap.dedent('''
         return rec
 
     def compact(slot, n_reads):       # stands in for dcrx_compact_hits_packed_device: same layout, made on the host
-        rec = np.frombuffer(slot["rec"].numpy().tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
+        rec = np.frombuffer(slot["rec"].np.tobytes(), dtype=nat.RECORD_DTYPE)[:n_reads]
         if os.environ.get("DCRX_TUPLE8") == "narrow":      # dcrx_compact_hits_narrow_device: one message, bitmap | low words | high bytes
             m = g.codec.pack(rec, n_slots=N)
-            slot["msg"][:len(m)] = torch.from_numpy(m.copy())
-            slot["n"][0] = int((rec["status"] == 0).sum())
+            slot["msg"].np[:len(m)] = m
+            slot["n"].np.view(np.int64)[0] = int((rec["status"] == 0).sum())
             return
         w, bm = (sharded.pack_tuples8 if os.environ.get("DCRX_TUPLE8") == "1" else sharded.pack_tuples12)(rec)
-        slot["hits"][:w.size * 4] = torch.from_numpy(w.reshape(-1).view(np.uint8).copy())
-        slot["bitmap"].zero_()
-        slot["bitmap"][:len(bm)] = torch.from_numpy(bm.view(np.int64).copy())
-        slot["n"][0] = len(w)
+        slot["hits"][:w.size * 4] = w.reshape(-1).view(np.uint8)
+        slot["bitmap"][:] = 0
+        slot["bitmap"][:len(bm)] = bm.view(np.int64)
+        slot["n"].np.view(np.int64)[0] = len(w)
 
-    g = sharded.TupleGather(N, world, rank, None, depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None,
+    g = sharded.TupleGather(N, GlooBackend(GlooComm()), depth=2, compact=compact, v_jumps=ts.v_jumps if os.environ.get("DCRX_TUPLE8") == "1" else None,
                             tables=t if os.environ.get("DCRX_TUPLE8") == "narrow" else None, max_read_len=150)
     assert g.TUPLE_BYTES == {"0": 12, "1": 8, "narrow": 5}[os.environ.get("DCRX_TUPLE8")]
     checked = 0
     for step in range(STEPS):
         g.before_scan()
         rec = shard_records(step, rank)
-        raw = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
-        g.records()[:raw.numel()] = raw                                              # "the scan wrote the records"
+        raw = rec.view(np.uint8).reshape(-1)
+        g.records().np[:raw.size] = raw                                              # "the scan wrote the records"
         g.step(len(rec))
         if step >= 1 and rank == 0:
             # the previous step is complete on rank 0 once its transfers are waited for: compare it in full
@@ -202,14 +205,15 @@ def test_shard_range_covers_everything():
 STAGE_WORKER = textwrap.dedent('''
     import json, os, sys
     import numpy as np
-    import torch
     import torch.distributed as dist
     sys.path.insert(0, os.environ["DCRX_ROOT"])
     from decombinator_amd import sharded, decombine as dec, io as dio, _native as nat
     from tests import golden_util as gu, parity_util as pu
+    from tests.gloo_backend import GlooComm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = GlooComm()
     work = os.environ["DCRX_WORK"]
     stage = json.load(open(os.path.join(os.environ["DCRX_ROOT"], "tests", "golden", "stage_human_extended_b.json")))
     ot = gu.oracle_tables(stage["tagset"])
@@ -219,9 +223,8 @@ STAGE_WORKER = textwrap.dedent('''
     nat.decombine = oracle_device
     dec.BATCH_READS = 7                       # many small batches: every rank gets several, the last one is short
     args = json.load(open(os.path.join(work, "args.json")))
-    rows = sharded.decombinator_sharded(args)
-    info = [None] * world
-    dist.all_gather_object(info, dict(dec.stage_info))
+    rows = sharded.decombinator_sharded(args, comm)
+    info = comm.allgather_object(dict(dec.stage_info))
     if rank == 0:
         json.dump({"rows": [list(r) for r in rows], "counts": {k: int(v) for k, v in dec.counts.items() if k not in ("start_time", "end_time")},
                    "info": info}, open(os.path.join(work, "sharded.json"), "w"))
@@ -341,9 +344,11 @@ FAIL_WORKER = textwrap.dedent('''
     sys.path.insert(0, os.environ["DCRX_ROOT"])
     from decombinator_amd import sharded, decombine as dec, _native as nat
     from tests import golden_util as gu, parity_util as pu
+    from tests.gloo_backend import GlooComm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = GlooComm()
     work = os.environ["DCRX_WORK"]
     stage = json.load(open(os.path.join(os.environ["DCRX_ROOT"], "tests", "golden", "stage_human_extended_b.json")))
     ot = gu.oracle_tables(stage["tagset"])
@@ -358,7 +363,7 @@ FAIL_WORKER = textwrap.dedent('''
     dec.BATCH_READS = 7
     args = json.load(open(os.path.join(work, "args.json")))
     try:
-        sharded.decombinator_sharded(args)
+        sharded.decombinator_sharded(args, comm)
     except ValueError as e:
         assert rank == 1, e
         print("RAISED_OWN", e)
@@ -414,9 +419,10 @@ def test_tuple_gather_refuses_tables_the_8_byte_tuple_cannot_hold():
     """the 8-byte tuple masks v to 11 and j to 9 bits — a larger tag set travels as 12-byte tuples, and a jump table
     that does not match the V tags is an error."""
     from decombinator_amd import sharded
-    g = sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 60, n_v=60, n_j=13)
+    from tests.gloo_backend import GlooBackend
+    g = sharded.TupleGather(64, GlooBackend(), v_jumps=[40] * 60, n_v=60, n_j=13)
     assert g.TUPLE_BYTES == 8
-    assert sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 2048).TUPLE_BYTES == 12
-    assert sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 60, n_v=60, n_j=512).TUPLE_BYTES == 12
+    assert sharded.TupleGather(64, GlooBackend(), v_jumps=[40] * 2048).TUPLE_BYTES == 12
+    assert sharded.TupleGather(64, GlooBackend(), v_jumps=[40] * 60, n_v=60, n_j=512).TUPLE_BYTES == 12
     with pytest.raises(ValueError):
-        sharded.TupleGather(64, 1, 0, None, v_jumps=[40] * 59, n_v=60, n_j=13)
+        sharded.TupleGather(64, GlooBackend(), v_jumps=[40] * 59, n_v=60, n_j=13)
