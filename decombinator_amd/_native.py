@@ -8,6 +8,7 @@ when no GPU is present.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -991,6 +992,23 @@ COMM_ID_BYTES = 128
 COMM_SUM, COMM_MAX = 0, 1
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL greets on the C library's stdout when a communicator is made (version, host, library path): a process whose stdout
+    is a result — bench.py prints ONE JSON line there — sends that to stderr instead (the descriptor itself, around the call)."""
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class Comm:
     """An RCCL communicator through the C ABI: one process per GPU (`Comm(uid, world, rank)` after dcrx_set_device), the id drawn
     by rank 0 (`Comm.unique_id()`) and carried to the others by the caller — `comm_from_env()` does that for ranks started on one
@@ -1000,7 +1018,9 @@ class Comm:
         assert len(uid) == COMM_ID_BYTES
         self._uid = np.frombuffer(uid, dtype=np.uint8).copy()
         h = C.c_void_p()
-        check(lib().dcrx_comm_create(self._uid.ctypes.data, int(world), int(rank), C.byref(h)))
+        with _c_stdout_to_stderr():
+            rc = lib().dcrx_comm_create(self._uid.ctypes.data, int(world), int(rank), C.byref(h))
+        check(rc)
         self.handle, self.world, self.rank = h.value, int(world), int(rank)
 
     @staticmethod
@@ -1080,7 +1100,8 @@ class Comm:
 
     def close(self):
         if getattr(self, "handle", None):
-            lib().dcrx_comm_destroy(self.handle)
+            with _c_stdout_to_stderr():
+                lib().dcrx_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

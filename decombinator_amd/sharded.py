@@ -295,6 +295,13 @@ class TupleGather:
         nat, be = self.nat, self.be
         s = self.slots[self.k % len(self.slots)]
         prev = self.slots[(self.k - 1) % len(self.slots)] if self.k else None
+        # The previous step's transfers go out FIRST — its counts are nearly a step old: the host waits for them here, with this
+        # step's scan already queued — so that on the side stream they stand in front of the wait for this step's scan and move
+        # beside it.  (Posted behind this step's count exchange, as rounds 3-5 had it, they — and the event the slot's next user
+        # waits for — stood behind this step's scan: a bubble of 40 us per step at the start of the scan after next, seen at one
+        # rank once the native backend recorded that event there too: profiles/r06/gather_one_rank.log.)
+        if prev is not None and prev is not s:
+            self._post(prev)
         be.side_wait_main()
         self._post(s)                # (a slot is reused only when its last transfers were posted ...
         if s["in_flight"]:
@@ -318,8 +325,6 @@ class TupleGather:
         s["posted"] = False
         s["step"] = self.k
         self.k += 1
-        if prev is not None and prev is not s:
-            self._post(prev)             # the previous step's counts are one step old by now
 
     def finish(self) -> None:
         """Posts what is still to be posted and makes the main stream wait for every transfer."""
