@@ -153,3 +153,63 @@ def test_pair_scan_table_is_built_only_when_safe():
     vt[0] = "ACACACACACACACACACAC"
     t2 = nat.Tables(vt, ts.v_jumps, ts.v_regions, ts.j_tags, ts.j_jumps, ts.j_regions, vs, js)
     assert t2.info()["pair_scan_bytes"] == 0
+
+
+def test_multi_gpu_entries_say_no_without_a_gpu_and_never_abort():
+    """The RCCL section of the ABI on a box without a GPU: the library opens librccl only when a communicator is asked for, a
+    failing call comes back as an error code with RCCL's text, bad arguments are refused before RCCL is touched — nothing aborts the
+    process, nothing falls back to anything.  (With a GPU: tests/test_gpu_parity.py runs one rank through RCCL proper.)"""
+    if nat.device_count() > 0:
+        pytest.skip("a GPU is present: covered by the GPU tests")
+    assert nat.lib().dcrx_comm_available() in (0, 1)
+    with pytest.raises(nat.DcrxError):
+        nat.Comm(nat.Comm.unique_id(), 1, 0)
+    h = C.c_void_p()
+    uid = np.zeros(nat.COMM_ID_BYTES, dtype=np.uint8)
+    assert nat.lib().dcrx_comm_create(uid.ctypes.data, 2, 2, C.byref(h)) == -1 and not h.value       # rank outside the world
+    assert nat.lib().dcrx_comm_create(None, 1, 0, C.byref(h)) == -1
+    assert nat.lib().dcrx_comm_allreduce_u64(None, None, None, 1, 0, None) == -1
+    assert nat.lib().dcrx_comm_gather_v(None, None, 0, None, None, 0, None) == -1
+    assert nat.lib().dcrx_decombine_sharded(None, None, None, None, None, None, None, None, 0, None, None, None) == -1
+    nat.lib().dcrx_comm_destroy(None)                                                                 # a no-op
+
+
+def test_comm_from_env_carries_the_id_through_a_file(tmp_path, monkeypatch):
+    """comm_from_env's rendezvous without RCCL: rank 0 leaves the id in a file (written under another name and renamed), the
+    others read it — here with Comm replaced by a recorder, three 'ranks' in turn."""
+    made = []
+
+    class FakeComm:
+        def __init__(self, uid, world, rank):
+            made.append((bytes(uid), world, rank))
+
+        @staticmethod
+        def unique_id():
+            return bytes(range(128))
+    monkeypatch.setattr(nat, "Comm", FakeComm)
+    path = tmp_path / "id"
+    monkeypatch.setenv("DCRX_COMM_ID_FILE", str(path))
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    for rank in (1, 2):                 # the others first: they must wait for the file, not read half of it
+        monkeypatch.setenv("RANK", str(rank))
+        with pytest.raises(TimeoutError):
+            nat.comm_from_env(timeout_s=0.05)
+    path.write_bytes(b"short")          # (a half-written file is not an id)
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(TimeoutError):
+        nat.comm_from_env(timeout_s=0.05)
+    path.unlink()
+    # rank 0 writes, then — in a real run once every rank has joined — removes the file: here the removal is rank 0's last act,
+    # so the others are served from a copy made in between
+    monkeypatch.setenv("RANK", "0")
+    import shutil
+    orig_remove = os.remove
+    monkeypatch.setattr(os, "remove", lambda p: (shutil.copy(p, str(path) + ".kept"), orig_remove(p)))
+    nat.comm_from_env()
+    monkeypatch.setattr(os, "remove", orig_remove)
+    assert not path.exists()
+    os.replace(str(path) + ".kept", str(path))
+    for rank in (1, 2):
+        monkeypatch.setenv("RANK", str(rank))
+        nat.comm_from_env(timeout_s=1.0)
+    assert made == [(bytes(range(128)), 3, 0), (bytes(range(128)), 3, 1), (bytes(range(128)), 3, 2)]
