@@ -576,6 +576,8 @@ class HipDevice:
         self.event_every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
         self.compact = None            # TupleGather then compacts with dcrx_compact_hits_packed_device
         nat.synchronize()
+        if os.environ.get("DCRX_BENCH_PRINT_PTRS") == "1":      # (experiments: where the buffers lie)
+            print("PTRS packed %x records %x counters %x" % (self.d_packed.ptr, self.d_recs[-1].ptr, self.d_cnts[-1][0].ptr), file=sys.stderr)
 
     def name(self):
         return self.nat.device_name()

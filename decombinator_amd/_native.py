@@ -428,7 +428,7 @@ class Tables:
         first, second = int(st.candidates) & 0xFFFF, int(st.candidates) >> 16
         return {"rescue_waves": int(st.rescue_waves), "launches": int(st.launches), f"us_{first}": round(float(st.us_first), 2),
                 f"us_{second}": round(float(st.us_second), 2),
-                "launch_form": {0: "none yet", 1: "three-launch form", 2: "v2, tail as a role", 3: "v2, tail inside the scan"}.get(int(st.launch_form), "?")}
+                "launch_form": {0: "none yet", 1: "three-launch form", 2: "v2, tail as a role", 3: "v2, tail inside the scan", 4: "v2, tail and list E inside the scan"}.get(int(st.launch_form), "?")}
 
     def close(self):
         if self._h is not None:

@@ -119,9 +119,15 @@ static void free_device_state(dcrx_tables *t) {
   (void)hipFree(t->d_blob); (void)hipFree(t->d_exc_flag); (void)hipFree(t->d_queue); (void)hipFree(t->d_v2_tail); (void)hipFree(t->d_v2_events); (void)hipFree(t->d_v2_counts);
   (void)hipFree(t->d_v2_slow);
   for (V2Tune &U : t->tune) {
-    for (V2TuneSlot &K : U.slot)
+    const bool may_wait = U.may_wait;
+    for (V2TuneSlot &K : U.slot) {
       if (K.created) for (auto &pair : K.ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+      if (K.ev_counts) (void)hipEventDestroy(K.ev_counts);
+      for (auto &pair : K.ev_e) for (auto &ev : pair) if (ev) (void)hipEventDestroy(ev);
+      if (K.h_counts) (void)hipHostFree(K.h_counts);
+    }
     U = V2Tune{};
+    U.may_wait = may_wait;
   }
   (void)hipFree(t->d_sink); (void)hipFree(t->d_sink_items); (void)hipFree(t->d_sink_ctr);
   t->d_sink = nullptr; t->d_sink_items = nullptr; t->d_sink_ctr = nullptr; t->sink_items_cap = 0; t->sink_regions_cap = 0;

@@ -206,6 +206,37 @@ __device__ __forceinline__ void v2_tally(uint32_t *lds_counts, const int lane, c
   }
 }
 
+// counters of a wave's lean-rescue statuses (rescue2_count, by ballot)
+__device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int lane, const int status, const uint32_t errs, const bool forward) {
+  const bool done = status >= 0;
+  const unsigned long long m_all = __ballot(done);
+  if (!m_all) return;
+  auto cnt = [&](const bool c) { return (uint32_t)__popcll(__ballot(done && c)); };
+  const uint32_t n_ok = cnt(status == DCRX_S_OK), n_v1 = cnt(status == DCRX_S_V_HALF1_EXHAUSTED), n_v2 = cnt(status == DCRX_S_V_HALF2_EXHAUSTED),
+                 n_vn = cnt(status == DCRX_S_V_NONE), n_jm = cnt(status == DCRX_S_J_MULTI), n_jn = cnt(status == DCRX_S_J_NONE),
+                 n_j1 = cnt(status == DCRX_S_J_HALF1_EXHAUSTED), n_j2 = cnt(status == DCRX_S_J_HALF2_EXHAUSTED),
+                 n_tl = cnt(status == DCRX_S_F_TOOLONG), n_im = cnt(status == DCRX_S_F_IMPOSS_DEL), n_ov = cnt(status == DCRX_S_F_OVERLAP),
+                 n_jw = cnt(status == DCRX_S_J_WALK_FAIL),       // (a full-tag walk that failed has counted its own counter)
+                 e_v1 = cnt((errs & 1u) != 0u), e_v2 = cnt((errs & 2u) != 0u), e_j1 = cnt((errs & 4u) != 0u), e_j2 = cnt((errs & 8u) != 0u);
+  if (lane == 0) {
+    auto add = [&](const int c, const uint32_t k) { if (k) atomicAdd(&lds_counts[c], k); };
+    add(DCRX_C_READ_COUNT, (uint32_t)__popcll(m_all));
+    add(DCRX_C_VJ_COUNT, n_ok);
+    if (forward) add(DCRX_C_FRAME_FORWARD, n_ok);
+    add(DCRX_C_FOUNDV1NOTV2, n_v1);
+    add(DCRX_C_FOUNDV2NOTV1, n_v2 + n_j2);            // the reference bumps the V key for the exhausted J half-2 list (:526)
+    add(DCRX_C_NO_VTAGS_FOUND, n_vn);
+    add(DCRX_C_MULTIPLE_J_MATCHES, n_jm);
+    add(DCRX_C_NO_J_ASSIGNED, n_jn);
+    add(DCRX_C_FOUNDJ1NOTJ2, n_j1);
+    add(DCRX_C_VJ_ASSIGNMENT_FAILED, n_jm + n_jn + n_j1 + n_j2 + n_jw);
+    add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG, n_tl);
+    add(DCRX_C_DCRFILTER_IMPOSS_DELETION, n_im);
+    add(DCRX_C_DCRFILTER_TAG_OVERLAP, n_ov);
+    add(DCRX_C_VERR1, e_v1); add(DCRX_C_VERR2, e_v2); add(DCRX_C_JERR1, e_j1); add(DCRX_C_JERR2, e_j2);
+  }
+}
+
 // One wave's item: 64 * RPL consecutive reads from `first`, lane l holding reads first + 64 q + l (q < RPL) while they
 // lie below `hi` (the end of the block's range).  With the words comes the wave's slice of the exception bitmap
 // (64-read groups start on multiples of 64: two words per group, the same for every lane).
@@ -317,8 +348,8 @@ __device__ __forceinline__ bool v2_left_push(uint4 *left_rows, uint32_t *__restr
 
 // LDS of the scan kernel behind the pair table and the counters: the block's work counters
 // next item; entries of each list (V2_WK_LIST + V2_L_*)
-enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_SINK = 19, V2_WK_FILLED = 32, V2_WK_GEN = 48,
-       V2_WK_WORDS = 64 };      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form; V2_WK_SINK: decombined reads of the tail waves, tuple sink)
+enum { V2_WK_NEXT = 0, V2_WK_LIST = 1, V2_WK_EXC = 8, V2_WK_HEAD = 16, V2_WK_CLAIM = 17, V2_WK_SCANNED = 18, V2_WK_SINK = 19, V2_WK_HEAD2 = 20, V2_WK_CLAIM2 = 21,
+       V2_WK_FILLED = 32, V2_WK_GEN = 48, V2_WK_FILLED2 = 64, V2_WK_GEN2 = 80, V2_WK_WORDS = 96 };      // (…2: the event ring of FUSE_E, same protocol as the tail ring)      // (V2_WK_EXC: six words of v2_exc_slice; from V2_WK_HEAD on: the tail ring of the fused form; V2_WK_SINK: decombined reads of the tail waves, tuple sink)
 // The fused form (FUSE >= 0 = the frame): the block's last waves — four of the sixteen, give or take (below) — do not scan: they take the tail entries
 // the scanning waves produce, in batches of 64, out of a ring in LDS, and finish them (tail2_fast) while the scan goes on.  The
 // scan is bound by its LDS look-ups, the tail by instruction issue: on one SIMD the two share what neither uses up, where the
@@ -358,14 +389,22 @@ constexpr int V2_FUSE_TAILWAVES = DCRX_V2_FUSE_TAILWAVES;
 constexpr uint32_t V2_TW6_FRAC256 = 243, V2_TW5_FRAC256 = 205, V2_TW4_FRAC256 = 136, V2_TW3_FRAC256 = 64;      // 95 % / 80 % / 53 % / 25 % of a region's reads
 constexpr int V2_RING_STRIDE = 15;
 constexpr uint32_t V2_RING_MAXBATCHES = 16;
+// FUSE_E (round 6): the event entries of list E — one gene to rescue: a tenth of the reads, a third of a step's vector work, and a
+// finishing launch of 90 us that runs alone on the chip — go through a second ring in LDS and are finished by `rescue_waves` further
+// waves of the scan block (rescue2_fast_to, V2_SHAPE_ONE) while the scan goes on, as the tail entries are since round 4.
+//   event ring slot (odd stride): the read's NW words, two zero words, read | flags, the flag log's NW words, the digest word, padding
+template <int NW> constexpr int v2_ering_stride() { return (2 * NW + 4) | 1; }      // 25 words for NW = 10
+constexpr uint32_t V2_ERING_BATCHES = 8;
+constexpr float V2_FUSE_E_MAX_SHARE = 0.25f;      // list E's share of the reads up to which finishing its entries inside the scan kernel is tried (and timed)
 
 // (SINK: the fused form's tail waves also leave the tuple sink's items — an instantiation of its own, so that the kernel of a
 // call without a sink carries none of that code: 0.6 % of the step, measured)
-template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, int FUSE = -1, bool SINK = false>
+template <bool UNIFORM_LEN, int NW, int RPL, bool NARROW, bool PREFETCH = true, int FUSE = -1, bool SINK = false, bool FUSE_E = false>
 __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records, unsigned long long *__restrict__ counters,
     V2Lists Q, uint32_t *__restrict__ queue, uint32_t *__restrict__ gqueue, uint32_t qcap, uint32_t *__restrict__ queue_count,
-    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S, uint32_t tail_waves) {
+    uint64_t per_block, uint32_t retry, const DevTables *__restrict__ Tmem, uint32_t ring_batches, V2SinkCall S, uint32_t tail_waves, uint32_t rescue_waves) {
+  static_assert(!FUSE_E || (FUSE >= 0 && !SINK), "the event ring rides on the fused form, without a tuple sink");
   extern __shared__ __align__(64) uint32_t smem[];
   if constexpr (FUSE >= 0 && !SINK) S.dev = nullptr;      // (the scanning form, FUSE < 0, only flushes a count: one kernel for both)
   const int o = FUSE >= 0 ? FUSE : (cfg.orientation == DCRX_ORIENT_FORWARD ? 0 : 1);
@@ -394,10 +433,14 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   uint32_t *lds_bk = lds_side + (T0.lds_image_bytes - T0.dfa_bytes) / 4;
   uint32_t *ring = lds_bk + V0.bk_bytes / 4;
   const uint32_t ring_mask = 64u * ring_batches - 1u;
+  constexpr uint32_t ES = (uint32_t)v2_ering_stride<NW>(), ering_mask = 64u * V2_ERING_BATCHES - 1u;
+  uint32_t *ring2 = ring + (size_t)(ring_mask + 1u) * V2_RING_STRIDE;            // (FUSE_E) the event ring, then a block of counters nobody reads
+  uint32_t *lds_dry = ring2 + (size_t)(ering_mask + 1u) * ES;
   if (FUSE >= 0) {
     stage_lds<DCRX_V2_BLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
     stage_lds<DCRX_V2_BLOCK>(V0.bk, lds_bk, V0.bk_bytes / 16, 0, 0, tid);
     for (uint32_t i = tid; i <= ring_mask; i += blockDim.x) { ring[i * V2_RING_STRIDE + NW] = 0u; ring[i * V2_RING_STRIDE + NW + 1] = 0u; }
+    if (FUSE_E) for (uint32_t i = tid; i <= ering_mask; i += blockDim.x) { ring2[i * ES + NW] = 0u; ring2[i * ES + NW + 1] = 0u; }
   }
   __syncthreads();
   const uint32_t nw = B.stride >> 2;
@@ -426,13 +469,98 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   if (FUSE >= 0 && tw == 0u) {
     const uint32_t h = Q.counts[V2_L_COUNTS * blockIdx.x + V2_L_TWHINT + (o ? 0 : 1)];      // (a hint per frame: the two passes of orientation `both` meet different shares)
     tw = (h >= 2u && h <= 8u) ? h : (uint32_t)V2_FUSE_TAILWAVES;
+    if (FUSE_E && tw > 2u) tw -= 1u;      // (fewer waves scan: the tail entries come in more slowly — 0.3158 against 0.3291 ms on two instead of three)
   }
-  const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? tw : 0u);
+  const uint32_t rw = FUSE_E ? rescue_waves : 0u;      // (FUSE_E) the block's last waves take the event ring
+  const uint32_t n_scan_waves = (blockDim.x >> 6) - (FUSE >= 0 ? tw : 0u) - rw;
   const size_t region = blockIdx.x;
 #ifdef DCRX_SCAN_STAMPS
   stamp_setup = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
+  if (FUSE_E && (uint32_t)(tid >> 6) >= n_scan_waves + tw) {
+   if constexpr (FUSE_E) {
+    // ---- a rescue wave (FUSE_E): batches of 64 event entries of list E out of the event ring, as the scanning waves fill them ----
+    constexpr bool REV = FUSE == 1;
+#if DCRX_V2_PRIO_TAIL
+    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
+#endif
+    uint32_t kw_base[K_NCLASS];
+#pragma unroll
+    for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
+    const Rescue2Tabs rt = rescue2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV, kw_base);
+    const Counters C{lds_counts}, Cdry{lds_dry};
+    constexpr uint32_t nb_mask = V2_ERING_BATCHES - 1u, nb_shift = (uint32_t)__builtin_ctz(V2_ERING_BATCHES);
+    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
+    for (uint32_t spins = 0;;) {
+      uint32_t c = 0, nvalid = 0;
+      if (lane == 0) {      // (the tail ring's protocol on the event ring's words)
+        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
+        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!mine) nvalid = 0;
+        else if (f == 64u) nvalid = 64u;
+        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
+          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t rem = h - 64u * c;
+          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
+        }
+        if (nvalid && nvalid != V2_RING_EXIT) {
+          uint32_t expect = c;
+          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM2], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
+        }
+      }
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
+      if (nvalid == V2_RING_EXIT) break;
+      if (!nvalid) {
+        if (++spins > (1u << 24)) { if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull); break; }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint32_t *sl = ring2 + ((64u * c + (uint32_t)lane) & ering_mask) * ES;
+      int status = -2;
+      uint32_t errs = 0, x0 = 0;
+      uint32_t lg[NW];
+#pragma unroll
+      for (int k = 0; k < NW; k++) lg[k] = 0u;
+      if ((uint32_t)lane < nvalid) {
+        x0 = sl[NW + 2];
+#pragma unroll
+        for (int k = 0; k < NW; k++) lg[k] = sl[NW + 3 + k];
+        const uint32_t dg = sl[2 * NW + 3];
+        const uint32_t r = x0 & V2_R_MASK;
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        const LdsWords lw{dcrx_ldsaddr_of(sl)};
+        auto on_ok = [&](dcrx_record_t rec, const uint32_t) {      // a decombined read's record, where its fields are known
+          rec.frame = (uint8_t)(o ? 0 : 1);
+          DCRX_STORE_FINISH(records + r, rec);
+        };
+        status = rescue2_fast_to<REV, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, dg);
+        if (status > 0) {      // settled, not decombined: the status alone
+          dcrx_record_t rec;
+          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+          rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1);
+          DCRX_STORE_FINISH(records + r, rec);
+        } else if (status < 0) errs = 0;
+      }
+      v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
+      if (__builtin_expect(status == RESCUE2_SLOW, 0)) {      // what the lean form does not settle: the launch's left list (its placeholder record stands)
+        uint32_t ww[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) ww[k] = sl[k];
+        if (!v2_left_push<NW>(Q.left, queue_count, x0, lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, x0 & V2_R_MASK, false);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_store(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        atomicAdd(&lds_work[V2_WK_GEN2 + (c & nb_mask)], 1u);
+      }
+      spins = 0;
+    }
+   }
+  } else if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
    if constexpr (FUSE >= 0) {
     // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
     constexpr bool REV = FUSE == 1;
@@ -661,7 +789,45 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
       };
       bool to_ev = lst == V2_L_E;
       const unsigned long long me0 = __ballot(to_ev);
-      if (me0) {
+      if (FUSE_E) {
+        // list E's entries of this read go into the block's event ring (one transaction: the slots of the wave's E lanes drawn with
+        // one LDS atomic, every ring batch's GEN fetched in the same wait; the entries; the batches' FILLED counts behind them)
+        if (me0) {
+          constexpr uint32_t nb_mask = V2_ERING_BATCHES - 1u, nb_shift = (uint32_t)__builtin_ctz(V2_ERING_BATCHES);
+          const uint32_t total = (uint32_t)__popcll(me0);
+          const uint32_t genv = __hip_atomic_load(&lds_work[V2_WK_GEN2 + ((uint32_t)lane & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&lds_work[V2_WK_HEAD2], total);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t gb0 = base >> 6, gbl = (base + total - 1u) >> 6;
+          bool room = true;
+          for (uint32_t g = gb0; g <= gbl; g++) room = room && (uint32_t)__builtin_amdgcn_readlane((int)genv, (int)(g & nb_mask)) >= (g >> nb_shift);
+          if (!room && lane == 0) {      // a ring batch's last occupants are still being finished: wait for them
+            bool ok = false;
+            for (uint32_t spins = 0; spins < (1u << 24) && !ok; spins++) {
+              ok = true;
+              for (uint32_t g = gb0; g <= gbl; g++)
+                ok = ok && __hip_atomic_load(&lds_work[V2_WK_GEN2 + (g & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (g >> nb_shift);
+              if (!ok) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull);
+          }
+          asm volatile("" ::: "memory");
+          if (to_ev) {
+            uint32_t *sl = ring2 + ((base + (uint32_t)__popcll(me0 & lt_mask)) & ering_mask) * ES;
+#pragma unroll
+            for (int k = 0; k < NW; k++) { sl[k] = w[q][k]; sl[NW + 3 + k] = lg[q][k]; }
+            sl[NW + 2] = (uint32_t)r; sl[2 * NW + 3] = rescue2_digest_pack(d);
+          }
+          asm volatile("" ::: "memory");       // (the entries before the counts that announce them, in program order: LDS keeps it)
+          if (lane == 0) {
+            for (uint32_t g = gb0; g <= gbl; g++) {
+              const uint32_t lo = max(base, g << 6), hi = min(base + total, (g + 1u) << 6);
+              atomicAdd(&lds_work[V2_WK_FILLED2 + (g & nb_mask)], hi - lo);
+            }
+          }
+        }
+      } else if (me0) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&lds_work[V2_WK_LIST + V2_L_E], (uint32_t)__popcll(me0));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -948,37 +1114,6 @@ __device__ __forceinline__ void v2_tail_jobs(const Tail2Tabs &tt, const V2Finish
       }
       if (lane == 0) s_left[0] = 0u;
     }
-  }
-}
-
-// counters of a wave's lean-rescue statuses (rescue2_count, by ballot)
-__device__ __forceinline__ void v2_tally_rescue(uint32_t *lds_counts, const int lane, const int status, const uint32_t errs, const bool forward) {
-  const bool done = status >= 0;
-  const unsigned long long m_all = __ballot(done);
-  if (!m_all) return;
-  auto cnt = [&](const bool c) { return (uint32_t)__popcll(__ballot(done && c)); };
-  const uint32_t n_ok = cnt(status == DCRX_S_OK), n_v1 = cnt(status == DCRX_S_V_HALF1_EXHAUSTED), n_v2 = cnt(status == DCRX_S_V_HALF2_EXHAUSTED),
-                 n_vn = cnt(status == DCRX_S_V_NONE), n_jm = cnt(status == DCRX_S_J_MULTI), n_jn = cnt(status == DCRX_S_J_NONE),
-                 n_j1 = cnt(status == DCRX_S_J_HALF1_EXHAUSTED), n_j2 = cnt(status == DCRX_S_J_HALF2_EXHAUSTED),
-                 n_tl = cnt(status == DCRX_S_F_TOOLONG), n_im = cnt(status == DCRX_S_F_IMPOSS_DEL), n_ov = cnt(status == DCRX_S_F_OVERLAP),
-                 n_jw = cnt(status == DCRX_S_J_WALK_FAIL),       // (a full-tag walk that failed has counted its own counter)
-                 e_v1 = cnt((errs & 1u) != 0u), e_v2 = cnt((errs & 2u) != 0u), e_j1 = cnt((errs & 4u) != 0u), e_j2 = cnt((errs & 8u) != 0u);
-  if (lane == 0) {
-    auto add = [&](const int c, const uint32_t k) { if (k) atomicAdd(&lds_counts[c], k); };
-    add(DCRX_C_READ_COUNT, (uint32_t)__popcll(m_all));
-    add(DCRX_C_VJ_COUNT, n_ok);
-    if (forward) add(DCRX_C_FRAME_FORWARD, n_ok);
-    add(DCRX_C_FOUNDV1NOTV2, n_v1);
-    add(DCRX_C_FOUNDV2NOTV1, n_v2 + n_j2);            // the reference bumps the V key for the exhausted J half-2 list (:526)
-    add(DCRX_C_NO_VTAGS_FOUND, n_vn);
-    add(DCRX_C_MULTIPLE_J_MATCHES, n_jm);
-    add(DCRX_C_NO_J_ASSIGNED, n_jn);
-    add(DCRX_C_FOUNDJ1NOTJ2, n_j1);
-    add(DCRX_C_VJ_ASSIGNMENT_FAILED, n_jm + n_jn + n_j1 + n_j2 + n_jw);
-    add(DCRX_C_DCRFILTER_TOOLONG_INTERTAG, n_tl);
-    add(DCRX_C_DCRFILTER_IMPOSS_DELETION, n_im);
-    add(DCRX_C_DCRFILTER_TAG_OVERLAP, n_ov);
-    add(DCRX_C_VERR1, e_v1); add(DCRX_C_VERR2, e_v2); add(DCRX_C_JERR1, e_j1); add(DCRX_C_JERR2, e_j2);
   }
 }
 
@@ -1636,7 +1771,78 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if constexpr (CAN_FUSE) {
     if (ring_batches) ks = o ? scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1> : scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0>;
   }
-  if (P.tune && ring_batches) P.tune[o].last_form = 3u;      // (launch_decombine has said 2)
+  // FUSE_E: list E through an event ring inside the scan kernel as well (the two-reads-per-lane shape of uniform 150-nt batches,
+  // one pass, no tuple sink, no A/B or profiling switch), where the block's LDS holds the event ring beside a tail ring of eight
+  // batches or more; DCRX_DEBUG_FUSE_E=0 keeps list E a role of the finishing launch (A/B), DCRX_DEBUG_FUSE_E_WAVES the rescue waves
+  constexpr bool CAN_FUSE_E = CAN_FUSE && UNIFORM && RPL == 2;
+  auto ks_e = ks;
+  bool fuse_e = false;
+  uint32_t ring_batches_e = 0, scan_lds_e = 0;
+  static const int fuse_e_env = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_FUSE_E"); return e ? atoi(e) : -1; }();
+  static const uint32_t rescue_waves_fused = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_FUSE_E_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? (uint32_t)v : 3u; }();
+  V2TuneSlot *eslot = nullptr;      // (the size class's slot, where the handle keeps its decision)
+  hipEvent_t e_ev_start = nullptr, e_ev_stop = nullptr;      // this call's pair, when it is one of the two timed samples
+  if constexpr (CAN_FUSE_E) {
+    const int ec = V2Tune::size_class(B.n_reads);
+    if (P.tune && ec >= 0 && !retry && !cfg.flags && ring_batches) eslot = &P.tune[o].slot[ec];
+    if (eslot && eslot->fuse_e < 0 && eslot->e_sampling && hipEventQuery(eslot->ev_counts) == hipSuccess) {
+      // the first launch's lists have been counted: list E's share of the reads decides (config 2: 10 % — inside the scan, three
+      // rescue waves per block, the step 0.316 ms whatever state the box is in against 0.31-0.35 as a role; config 5's mouse chains
+      // at 2 % substitutions: 30 % — a role: 0.609 against 0.691 ms; profiles/r06/list_e_in_the_scan_ab.log)
+      uint64_t e_entries = 0;
+      for (uint32_t r = 0; r < eslot->e_regions; r++) e_entries += eslot->h_counts[(size_t)V2_L_COUNTS * r + V2_L_E];
+      eslot->e_share = eslot->e_reads ? (float)((double)e_entries / (double)eslot->e_reads) : 0.f;
+      eslot->fuse_e = eslot->e_share <= V2_FUSE_E_MAX_SHARE ? -2 : 0;
+      eslot->e_sampling = false;
+      static const bool say = dcrx_debug_env("DCRX_DEBUG_TUNE") != nullptr;
+      if (say) fprintf(stderr, "dcrx tune: list E holds %.1f %% of %llu reads, frame %d: %s\n", 100.0 * eslot->e_share, (unsigned long long)eslot->e_reads, o,
+                       eslot->fuse_e ? "both forms will be timed" : "stays a role of the finishing launch");
+    }
+    (void)hipGetLastError();
+    bool want = fuse_e_env >= 0 ? fuse_e_env != 0 : (eslot && eslot->fuse_e == 1);
+    // The share allows it: one launch as a role and one fused under a pair of events each (start on the scan's dispatch, stop on the
+    // finishing launch's), once the handle's rescue waves are settled and on launches that carry no events of the caller's; the
+    // faster form stays.  What decides is not the share alone: config 5's mouse chains hold 10 % of list-E entries per chain as
+    // config 2 does and lose 13-28 % fused (their entries take a rescue wave half as long again), and on a box whose scan runs at
+    // its faster pace the two forms of config 2 are within 2 % of each other (profiles/r06/list_e_in_the_scan_ab.log).
+    if (fuse_e_env < 0 && eslot && eslot->fuse_e == -2 && eslot->choice != 0u && !ev_start && !ev_stop && !P.ev_step_start && !P.ev_step_stop && !(sink && P.sink.dev)) {
+      bool ok = true;
+      constexpr int NP = V2TuneSlot::E_PAIRS, FIRST = V2TuneSlot::E_FIRST;
+      if (!eslot->ev_e[0][0])
+        for (int a = 0; a < 2 * NP && ok; a++) for (int b = 0; b < 2 && ok; b++) ok = hipEventCreate(&eslot->ev_e[a][b]) == hipSuccess;
+      const int k = eslot->e_phase - FIRST;      // index of this launch among the timed ones
+      if (!ok) { (void)hipGetLastError(); eslot->fuse_e = 0; }
+      else if (k < 0) eslot->e_phase++;
+      else if (k < 2 * NP) { e_ev_start = eslot->ev_e[k][0]; e_ev_stop = eslot->ev_e[k][1]; want = (k & 1) != 0; eslot->e_phase++; }
+      else {
+        bool ready = true;
+        for (int a = 0; a < 2 * NP && ready; a++) ready = hipEventQuery(eslot->ev_e[a][1]) == hipSuccess;
+        if (ready) {
+          float ms[2] = {0.f, 0.f};
+          for (int a = 0; a < 2 * NP && ok; a++) { float t = 0.f; ok = hipEventElapsedTime(&t, eslot->ev_e[a][0], eslot->ev_e[a][1]) == hipSuccess; ms[a & 1] += t; }
+          eslot->us_e[0] = 1e3f * ms[0] / NP; eslot->us_e[1] = 1e3f * ms[1] / NP;
+          eslot->fuse_e = (ok && ms[1] > 0.f && ms[1] < 0.985f * ms[0]) ? 1 : 0;
+          want = eslot->fuse_e == 1;
+          static const bool say = dcrx_debug_env("DCRX_DEBUG_TUNE") != nullptr;
+          if (say) fprintf(stderr, "dcrx tune: scan + finishing launch of %llu reads, frame %d: %.1f us with list E a role, %.1f inside the scan -> %s\n",
+                           (unsigned long long)B.n_reads, o, eslot->us_e[0], eslot->us_e[1], eslot->fuse_e ? "inside the scan" : "a role");
+        }
+      }
+      (void)hipGetLastError();
+    }
+    if (ring_batches && want && !retry && !(cfg.flags & ~(DCRX_F_V2_SHAPE(3)))) {
+      const uint32_t fixed = v2_scan_lds_bytes(T, o) + (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + 64u * V2_ERING_BATCHES * (uint32_t)v2_ering_stride<NW>() * 4u +
+                             DCRX_N_COUNTERS * 4u;
+      for (uint32_t nb = ring_batches; nb >= 8u; nb >>= 1)
+        if (fixed + nb * 64u * V2_RING_STRIDE * 4u <= 160u * 1024u) { ring_batches_e = nb; scan_lds_e = fixed + nb * 64u * V2_RING_STRIDE * 4u; break; }
+      if (!ring_batches_e && eslot && fuse_e_env < 0) eslot->fuse_e = 0;      // (no room for the event ring beside this table: a role it stays)
+      if (ring_batches_e) {
+        fuse_e = true;
+        ks_e = o ? scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1, false, true> : scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0, false, true>;
+      }
+    }
+  }
+  if (P.tune && ring_batches) P.tune[o].last_form = 3u;      // (launch_decombine has said 2; 4 below where list E rides inside the scan as well)
   const uint32_t scan_lds = v2_scan_lds_bytes(T, o) + (ring_batches ? (T.lds_image_bytes - T.dfa_bytes) + T.v2[o].bk_bytes + ring_batches * 64u * V2_RING_STRIDE * 4u : 0u);
   auto ke = o ? events2_kernel<UNIFORM, NW, 1> : events2_kernel<UNIFORM, NW, 0>;
   auto kt = o ? tail2_kernel<UNIFORM, NW, 1> : tail2_kernel<UNIFORM, NW, 0>;
@@ -1669,6 +1875,18 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    if constexpr (CAN_FUSE_E) {
+      const void *ke2[] = {reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0, false, true>),
+                           reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 1, false, true>)};
+      for (const void *k : ke2) {
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, k);
+        if (e != hipSuccess) return e;
+        if (fa.sharedSizeBytes != 0) return hipErrorNotSupported;
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+    }
     if constexpr (CAN_FUSE) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan2_kernel<UNIFORM, NW, RPL, NARROW, PREFETCH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
@@ -1755,10 +1973,24 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       sink->counts = Q.counts;
     }
   }
-  hipExtLaunchKernelGGL(S.dev ? ks_sink : ks, dim3(grid), dim3(DCRX_V2_BLOCK), scan_lds, s, ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
-                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, ring_batches, S, tail_waves_forced);
+  if (S.dev) fuse_e = false;      // (a call that leaves a tuple sink's message keeps list E a role: its items are placed by list position)
+  if (P.tune && fuse_e) P.tune[o].last_form = 4u;
+  hipExtLaunchKernelGGL(S.dev ? ks_sink : (fuse_e ? ks_e : ks), dim3(grid), dim3(DCRX_V2_BLOCK), fuse_e ? scan_lds_e : scan_lds, s, ev_start ? ev_start : e_ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
+                        d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, fuse_e ? ring_batches_e : ring_batches, S, tail_waves_forced,
+                        fuse_e ? rescue_waves_fused : 0u);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if constexpr (CAN_FUSE_E) {
+    if (eslot && eslot->fuse_e < 0 && !eslot->e_sampling && !fuse_e && fuse_e_env < 0 && !S.dev && finish) {
+      // the class's first launch: its regions' list counts to pinned memory behind the scan (once per handle, frame and size class)
+      bool ok = eslot->h_counts || hipHostMalloc(reinterpret_cast<void **>(&eslot->h_counts), (size_t)4096 * V2_L_COUNTS * 4, hipHostMallocDefault) == hipSuccess;
+      ok = ok && (eslot->ev_counts || hipEventCreateWithFlags(&eslot->ev_counts, hipEventDisableTiming) == hipSuccess);
+      ok = ok && grid <= 4096u && hipMemcpyAsync(eslot->h_counts, Q.counts, (size_t)grid * V2_L_COUNTS * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+           hipEventRecord(eslot->ev_counts, s) == hipSuccess;
+      if (ok) { eslot->e_sampling = true; eslot->e_regions = grid; eslot->e_reads = B.n_reads; }
+      else { (void)hipGetLastError(); eslot->fuse_e = 0; }
+    }
+  }
   if (finish) {
     // waves of the finishing roles that share a region (a scan block's list): as many as keep 8192 waves on the tail list and
     // 4096 on each rescue list of a full-size launch
@@ -1822,9 +2054,11 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
     static const uint32_t tail_role_waves_env = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_TAIL_ROLE_WAVES"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
     const uint32_t tail_role_waves = tail_role_waves_env ? tail_role_waves_env : (separate ? 8192u : 4096u);
-    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions)), rsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
+    const uint32_t tsplit = std::max<uint32_t>(1u, std::min<uint32_t>(64u, tail_role_waves / n_regions));
+    const uint32_t rsplit_full = std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves / n_regions));
+    const uint32_t rsplit = fuse_e ? 1u : rsplit_full;      // (FUSE_E: list E is empty — its entries went through the scan's event ring —: one wave per region looks)
     static const uint32_t rescue_waves_c = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_RESCUE_WAVES_C"); const int v = e ? atoi(e) : 0; return v >= 256 ? (uint32_t)v : 0u; }();      // (A/B)
-    const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit;
+    const uint32_t csplit = rescue_waves_c ? std::max<uint32_t>(1u, std::min<uint32_t>(64u, rescue_waves_c / n_regions)) : rsplit_full;
     // (list C's jobs behind list E's on the same waves — one round of blocks instead of two — were measured: the step 3 % longer
     // on config 2, 8 % on config 5: list C's batches are the slow ones, two sweeps each, and want to start with the launch;
     // profiles/r05/finish_list_c_folded_ab.log.  List C's jobs IN FRONT of list E's on the same waves: 1-2 % longer still
@@ -1833,7 +2067,10 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     const uint32_t egrid = (n_regions + DCRX_V2_FBLOCK / 64 - 1) / (DCRX_V2_FBLOCK / 64);      // the general form over a whole event list (A/B): a block takes four regions
     // blocks of a short list's pass that share a region: as a pass of its own (A/B forms) the list's latency is the launch's, and
     // four blocks per region halve it; as a role under the lean rescue one block per region does (its rounds run hidden)
-    const uint32_t bsplit = separate ? std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions)) : 1u;
+    static const uint32_t bsplit_env = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_X_BSPLIT"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 16) ? (uint32_t)v : 0u; }();      // (A/B)
+    // (FUSE_E: with list E gone the launch is as long as list X's chains of single reads: two blocks per region 46 us, one 57, four 65 —
+    // profiles/r06/list_e_in_the_scan_ab.log)
+    const uint32_t bsplit = bsplit_env ? bsplit_env : (separate ? std::max<uint32_t>(1u, std::min<uint32_t>(16u, 1024u / n_regions)) : (fuse_e ? 2u : 1u));
     const uint32_t sgrid = n_regions * bsplit;
     const uint32_t flds = v2_finish_lds_bytes(T, o);
     const uint32_t llds = v2_finish_block_lds<NW>(T, o, DCRX_V2_FBLOCK);      // the lean roles: + a strip per lane (+ the rescue's scratch counters)
@@ -1851,7 +2088,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     A.queue = queue; A.gqueue = gqueue; A.qcap = qcap; A.queue_count = queue_count; A.Tmem = P.dev_tables; A.S = S;
     if (!separate) {
       hipExtLaunchKernelGGL(S.dev ? (ring_batches ? kf0_sink : kf_sink) : (ring_batches ? kf0 : kf), dim3(R.xgrid + R.rgrid + R.tgrid), dim3(DCRX_V2_FBLOCK), llds, s, tune_start,
-                            tune_stop, 0, A);
+                            tune_stop ? tune_stop : e_ev_stop, 0, A);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     } else {

@@ -57,6 +57,20 @@ struct V2TuneSlot {
   int launches = 0;                  // launches seen in this size class
   hipEvent_t ev[SAMPLES][2] = {};    // (start, stop) of the finishing launch of sample k
   bool created = false;
+  // list E inside the scan kernel (FUSE_E) or a role of the finishing launch: decided once per size class from the share of the
+  // reads that were list-E entries in the class's first launch (the regions' counts copied to pinned memory behind that launch,
+  // read when the copy's event has passed: no wait)
+  int fuse_e = -1;                   // -1 not known yet, -2 the share allows it: the two forms are being timed, 0 a role, 1 inside the scan
+  static constexpr int E_PAIRS = 3, E_FIRST = 8;      // pairs of timed launches (a role, fused), from the class's E_FIRST-th eligible launch on (the clocks have come up by then)
+  int e_phase = 0;                   // (fuse_e == -2) eligible launches seen: E_FIRST + 2 k runs as a role under a pair of events, E_FIRST + 2 k + 1 fused; then the events are read
+  hipEvent_t ev_e[2 * E_PAIRS][2] = {};      // (start on the scan's dispatch, stop on the finishing launch's) per timed launch
+  float us_e[2] = {0.f, 0.f};        // what the samples said: mean of the launches with list E a role / inside the scan
+  bool e_sampling = false;
+  hipEvent_t ev_counts = nullptr;
+  uint32_t *h_counts = nullptr;      // pinned, V2_L_COUNTS words per region
+  uint32_t e_regions = 0;
+  uint64_t e_reads = 0;
+  float e_share = -1.f;
   float us[2] = {0.f, 0.f};          // what the samples said: a finishing launch on 4 096 / on 3 072 rescue waves (dcrx_tune_state)
 };
 // ... per size class (batches of 2^(20 + k) .. 2^(21 + k) - 1 reads share a slot): a short last chunk of a host call, or the

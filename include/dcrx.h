@@ -483,7 +483,8 @@ typedef struct dcrx_tune_state {
   float us_first, us_second;
   uint32_t launch_form;      /* the frame's last call, whatever its size: 0 none yet, 1 the three-launch form (tag sets or shapes the
                                 v2 kernels do not serve), 2 the v2 kernels with the tail a role of the finishing launch, 3 the v2
-                                kernels with the tail inside the scan kernel */
+                                kernels with the tail inside the scan kernel, 4 the same with list E's entries finished inside the scan kernel as
+                                well (chosen per size class from the share of list-E entries in the class's first launch) */
   uint32_t candidates;
 } dcrx_tune_state_t;
 int dcrx_tune_state(const dcrx_tables_t *tables, int orientation, uint64_t n_reads, dcrx_tune_state_t *out);

@@ -293,8 +293,20 @@ def test_big_batches_settle_between_8192_and_4096_rescue_waves():
             assert parts == first_rec, f"call {call}"
             assert (cnt == first_cnt).all(), f"call {call}"
     st = t.tune_state(n)
-    assert st["rescue_waves"] in (8192, 4096) and st["launch_form"] == "v2, tail inside the scan", st
+    assert st["rescue_waves"] in (8192, 4096) and st["launch_form"].startswith("v2, tail"), st
     assert "us_8192" in st and "us_4096" in st and st["us_8192"] > 0 and st["us_4096"] > 0, st
+
+
+def test_full_size_10M_with_list_e_inside_the_scan():
+    """BASELINE config 2 at full size through the form the handle takes where its own timing says so (round 6: list E's entries
+    finished inside the scan kernel, FUSE_E — forced here, in a process of its own): all 10 M records and every counter against
+    the oracle, two launches on one handle."""
+    import subprocess
+    import sys
+    e = dict(os.environ, DCRX_DEBUG_FLAGS="1", DCRX_DEBUG_FUSE_E="1")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_shape_worker.py"), "2", "10000000", "2"],
+                       env=e, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "SHAPE_OK" in p.stdout and "tail and list E inside the scan" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
 
 
 @pytest.mark.parametrize("which", ["config3_alpha", "config3_beta", "config5_mouse_g", "config5_mouse_d"])
@@ -887,6 +899,12 @@ def test_tail_waves_follow_the_workload_on_one_handle():
     (2, {"DCRX_DEBUG_TAIL_WAVES": "2"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "3"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "4"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "5"}), (2, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
     (2, {"DCRX_DEBUG_NO_TUNE": "1"}),
     (5, {}), (5, {"DCRX_DEBUG_RESCUE_WAVES": "3072"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "2"}), (5, {"DCRX_DEBUG_TAIL_WAVES": "6"}),
+    # round 6: list E finished inside the scan kernel (FUSE_E: an event ring in LDS, rescue waves beside the tail waves) — the form
+    # a handle takes when its own timing of both says so; forced here, by rescue and tail waves, and with the shortest tail ring
+    (2, {"DCRX_DEBUG_FUSE_E": "1"}), (2, {"DCRX_DEBUG_FUSE_E": "1", "DCRX_DEBUG_FUSE_E_WAVES": "2"}), (2, {"DCRX_DEBUG_FUSE_E": "1", "DCRX_DEBUG_FUSE_E_WAVES": "5"}),
+    (2, {"DCRX_DEBUG_FUSE_E": "1", "DCRX_DEBUG_TAIL_WAVES": "2"}), (2, {"DCRX_DEBUG_FUSE_E": "1", "DCRX_DEBUG_TAIL_WAVES": "5"}),
+    (5, {"DCRX_DEBUG_FUSE_E": "1"}), (5, {"DCRX_DEBUG_FUSE_E": "1", "DCRX_DEBUG_FUSE_E_WAVES": "4"}),
+    (2, {"DCRX_DEBUG_FUSE_E": "0"}),
 ], ids=lambda x: x if isinstance(x, int) else ("own-choice" if not x else "-".join(f"{k[11:].lower()}{v}" for k, v in x.items())))
 def test_timed_launch_shapes_at_size(config, env):
     """What bench.py times is a launch of >= 2^20 reads on a fused handle whose finishing launch runs on 3 072 or 4 096 rescue
@@ -901,3 +919,7 @@ def test_timed_launch_shapes_at_size(config, env):
     assert p.returncode == 0 and "SHAPE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     if not env:      # the handle has settled, on one of the two settings
         assert "'rescue_waves': 3072" in p.stdout or "'rescue_waves': 4096" in p.stdout, p.stdout
+    if env.get("DCRX_DEBUG_FUSE_E") == "1":
+        assert "tail and list E inside the scan" in p.stdout, p.stdout
+    if env.get("DCRX_DEBUG_FUSE_E") == "0":
+        assert "'launch_form': 'v2, tail inside the scan'" in p.stdout, p.stdout
