@@ -446,7 +446,9 @@ def run_rank(args, device_factory=None, comm_factory=None):
             # an average step are what the device time is set against)
             achieved = algo_bytes * (total_reads / world / args.steps) / (step_avg_ms * 1e-3) / 1e9
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            forms = [tb.tune_state(n)["launch_form"] for tb in all_tables]
+            # (a handle settles on one of two forms — list E a role of the finishing launch or inside the scan kernel —: each has its own profile)
+            tpath = os.path.join(ROOT, "profiles", "traffic_list_e_inside_the_scan.json" if forms and "list E inside" in forms[-1] else "traffic.json")
             v2 = bool(info.get("v2_tables")) and not (args.cfg_flags & 64)
             roofline_lds = None
             if os.path.exists(tpath) and args.config == 2:
@@ -480,7 +482,8 @@ def run_rank(args, device_factory=None, comm_factory=None):
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_read": algo_bytes,
                 "step_device_ms_avg": round(step_avg_ms, 5), "step_device_ms_min": round(min(step_ms), 5),
-                "dominant_kernel": ("dcrx::scan2_kernel (scan + lean tail fused: the tail entries go through a ring in LDS)" if v2 else "dcrx::decombine_kernel"), "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
+                "dominant_kernel": (("dcrx::scan2_kernel (scan + lean tail + list E's rescue fused: tail and event entries go through rings in LDS)" if "list E inside" in forms[-1]
+                                     else "dcrx::scan2_kernel (scan + lean tail fused: the tail entries go through a ring in LDS)") if v2 else "dcrx::decombine_kernel"), "dominant_kernel_ms_avg": round(kern_avg_ms, 5),
                 "dominant_kernel_ms_min": round(min(kern_ms), 5),
                 "roofline_lds": roofline_lds,
                 "events": f"HIP events on {len(timed)} of the {args.steps} timed steps (every {every}th, in turn the step's pair — on its first and last "
@@ -586,7 +589,8 @@ class HipDevice:
         return "v2" if bool(info.get("v2_tables")) and not (self.cfg_flags & 64) else "v1"
 
     def kernels(self, info):
-        return "v2 (scan2 with the lean tail inside / finish2: lean rescue + general form / list kernel)" if self.kernels_tag(info) == "v2" else "three-launch form"
+        return ("v2 (scan2 with the lean tail inside — and list E's rescue where the handle's timing of both forms says so: tune.launch_form — / finish2: lean rescue + "
+                "general form / list kernel)") if self.kernels_tag(info) == "v2" else "three-launch form"
 
     def make_events(self, steps, timed):
         nat = self.nat

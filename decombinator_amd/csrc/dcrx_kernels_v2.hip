@@ -1785,7 +1785,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   if constexpr (CAN_FUSE_E) {
     const int ec = V2Tune::size_class(B.n_reads);
     if (P.tune && ec >= 0 && !retry && !cfg.flags && ring_batches) eslot = &P.tune[o].slot[ec];
-    if (eslot && eslot->fuse_e < 0 && eslot->e_sampling && hipEventQuery(eslot->ev_counts) == hipSuccess) {
+    if (eslot && eslot->fuse_e == -1 && eslot->e_sampling && hipEventQuery(eslot->ev_counts) == hipSuccess) {
       // the first launch's lists have been counted: list E's share of the reads decides (config 2: 10 % — inside the scan, three
       // rescue waves per block, the step 0.316 ms whatever state the box is in against 0.31-0.35 as a role; config 5's mouse chains
       // at 2 % substitutions: 30 % — a role: 0.609 against 0.691 ms; profiles/r06/list_e_in_the_scan_ab.log)
@@ -1800,9 +1800,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
     }
     (void)hipGetLastError();
     bool want = fuse_e_env >= 0 ? fuse_e_env != 0 : (eslot && eslot->fuse_e == 1);
-    // The share allows it: one launch as a role and one fused under a pair of events each (start on the scan's dispatch, stop on the
-    // finishing launch's), once the handle's rescue waves are settled and on launches that carry no events of the caller's; the
-    // faster form stays.  What decides is not the share alone: config 5's mouse chains hold 10 % of list-E entries per chain as
+    // The share allows it: three launches as a role and three fused under a pair of events each (start on the scan's dispatch, stop on
+    // the finishing launch's), from the class's ninth eligible launch on (the clocks have come up), once the handle's rescue waves
+    // are settled and on launches that carry no events of the caller's; the faster form stays.  What decides is not the share alone: config 5's mouse chains hold 10 % of list-E entries per chain as
     // config 2 does and lose 13-28 % fused (their entries take a rescue wave half as long again), and on a box whose scan runs at
     // its faster pace the two forms of config 2 are within 2 % of each other (profiles/r06/list_e_in_the_scan_ab.log).
     if (fuse_e_env < 0 && eslot && eslot->fuse_e == -2 && eslot->choice != 0u && !ev_start && !ev_stop && !P.ev_step_start && !P.ev_step_stop && !(sink && P.sink.dev)) {
@@ -1813,13 +1813,19 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
       const int k = eslot->e_phase - FIRST;      // index of this launch among the timed ones
       if (!ok) { (void)hipGetLastError(); eslot->fuse_e = 0; }
       else if (k < 0) eslot->e_phase++;
-      else if (k < 2 * NP) { e_ev_start = eslot->ev_e[k][0]; e_ev_stop = eslot->ev_e[k][1]; want = (k & 1) != 0; eslot->e_phase++; }
+      // NP launches with list E a role, one fused launch that is not timed (the other kernel's code is cold, the blocks' hints are the
+      // role form's), NP fused ones: timed in turns the two forms paid for each switch and read within 1 % of each other on a box
+      // where the fused form is 5 % faster in the steady state
+      else if (k < NP) { e_ev_start = eslot->ev_e[k][0]; e_ev_stop = eslot->ev_e[k][1]; want = false; eslot->e_phase++; }
+      else if (k == NP) { want = true; eslot->e_phase++; }
+      else if (k <= 2 * NP) { e_ev_start = eslot->ev_e[k - 1][0]; e_ev_stop = eslot->ev_e[k - 1][1]; want = true; eslot->e_phase++; }
       else {
         bool ready = true;
         for (int a = 0; a < 2 * NP && ready; a++) ready = hipEventQuery(eslot->ev_e[a][1]) == hipSuccess;
+        want = true;      // (the fused form runs on while its samples are read: one switch fewer if it stays)
         if (ready) {
           float ms[2] = {0.f, 0.f};
-          for (int a = 0; a < 2 * NP && ok; a++) { float t = 0.f; ok = hipEventElapsedTime(&t, eslot->ev_e[a][0], eslot->ev_e[a][1]) == hipSuccess; ms[a & 1] += t; }
+          for (int a = 0; a < 2 * NP && ok; a++) { float t = 0.f; ok = hipEventElapsedTime(&t, eslot->ev_e[a][0], eslot->ev_e[a][1]) == hipSuccess; ms[a < NP ? 0 : 1] += t; }
           eslot->us_e[0] = 1e3f * ms[0] / NP; eslot->us_e[1] = 1e3f * ms[1] / NP;
           eslot->fuse_e = (ok && ms[1] > 0.f && ms[1] < 0.985f * ms[0]) ? 1 : 0;
           want = eslot->fuse_e == 1;
@@ -1981,7 +1987,7 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if constexpr (CAN_FUSE_E) {
-    if (eslot && eslot->fuse_e < 0 && !eslot->e_sampling && !fuse_e && fuse_e_env < 0 && !S.dev && finish) {
+    if (eslot && eslot->fuse_e == -1 && !eslot->e_sampling && !fuse_e && fuse_e_env < 0 && !S.dev && finish) {
       // the class's first launch: its regions' list counts to pinned memory behind the scan (once per handle, frame and size class)
       bool ok = eslot->h_counts || hipHostMalloc(reinterpret_cast<void **>(&eslot->h_counts), (size_t)4096 * V2_L_COUNTS * 4, hipHostMallocDefault) == hipSuccess;
       ok = ok && (eslot->ev_counts || hipEventCreateWithFlags(&eslot->ev_counts, hipEventDisableTiming) == hipSuccess);

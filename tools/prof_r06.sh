@@ -13,18 +13,32 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py "$@" > $O/bench_default.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench_under_kernel_trace.log 2>&1
+DCRX_DEBUG_FLAGS=1 DCRX_DEBUG_FUSE_E=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench_under_kernel_trace.log 2>&1
 python3 $R/tools/timeline.py $O/trace > $O/timeline.txt 2>&1
 B="--steps 3 --warmup 1 --no-cpu-baseline"
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_a -- python3 $R/bench.py $B "$@" > $O/pmc_a.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_b -- python3 $R/bench.py $B "$@" > $O/pmc_b.log 2>&1
-timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O/pmc_rd -- python3 $R/bench.py $B "$@" > $O/pmc_rd.log 2>&1
-timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O/pmc_wr -- python3 $R/bench.py $B "$@" > $O/pmc_wr.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $B "$@" > $O/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $B "$@" > $O/pmc_write.log 2>&1
+# The counters of BOTH forms a config-2 handle may settle on (round 6: list E a role of the finishing launch / inside the scan kernel —
+# the handle times both and keeps the faster, which differs from box to box): each form forced for its passes (DCRX_DEBUG_FUSE_E), the
+# bench line quotes the traffic of the form it ran.
+pmc_passes() {   # $1: directory suffix, $2: DCRX_DEBUG_FUSE_E
+  export DCRX_DEBUG_FLAGS=1 DCRX_DEBUG_FUSE_E=$2
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O$1/pmc_a -- python3 $R/bench.py $B "$@" > $O$1/pmc_a.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O$1/pmc_b -- python3 $R/bench.py $B "$@" > $O$1/pmc_b.log 2>&1
+  timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O$1/pmc_rd -- python3 $R/bench.py $B "$@" > $O$1/pmc_rd.log 2>&1
+  timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O$1/pmc_wr -- python3 $R/bench.py $B "$@" > $O$1/pmc_wr.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O$1/pmc_fetch -- python3 $R/bench.py $B "$@" > $O$1/pmc_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O$1/pmc_write -- python3 $R/bench.py $B "$@" > $O$1/pmc_write.log 2>&1
+  unset DCRX_DEBUG_FLAGS DCRX_DEBUG_FUSE_E
+}
+pmc_passes "" 0
+mkdir -p ${O}_fused; cp $O/bench_default.log ${O}_fused/ 2>/dev/null
+DCRX_DEBUG_FLAGS=1 DCRX_DEBUG_FUSE_E=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${O}_fused/trace -- python3 $R/bench.py --no-cpu-baseline "$@" > ${O}_fused/bench_under_kernel_trace.log 2>&1
+python3 $R/tools/timeline.py ${O}_fused/trace > ${O}_fused/timeline.txt 2>&1
+pmc_passes "_fused" 1
+python3 $R/tools/prof_summary_r05.py ${O}_fused > ${O}_fused/summary.txt 2>&1
 python3 $R/tools/prof_summary_r05.py $O > $O/summary.txt 2>&1
 S=$O/summary
 cp $O/timeline.txt $S/timeline.txt
+mkdir -p $S/list_e_inside_the_scan; cp ${O}_fused/summary/* $S/list_e_inside_the_scan/ 2>/dev/null; cp ${O}_fused/timeline.txt ${O}_fused/summary.txt $S/list_e_inside_the_scan/ 2>/dev/null
 export DCRX_DEBUG_FLAGS=1
 for spec in tail_as_a_role:131072 side_streams:65536 separate_launches:32768 three_launch_form:64 scan_only:2; do
   name=${spec%%:*}; fl=${spec##*:}
@@ -50,5 +64,5 @@ timeout 900 python3 $R/tools/stage.py --reads 4000000 --py-gzip 2>/dev/null | gr
 timeout 600 python3 $R/tools/long_reads.py 2>/dev/null | tail -8 > $S/long_reads.log
 bash $R/tools/r04_cliff.sh > $S/cliff_clustered_n.log 2>&1
 timeout 300 $R/tools/micro/lds_gather > $S/lds_gather_layouts.log 2>&1
-rm -rf $O/trace $O/pmc_*
+rm -rf $O/trace $O/pmc_* ${O}_fused/trace ${O}_fused/pmc_*
 cat $O/summary.txt | tail -12
