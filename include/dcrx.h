@@ -477,7 +477,11 @@ int64_t dcrx_cdr3_batch(const dcrx_cdr3_genes_t *genes, uint64_t n, const int32_
  * for batches of 2^25 reads and more: the fourth call of such a class then waits for the third's finishing launch, once
  * (milliseconds; such batches gain up to 6 % from the choice).  The default is never to wait.
  * orientation: DCRX_ORIENT_REVERSE or DCRX_ORIENT_FORWARD, as in dcrx_cfg_t (the frame whose launches are meant).
- * DCRX_E_INVALID for a null argument. */
+ * DCRX_E_INVALID for a null argument.
+ * Round 6: where the scan kernel takes the tail, a handle also settles per size class whether list E's entries (one gene to rescue) are
+ * finished inside the scan kernel as well (launch_form 4) or by the finishing launch (3): where list E held at most a quarter of the
+ * reads of the class's first launch, three launches of each form are timed (events on the dispatches, read without waiting) from
+ * the class's ninth launch on, and the faster form stays. */
 typedef struct dcrx_tune_state {
   uint32_t rescue_waves, launches;
   float us_first, us_second;

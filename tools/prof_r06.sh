@@ -8,6 +8,7 @@
 # lengths, clustered exception bytes, the LDS layout micro-benchmark, the read-fetch layouts by themselves.
 TAG=${1:-r06}
 shift
+ARGS=("$@")      # further bench arguments (the counter passes below are a function: its own "$@" are not these)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -21,12 +22,12 @@ B="--steps 3 --warmup 1 --no-cpu-baseline"
 # bench line quotes the traffic of the form it ran.
 pmc_passes() {   # $1: directory suffix, $2: DCRX_DEBUG_FUSE_E
   export DCRX_DEBUG_FLAGS=1 DCRX_DEBUG_FUSE_E=$2
-  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O$1/pmc_a -- python3 $R/bench.py $B "$@" > $O$1/pmc_a.log 2>&1
-  timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O$1/pmc_b -- python3 $R/bench.py $B "$@" > $O$1/pmc_b.log 2>&1
-  timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O$1/pmc_rd -- python3 $R/bench.py $B "$@" > $O$1/pmc_rd.log 2>&1
-  timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O$1/pmc_wr -- python3 $R/bench.py $B "$@" > $O$1/pmc_wr.log 2>&1
-  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O$1/pmc_fetch -- python3 $R/bench.py $B "$@" > $O$1/pmc_fetch.log 2>&1
-  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O$1/pmc_write -- python3 $R/bench.py $B "$@" > $O$1/pmc_write.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O$1/pmc_a -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_a.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O$1/pmc_b -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_b.log 2>&1
+  timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $O$1/pmc_rd -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_rd.log 2>&1
+  timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $O$1/pmc_wr -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_wr.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O$1/pmc_fetch -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O$1/pmc_write -- python3 $R/bench.py $B "${ARGS[@]}" > $O$1/pmc_write.log 2>&1
   unset DCRX_DEBUG_FLAGS DCRX_DEBUG_FUSE_E
 }
 pmc_passes "" 0
