@@ -634,6 +634,19 @@ DCRX_DEVNI bool rescue(const DevTables &T, const uint32_t *lds_trans, const Fram
     const int kk = REV ? top - wi : wi;                       // word index in scan order
     const int cnt = (kk == top) ? ((n - 1) & 15) + 1 : 16;    // bases it holds
     uint32_t wv = F.r.words[kk];
+    if (cnt == 16 && xc.nextpos >= i + 16) {
+      // a whole word without an unknown byte: sixteen look-ups with nothing but the OR of the entries; only a word inside which
+      // a keyword of the class ends is walked base by base (round 6: the long form's reads meet this loop whenever a class has
+      // more hits than its list holds — short half tags in 600 nt and more)
+      const uint32_t wf = REV ? ~wv : wv;
+      uint32_t ef = e, accw = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        ef = trans_at<TABLE_LDS>(lds_trans, T, (ef & TE_ROW_MASK) + (dcrx_ubfe(wf, REV ? 30 - 2 * j : 2 * j, 2) << 2));
+        accw |= ef;
+      }
+      if (!((accw >> BIT) & 1u)) { e = ef; i += 16; continue; }
+    }
     if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
 #pragma unroll 1
     for (int k = 0; k < cnt; k++, i++) {
@@ -658,6 +671,8 @@ struct HalfHits {
   uint32_t cnts;
   uint32_t keep = 0xFu;   // classes that are collected at all
   uint32_t compact = 0;   // 1: two lists only (V classes share list 0, J classes list 1; `keep` holds one class of each)
+  uint32_t cap = 4;       // entries per list (HH_K; the long form's two compact lists hold 2 * HH_K each)
+  uint32_t wide = 0;      // 1: entries `1 | state (relative to the first row) << 1 | end_pos << 15` — positions up to 65 535 (the long form)
   DCRX_DEV int list_of(int cls4) const { return compact ? (cls4 >> 1) : cls4; }
   DCRX_DEV int count(int cls4) const { return (int)((cnts >> (8 * cls4)) & 0xFFu); }
 };
@@ -669,8 +684,9 @@ DCRX_DEVNI bool rescue_list(const DevTables &T, const Frame<REV> &F, const HalfH
   const int cls4 = GENE * 2 + (HALF - 1);
   const int cnt = hh.count(cls4);
   for (int h = 0; h < cnt; h++) {
-    const uint32_t t = hh.slot[hh.list_of(cls4) * HH_K + h];
-    if (rescue_at<REV>(T, F, GENE, HALF, ((t >> 9) & 0x3FFFu) - (T.row0 >> 4), (int)(t >> 23), end_of_v, out, C)) return true;
+    const uint32_t t = hh.slot[hh.list_of(cls4) * (int)hh.cap + h];
+    const uint32_t st = hh.wide ? ((t >> 1) & 0x3FFFu) : ((t >> 9) & 0x3FFFu) - (T.row0 >> 4);
+    if (rescue_at<REV>(T, F, GENE, HALF, st, hh.wide ? (int)(t >> 15) : (int)(t >> 23), end_of_v, out, C)) return true;
   }
   return false;
 }
@@ -918,7 +934,7 @@ DCRX_DEV void collect_hits(HalfHits &hh, uint32_t hb, uint32_t t) {
     const int c = dcrx_ctz32(hb);
     hb &= hb - 1u;
     const uint32_t idx = (hh.cnts >> (8 * c)) & 0xFFu;
-    if (idx < (uint32_t)HH_K) hh.slot[hh.list_of(c) * HH_K + (int)idx] = t;
+    if (idx < hh.cap) hh.slot[hh.list_of(c) * (int)hh.cap + (int)idx] = t;
     if (idx < 255u) hh.cnts += 1u << (8 * c);
   }
 }
@@ -1037,7 +1053,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_VH1_BIT) & 3u) {                // a V half1 (:294-335) or half2 (:339-390) keyword occurs
       if (DEFER) return DCRX_S_DEFER;
       const int half = ((so.acc >> TE_VH1_BIT) & 1u) ? 1 : 2;  // half2 is tried only when no half1 hit exists
-      if (!((hh && hh->count(half - 1) <= HH_K) ? rescue_list<REV>(T, F, *hh, 0, half, 0, vdat, C)
+      if (!((hh && hh->count(half - 1) <= (int)hh->cap) ? rescue_list<REV>(T, F, *hh, 0, half, 0, vdat, C)
                : rescue<REV, TABLE_LDS>(T, lds_trans, F, 0, half, 0, vdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDV1NOTV2 : DCRX_C_FOUNDV2NOTV1);       // :334 / :389
         return half == 1 ? DCRX_S_V_HALF1_EXHAUSTED : DCRX_S_V_HALF2_EXHAUSTED;
@@ -1066,7 +1082,7 @@ DCRX_DEVNI int dcr_frame(const DevTables &T, const uint32_t *lds_trans, const Re
     } else if ((so.acc >> TE_JH1_BIT) & 3u) {                // a J half1 (:422-470) or half2 (:473-527) keyword occurs
       if (DEFER) return DCRX_S_DEFER;                        // nothing has been counted for this read yet
       const int half = ((so.acc >> TE_JH1_BIT) & 1u) ? 1 : 2;
-      if (!((hh && hh->count(2 + half - 1) <= HH_K) ? rescue_list<REV>(T, F, *hh, 1, half, end_of_v, jdat, C)
+      if (!((hh && hh->count(2 + half - 1) <= (int)hh->cap) ? rescue_list<REV>(T, F, *hh, 1, half, end_of_v, jdat, C)
                : rescue<REV, TABLE_LDS>(T, lds_trans, F, 1, half, end_of_v, jdat, C))) {
         C.add(half == 1 ? DCRX_C_FOUNDJ1NOTJ2 : DCRX_C_FOUNDV2NOTV1);       // :469 / :526 (the reference bumps the V key)
         jstatus = half == 1 ? DCRX_S_J_HALF1_EXHAUSTED : DCRX_S_J_HALF2_EXHAUSTED;
@@ -1667,28 +1683,66 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
 // ------------------------------------------------------------------------------
 // Reads beyond the register shapes and the packed hit lists (512 .. 65 535 nt: merged pairs, long amplicons — the
 // reference has no length limit, decombine.py:228-265, :534-585): one read per lane in the plainest form there is.
-// One scan per frame over the packed words in memory with the one-base table — in LDS where the tables' image fits beside the
-// block's counters (every BASELINE tag set's does: 28 KB of rows for config 2, 59 KB for the extended alpha set), else in
-// global memory — OR of the entry flags,
-// and per full-tag class the count and the first hit's state and end, all in plain integers (the accumulators and hit
-// lists of the forms above pack a position into nine bits) —, then dcr_frame with the rescue by re-scanning.
-// Slow by design: such reads are rare, and everything else of their batch stays on the fast shapes.
+// Per frame a scan over the packed words in memory with the one-base table — in LDS where the tables' image fits beside the
+// block's counters and the lanes' slots (every BASELINE tag set's does: 28 KB of rows for config 2, 59 KB for the extended alpha
+// set), else in global memory —: the OR of the entry flags, per full-tag class the count and the first hit's state and end, the
+// half-tag hits in lists per class, all positions in plain integers (the accumulators and hit lists of the forms above pack a
+// position into nine bits); then dcr_frame with the rescue from the lists.
 // ------------------------------------------------------------------------------
-template <bool REV, bool TABLE_LDS = false>
-DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv) {
-  const Frame<REV> F(rv);
+// The long form's scan, in two passes over the words of the frame (round 6; scan_plain before: one pass, every base with its
+// tests — 12 of the form's 62 vector instructions per base and lane — and dcr_frame's rescue by re-scanning the whole read, once
+// per half-tag class, for every wave that held one such read: nearly all).
+//   pass 1: word by word, sixteen unrolled look-ups with nothing but the OR of the entries (4 instructions per base); a word whose
+//           OR shows a flag — some keyword ends inside it: two to four words of a rearranged read, none of the others — is noted
+//           with the state in front of it (7 to 15 notes per lane in LDS).  The partial word and words that hold an exception
+//           byte go base by base.
+//   pass 2: the noted words again, base by base with scan_plain's bookkeeping and every half-tag hit into the read's hit lists
+//           (HalfHits, wide entries): dcr_frame rescues from the lists and re-scans only a class with more than HH_K hits.
+//           Where a lane's notes could run out, every lane of the wave takes pass 2 over the notes it has and goes on with pass 1.
+#ifdef DCRX_LONG_STATS
+static unsigned long long g_long_stats[32];
+#endif
+constexpr int LONG_FW_MIN = 7, LONG_FW_MAX = 15;      // notes per lane: as many as the block's LDS holds beside the tables (the launch's choice, an odd slot)
+constexpr int DCRX_LONG_SLOT_MIN = (HH_STRIDE + LONG_FW_MIN) | 1, DCRX_LONG_SLOT_MAX = (HH_STRIDE + LONG_FW_MAX) | 1;      // dwords of LDS per lane (odd: the lanes' slots on different banks)
+constexpr uint32_t TE_FLAGS_MASK = 0xFFu << TE_VFULL_BIT;
+
+template <bool REV, bool TABLE_LDS>
+struct LongScan {
+  const DevTables &T;
+  const uint32_t *lds_trans;
+  const ReadView &rv;
+  HalfHits &hh;
   ScanOut so;
-  so.acc = 0; so.vcount = so.jcount = 0; so.vstate = so.jstate = 0; so.vend = so.jend = 0;
-  const int n = F.n();
-  if (n <= 0) return so;
-  uint32_t e = T.row0;
-  ExcCursor<REV> xc(F.r);
-  const int top = (n - 1) >> 4;
-  int i = 0;
-  for (int wi = 0; wi <= top; wi++) {
-    const int kk = REV ? top - wi : wi;                       // word index in scan order
-    const int cnt = (kk == top) ? ((n - 1) & 15) + 1 : 16;    // bases it holds
-    uint32_t wv = F.r.words[kk];
+  ExcCursor<REV> xc;
+  int top, cnt_top;
+  DCRX_DEV LongScan(const DevTables &T_, const uint32_t *lt, const ReadView &rv_, HalfHits &hh_) : T(T_), lds_trans(lt), rv(rv_), hh(hh_), xc(rv_) {
+    so.acc = 0; so.vcount = so.jcount = 0; so.vstate = so.jstate = 0; so.vend = so.jend = 0;
+    top = (rv.n - 1) >> 4; cnt_top = ((rv.n - 1) & 15) + 1;
+  }
+  DCRX_DEV int word_of(int wi) const { return REV ? top - wi : wi; }                      // word index of the wi-th word in scan order
+  DCRX_DEV int first_pos(int wi) const { return REV ? (wi == 0 ? 0 : cnt_top + 16 * (wi - 1)) : 16 * wi; }
+  // pass 2 of one word: from entry `e` in front of it; returns the entry behind it
+  // what a flagged entry (reached behind frame position i) leaves in the scan's results
+  DCRX_DEV void note_hit(const uint32_t e, const int i) {
+    const uint32_t fl = e & ~TE_ROW_MASK;
+    so.acc |= fl;
+    const uint32_t st = ((e & TE_ROW_MASK) - T.row0) >> 4;
+    if ((fl >> TE_VFULL_BIT) & 1u) { if (so.vcount == 0) { so.vstate = st; so.vend = i; } so.vcount++; }
+    if ((fl >> TE_JFULL_BIT) & 1u) { if (so.jcount == 0) { so.jstate = st; so.jend = i; } so.jcount++; }
+    if ((fl >> TE_VMULTI_BIT) & 1u) so.vcount = so.vcount < 2 ? 2 : so.vcount;      // two tags ended at one position
+    if ((fl >> TE_JMULTI_BIT) & 1u) so.jcount = so.jcount < 2 ? 2 : so.jcount;
+    const uint32_t hb = (e >> TE_VH1_BIT) & 0xFu;
+    if (hb) collect_hits(hh, hb, 1u | (st << 1) | ((uint32_t)i << 15));
+  }
+  // pass 2 of one word: from entry `e` in front of it; returns the entry behind it.  wv: the word, rv.words[word_of(wi)]
+  DCRX_DEVNI uint32_t replay(const int wi, uint32_t e, uint32_t wv) {
+    const int kk = word_of(wi);
+    const int cnt = (kk == top) ? cnt_top : 16;
+    int i = first_pos(wi);
+    while (xc.nextpos < i) xc.advance();
+    // (measured and dropped: the sixteen entries of a clean word first, a bit per flagged one, then the flagged ones in turn — so
+    // that the lanes of a wave, each at another base of its word, do not take the bookkeeping one after the other —: 16 more
+    // registers in a kernel at its 128, 30 of them spilled: 600 nt 0.745 -> 0.796 ms per 2 M reads)
     if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
 #pragma unroll 1
     for (int k = 0; k < cnt; k++, i++) {
@@ -1696,22 +1750,135 @@ DCRX_DEVNI ScanOut scan_plain(const DevTables &T, const uint32_t *lds_trans, con
       wv = REV ? (wv << 2) : (wv >> 2);
       if (xc.hit(i)) { e = T.row0; continue; }                // unknown byte: machine back to the root
       e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
-      const uint32_t fl = e & ~TE_ROW_MASK;
-      if (!fl) continue;
-      so.acc |= fl;
-      const uint32_t st = ((e & TE_ROW_MASK) - T.row0) >> 4;
-      if ((fl >> TE_VFULL_BIT) & 1u) { if (so.vcount == 0) { so.vstate = st; so.vend = i; } so.vcount++; }
-      if ((fl >> TE_JFULL_BIT) & 1u) { if (so.jcount == 0) { so.jstate = st; so.jend = i; } so.jcount++; }
-      if ((fl >> TE_VMULTI_BIT) & 1u) so.vcount = so.vcount < 2 ? 2 : so.vcount;      // two tags ended at one position
-      if ((fl >> TE_JMULTI_BIT) & 1u) so.jcount = so.jcount < 2 ? 2 : so.jcount;
+      if (e & ~TE_ROW_MASK) note_hit(e, i);
+    }
+    return e;
+  }
+};
+
+template <bool REV, bool TABLE_LDS = false>
+DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh, dcrx_lds_u32 *fw, const int fwk,
+                             const bool pass1_only = false) {
+  hh.cnts = 0; hh.wide = 1u;
+  LongScan<REV, TABLE_LDS> L(T, lds_trans, rv, hh);
+  const int n = rv.n;
+  if (n <= 0) return L.so;
+  const int top = L.top, cnt_top = L.cnt_top;
+  // ---- pass 1 ----
+  uint32_t e = T.row0, acc1 = 0;
+  int nfw = 0;
+  // pass 2 over the notes in hand (the next note's word is asked for before this one's bases are walked: a load per note,
+  // each a trip to memory of its own, was a third of the pass)
+  auto take_back = [&]() {
+    if (nfw <= 0) return;
+    uint32_t t = fw[0];
+    uint32_t wv = rv.words[L.word_of((int)(t >> 14))];
+    for (int k = 0; k < nfw; k++) {
+      uint32_t tn = t, wn = wv;
+      if (k + 1 < nfw) { tn = fw[k + 1]; wn = rv.words[L.word_of((int)(tn >> 14))]; }
+      (void)L.replay((int)(t >> 14), T.row0 + ((t & 0x3FFFu) << 4), wv);
+      t = tn; wv = wn;
+    }
+    nfw = 0;
+  };
+  bool mid = false;      // the notes were taken back before the scan's end (the hit lists then hold every class)
+  hh.keep = 0xFu; hh.compact = 0u; hh.cap = (uint32_t)HH_K;
+  {
+    ExcCursor<REV> x1(rv);
+    // The words come in chunks of sixteen (64 bytes, eight 8-byte loads at consecutive addresses: a read starts on an 8-byte boundary
+    // and its stride is a multiple of 8) and are scanned out of registers, four at a time.
+    const int ptop = top >> 1, ctop = top >> 4;
+    const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
+#pragma unroll 1
+    for (int ci = 0; ci <= ctop; ci++) {
+      const int cp = REV ? ctop - ci : ci;
+      uint32_t cw[16];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint2 t; t.x = 0u; t.y = 0u;
+        if (8 * cp + k <= ptop) t = wp2[8 * cp + k];
+        cw[2 * k] = t.x; cw[2 * k + 1] = t.y;
+      }
+#pragma unroll 1
+      for (int g = 0; g < 4; g++) {
+        const int gg = REV ? 3 - g : g;
+        if (16 * cp + 4 * gg > top) continue;                    // (the whole group lies beyond the read)
+        uint32_t w4[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) w4[h] = gg == 0 ? cw[h] : (gg == 1 ? cw[4 + h] : (gg == 2 ? cw[8 + h] : cw[12 + h]));
+        // The notes are taken back whenever a lane of the wave could run out of them inside the next four words — by every lane of the
+        // wave at once: a lane that did so on its own would have the other sixty-three wait for it, each in its turn.
+#ifndef DCRX_HOST_EMUL
+        if (__ballot(nfw > fwk - 4))
+#else
+        if (nfw > fwk - 4)
+#endif
+        {
+          if (pass1_only) nfw = 0;      // (profiling: the first pass alone)
+          take_back(); mid = true;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+          const int hw = REV ? 3 - h : h;
+          const int kk = 16 * cp + 4 * gg + hw;
+          if (kk > top) continue;                                  // (beyond the read's last word)
+          const int wi = REV ? top - kk : kk;
+          const uint32_t word = w4[hw];
+          const int cnt = (kk == top) ? cnt_top : 16;
+          const int i0 = L.first_pos(wi);
+          const uint32_t e0 = e;
+          uint32_t accw = 0;
+          if (cnt == 16 && x1.nextpos >= i0 + 16) {
+            const uint32_t wv = REV ? ~word : word;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              const uint32_t code = dcrx_ubfe(wv, REV ? 30 - 2 * j : 2 * j, 2);
+              e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
+              accw |= e;
+            }
+          } else {
+            uint32_t wv = word;
+            if (REV) wv = ~wv << (2 * (16 - cnt));
+            int i = i0;
+#pragma unroll 1
+            for (int k = 0; k < cnt; k++, i++) {
+              const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
+              wv = REV ? (wv << 2) : (wv >> 2);
+              if (i == x1.nextpos) { e = T.row0; x1.advance(); continue; }
+              e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (code << 2));
+              accw |= e;
+            }
+          }
+          acc1 |= accw;
+          if (accw & TE_FLAGS_MASK) fw[nfw++] = ((uint32_t)wi << 14) | (((e0 & TE_ROW_MASK) - T.row0) >> 4);
+        }
+      }
     }
   }
-  return so;
+#ifdef DCRX_LONG_STATS
+  g_long_stats[nfw < 15 ? nfw : 15]++; g_long_stats[16] += (unsigned long long)(top + 1);
+#endif
+  // ---- pass 2: the notes that are left ----
+  if (pass1_only) { L.so.acc = e; return L.so; }
+  if (!mid) {
+    // Every flag of the read is known before its first hit is noted: dcr_frame will ask for one half-tag class per gene at most
+    // (none where a full tag was seen; half 1 where a half-1 keyword occurs, else half 2 — :294/:339, :422/:473), so the lists
+    // hold only those — two lists of 2 * HH_K entries in the room of four (short half tags meet a long read by chance: with
+    // four entries a list every wave held a lane that overflowed and scanned its whole read again, base by base).
+    uint32_t keep = 0u;
+    if (!((acc1 >> TE_VFULL_BIT) & 1u)) keep |= ((acc1 >> TE_VH1_BIT) & 1u) ? 1u : 2u;
+    if (!((acc1 >> TE_JFULL_BIT) & 1u)) keep |= ((acc1 >> TE_JH1_BIT) & 1u) ? 4u : 8u;
+    hh.keep = keep; hh.compact = 1u; hh.cap = 2u * (uint32_t)HH_K;
+  }
+  take_back();
+  return L.so;
 }
 
+// `slot`: slot_dwords (DCRX_LONG_SLOT_MIN .. _MAX) dwords of LDS for this lane (the hit lists, then the notes of pass 1)
 template <bool UNIFORM_LEN, bool TABLE_LDS = false>
 DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
-                                 const Counters &C, dcrx_record_t *records) {
+                                 const Counters &C, dcrx_record_t *records, uint32_t *slot, const int slot_dwords) {
+  const int fwk = slot_dwords - HH_STRIDE;
   ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
@@ -1725,19 +1892,25 @@ DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, 
     while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
     rv.e1 = (int)lo;
   }
+  HalfHits hh;
+  hh.slot = DCRX_TO_LDS(slot);
+  dcrx_lds_u32 *fw = DCRX_TO_LDS(slot) + HH_STRIDE;
   __align__(16) dcrx_record_t rec;
   rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0;
   rec.vdel = rec.jdel = 0;
   // (the orientation dispatch of decombine.py:999-1010, as decombine_list_one has it)
   int status = DCRX_S_V_NONE, frame = 0;
   for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
+    const bool p1 = (cfg.flags & DCRX_F_PROFILE_LIST_SCAN_ONLY) != 0u, p12 = (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) != 0u;      // profiling aids: price the scan's passes alone (records are NOT results)
     if (attempt == 0) {
-      const ScanOut so = scan_plain<true, TABLE_LDS>(T, lds_trans, rv);
-      status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, nullptr); frame = 0;
+      const ScanOut so = scan_long<true, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1);
+      if (p1 || p12) { rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend); rec.j_end = (uint16_t)hh.cnts; status = 254; break; }
+      status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
       if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
     } else {
-      const ScanOut so = scan_plain<false, TABLE_LDS>(T, lds_trans, rv);
-      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, nullptr); frame = 1;
+      const ScanOut so = scan_long<false, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1);
+      if (p1 || p12) { rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend); rec.j_end = (uint16_t)hh.cnts; status = 254; break; }
+      status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
     }
   }
   C.add(DCRX_C_READ_COUNT);                                           // :991

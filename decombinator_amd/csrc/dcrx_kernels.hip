@@ -771,12 +771,14 @@ __global__ void zero_counters_kernel(unsigned long long *__restrict__ counters) 
 // one texture-address unit (the launch ran at 0.18 T bases/s), out of LDS a gather over 32 banks.
 template <bool UNIFORM_LEN, bool TABLE_LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void decombine_long_kernel(DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records,
-                                                               unsigned long long *__restrict__ counters) {
+                                                               unsigned long long *__restrict__ counters, const uint32_t slot_dwords) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_trans = smem + DCRX_N_COUNTERS;
   static_assert(DCRX_N_COUNTERS % 4 == 0, "the rows stay 16-byte aligned");
   const int tid = threadIdx.x;
+  // a lane's slot (hit lists, the notes of the scan's first pass) behind the tables' image
+  uint32_t *slot = lds_trans + (TABLE_LDS ? T0.lds_image_bytes / 4 : 0u) + (size_t)tid * slot_dwords;
   if (tid < DCRX_N_COUNTERS) lds_counts[tid] = 0;
   DevTables T = T0;
   if (TABLE_LDS) {
@@ -788,13 +790,13 @@ __global__ __launch_bounds__(BLOCK) void decombine_long_kernel(DevTables T0, Bat
   __syncthreads();
   const Counters C{lds_counts};
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + tid; r < B.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
-    decombine_long_one<UNIFORM_LEN, TABLE_LDS>(T, lds_trans, B, cfg, r, C, records);
+    decombine_long_one<UNIFORM_LEN, TABLE_LDS>(T, lds_trans, B, cfg, r, C, records, slot, (int)slot_dwords);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
 template <bool TABLE_LDS, int BLOCK>
 static hipError_t launch_long_as(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
-                                 unsigned long long *d_counters, hipStream_t s, const uint32_t grid, const uint32_t lds) {
+                                 unsigned long long *d_counters, hipStream_t s, const uint32_t grid, const uint32_t lds, const uint32_t slot_dwords) {
   auto ku = decombine_long_kernel<true, TABLE_LDS, BLOCK>;
   auto kr = decombine_long_kernel<false, TABLE_LDS, BLOCK>;
   static bool attr_seen[64];
@@ -805,30 +807,37 @@ static hipError_t launch_long_as(const LaunchPlan &P, const DevTables &T, const 
     if (e != hipSuccess) return e;
     attributes_set_on_device(attr_seen);
   }
-  if (B.lens) hipExtLaunchKernelGGL(kr, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
-  else hipExtLaunchKernelGGL(ku, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters);
+  if (B.lens) hipExtLaunchKernelGGL(kr, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords);
+  else hipExtLaunchKernelGGL(ku, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords);
   return hipGetLastError();
 }
 static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                               unsigned long long *d_counters, hipStream_t s) {
   hipExtLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, s, P.ev_step_start, nullptr, 0, d_counters);
   const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
-  // the tables in LDS where a block's image leaves room for two blocks of 512 threads per compute unit or one of 1 024 (long
-  // dependent chains: the waves of a unit hide one another's look-ups); a batch of a few reads keeps the form without staging
-  const uint32_t lds = DCRX_N_COUNTERS * 4u + T.lds_image_bytes;
+  // the tables in LDS where a block's image and its lanes' slots leave room for a block of 1 024 threads per compute unit (long dependent
+  // chains: the waves of a unit hide one another's look-ups; 4 waves per SIMD is what the kernel's registers allow), else one of 512;
+  // a batch of a few reads keeps the form without staging
+  constexpr uint32_t LDS_CU = 160u * 1024u;
+  auto lds_of = [&](const uint32_t block, const bool tables, const uint32_t slot) { return DCRX_N_COUNTERS * 4u + (tables ? T.lds_image_bytes : 0u) + block * slot * 4u; };
+  // the largest slot (an odd number of dwords, DCRX_LONG_SLOT_MIN .. _MAX: the more notes a lane holds, the fewer times its wave takes them back mid-scan) that `per_cu` blocks leave room for; 0: none
+  auto slot_for = [&](const uint32_t block, const uint32_t per_cu) {
+    for (uint32_t sl = DCRX_LONG_SLOT_MAX; sl >= (uint32_t)DCRX_LONG_SLOT_MIN; sl -= 2u) if (per_cu * lds_of(block, true, sl) <= LDS_CU) return sl;
+    return 0u;
+  };
   static const bool no_lds = dcrx_debug_env("DCRX_DEBUG_LONG_GLOBAL_TABLES") != nullptr;      // (A/B)
-  if (!no_lds && T.lds_image_bytes && lds <= 156u * 1024u && B.n_reads >= 4096u) {
-    if (lds <= 78u * 1024u) {
-      const uint32_t per_cu = std::min<uint32_t>(4u, (160u * 1024u) / lds);
-      const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, (B.n_reads + 511) / 512));
-      return launch_long_as<true, 512>(P, T, B, cfg, rec, d_counters, s, grid, lds);
+  if (!no_lds && T.lds_image_bytes && slot_for(512, 1) && B.n_reads >= 4096u) {
+    if (const uint32_t sl = slot_for(1024, 1)) {
+      const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 1023) / 1024));
+      return launch_long_as<true, 1024>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(1024, true, sl), sl);
     }
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 1023) / 1024));
-    return launch_long_as<true, 1024>(P, T, B, cfg, rec, d_counters, s, grid, lds);
+    const uint32_t sl = slot_for(512, 1);
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 511) / 512));
+    return launch_long_as<true, 512>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(512, true, sl), sl);
   }
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, (B.n_reads + 63) / 64));      // (a wave per block where the batch is small: long chains, few reads)
-  if (B.n_reads > (uint64_t)grid * 64) return launch_long_as<false, 256>(P, T, B, cfg, rec, d_counters, s, grid, DCRX_N_COUNTERS * 4u);
-  return launch_long_as<false, 64>(P, T, B, cfg, rec, d_counters, s, grid, DCRX_N_COUNTERS * 4u);
+  if (B.n_reads > (uint64_t)grid * 64) return launch_long_as<false, 256>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(256, false, DCRX_LONG_SLOT_MAX), DCRX_LONG_SLOT_MAX);
+  return launch_long_as<false, 64>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(64, false, DCRX_LONG_SLOT_MAX), DCRX_LONG_SLOT_MAX);
 }
 
 hipError_t launch_decombine(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg,

@@ -395,6 +395,9 @@ constexpr uint32_t V2_RING_MAXBATCHES = 16;
 //   event ring slot (odd stride): the read's NW words, two zero words, read | flags, the flag log's NW words, the digest word, padding
 template <int NW> constexpr int v2_ering_stride() { return (2 * NW + 4) | 1; }      // 25 words for NW = 10
 constexpr uint32_t V2_ERING_BATCHES = 8;
+#ifndef DCRX_V2_HELP_DRAIN
+#define DCRX_V2_HELP_DRAIN 0      // 1: scanning waves that have left their loop help to empty the rings — measured level (profiles/r06/scanning_waves_help_to_drain_ab.log): off
+#endif
 constexpr float V2_FUSE_E_MAX_SHARE = 0.25f;      // list E's share of the reads up to which finishing its entries inside the scan kernel is tried (and timed)
 
 // (SINK: the fused form's tail waves also leave the tuple sink's items — an instantiation of its own, so that the kernel of a
@@ -477,181 +480,13 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
 #ifdef DCRX_SCAN_STAMPS
   stamp_setup = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (FUSE_E && (uint32_t)(tid >> 6) >= n_scan_waves + tw) {
-   if constexpr (FUSE_E) {
-    // ---- a rescue wave (FUSE_E): batches of 64 event entries of list E out of the event ring, as the scanning waves fill them ----
-    constexpr bool REV = FUSE == 1;
-#if DCRX_V2_PRIO_TAIL
-    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
-#endif
-    uint32_t kw_base[K_NCLASS];
-#pragma unroll
-    for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
-    const Rescue2Tabs rt = rescue2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV, kw_base);
-    const Counters C{lds_counts}, Cdry{lds_dry};
-    constexpr uint32_t nb_mask = V2_ERING_BATCHES - 1u, nb_shift = (uint32_t)__builtin_ctz(V2_ERING_BATCHES);
-    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
-    for (uint32_t spins = 0;;) {
-      uint32_t c = 0, nvalid = 0;
-      if (lane == 0) {      // (the tail ring's protocol on the event ring's words)
-        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
-        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!mine) nvalid = 0;
-        else if (f == 64u) nvalid = 64u;
-        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
-          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t rem = h - 64u * c;
-          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
-        }
-        if (nvalid && nvalid != V2_RING_EXIT) {
-          uint32_t expect = c;
-          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM2], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
-        }
-      }
-      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
-      if (nvalid == V2_RING_EXIT) break;
-      if (!nvalid) {
-        if (++spins > (1u << 24)) { if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull); break; }
-        __builtin_amdgcn_s_sleep(4);
-        continue;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      uint32_t *sl = ring2 + ((64u * c + (uint32_t)lane) & ering_mask) * ES;
-      int status = -2;
-      uint32_t errs = 0, x0 = 0;
-      uint32_t lg[NW];
-#pragma unroll
-      for (int k = 0; k < NW; k++) lg[k] = 0u;
-      if ((uint32_t)lane < nvalid) {
-        x0 = sl[NW + 2];
-#pragma unroll
-        for (int k = 0; k < NW; k++) lg[k] = sl[NW + 3 + k];
-        const uint32_t dg = sl[2 * NW + 3];
-        const uint32_t r = x0 & V2_R_MASK;
-        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
-        const LdsWords lw{dcrx_ldsaddr_of(sl)};
-        auto on_ok = [&](dcrx_record_t rec, const uint32_t) {      // a decombined read's record, where its fields are known
-          rec.frame = (uint8_t)(o ? 0 : 1);
-          DCRX_STORE_FINISH(records + r, rec);
-        };
-        status = rescue2_fast_to<REV, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, dg);
-        if (status > 0) {      // settled, not decombined: the status alone
-          dcrx_record_t rec;
-          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-          rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1);
-          DCRX_STORE_FINISH(records + r, rec);
-        } else if (status < 0) errs = 0;
-      }
-      v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
-      if (__builtin_expect(status == RESCUE2_SLOW, 0)) {      // what the lean form does not settle: the launch's left list (its placeholder record stands)
-        uint32_t ww[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) ww[k] = sl[k];
-        if (!v2_left_push<NW>(Q.left, queue_count, x0, lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, x0 & V2_R_MASK, false);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        __hip_atomic_store(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        atomicAdd(&lds_work[V2_WK_GEN2 + (c & nb_mask)], 1u);
-      }
-      spins = 0;
-    }
-   }
-  } else if (FUSE >= 0 && (uint32_t)(tid >> 6) >= n_scan_waves) {
-   if constexpr (FUSE >= 0) {
-    // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
-    constexpr bool REV = FUSE == 1;
-#if DCRX_V2_PRIO_TAIL
-    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
-#endif
-    const Tail2Tabs tt = tail2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV);
-    const Counters C{lds_counts};
-    const uint32_t nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
-    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
-    for (uint32_t spins = 0;;) {
-      uint32_t c = 0, nvalid = 0;
-      if (lane == 0) {
-        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // (FILLED speaks of batch c only once the ring batch's earlier occupants have been finished: with a short ring a wave may
-        // still be at work on batch c - NB, its count not yet taken back)
-        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
-        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!mine) nvalid = 0;
-        else if (f == 64u) nvalid = 64u;
-        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
-          // every scanning wave has signed off (its last entries and its share of FILLED before that): what is left is final
-          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t rem = h - 64u * c;
-          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
-        }
-        if (nvalid && nvalid != V2_RING_EXIT) {
-          uint32_t expect = c;
-          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
-        }
-      }
-      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
-      if (nvalid == V2_RING_EXIT) break;
-      if (!nvalid) {
-        if (++spins > (1u << 24)) {           // (never seen: a scanning wave that does not sign off) — said in the call's counters, not passed over in silence
-          if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-        continue;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries were written before FILLED said so: nothing is read early)
-      uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
-      int status = -2;
-      uint32_t r = 0, dg = 0;
-      uint64_t tup = 0;
-      if ((uint32_t)lane < nvalid) {
-        r = sl[NW + 2]; dg = sl[NW + 3];
-        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
-        dcrx_record_t rec;
-        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-        const LdsWords lw{dcrx_ldsaddr_of(sl)};
-        if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(sl[0] ^ sl[NW - 1]); }      // profiling: the ring without the arithmetic
-        else
-        status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
-        rec.frame = (uint8_t)(o ? 0 : 1);
-        if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
-        if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, false);      // (a tail read's J tag is whole)
-      }
-      v2_tally(lds_counts, lane, status, o == 0);
-      // tuple sink: the item of every entry of the batch, at the entry's place in the ring's sequence
-      if (S.dev) sink_put(S, (uint32_t)region, 0u, 64u * c + (uint32_t)lane, (uint32_t)lane < nvalid, status == DCRX_S_OK, r, tup, lane, &lds_work[V2_WK_SINK]);
-      if (__builtin_expect(status == TAIL2_SLOW, 0)) {
-        // what the lean form does not settle (one read in millions): an event entry of the launch's left list (the finishing
-        // launch's polling wave takes it), behind a placeholder record
-        __align__(16) dcrx_record_t rec;
-        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
-        rec.status = (uint8_t)DCRX_S_DEFER; rec.frame = (uint8_t)(o ? 0 : 1);
-        DCRX_STORE_FINISH(records + r, rec);
-        const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
-        uint32_t lg[NW], ww[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-          uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
-          if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
-          lg[k] = l; ww[k] = sl[k];
-        }
-        if (!v2_left_push<NW>(Q.left, queue_count, r | (jc == 2u ? V2_R_JMULTI : 0u), lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
-      }
-      // the ring batch is free again: FILLED back to zero, then GEN (a scanning wave looks at GEN first)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        __hip_atomic_store(&lds_work[V2_WK_FILLED + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        atomicAdd(&lds_work[V2_WK_GEN + (c & nb_mask)], 1u);
-      }
-      spins = 0;
-    }
-   }
-  } else {
+  // The block's waves by role: scanning waves first; where the fused forms are compiled in, the last `rw` waves take the event ring and
+  // the `tw` before them the tail ring from the start.  A scanning wave that has left its loop (and signed off) does not idle at the
+  // barrier while the rings still hold entries: it goes through the rescue loop and then the tail loop as well (round 6: the rings'
+  // last batches otherwise wait for the three and two waves of those roles, one batch after the other, while eleven waves stand by).
+  const uint32_t wv = (uint32_t)(tid >> 6);
+  const bool scans = wv < n_scan_waves;
+  if (scans) {
 #ifdef DCRX_V2_PRIO_SCAN
   if (FUSE >= 0) __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_SCAN);
 #endif
@@ -920,6 +755,182 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     atomicAdd(&lds_work[V2_WK_SCANNED], 1u);
   }
+  }
+  if (FUSE_E && (wv >= n_scan_waves + tw || (DCRX_V2_HELP_DRAIN && scans))) {
+   if constexpr (FUSE_E) {
+    // ---- a rescue wave (FUSE_E): batches of 64 event entries of list E out of the event ring, as the scanning waves fill them ----
+    constexpr bool REV = FUSE == 1;
+#if DCRX_V2_PRIO_TAIL
+    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
+#endif
+    uint32_t kw_base[K_NCLASS];
+#pragma unroll
+    for (int c = 0; c < K_NCLASS; c++) kw_base[c] = T0.kw_base[c];
+    const Rescue2Tabs rt = rescue2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV, kw_base);
+    const Counters C{lds_counts}, Cdry{lds_dry};
+    constexpr uint32_t nb_mask = V2_ERING_BATCHES - 1u, nb_shift = (uint32_t)__builtin_ctz(V2_ERING_BATCHES);
+    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
+    for (uint32_t spins = 0;;) {
+      uint32_t c = 0, nvalid = 0;
+      if (lane == 0) {      // (the tail ring's protocol on the event ring's words)
+        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
+        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!mine) nvalid = 0;
+        else if (f == 64u) nvalid = 64u;
+        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
+          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t rem = h - 64u * c;
+          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
+        }
+        if (nvalid && nvalid != V2_RING_EXIT) {
+          uint32_t expect = c;
+          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM2], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
+        }
+      }
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
+      if (nvalid == V2_RING_EXIT) break;
+      if (!nvalid) {
+        if (++spins > (1u << 24)) { if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull); break; }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint32_t *sl = ring2 + ((64u * c + (uint32_t)lane) & ering_mask) * ES;
+      int status = -2;
+      uint32_t errs = 0, x0 = 0;
+      uint32_t lg[NW];
+#pragma unroll
+      for (int k = 0; k < NW; k++) lg[k] = 0u;
+      if ((uint32_t)lane < nvalid) {
+        x0 = sl[NW + 2];
+#pragma unroll
+        for (int k = 0; k < NW; k++) lg[k] = sl[NW + 3 + k];
+        const uint32_t dg = sl[2 * NW + 3];
+        const uint32_t r = x0 & V2_R_MASK;
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        const LdsWords lw{dcrx_ldsaddr_of(sl)};
+        auto on_ok = [&](dcrx_record_t rec, const uint32_t) {      // a decombined read's record, where its fields are known
+          rec.frame = (uint8_t)(o ? 0 : 1);
+          DCRX_STORE_FINISH(records + r, rec);
+        };
+        status = rescue2_fast_to<REV, NW, V2_SHAPE_ONE>(rt, lw, lg, n, cfg, on_ok, errs, *Tmem, C, Cdry, dg);
+        if (status > 0) {      // settled, not decombined: the status alone
+          dcrx_record_t rec;
+          rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+          rec.status = (uint8_t)status; rec.frame = (uint8_t)(o ? 0 : 1);
+          DCRX_STORE_FINISH(records + r, rec);
+        } else if (status < 0) errs = 0;
+      }
+      v2_tally_rescue(lds_counts, lane, status, errs, o == 0);
+      if (__builtin_expect(status == RESCUE2_SLOW, 0)) {      // what the lean form does not settle: the launch's left list (its placeholder record stands)
+        uint32_t ww[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) ww[k] = sl[k];
+        if (!v2_left_push<NW>(Q.left, queue_count, x0, lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, x0 & V2_R_MASK, false);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_store(&lds_work[V2_WK_FILLED2 + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        atomicAdd(&lds_work[V2_WK_GEN2 + (c & nb_mask)], 1u);
+      }
+      spins = 0;
+    }
+   }
+  }
+  if (FUSE >= 0 && (DCRX_V2_HELP_DRAIN || (wv >= n_scan_waves && wv < n_scan_waves + tw))) {
+   if constexpr (FUSE >= 0) {
+    // ---- a tail wave of the fused form: batches of 64 tail entries out of the ring, as the scanning waves fill them ----
+    constexpr bool REV = FUSE == 1;
+#if DCRX_V2_PRIO_TAIL
+    __builtin_amdgcn_s_setprio(DCRX_V2_PRIO_TAIL);
+#endif
+    const Tail2Tabs tt = tail2_tabs(T0, V0, reinterpret_cast<const uint8_t *>(lds_side), reinterpret_cast<const uint8_t *>(lds_bk), REV);
+    const Counters C{lds_counts};
+    const uint32_t nb_mask = ring_batches - 1u, nb_shift = (uint32_t)__builtin_ctz(ring_batches);
+    constexpr uint32_t V2_RING_EXIT = 0xFFFFFFFFu;
+    for (uint32_t spins = 0;;) {
+      uint32_t c = 0, nvalid = 0;
+      if (lane == 0) {
+        c = __hip_atomic_load(&lds_work[V2_WK_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (FILLED speaks of batch c only once the ring batch's earlier occupants have been finished: with a short ring a wave may
+        // still be at work on batch c - NB, its count not yet taken back)
+        const bool mine = __hip_atomic_load(&lds_work[V2_WK_GEN + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (c >> nb_shift);
+        const uint32_t f = __hip_atomic_load(&lds_work[V2_WK_FILLED + (c & nb_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!mine) nvalid = 0;
+        else if (f == 64u) nvalid = 64u;
+        else if (__hip_atomic_load(&lds_work[V2_WK_SCANNED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n_scan_waves) {
+          // every scanning wave has signed off (its last entries and its share of FILLED before that): what is left is final
+          const uint32_t h = __hip_atomic_load(&lds_work[V2_WK_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t rem = h - 64u * c;
+          nvalid = (int32_t)rem <= 0 ? V2_RING_EXIT : min(rem, 64u);
+        }
+        if (nvalid && nvalid != V2_RING_EXIT) {
+          uint32_t expect = c;
+          if (!__hip_atomic_compare_exchange_strong(&lds_work[V2_WK_CLAIM], &expect, c + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) nvalid = 0;
+        }
+      }
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
+      if (nvalid == V2_RING_EXIT) break;
+      if (!nvalid) {
+        if (++spins > (1u << 24)) {           // (never seen: a scanning wave that does not sign off) — said in the call's counters, not passed over in silence
+          if (lane == 0) atomicAdd(&counters[DCRX_C_DEVICE_ERRORS], 1ull);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the entries were written before FILLED said so: nothing is read early)
+      uint32_t *sl = ring + ((64u * c + (uint32_t)lane) & ring_mask) * V2_RING_STRIDE;
+      int status = -2;
+      uint32_t r = 0, dg = 0;
+      uint64_t tup = 0;
+      if ((uint32_t)lane < nvalid) {
+        r = sl[NW + 2]; dg = sl[NW + 3];
+        const int n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
+        dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+        const LdsWords lw{dcrx_ldsaddr_of(sl)};
+        if (cfg.flags & DCRX_F_PROFILE_TAIL_STREAM_ONLY) { status = DCRX_S_J_NONE; rec.v = (uint16_t)(sl[0] ^ sl[NW - 1]); }      // profiling: the ring without the arithmetic
+        else
+        status = tail2_fast<REV>(tt, lw, n, dg, cfg, rec, *Tmem, C);
+        rec.frame = (uint8_t)(o ? 0 : 1);
+        if (status >= 0) { rec.status = (uint8_t)status; DCRX_STORE_FINISH(records + r, rec); }
+        if (S.dev && status == DCRX_S_OK) tup = sink_tuple_lean(rec, S.wpack, false);      // (a tail read's J tag is whole)
+      }
+      v2_tally(lds_counts, lane, status, o == 0);
+      // tuple sink: the item of every entry of the batch, at the entry's place in the ring's sequence
+      if (S.dev) sink_put(S, (uint32_t)region, 0u, 64u * c + (uint32_t)lane, (uint32_t)lane < nvalid, status == DCRX_S_OK, r, tup, lane, &lds_work[V2_WK_SINK]);
+      if (__builtin_expect(status == TAIL2_SLOW, 0)) {
+        // what the lean form does not settle (one read in millions): an event entry of the launch's left list (the finishing
+        // launch's polling wave takes it), behind a placeholder record
+        __align__(16) dcrx_record_t rec;
+        rec.v = rec.j = rec.v_start = rec.j_end = rec.ins_start = rec.ins_len = 0; rec.vdel = rec.jdel = 0;
+        rec.status = (uint8_t)DCRX_S_DEFER; rec.frame = (uint8_t)(o ? 0 : 1);
+        DCRX_STORE_FINISH(records + r, rec);
+        const uint32_t vp = dg & 0xFFu, jp = (dg >> 8) & 0xFFu, jc = (dg >> 16) & 3u;
+        uint32_t lg[NW], ww[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          uint32_t l = (vp >> 3) == (uint32_t)k ? (V2_F_VF << (4 * (vp & 7u))) : 0u;
+          if (jc == 1u && (jp >> 3) == (uint32_t)k) l |= V2_F_JF << (4 * (jp & 7u));
+          lg[k] = l; ww[k] = sl[k];
+        }
+        if (!v2_left_push<NW>(Q.left, queue_count, r | (jc == 2u ? V2_R_JMULTI : 0u), lg, ww)) v2_hand_over(B, queue, gqueue, qcap, queue_count, tagged, r, false);
+      }
+      // the ring batch is free again: FILLED back to zero, then GEN (a scanning wave looks at GEN first)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_store(&lds_work[V2_WK_FILLED + (c & nb_mask)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        atomicAdd(&lds_work[V2_WK_GEN + (c & nb_mask)], 1u);
+      }
+      spins = 0;
+    }
+   }
   }
 #ifdef DCRX_SCAN_STAMPS
   stamp_loop_end = __builtin_amdgcn_s_memrealtime();

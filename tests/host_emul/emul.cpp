@@ -215,6 +215,14 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     // when deferred, the rescue kernel's form.
     uint32_t slot[DCRX_GENERAL_SLOT + 2];
     const uint32_t nw = b->stride / 4;
+    if (B.stride > 4 * DCRX_V2_NWLONG) {      // reads of 512 nt and more: the long form (dcrx_kernels.hip, launch_long), every read of the batch
+      uint32_t lslot[DCRX_LONG_SLOT_MAX];
+      const int sl = (r & 1) ? DCRX_LONG_SLOT_MIN : DCRX_LONG_SLOT_MAX;      // (the launch's choice by the tables' size: both ends of it)
+      if (b->lens) decombine_long_one<false, false>(T, nullptr, B, C, r, CC, records, lslot, sl);
+      else decombine_long_one<true, false>(T, nullptr, B, C, r, CC, records, lslot, sl);
+      for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
+      continue;
+    }
     const bool pair_scan = T.dfa16_bytes != 0 && !(C.flags & DCRX_F_ONE_BASE_SCAN);
     const bool pair_rescue = pair_scan && T.pair_rescue && !(C.flags & DCRX_F_LIST_RESCUE);
     // the launch's choice of kernels (dcrx_kernels.hip, v2_applies); reads beyond the three-launch form's 320 nt stay on the

@@ -124,6 +124,56 @@ def test_emul_reads_of_321_to_511_nt():
     assert _long_reads("emul", 3000) == 3000
 
 
+def _reads_of_512_nt_and_more(kind, n, which=2):
+    """Reads of 512 nt and more (strides beyond 128 bytes): the long form — a two-pass scan with the one-base table (whole words
+    with nothing but the OR of the entries, then the flagged words base by base), hit lists with plain-integer positions,
+    dcr_frame with the rescue from the lists.  Real rearrangements in random flanks, substitutions, exception bytes, both
+    strands; a uniform batch of 600 nt and a ragged one (512 .. 5 000 nt), the three orientations."""
+    import random
+    from decombinator_amd import synth
+    from oracle import oracle as orc
+    ts = synth.config_tagset(2) if which == 2 else synth.config3_tagsets()[0]
+    d = dict(v_tags=ts.v_tags, v_jumps=ts.v_jumps, v_regions=ts.v_regions, j_tags=ts.j_tags, j_jumps=ts.j_jumps,
+             j_regions=ts.j_regions, v_half_split=ts.half_splits[0], j_half_split=ts.half_splits[1])
+    t = pu.native_tables(d)
+    ot = orc.OracleTables(ts.v_tags, ts.v_jumps, [r.upper() for r in ts.v_regions], ts.j_tags, ts.j_jumps,
+                          [r.upper() for r in ts.j_regions], *ts.half_splits)
+    be = pu.Backend(kind, d)
+    rng = random.Random(11)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=78, p_rearranged=0.8, sub_rate=0.01, n_rate=0.002), 0, 2 * n)
+    cores = nat.unpack_reads(hb)
+    rnd = lambda k: "".join(rng.choice("ACGT") for _ in range(k))
+
+    def lengthen(r, m):
+        a = rng.randrange(0, m - len(r) + 1)
+        s = rnd(a) + r + rnd(m - len(r) - a)
+        if rng.random() < 0.02:      # a run of exception bytes and a lone one somewhere in the flanks or the rearrangement
+            k = rng.randrange(0, m - 8)
+            s = s[:k] + "NNN" + s[k + 3:]
+        if rng.random() < 0.02:
+            k = rng.randrange(0, m)
+            s = s[:k] + rng.choice("NRY") + s[k + 1:]
+        return orc.revcomp(s) if rng.random() < 0.3 else s
+    uniform = [lengthen(r, 600) for r in cores[:n]]
+    ragged = [lengthen(r, rng.choice([512, 513, 527, 528, 529, 600, 777, 1500, 5000])) for r in cores[n:2 * n]]
+    n_ok = 0
+    for reads in (uniform, ragged):
+        b = nat.pack_reads(reads)
+        assert b.stride > 128
+        for orientation in ("reverse", "forward", "both"):
+            rec, cnt = be.run(b, orientation, flags=0)
+            orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+            pu.assert_records_equal(rec, orec, reads, "long form, " + orientation)
+            pu.assert_counters_equal(cnt, ocnt)
+            n_ok += int((orec["status"] == 0).sum())
+    return n_ok
+
+
+def test_emul_reads_of_512_nt_and_more():
+    assert _reads_of_512_nt_and_more("emul", 1500) > 1500
+    assert _reads_of_512_nt_and_more("emul", 400, which=3) > 400
+
+
 def _synthetic_vs_oracle(kind, ts, n, orientation, flags, forward_strand=False, **synth_kw):
     """`n` synthetic reads of tag set `ts` through backend `kind` against the oracle: records and counters.  The
     generator writes the reverse strand; forward_strand hands the backend the reverse complements instead."""

@@ -765,10 +765,10 @@ print("ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["original-like beta (blocks of 512 threads)", "extended-like alpha (one block of 1 024 per unit)"])
+@pytest.mark.parametrize("which", ["original-like beta (fifteen notes per lane)", "extended-like alpha (seven notes per lane beside its larger tables)"])
 def test_long_form_with_its_tables_in_lds(which):
     """Batches of 4 096 reads and more of 512 nt and longer take the long form with the tables' image staged in LDS (round 5:
-    dcrx_kernels.hip, launch_long) — two launch shapes by the image's size; 6 000 reads of 600 nt and a ragged batch of
+    dcrx_kernels.hip, launch_long) — the lanes' slots beside it sized by what the image leaves (round 6); 6 000 reads of 600 nt and a ragged batch of
     512-3 000 nt, real rearrangements in random flanks with substitutions and exception bytes, reverse and `both`, against
     the oracle (smaller batches keep the form without staging: the test below)."""
     import random
@@ -794,6 +794,45 @@ def test_long_form_with_its_tables_in_lds(which):
             pu.assert_records_equal(rec, orec, reads, "long, tables in LDS, " + orientation)
             assert (cnt == ocnt).all()
         assert int((rec["status"] == 0).sum()) > len(reads) // 2
+
+
+@pytest.mark.gpu
+def test_long_form_on_100_000_reads_of_600_nt_in_all_orientations():
+    """VERDICT r5 item 6 ("extended to 10^5 reads"): 100 000 reads of 600 nt — real rearrangements at random places in random
+    flanks, 1 % substitutions, exception bytes, 30 % of them on the other strand — through the long form (round 6: a two-pass scan,
+    hit lists with plain-integer positions, the notes taken back by a whole wave at once) in the three orientations, every record
+    and counter against the oracle."""
+    ts = synth.config_tagset(2)
+    t, ot = _tables(ts)
+    n = 100_000
+    rng = np.random.default_rng(600)
+    hb = nat.synth_reads_host(t, nat.synth_cfg(seed=606, p_rearranged=0.8, sub_rate=0.01, n_rate=0.002), 0, n)
+    cores = nat.unpack_reads(hb)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[:] = np.arange(256, dtype=np.uint8)
+    for a, b_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b_
+    reads = []
+    flank = acgt[rng.integers(0, 4, size=(n, 450))]
+    left = rng.integers(0, 451, size=n)
+    flip = rng.random(n) < 0.3
+    for k, r in enumerate(cores):
+        row = np.concatenate([flank[k, :left[k]], np.frombuffer(r.encode(), dtype=np.uint8), flank[k, left[k]:]])
+        if flip[k]:
+            row = comp[row[::-1]]
+        reads.append(row.tobytes().decode())
+    assert all(len(r) == 600 for r in reads[:100])
+    b = nat.pack_reads(reads)
+    assert b.stride > 128
+    n_ok = 0
+    for orientation in ("reverse", "forward", "both"):
+        rec, cnt = nat.decombine(t, b, orientation=orientation)
+        orec, ocnt = pu.oracle_records(ot, reads, orientation, False, 130)
+        pu.assert_records_equal(rec, orec, reads, "long form at size, " + orientation)
+        assert (cnt == ocnt).all()
+        n_ok += int((rec["status"] == 0).sum())
+    assert n_ok > n
 
 
 @pytest.mark.gpu
