@@ -74,6 +74,10 @@ def parse_args(argv=None):
                     help="BASELINE.json workload: 2 (default; the recorded metric), 3 = alpha+beta extended-like sets, "
                          "4 = a fixed total of reads sharded over the ranks (strong scaling), 5 = mouse gamma+delta")
     ap.add_argument("--total-reads", type=int, default=10**9, help="config 4: reads of the whole job")
+    ap.add_argument("--in-flight", type=int, default=0, choices=(0, 1, 2),
+                    help="batches in flight: 2 = consecutive steps alternate between two handles (streams, record planes, counter blocks) "
+                         "so that a step's finishing launches run beside the next step's scan; 1 = one stream, each step behind the last; "
+                         "0 (default) = 2 for config 2 on one rank without a gather, else 1 (configs 3 and 5 overlap their two chains instead: a stream per chain)")
     ap.add_argument("--no-gather-ab", action="store_true", help="N > 1: skip the second loop that prices the exposed gather time")
     return ap.parse_args(argv)
 
@@ -299,6 +303,14 @@ def run_rank(args, device_factory=None, comm_factory=None):
         device = device_factory(nat, all_tables, tagsets, cfg_synth, batches, n)
     else:
         device = HipDevice(nat, np, sptr, all_tables, cfg_synth, batches, n, stride, args.cfg_flags)
+        # Two batches in flight (round 6): consecutive steps alternate between two handles of the same tag set — each with its stream,
+        # workspace, record plane and counter block, as the library's host entry keeps two chunks in flight (dcrx_decombine) — so that
+        # a step's finishing launches, latency-bound and alone on the chip otherwise, run beside the next step's scan.  Where tuples are
+        # gathered (several ranks, config 4, DCRX_BENCH_FORCE_GATHER) the gather's own alternating buffers set the order: one in flight.
+        plain = not use_dist and os.environ.get("DCRX_BENCH_FORCE_GATHER") != "1" and args.config != 4 and not args.cfg_flags
+        in_flight = int(os.environ.get("DCRX_BENCH_BATCHES_IN_FLIGHT", "0")) or args.in_flight or (2 if plain and len(all_tables) == 1 else 1)      # (two chains on a stream each already overlap: a second pair of handles adds nothing, measured)
+        if in_flight == 2 and plain:
+            device.second_slot([nat.Tables(x.v_tags, x.v_jumps, x.v_regions, x.j_tags, x.j_jumps, x.j_regions, *x.half_splits) for x in tagsets])
     # what travels: the narrow tuple of the tag set (5 bytes here) left by the decombine call itself (the handle's tuple sink);
     # A/B (DCRX_BENCH_GATHER_MODE): "narrow" = the same tuples compacted from the records on a side stream, "tuple8" = round 3's
     # 8-byte tuples, compacted
@@ -408,6 +420,7 @@ def run_rank(args, device_factory=None, comm_factory=None):
     if rank == 0:
         total_reads = args.total_reads if args.config == 4 else n * world * args.steps
         value = total_reads / elapsed / 1e6
+        overlapped = 0 if dry else (2 if len(getattr(device, 'slots', [0])) > 1 else (1 if getattr(device, 'chain_streams', None) else 0))      # launches of different steps / chains overlap
         line = {
             "metric": "Mreads/s decombined (150 bp human-beta)" if args.config in (2, 4) else f"Mreads/s decombined (150 bp, BASELINE config {args.config})",
             "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -432,7 +445,10 @@ def run_rank(args, device_factory=None, comm_factory=None):
                 "kernels": device.kernels(info),
                 "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if info.get("v2_tables") else info["dfa_bytes"],
                 "decombined_fraction": round(hits_all / max(1, device.expected_read_count() * world if args.config != 4 else args.total_reads), 4),
-                "parallelism": f"reads sharded x{world}, gather of DCR tuples to rank 0 ({'gloo' if dry else 'RCCL'})" if world > 1 else "single GPU",
+                "parallelism": f"reads sharded x{world}, gather of DCR tuples to rank 0 ({'gloo' if dry else 'RCCL'})" if world > 1 else
+                               ("single GPU" + (", two batches in flight (consecutive steps alternate between two handles, each with its stream, workspace and record plane)" if overlapped == 2 else "")
+                                + (", a stream per chain" if overlapped and len(all_tables) > 1 else "")),
+                "batches_in_flight": 2 if overlapped == 2 else 1,
                 "world_size": comm.world if use_dist else 1, "devices": names,
                 "collectives": ("gloo (dry run)" if dry else "RCCL through libdcrx (dcrx_comm_*: no torch in this process)") if use_dist else None,
             },
@@ -445,40 +461,51 @@ def run_rank(args, device_factory=None, comm_factory=None):
             # (the timed steps that carry events: for config 4 the last, shorter step of a shard may be among them; the reads of
             # an average step are what the device time is set against)
             achieved = algo_bytes * (total_reads / world / args.steps) / (step_avg_ms * 1e-3) / 1e9
+            if overlapped:      # the spans of a step's launches on their streams overlap with the next step's (the other chain's): the timed region's own clock
+                achieved = algo_bytes * (total_reads / world) / elapsed / 1e9
             traffic, traffic_source = None, None
-            forms = [tb.tune_state(n)["launch_form"] for tb in all_tables]
+            handles = [tb for sl in getattr(device, "slots", [(all_tables,)]) for tb in sl[0]]      # (two batches in flight: both handles of a chain)
+            forms = [tb.tune_state(n)["launch_form"] for tb in handles]
             # (a handle settles on one of two forms — list E a role of the finishing launch or inside the scan kernel —: each has its own profile)
-            tpath = os.path.join(ROOT, "profiles", "traffic_list_e_inside_the_scan.json" if forms and "list E inside" in forms[-1] else "traffic.json")
             v2 = bool(info.get("v2_tables")) and not (args.cfg_flags & 64)
             roofline_lds = None
-            if os.path.exists(tpath) and args.config == 2:
-                # (a constant from a profile: quoted only while the sources it was measured on are the tree's — the digest of
-                # decombinator_amd/csrc that tools/prof_summary_r05.py left in the file — else null, not a stale figure)
-                try:
-                    tj = json.load(open(tpath))
-                    if (tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == device.kernels_tag(info)
-                            and tj.get("csrc_sha16") == csrc_digest()):
-                        traffic = tj.get("hbm_bytes_per_step")
-                        traffic_source = ("profiles/traffic.json: rocprofv3 --pmc passes of this command on an earlier run (" +
-                                          tj.get("profile", "?") + ") of the same kernel sources (csrc_sha16 " + tj["csrc_sha16"] + "), not measured by this run")
-                        roofline_lds = tj.get("roofline_lds")
-                    else:
-                        traffic_source = "profiles/traffic.json was measured on other kernel sources or another workload: not quoted"
-                except Exception:
-                    traffic = None
+            if args.config == 2:
+                # (constants from a profile, one file per launch form — a handle settles on list E as a role of the finishing launch or inside
+                # the scan kernel —: quoted only while the sources they were measured on are the tree's — the digest of decombinator_amd/csrc
+                # that tools/prof_summary_r05.py left in the file — else null, not a stale figure; two handles in flight: the mean of theirs)
+                got = []
+                for f in forms:
+                    tpath = os.path.join(ROOT, "profiles", "traffic_list_e_inside_the_scan.json" if "list E inside" in f else "traffic.json")
+                    try:
+                        tj = json.load(open(tpath))
+                        if (tj.get("reads_per_launch") == n and tj.get("read_len") == READ_LEN and tj.get("kernels") == device.kernels_tag(info)
+                                and tj.get("csrc_sha16") == csrc_digest()):
+                            got.append((os.path.basename(tpath), tj))
+                    except Exception:
+                        pass
+                if forms and len(got) == len(forms):
+                    traffic = int(sum(tj.get("hbm_bytes_per_step") or 0 for _, tj in got) / len(got))
+                    traffic_source = ("profiles/" + " + ".join(sorted({nm for nm, _ in got})) + ": rocprofv3 --pmc passes of this command (one batch in flight) on an earlier run (" +
+                                      got[0][1].get("profile", "?") + ") of the same kernel sources (csrc_sha16 " + got[0][1]["csrc_sha16"] + "), not measured by this run")
+                    roofline_lds = got[0][1].get("roofline_lds")
+                else:
+                    traffic_source = "profiles/traffic*.json were measured on other kernel sources or another workload: not quoted"
             # what the timed steps ran on: the handle's own choice for its finishing launches (dcrx_tune_state: settled inside
             # the warm-up when that has five steps or more; 0 = not settled, the launches ran on 4096) and the scan blocks' choice
             # of tail waves (per block, from its region's share of tail reads in the launch before: no host-side state to report)
             line["tune"] = {
-                "rescue_waves": [tb.tune_state(n)["rescue_waves"] for tb in all_tables],
-                "samples_us": [{k: v for k, v in tb.tune_state(n).items() if k.startswith("us_")} for tb in all_tables],
-                "launches_in_size_class": [tb.tune_state(n)["launches"] for tb in all_tables],
-                "launch_form": [tb.tune_state(n)["launch_form"] for tb in all_tables],      # (what really ran: a tag set the v2 kernels do not serve shows here)
+                "rescue_waves": [tb.tune_state(n)["rescue_waves"] for tb in handles],
+                "samples_us": [{k: v for k, v in tb.tune_state(n).items() if k.startswith("us_")} for tb in handles],
+                "launches_in_size_class": [tb.tune_state(n)["launches"] for tb in handles],
+                "launch_form": forms,      # (what really ran: a tag set the v2 kernels do not serve shows here)
                 "tail_waves": "per scan block: 2-6 by its region's share of tail reads in the previous launch (3 on a handle's first launch)",
                 "first_launch_ms": None if first_launch_ms is None else round(first_launch_ms, 3),
             }
             line["roofline"] = {
-                "bound": "hbm", "kernel": "all launches of a step (dcrx_decombine_device)",
+                "bound": "hbm", "kernel": "all launches of a step (dcrx_decombine_device)" + (
+                    "; launches of consecutive steps" + (" and of the two chains" if len(all_tables) > 1 else "") + " overlap on their streams: `achieved` is the algorithmic bytes of "
+                    "the timed steps over the timed region's wall clock (barrier to barrier), step_device_ms_* the span of one step's launches on its own stream "
+                    "(beside the neighbouring step's: longer than ms_per_step); --in-flight 1 times one step behind the other" if overlapped else ""),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_read": algo_bytes,
                 "step_device_ms_avg": round(step_avg_ms, 5), "step_device_ms_min": round(min(step_ms), 5),
@@ -572,8 +599,12 @@ class HipDevice:
         # a counter block per chain and batch of a pass (every call overwrites its own block): config 4's pass is summed on the host
         self.d_cnts = [[nat.DeviceBuffer.from_host(np.zeros(nat.N_COUNTERS, dtype=np.uint64)) for _ in self.bc] for _ in all_tables]
         self.cfg = nat.make_cfg("reverse", False, 130, cfg_flags)
+        # a stream per chain (configs 3 and 5: two handles, two record planes): one chain's finishing launches run beside the other's scan
+        # (round 6: 17.7 -> 19.5 and 16.3 -> 19.3 G reads/s, profiles/r06/a_stream_per_chain_ab.log; DCRX_BENCH_CHAIN_STREAMS=0: one stream, A/B)
+        self.chain_streams = [nat.Stream() for _ in all_tables] if os.environ.get("DCRX_BENCH_CHAIN_STREAMS", "1") == "1" and len(all_tables) > 1 else None
         for tb in all_tables:
             nat.check(nat.lib().dcrx_reserve_device(tb.handle, n))
+        self.slots = [(all_tables, self.d_recs, self.d_cnts, self.chain_streams)]      # (handles, record planes, counter blocks, streams) per batch in flight
         self.accumulate = len(batches) > 1
         self.last_batch = 0
         self.event_every = max(1, int(os.environ.get("DCRX_BENCH_EVENT_EVERY", "5")))
@@ -581,6 +612,17 @@ class HipDevice:
         nat.synchronize()
         if os.environ.get("DCRX_BENCH_PRINT_PTRS") == "1":      # (experiments: where the buffers lie)
             print("PTRS packed %x records %x counters %x" % (self.d_packed.ptr, self.d_recs[-1].ptr, self.d_cnts[-1][0].ptr), file=sys.stderr)
+
+    def second_slot(self, tables2):
+        nat, np = self.nat, self.np
+        for tb in tables2:
+            nat.check(nat.lib().dcrx_reserve_device(tb.handle, self.n))
+        recs = [nat.DeviceBuffer(self.n * 16) for _ in tables2]
+        cnts = [[nat.DeviceBuffer.from_host(np.zeros(nat.N_COUNTERS, dtype=np.uint64)) for _ in self.bc] for _ in tables2]
+        if self.chain_streams is None:
+            self.slots[0] = (self.all_tables, self.d_recs, self.d_cnts, [nat.Stream() for _ in self.all_tables])
+        self.slots.append((tables2, recs, cnts, [nat.Stream() for _ in tables2]))
+        nat.synchronize()
 
     def name(self):
         return self.nat.device_name()
@@ -603,12 +645,14 @@ class HipDevice:
         kb = k % len(self.bc)
         b = self.bc[kb]
         self.last_batch = kb
-        rec = self.d_recs[-1]
+        tables, d_recs, d_cnts, streams = self.slots[k % len(self.slots)]
+        self.d_recs, self.d_cnts = d_recs, d_cnts      # (what the checks behind the timed region read: the last step's)
+        rec = d_recs[-1]
         if gather is not None:           # alternating record buffers: the previous step's tuples are still being compacted
             gather.before_scan()
             rec = gather.records()
-        for c, tb in enumerate(self.all_tables):
-            last = c == len(self.all_tables) - 1
+        for c, tb in enumerate(tables):
+            last = c == len(tables) - 1
             if ev is not None:           # events: (step start, step stop, kernel start, kernel stop) per chain; the step's pair on
                 kind = self.event_kind[k]             # every other event-carrying step, the kernel's pair on the ones between
                 if kind in (0, 2):
@@ -616,7 +660,8 @@ class HipDevice:
                 if kind in (1, 2):
                     nat.check(nat.lib().dcrx_set_timing_events(tb.handle, ev[c][2].ptr, ev[c][3].ptr))
             nat.check(nat.lib().dcrx_decombine_device(tb.handle, nat.C.byref(self.cfg), nat.C.byref(b),
-                                                      (rec if last else self.d_recs[c]).ptr, self.d_cnts[c][kb].ptr, self.sptr))
+                                                      (rec if last else d_recs[c]).ptr, d_cnts[c][kb].ptr,
+                                                      streams[c].ptr if streams else self.sptr))
             if ev is not None:
                 nat.check(nat.lib().dcrx_set_step_events(tb.handle, None, None))
                 nat.check(nat.lib().dcrx_set_timing_events(tb.handle, None, None))
