@@ -309,7 +309,7 @@ def run_rank(args, device_factory=None, comm_factory=None):
         # gathered (several ranks, config 4, DCRX_BENCH_FORCE_GATHER) the gather's own alternating buffers set the order: one in flight.
         plain = not use_dist and os.environ.get("DCRX_BENCH_FORCE_GATHER") != "1" and args.config != 4 and not args.cfg_flags
         in_flight = int(os.environ.get("DCRX_BENCH_BATCHES_IN_FLIGHT", "0")) or args.in_flight or (2 if plain and len(all_tables) == 1 else 1)      # (two chains on a stream each already overlap: a second pair of handles adds nothing, measured)
-        if in_flight == 2 and plain:
+        for _ in range(in_flight - 1 if plain else 0):
             device.second_slot([nat.Tables(x.v_tags, x.v_jumps, x.v_regions, x.j_tags, x.j_jumps, x.j_regions, *x.half_splits) for x in tagsets])
     # what travels: the narrow tuple of the tag set (5 bytes here) left by the decombine call itself (the handle's tuple sink);
     # A/B (DCRX_BENCH_GATHER_MODE): "narrow" = the same tuples compacted from the records on a side stream, "tuple8" = round 3's
@@ -420,7 +420,7 @@ def run_rank(args, device_factory=None, comm_factory=None):
     if rank == 0:
         total_reads = args.total_reads if args.config == 4 else n * world * args.steps
         value = total_reads / elapsed / 1e6
-        overlapped = 0 if dry else (2 if len(getattr(device, 'slots', [0])) > 1 else (1 if getattr(device, 'chain_streams', None) else 0))      # launches of different steps / chains overlap
+        overlapped = 0 if dry else (len(device.slots) if len(getattr(device, 'slots', [0])) > 1 else (1 if getattr(device, 'chain_streams', None) else 0))      # launches of different steps / chains overlap
         line = {
             "metric": "Mreads/s decombined (150 bp human-beta)" if args.config in (2, 4) else f"Mreads/s decombined (150 bp, BASELINE config {args.config})",
             "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -446,9 +446,9 @@ def run_rank(args, device_factory=None, comm_factory=None):
                 "dfa_states": info["n_states"], "dfa_bytes_in_lds": info.get("v2_scan_bytes") if info.get("v2_tables") else info["dfa_bytes"],
                 "decombined_fraction": round(hits_all / max(1, device.expected_read_count() * world if args.config != 4 else args.total_reads), 4),
                 "parallelism": f"reads sharded x{world}, gather of DCR tuples to rank 0 ({'gloo' if dry else 'RCCL'})" if world > 1 else
-                               ("single GPU" + (", two batches in flight (consecutive steps alternate between two handles, each with its stream, workspace and record plane)" if overlapped == 2 else "")
+                               ("single GPU" + (f", {overlapped} batches in flight (consecutive steps alternate between {overlapped} handles, each with its stream, workspace and record plane)" if overlapped >= 2 else "")
                                 + (", a stream per chain" if overlapped and len(all_tables) > 1 else "")),
-                "batches_in_flight": 2 if overlapped == 2 else 1,
+                "batches_in_flight": overlapped if overlapped >= 2 else 1,
                 "world_size": comm.world if use_dist else 1, "devices": names,
                 "collectives": ("gloo (dry run)" if dry else "RCCL through libdcrx (dcrx_comm_*: no torch in this process)") if use_dist else None,
             },

@@ -440,8 +440,12 @@ __global__ __launch_bounds__(DCRX_V2_BLOCK) void scan2_kernel(
   uint32_t *ring2 = ring + (size_t)(ring_mask + 1u) * V2_RING_STRIDE;            // (FUSE_E) the event ring, then a block of counters nobody reads
   uint32_t *lds_dry = ring2 + (size_t)(ering_mask + 1u) * ES;
   if (FUSE >= 0) {
-    stage_lds<DCRX_V2_BLOCK>(T0.image + T0.dfa_bytes, lds_side, (T0.lds_image_bytes - T0.dfa_bytes) / 16, 0, 0, tid);
-    stage_lds<DCRX_V2_BLOCK>(V0.bk, lds_bk, V0.bk_bytes / 16, 0, 0, tid);
+    {      // (the stride is the block's own size, as above)
+      const uint4 *s1 = reinterpret_cast<const uint4 *>(T0.image + T0.dfa_bytes), *s2 = reinterpret_cast<const uint4 *>(V0.bk);
+      uint4 *d1 = reinterpret_cast<uint4 *>(lds_side), *d2 = reinterpret_cast<uint4 *>(lds_bk);
+      for (uint32_t i = tid; i < (T0.lds_image_bytes - T0.dfa_bytes) / 16; i += blockDim.x) d1[i] = s1[i];
+      for (uint32_t i = tid; i < V0.bk_bytes / 16; i += blockDim.x) d2[i] = s2[i];
+    }
     for (uint32_t i = tid; i <= ring_mask; i += blockDim.x) { ring[i * V2_RING_STRIDE + NW] = 0u; ring[i * V2_RING_STRIDE + NW + 1] = 0u; }
     if (FUSE_E) for (uint32_t i = tid; i <= ering_mask; i += blockDim.x) { ring2[i * ES + NW] = 0u; ring2[i * ES + NW + 1] = 0u; }
   }
@@ -1992,7 +1996,9 @@ static hipError_t launch_v2(const LaunchPlan &P, const DevTables &T, const Batch
   }
   if (S.dev) fuse_e = false;      // (a call that leaves a tuple sink's message keeps list E a role: its items are placed by list position)
   if (P.tune && fuse_e) P.tune[o].last_form = 4u;
-  hipExtLaunchKernelGGL(S.dev ? ks_sink : (fuse_e ? ks_e : ks), dim3(grid), dim3(DCRX_V2_BLOCK), fuse_e ? scan_lds_e : scan_lds, s, ev_start ? ev_start : e_ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
+  // (experiment, DCRX_DEBUG_SCAN_THREADS=768: three waves per SIMD in a scan block, so that a wave of another stream's finishing launch fits beside it)
+  static const uint32_t scan_threads = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_SCAN_THREADS"); const int v = e ? atoi(e) : 0; return (v >= 512 && v <= DCRX_V2_BLOCK && v % 64 == 0) ? (uint32_t)v : (uint32_t)DCRX_V2_BLOCK; }();
+  hipExtLaunchKernelGGL(S.dev ? ks_sink : (fuse_e ? ks_e : ks), dim3(grid), dim3(scan_threads), fuse_e ? scan_lds_e : scan_lds, s, ev_start ? ev_start : e_ev_start, side ? fork_ev : ev_stop, 0, T, B, cfg, rec,
                         d_counters, Q, queue, gqueue, qcap, queue_count, per_block, retry, P.dev_tables, fuse_e ? ring_batches_e : ring_batches, S, tail_waves_forced,
                         fuse_e ? rescue_waves_fused : 0u);
   e = hipGetLastError();
