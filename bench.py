@@ -380,6 +380,15 @@ def run_rank(args, device_factory=None, comm_factory=None):
     steady_steps = int(os.environ.get("DCRX_BENCH_STEADY_STEPS", "200"))
     if not dry and steady_steps > 0 and args.config != 4:
         elapsed_steady = timed_loop(gather, steady_steps)
+    # ... and, where two batches are in flight, as many steps as the timed region's on the first handle alone — each step behind the
+    # last, as rounds 1-5 timed them: the figure beside the headline (an extra key)
+    elapsed_one = None
+    if not dry and len(getattr(device, "slots", [0])) > 1:
+        all_slots = device.slots
+        device.slots = all_slots[:1]
+        timed_loop(None, 5)
+        elapsed_one = timed_loop(None, max(args.steps, 50))
+        device.slots = all_slots
     elapsed_nogather = None
     if gather is not None and not args.no_gather_ab:
         # the same steps without the gather: the difference is the gather time the steps do not hide
@@ -426,6 +435,7 @@ def run_rank(args, device_factory=None, comm_factory=None):
             "value": None if dry else round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "ms_per_step_steady": None if elapsed_steady is None else round(elapsed_steady / steady_steps * 1e3, 4),
+            "ms_per_step_one_batch_in_flight": None if elapsed_one is None else round(elapsed_one / max(args.steps, 50) * 1e3, 4),
             "preroll_steps": preroll_steps,
             "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic", "world_size": world, "per_rank_ms_per_step": per_rank_ms,
