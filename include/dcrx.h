@@ -252,7 +252,10 @@ int dcrx_decombine(dcrx_tables_t *tables, const dcrx_cfg_t *cfg, const dcrx_batc
  * (dcrx_reserve_device does that up front) — with ONE exception, and only where the caller has asked for it
  * (dcrx_set_tune_wait, below): the fourth call of a size class of 2^25 reads and more may then wait for the third
  * call's finishing launch, once per class.  Without that call nothing in here ever waits for the device, so the
- * stream may be captured or run arbitrarily far ahead of the host. */
+ * stream may be captured or run arbitrarily far ahead of the host.
+ * Calls on one handle are ordered on one stream (the workspace hangs off the handle); batches that should overlap —
+ * a batch's finishing launch beside the next batch's scan, or the two chains of a two-chain library — take one handle
+ * and one stream each ("Ownership, errors, threading"). */
 int dcrx_decombine_device(dcrx_tables_t *tables, const dcrx_cfg_t *cfg,
                           const dcrx_batch_t *device_batch, dcrx_record_t *d_records,
                           uint64_t *d_counters, void *hip_stream);
