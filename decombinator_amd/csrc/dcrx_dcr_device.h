@@ -1699,9 +1699,6 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
 //   pass 2: the noted words again, base by base with scan_plain's bookkeeping and every half-tag hit into the read's hit lists
 //           (HalfHits, wide entries): dcr_frame rescues from the lists and re-scans only a class with more than HH_K hits.
 //           Where a lane's notes could run out, every lane of the wave takes pass 2 over the notes it has and goes on with pass 1.
-#ifdef DCRX_LONG_STATS
-static unsigned long long g_long_stats[32];
-#endif
 constexpr int LONG_FW_MIN = 7, LONG_FW_MAX = 15;      // notes per lane: as many as the block's LDS holds beside the tables (the launch's choice, an odd slot)
 constexpr int DCRX_LONG_SLOT_MIN = (HH_STRIDE + LONG_FW_MIN) | 1, DCRX_LONG_SLOT_MAX = (HH_STRIDE + LONG_FW_MAX) | 1;      // dwords of LDS per lane (odd: the lanes' slots on different banks)
 constexpr uint32_t TE_FLAGS_MASK = 0xFFu << TE_VFULL_BIT;
@@ -1855,9 +1852,6 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
       }
     }
   }
-#ifdef DCRX_LONG_STATS
-  g_long_stats[nfw < 15 ? nfw : 15]++; g_long_stats[16] += (unsigned long long)(top + 1);
-#endif
   // ---- pass 2: the notes that are left ----
   if (pass1_only) { L.so.acc = e; return L.so; }
   if (!mid) {

@@ -6,10 +6,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O ${O}_fused
 cd /tmp && export TMPDIR=/tmp
-B="--steps 3 --warmup 1 --no-cpu-baseline"
+B="--steps 3 --warmup 1 --no-cpu-baseline --in-flight 1"
 pmc_passes() {   # $1: directory, $2: DCRX_DEBUG_FUSE_E
   export DCRX_DEBUG_FLAGS=1 DCRX_DEBUG_FUSE_E=$2
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $1/trace -- python3 $R/bench.py --no-cpu-baseline > $1/bench_under_kernel_trace.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $1/trace -- python3 $R/bench.py --no-cpu-baseline --in-flight 1 > $1/bench_under_kernel_trace.log 2>&1
   python3 $R/tools/timeline.py $1/trace > $1/timeline.txt 2>&1
   timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $1/pmc_a -- python3 $R/bench.py $B > $1/pmc_a.log 2>&1
   timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $1/pmc_b -- python3 $R/bench.py $B > $1/pmc_b.log 2>&1
