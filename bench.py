@@ -308,6 +308,9 @@ def run_rank(args, device_factory=None, comm_factory=None):
         # a step's finishing launches, latency-bound and alone on the chip otherwise, run beside the next step's scan.  Where tuples are
         # gathered (several ranks, config 4, DCRX_BENCH_FORCE_GATHER) the gather's own alternating buffers set the order: one in flight.
         plain = not use_dist and os.environ.get("DCRX_BENCH_FORCE_GATHER") != "1" and args.config != 4 and not args.cfg_flags
+        if use_dist and device.chain_streams is not None:      # (the gather orders its buffers on the rank's one stream: the chains stay on it)
+            device.chain_streams = None
+            device.slots = [(device.all_tables, device.d_recs, device.d_cnts, None)]
         in_flight = int(os.environ.get("DCRX_BENCH_BATCHES_IN_FLIGHT", "0")) or args.in_flight or (2 if plain and len(all_tables) == 1 else 1)      # (two chains on a stream each already overlap: a second pair of handles adds nothing, measured)
         for _ in range(in_flight - 1 if plain else 0):
             device.second_slot([nat.Tables(x.v_tags, x.v_jumps, x.v_regions, x.j_tags, x.j_jumps, x.j_regions, *x.half_splits) for x in tagsets])
