@@ -12,7 +12,6 @@ _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)
 
 import numpy as np
 
-import torch  # noqa: F401  (first: one HIP runtime for the process, see _native.py)
 from decombinator_amd import _native as nat, decombine as dec, io as dio, synth, collapse
 
 ap = argparse.ArgumentParser()
