@@ -697,9 +697,11 @@ def _decombinator_loop(inputargs: dict, rank: int, world: int, state: dict, plan
                 if spans.last:
                     break
         finally:
+            tc = time()
             rd1.close()
             if rd2 is not None:
                 rd2.close()
+            stage_seconds["close"] = time() - tc
     else:
         # reference behaviour: with nobarcoding the read loop never runs
         if inputargs["extension"] == "n12":
