@@ -218,11 +218,11 @@ def test_empty_batch_and_single_read():
 def test_two_batches_in_flight_on_two_handles_and_streams():
     """bench.py's default since round 6 (and what INTEGRATION.md tells a caller with a queue of batches): consecutive batches alternate
     between TWO handles of one tag set, each with its own stream, workspace, record plane and counter block, so that their launches
-    overlap on the chip.  Forty-four batches of 2.2 M reads (different reads each; each handle meets both launch forms of config 2 on
+    overlap on the chip.  Forty-four batches of 1.2 M reads (different reads each; each handle meets both launch forms of config 2 on
     the way: its first launches run list E as a role of the finishing launch, four of its launches between the thirteenth and the
     twentieth — the handle's own timing of the other form — finish it inside the scan), nothing waited for until all are issued:
     every record and every counter of every batch against the oracle."""
-    n, n_batches = 2_200_000, 44
+    n, n_batches = 1_200_000, 44
     ts = synth.config_tagset(2)
     t0, ot = _tables(ts)
     t1, _ = _tables(ts)
