@@ -215,37 +215,23 @@ def test_empty_batch_and_single_read():
     assert len(rec) == 1 and int(cnt[20]) == 1
 
 
-def test_two_batches_in_flight_on_two_handles_and_streams():
+@pytest.mark.parametrize("form", ["the handle's own choice of launch form", "list E inside the scan, forced"])
+def test_two_batches_in_flight_on_two_handles_and_streams(form):
     """bench.py's default since round 6 (and what INTEGRATION.md tells a caller with a queue of batches): consecutive batches alternate
     between TWO handles of one tag set, each with its own stream, workspace, record plane and counter block, so that their launches
-    overlap on the chip.  Forty-four batches of 1.2 M reads (different reads each; each handle meets both launch forms of config 2 on
-    the way: its first launches run list E as a role of the finishing launch, four of its launches between the thirteenth and the
-    twentieth — the handle's own timing of the other form — finish it inside the scan), nothing waited for until all are issued:
-    every record and every counter of every batch against the oracle."""
-    n, n_batches = 1_200_000, 44
-    ts = synth.config_tagset(2)
-    t0, ot = _tables(ts)
-    t1, _ = _tables(ts)
-    handles, streams = (t0, t1), (nat.Stream(), nat.Stream())
-    cfg = nat.synth_cfg(seed=66, sub_rate=0.01)
-    batches = [nat.synth_reads_device(t0, cfg, k * n, n) for k in range(n_batches)]
-    recs = [nat.DeviceBuffer(n * 16) for _ in range(n_batches)]
-    cnts = [nat.DeviceBuffer(nat.N_COUNTERS * 8) for _ in range(n_batches)]
-    nat.synchronize()
-    for k in range(n_batches):
-        nat.decombine_device(handles[k % 2], batches[k], recs[k], cnts[k], stream=streams[k % 2].ptr)
-    nat.synchronize()
-    forms = {h.tune_state(n)["launch_form"] for h in handles}
-    assert all(f.startswith("v2, tail") for f in forms), forms
-    for k in range(n_batches):
-        hb = nat.synth_reads_host(t0, cfg, k * n, n)
-        buf, offsets = nat.unpack_reads_raw(hb)
-        ores, ocnt = ot.decombine_batch_mt(buf, offsets)
-        orec = pu.oracle_to_records(ores)
-        rec = recs[k].to_host(nat.RECORD_DTYPE, n)
-        if rec.tobytes() != orec.tobytes():
-            pu.assert_records_equal(rec, orec, nat.unpack_reads(hb), f"batch {k}")
-        pu.assert_counters_equal(cnts[k].to_host(np.uint64, nat.N_COUNTERS), ocnt, f"batch {k}")
+    overlap on the chip.  Forty-four batches of 1.2 M reads (different reads each), nothing waited for until all are issued: every
+    record and every counter of every batch against the oracle (tests/in_flight_worker.py, a process of its own: the second case
+    forces the launch form with list E's rescue inside the scan kernel on both handles — DCRX_DEBUG_FUSE_E is read once per process)."""
+    import subprocess
+    import sys
+    e = dict(os.environ, DCRX_DEBUG_FLAGS="1")
+    if form.startswith("list E"):
+        e["DCRX_DEBUG_FUSE_E"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "in_flight_worker.py"), "1200000", "44"],
+                       env=e, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "IN_FLIGHT_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    if form.startswith("list E"):
+        assert p.stdout.count("tail and list E inside the scan") == 2, p.stdout[-500:]
 
 
 def test_full_size_10M_properties_and_sampled_blocks():
