@@ -1697,7 +1697,8 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
 //           with the state in front of it (7 to 15 notes per lane in LDS).  The partial word and words that hold an exception
 //           byte go base by base.
 //   pass 2: the noted words again, base by base with scan_plain's bookkeeping and every half-tag hit into the read's hit lists
-//           (HalfHits, wide entries): dcr_frame rescues from the lists and re-scans only a class with more than HH_K hits.
+//           (HalfHits, wide entries, one list of 2 * HH_K per gene: note_hit): dcr_frame rescues from the lists and re-scans only a
+//           class with more hits than its list holds.
 //           Where a lane's notes could run out, every lane of the wave takes pass 2 over the notes it has and goes on with pass 1.
 constexpr int LONG_FW_MIN = 7, LONG_FW_MAX = 15;      // notes per lane: as many as the block's LDS holds beside the tables (the launch's choice, an odd slot)
 constexpr int DCRX_LONG_SLOT_MIN = (HH_STRIDE + LONG_FW_MIN) | 1, DCRX_LONG_SLOT_MAX = (HH_STRIDE + LONG_FW_MAX) | 1;      // dwords of LDS per lane (odd: the lanes' slots on different banks)
@@ -1728,7 +1729,17 @@ struct LongScan {
     if ((fl >> TE_JFULL_BIT) & 1u) { if (so.jcount == 0) { so.jstate = st; so.jend = i; } so.jcount++; }
     if ((fl >> TE_VMULTI_BIT) & 1u) so.vcount = so.vcount < 2 ? 2 : so.vcount;      // two tags ended at one position
     if ((fl >> TE_JMULTI_BIT) & 1u) so.jcount = so.jcount < 2 ? 2 : so.jcount;
+    // The hit lists hold what dcr_frame will ask for, whatever is still to come: per gene ONE list — no hit once a full tag
+    // was seen, the half-1 hits from the first of them on, the half-2 hits as long as no half-1 keyword has occurred (the
+    // reference consults the half-2 list only then, :294/:339, :422/:473) —, two lists of 2 * HH_K entries in the room of four
+    // of HH_K.  A half-1 hit drops its gene's half-2 class: its own first entry then overwrites what the list held.
+    // (Short half tags meet a long read by chance: with four entries a list nearly every wave held a lane that overflowed and
+    // scanned its whole read again.)
+    if ((fl >> TE_VFULL_BIT) & 1u) hh.keep &= ~3u;
+    if ((fl >> TE_JFULL_BIT) & 1u) hh.keep &= ~12u;
     const uint32_t hb = (e >> TE_VH1_BIT) & 0xFu;
+    if (hb & 1u) hh.keep &= ~2u;
+    if (hb & 4u) hh.keep &= ~8u;
     if (hb) collect_hits(hh, hb, 1u | (st << 1) | ((uint32_t)i << 15));
   }
   // pass 2 of one word: from entry `e` in front of it; returns the entry behind it.  wv: the word, rv.words[word_of(wi)]
@@ -1737,9 +1748,35 @@ struct LongScan {
     const int cnt = (kk == top) ? cnt_top : 16;
     int i = first_pos(wi);
     while (xc.nextpos < i) xc.advance();
-    // (measured and dropped: the sixteen entries of a clean word first, a bit per flagged one, then the flagged ones in turn — so
-    // that the lanes of a wave, each at another base of its word, do not take the bookkeeping one after the other —: 16 more
-    // registers in a kernel at its 128, 30 of them spilled: 600 nt 0.745 -> 0.796 ms per 2 M reads)
+    if (cnt == 16 && xc.nextpos >= i + 16) {
+      // A whole word without an unknown byte, in two halves: eight entries first, as pass 1 met them, with a bit per flagged one, then
+      // the flagged ones in turn.  (Base by base with the bookkeeping behind a test per base, the lanes of a wave — each at another
+      // base of its word — took the bookkeeping one after the other: sixteen turns per word where a lane needs one or two.  Eight
+      // entries and a select chain; sixteen and a select tree spilled 30 registers of a kernel at its 128 and were slower than the
+      // loop: 600 nt 0.745 / 0.796 / 0.561 ms per 2 M reads for the loop / the tree of 16 / this, profiles/r06/long_form_two_pass_scan.log.)
+      constexpr int GE = 8;
+      const uint32_t wf = REV ? ~wv : wv;
+#pragma unroll
+      for (int hf = 0; hf < 16 / GE; hf++) {
+        uint32_t ee[GE], m = 0;
+#pragma unroll
+        for (int j = 0; j < GE; j++) {
+          const int jj = GE * hf + j;
+          e = trans_at<TABLE_LDS>(lds_trans, T, (e & TE_ROW_MASK) + (dcrx_ubfe(wf, REV ? 30 - 2 * jj : 2 * jj, 2) << 2));
+          ee[j] = e;
+          m |= ((e & ~TE_ROW_MASK) ? 1u : 0u) << j;
+        }
+        while (m) {
+          const int j = dcrx_ctz32(m);
+          m &= m - 1u;
+          uint32_t sel = ee[0];
+#pragma unroll
+          for (int q = 1; q < GE; q++) sel = (j == q) ? ee[q] : sel;
+          note_hit(sel, i + GE * hf + j);
+        }
+      }
+      return e;
+    }
     if (REV) wv = ~wv << (2 * (16 - cnt));                    // complement; first base of the frame on top
 #pragma unroll 1
     for (int k = 0; k < cnt; k++, i++) {
@@ -1762,7 +1799,7 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
   if (n <= 0) return L.so;
   const int top = L.top, cnt_top = L.cnt_top;
   // ---- pass 1 ----
-  uint32_t e = T.row0, acc1 = 0;
+  uint32_t e = T.row0;
   int nfw = 0;
   // pass 2 over the notes in hand (the next note's word is asked for before this one's bases are walked: a load per note,
   // each a trip to memory of its own, was a third of the pass)
@@ -1778,31 +1815,35 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
     }
     nfw = 0;
   };
-  bool mid = false;      // the notes were taken back before the scan's end (the hit lists then hold every class)
-  hh.keep = 0xFu; hh.compact = 0u; hh.cap = (uint32_t)HH_K;
+  hh.keep = 0xFu; hh.compact = 1u; hh.cap = 2u * (uint32_t)HH_K;      // (LongScan::note_hit narrows `keep` as the flags come in)
   {
     ExcCursor<REV> x1(rv);
     // The words come in chunks of sixteen (64 bytes, eight 8-byte loads at consecutive addresses: a read starts on an 8-byte boundary
     // and its stride is a multiple of 8) and are scanned out of registers, four at a time.
-    const int ptop = top >> 1, ctop = top >> 4;
+    constexpr int CW = 16;      // words fetched per trip and lane (8 measured level)
+    const int ptop = top >> 1, ctop = top / CW;
     const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv.words);
 #pragma unroll 1
     for (int ci = 0; ci <= ctop; ci++) {
       const int cp = REV ? ctop - ci : ci;
-      uint32_t cw[16];
+      uint32_t cw[CW];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
+      for (int k = 0; k < CW / 2; k++) {
         uint2 t; t.x = 0u; t.y = 0u;
-        if (8 * cp + k <= ptop) t = wp2[8 * cp + k];
+        if ((CW / 2) * cp + k <= ptop) t = wp2[(CW / 2) * cp + k];
         cw[2 * k] = t.x; cw[2 * k + 1] = t.y;
       }
 #pragma unroll 1
-      for (int g = 0; g < 4; g++) {
-        const int gg = REV ? 3 - g : g;
-        if (16 * cp + 4 * gg > top) continue;                    // (the whole group lies beyond the read)
+      for (int g = 0; g < CW / 4; g++) {
+        const int gg = REV ? CW / 4 - 1 - g : g;
+        if (CW * cp + 4 * gg > top) continue;                    // (the whole group lies beyond the read)
         uint32_t w4[4];
 #pragma unroll
-        for (int h = 0; h < 4; h++) w4[h] = gg == 0 ? cw[h] : (gg == 1 ? cw[4 + h] : (gg == 2 ? cw[8 + h] : cw[12 + h]));
+        for (int h = 0; h < 4; h++) {
+          w4[h] = cw[h];
+#pragma unroll
+          for (int q = 1; q < CW / 4; q++) w4[h] = gg == q ? cw[4 * q + h] : w4[h];
+        }
         // The notes are taken back whenever a lane of the wave could run out of them inside the next four words — by every lane of the
         // wave at once: a lane that did so on its own would have the other sixty-three wait for it, each in its turn.
 #ifndef DCRX_HOST_EMUL
@@ -1812,12 +1853,12 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
 #endif
         {
           if (pass1_only) nfw = 0;      // (profiling: the first pass alone)
-          take_back(); mid = true;
+          take_back();
         }
 #pragma unroll
         for (int h = 0; h < 4; h++) {
           const int hw = REV ? 3 - h : h;
-          const int kk = 16 * cp + 4 * gg + hw;
+          const int kk = CW * cp + 4 * gg + hw;
           if (kk > top) continue;                                  // (beyond the read's last word)
           const int wi = REV ? top - kk : kk;
           const uint32_t word = w4[hw];
@@ -1846,7 +1887,6 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
               accw |= e;
             }
           }
-          acc1 |= accw;
           if (accw & TE_FLAGS_MASK) fw[nfw++] = ((uint32_t)wi << 14) | (((e0 & TE_ROW_MASK) - T.row0) >> 4);
         }
       }
@@ -1854,16 +1894,6 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
   }
   // ---- pass 2: the notes that are left ----
   if (pass1_only) { L.so.acc = e; return L.so; }
-  if (!mid) {
-    // Every flag of the read is known before its first hit is noted: dcr_frame will ask for one half-tag class per gene at most
-    // (none where a full tag was seen; half 1 where a half-1 keyword occurs, else half 2 — :294/:339, :422/:473), so the lists
-    // hold only those — two lists of 2 * HH_K entries in the room of four (short half tags meet a long read by chance: with
-    // four entries a list every wave held a lane that overflowed and scanned its whole read again, base by base).
-    uint32_t keep = 0u;
-    if (!((acc1 >> TE_VFULL_BIT) & 1u)) keep |= ((acc1 >> TE_VH1_BIT) & 1u) ? 1u : 2u;
-    if (!((acc1 >> TE_JFULL_BIT) & 1u)) keep |= ((acc1 >> TE_JH1_BIT) & 1u) ? 4u : 8u;
-    hh.keep = keep; hh.compact = 1u; hh.cap = 2u * (uint32_t)HH_K;
-  }
   take_back();
   return L.so;
 }

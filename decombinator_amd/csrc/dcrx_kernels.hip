@@ -827,6 +827,14 @@ static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const Bat
   };
   static const bool no_lds = dcrx_debug_env("DCRX_DEBUG_LONG_GLOBAL_TABLES") != nullptr;      // (A/B)
   if (!no_lds && T.lds_image_bytes && slot_for(512, 1) && B.n_reads >= 4096u) {
+    // (experiment, DCRX_DEBUG_LONG_BLOCK=768: three waves per SIMD with 170 registers each instead of four with 128)
+    static const int long_block = [] { const char *e = dcrx_debug_env("DCRX_DEBUG_LONG_BLOCK"); return e ? atoi(e) : 0; }();
+    if (long_block == 768) {
+      if (const uint32_t sl = slot_for(768, 1)) {
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 767) / 768));
+        return launch_long_as<true, 768>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(768, true, sl), sl);
+      }
+    }
     if (const uint32_t sl = slot_for(1024, 1)) {
       const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (B.n_reads + 1023) / 1024));
       return launch_long_as<true, 1024>(P, T, B, cfg, rec, d_counters, s, grid, lds_of(1024, true, sl), sl);
