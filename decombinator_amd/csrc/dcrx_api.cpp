@@ -85,7 +85,6 @@ struct dcrx_tables {
   // where the scan takes the tail through its ring in LDS nothing is ever stored in it.  Unknown: decided by the first use
   // (table sizes), corrected by the first launch that turns out to need the list (dcrx_decombine_device allocates it and launches again)
   int want_tail = -1;
-  void *d_long_notes = nullptr;     // the long form's pass-1 notes (reads of 512 nt and more)
   void *d_v2_left = nullptr;        // the finishing launch's left list
   uint64_t *d_v2_acc = nullptr;     // the v2 kernels' tallies of the call in flight (zero between calls)  // v2 kernels: the per-wave lists between scan and finishing
   hipStream_t v2_side = nullptr, v2_side2 = nullptr; hipEvent_t v2_ev_fork = nullptr, v2_ev_join = nullptr, v2_ev_join2 = nullptr;
@@ -140,7 +139,6 @@ static void free_device_state(dcrx_tables *t) {
   t->v2_side = t->v2_side2 = nullptr; t->v2_ev_fork = t->v2_ev_join = t->v2_ev_join2 = nullptr;
   t->d_v2_tail = nullptr; t->d_v2_events = nullptr; t->d_v2_counts = nullptr; t->d_v2_slow = nullptr;
   (void)hipFree(t->d_v2_acc); t->d_v2_acc = nullptr; t->plan.v2_acc = nullptr;
-  (void)hipFree(t->d_long_notes); t->d_long_notes = nullptr; t->plan.long_notes = nullptr; t->plan.long_notes_reads = 0;
   (void)hipFree(t->d_v2_left); t->d_v2_left = nullptr; t->plan.v2_left = nullptr;
   (void)hipFree(t->d_stage);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
@@ -298,12 +296,6 @@ static int ensure_device(dcrx_tables *t, uint64_t max_reads, uint32_t stride = 4
     HIP_TRY(hipMalloc(&t->d_queue, (3 * max_reads + DCRX_QUEUE_HEADER) * 4));  // [work counters][rescue queue][general list][its exception-list offsets]
     t->exc_flag_reads = max_reads;
     t->ws_dirty = true;
-  }
-  if (stride > DCRX_FAST_MAX_STRIDE && max_reads > t->plan.long_notes_reads) {
-    // reads of 512 nt and more: the notes of the long form's first pass, 17 words per read
-    (void)hipFree(t->d_long_notes); t->d_long_notes = nullptr; t->plan.long_notes = nullptr; t->plan.long_notes_reads = 0;
-    HIP_TRY(hipMalloc(&t->d_long_notes, max_reads * 17 * 4));
-    t->plan.long_notes = reinterpret_cast<uint32_t *>(t->d_long_notes); t->plan.long_notes_reads = max_reads;
   }
   if (t->host.rel.v2_ok && stride <= DCRX_FAST_MAX_STRIDE) {
     // the lists between the v2 kernels: every wave of the scan kernel (16 per CU) owns a region of tail and of event

@@ -1700,7 +1700,6 @@ DCRX_DEV void decombine_list_one(const DevTables &T, const uint32_t *lds_trans, 
 //           (HalfHits, wide entries, one list of 2 * HH_K per gene: note_hit): dcr_frame rescues from the lists and re-scans only a
 //           class with more hits than its list holds.
 //           Where a lane's notes could run out, every lane of the wave takes pass 2 over the notes it has and goes on with pass 1.
-constexpr int LONG_GN = 16;      // notes per read in the workspace of long_pass1_pairs (pass 1 as a kernel of its own)
 constexpr int LONG_FW_MIN = 7, LONG_FW_MAX = 15;      // notes per lane: as many as the block's LDS holds beside the tables (the launch's choice, an odd slot)
 constexpr int DCRX_LONG_SLOT_MIN = (HH_STRIDE + LONG_FW_MIN) | 1, DCRX_LONG_SLOT_MAX = (HH_STRIDE + LONG_FW_MAX) | 1;      // dwords of LDS per lane (odd: the lanes' slots on different banks)
 constexpr uint32_t TE_FLAGS_MASK = 0xFFu << TE_VFULL_BIT;
@@ -1793,27 +1792,11 @@ struct LongScan {
 
 template <bool REV, bool TABLE_LDS = false>
 DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, const ReadView &rv, HalfHits &hh, dcrx_lds_u32 *fw, const int fwk,
-                             const bool pass1_only = false, const uint32_t *gnotes = nullptr) {
+                             const bool pass1_only = false) {
   hh.cnts = 0; hh.wide = 1u;
   LongScan<REV, TABLE_LDS> L(T, lds_trans, rv, hh);
   const int n = rv.n;
   if (n <= 0) return L.so;
-  if (gnotes && !pass1_only) {
-    // pass 1 was a kernel of its own (long_pass1_pairs): its notes for this read and frame, if they all fitted — pass 2 over them
-    const int cnt = (int)gnotes[0];
-    if (cnt <= LONG_GN) {
-      hh.keep = 0xFu; hh.compact = 1u; hh.cap = 2u * (uint32_t)HH_K;
-      uint32_t t = cnt > 0 ? gnotes[1] : 0u;
-      uint32_t wv = cnt > 0 ? rv.words[L.word_of((int)(t >> 14))] : 0u;
-      for (int k = 0; k < cnt; k++) {
-        uint32_t tn = t, wn = wv;
-        if (k + 1 < cnt) { tn = gnotes[2 + k]; wn = rv.words[L.word_of((int)(tn >> 14))]; }
-        (void)L.replay((int)(t >> 14), T.row0 + ((t & 0x3FFFu) << 4), wv);
-        t = tn; wv = wn;
-      }
-      return L.so;
-    }
-  }
   const int top = L.top, cnt_top = L.cnt_top;
   // ---- pass 1 ----
   uint32_t e = T.row0;
@@ -1915,170 +1898,24 @@ DCRX_DEVNI ScanOut scan_long(const DevTables &T, const uint32_t *lds_trans, cons
   return L.so;
 }
 
-// Pass 1 as a kernel of its own (round 6), on the PAIR table where that fits the LDS by itself (config 2's: 1 769 states x 64 B =
-// 113 KB; the kernel holds nothing else there — the long kernel has neither the LDS nor the registers for it): eight look-ups per
-// word instead of sixteen, RPL reads per lane.  The pass is bound by the LDS's gather rate, not by its answer time: on the one-base
-// table two chains per lane in a kernel of their own ran no faster than one inside the long kernel (0.40 against 0.32 ms per 2 M
-// reads of 600 nt).  The notes go into a workspace in global memory: per read LONG_GN + 1 words, word 0 = the number of flagged
-// words (more than LONG_GN: none of them is trusted and the long kernel scans the read itself, as it does without a workspace).
-// T16: the tables with row16_0 = the pair table's LDS address (its rows absolute); the partial word and words with an unknown byte
-// go base by base on the one-base table in global memory (T0: the states' numbers are the same in both).  A reverse frame whose
-// first word holds an odd number of bases would pair bases across words: such a read's notes are marked untrusted (count
-// LONG_GN + 1) and the long kernel scans it itself.
-template <bool REV, int RPL>
-DCRX_DEV void long_pass1_pairs(const DevTables &T16, const DevTables &T0, const ReadView (&rv)[RPL], const bool (&live)[RPL], uint32_t *const (&out)[RPL]) {
-  constexpr int CW = 16;
-  uint32_t e[RPL];                 // pair-table entry (row of the state in its low bits)
-  int nfw[RPL], top[RPL], cnt_top[RPL], ctop[RPL], ptop[RPL], nx[RPL], xx[RPL];      // (nx / xx: the exception cursor of ExcCursor, by hand: an array of them)
-  bool ok[RPL];
-  int cmax = -1;
-#pragma unroll
-  for (int q = 0; q < RPL; q++) {
-    e[q] = T16.row16_0; nfw[q] = 0;
-    const int n = live[q] ? rv[q].n : 0;
-    top[q] = n > 0 ? (n - 1) >> 4 : -1; cnt_top[q] = n > 0 ? ((n - 1) & 15) + 1 : 0;
-    ok[q] = live[q] && !(REV && (cnt_top[q] & 1));
-    if (!ok[q]) top[q] = -1;
-    ctop[q] = top[q] >= 0 ? top[q] / CW : -1; ptop[q] = top[q] >> 1;
-    cmax = ctop[q] > cmax ? ctop[q] : cmax;
-    xx[q] = REV ? rv[q].e1 - 1 : rv[q].e0;
-    const bool any = ok[q] && (REV ? (xx[q] >= rv[q].e0) : (xx[q] < rv[q].e1));
-    nx[q] = any ? (REV ? rv[q].n - 1 - (int)rv[q].exc_pos[xx[q]] : (int)rv[q].exc_pos[xx[q]]) : 0x7FFFFFFF;
-  }
-  auto advance = [&](const int q) {
-    xx[q] += REV ? -1 : 1;
-    const bool any = REV ? (xx[q] >= rv[q].e0) : (xx[q] < rv[q].e1);
-    nx[q] = any ? (REV ? rv[q].n - 1 - (int)rv[q].exc_pos[xx[q]] : (int)rv[q].exc_pos[xx[q]]) : 0x7FFFFFFF;
-  };
-#pragma unroll 1
-  for (int ci = 0; ci <= cmax; ci++) {
-    uint32_t cw[RPL][CW];
-    int cp[RPL];
-#pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      // (a shorter read of the lane is done before the longer one: its chunks then lie beyond its words and nothing is asked for)
-      cp[q] = REV ? ctop[q] - ci : ci;
-      const uint2 *wp2 = reinterpret_cast<const uint2 *>(rv[q].words);
-#pragma unroll
-      for (int k = 0; k < CW / 2; k++) {
-        uint2 t; t.x = 0u; t.y = 0u;
-        if (ci <= ctop[q] && (CW / 2) * cp[q] + k <= ptop[q]) t = wp2[(CW / 2) * cp[q] + k];
-        cw[q][2 * k] = t.x; cw[q][2 * k + 1] = t.y;
-      }
-    }
-#pragma unroll 1
-    for (int g = 0; g < CW / 4; g++) {
-      const int gg = REV ? CW / 4 - 1 - g : g;
-      uint32_t w4[RPL][4];
-#pragma unroll
-      for (int q = 0; q < RPL; q++)
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-          w4[q][h] = cw[q][h];
-#pragma unroll
-          for (int z = 1; z < CW / 4; z++) w4[q][h] = gg == z ? cw[q][4 * z + h] : w4[q][h];
-        }
-#pragma unroll
-      for (int h = 0; h < 4; h++) {
-        const int hw = REV ? 3 - h : h;
-        int kk[RPL], i0[RPL];
-        bool on[RPL], fast[RPL];
-        bool all_fast = true;
-#pragma unroll
-        for (int q = 0; q < RPL; q++) {
-          kk[q] = CW * cp[q] + 4 * gg + hw;
-          on[q] = ci <= ctop[q] && kk[q] <= top[q];
-          const int wi = REV ? top[q] - kk[q] : kk[q];
-          i0[q] = REV ? (wi == 0 ? 0 : cnt_top[q] + 16 * (wi - 1)) : 16 * wi;
-          fast[q] = on[q] && (kk[q] != top[q] || cnt_top[q] == 16) && nx[q] >= i0[q] + 16;
-          all_fast = all_fast && fast[q];
-        }
-        uint32_t e0[RPL], accw[RPL];
-#pragma unroll
-        for (int q = 0; q < RPL; q++) { e0[q] = e[q]; accw[q] = 0u; }
-        // a word's eight pairs in frame order, four bits each with the pair's first base on top: forward, the two bases of every
-        // nibble change places; reverse, the complemented word read from its top nibble down is that already
-        auto pairs_of = [&](const uint32_t w) -> uint32_t { return REV ? ~w : (((w & 0x33333333u) << 2) | ((w >> 2) & 0x33333333u)); };
-        if (all_fast) {      // the lane's reads side by side
-          uint32_t pw[RPL];
-#pragma unroll
-          for (int q = 0; q < RPL; q++) pw[q] = pairs_of(w4[q][hw]);
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int q = 0; q < RPL; q++) {
-              e[q] = trans16_at<true>(T16, (e[q] & TE16_ROW_MASK) | (dcrx_ubfe(pw[q], REV ? 28 - 4 * j : 4 * j, 4) << 2));
-              accw[q] |= e[q];
-            }
-        } else {
-#pragma unroll
-          for (int q = 0; q < RPL; q++) {
-            if (!on[q]) continue;
-            if (fast[q]) {
-              const uint32_t pw = pairs_of(w4[q][hw]);
-#pragma unroll
-              for (int j = 0; j < 8; j++) {
-                e[q] = trans16_at<true>(T16, (e[q] & TE16_ROW_MASK) | (dcrx_ubfe(pw, REV ? 28 - 4 * j : 4 * j, 4) << 2));
-                accw[q] |= e[q];
-              }
-            } else {      // the partial word, a word with an unknown byte: base by base on the one-base table in global memory
-              const int cnt = (kk[q] == top[q]) ? cnt_top[q] : 16;
-              uint32_t wv = w4[q][hw];
-              if (REV) wv = ~wv << (2 * (16 - cnt));
-              uint32_t e1 = T0.row0 + ((((e[q] & TE16_ROW_MASK) - T16.row16_0) >> 6) << 4);
-              int i = i0[q];
-#pragma unroll 1
-              for (int k = 0; k < cnt; k++, i++) {
-                const uint32_t code = REV ? (wv >> 30) : (wv & 3u);
-                wv = REV ? (wv << 2) : (wv >> 2);
-                if (i == nx[q]) { e1 = T0.row0; advance(q); continue; }
-                e1 = trans_at<false>(nullptr, T0, (e1 & TE_ROW_MASK) + (code << 2));
-                accw[q] |= e1 & ~TE_ROW_MASK;
-              }
-              e[q] = T16.row16_0 + ((((e1 & TE_ROW_MASK) - T0.row0) >> 4) << 6);
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < RPL; q++)
-          if (on[q] && (accw[q] & ~TE16_ROW_MASK)) {
-            const int wi = REV ? top[q] - kk[q] : kk[q];
-            if (nfw[q] < LONG_GN) out[q][1 + nfw[q]] = ((uint32_t)wi << 14) | (((e0[q] & TE16_ROW_MASK) - T16.row16_0) >> 6);
-            nfw[q]++;
-          }
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < RPL; q++)
-    if (live[q]) out[q][0] = ok[q] ? (uint32_t)nfw[q] : (uint32_t)(LONG_GN + 1);
-}
-
-// a read of a long batch: its words, its length, its slice of the sorted exception list
-template <bool UNIFORM_LEN>
-DCRX_DEV void long_read_view(const DevTables &T, const BatchDev &B, const uint64_t r, ReadView &rv) {
+// `slot`: slot_dwords (DCRX_LONG_SLOT_MIN .. _MAX) dwords of LDS for this lane (the hit lists, then the notes of pass 1)
+template <bool UNIFORM_LEN, bool TABLE_LDS = false>
+DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
+                                 const Counters &C, dcrx_record_t *records, uint32_t *slot, const int slot_dwords) {
+  const int fwk = slot_dwords - HH_STRIDE;
+  ReadView rv;
   rv.comp = T.comp;
   rv.words = reinterpret_cast<const uint32_t *>(B.packed + r * B.stride);
   rv.n = UNIFORM_LEN ? (int)B.read_len : (int)B.lens[r];
   rv.e0 = rv.e1 = 0;
   rv.exc_pos = B.exc_pos; rv.exc_chr = B.exc_chr;
-  if (B.n_exc) {
+  if (B.n_exc) {      // this read's slice of the sorted exception list
     uint64_t lo = 0, hi = B.n_exc;
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (B.exc_read[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
     rv.e0 = (int)lo;
     while (lo < B.n_exc && B.exc_read[lo] == (uint32_t)r) lo++;
     rv.e1 = (int)lo;
   }
-}
-
-// `slot`: slot_dwords (DCRX_LONG_SLOT_MIN .. _MAX) dwords of LDS for this lane (the hit lists, then the notes of pass 1)
-template <bool UNIFORM_LEN, bool TABLE_LDS = false>
-DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, const BatchDev &B, const CfgDev &cfg, const uint64_t r,
-                                 const Counters &C, dcrx_record_t *records, uint32_t *slot, const int slot_dwords,
-                                 const uint32_t *gnotes = nullptr) {      // gnotes: long_pass1_pairs' notes of this read in the call's first frame, or none
-  const int fwk = slot_dwords - HH_STRIDE;
-  ReadView rv;
-  long_read_view<UNIFORM_LEN>(T, B, r, rv);
   HalfHits hh;
   hh.slot = DCRX_TO_LDS(slot);
   dcrx_lds_u32 *fw = DCRX_TO_LDS(slot) + HH_STRIDE;
@@ -2090,12 +1927,12 @@ DCRX_DEV void decombine_long_one(const DevTables &T, const uint32_t *lds_trans, 
   for (int attempt = (cfg.orientation == DCRX_ORIENT_FORWARD) ? 1 : 0; attempt < 2; attempt++) {
     const bool p1 = (cfg.flags & DCRX_F_PROFILE_LIST_SCAN_ONLY) != 0u, p12 = (cfg.flags & DCRX_F_PROFILE_SCAN_ONLY) != 0u;      // profiling aids: price the scan's passes alone (records are NOT results)
     if (attempt == 0) {
-      const ScanOut so = scan_long<true, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1, gnotes);
+      const ScanOut so = scan_long<true, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1);
       if (p1 || p12) { rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend); rec.j_end = (uint16_t)hh.cnts; status = 254; break; }
       status = dcr_frame<true, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 0;
       if (status == DCRX_S_OK || cfg.orientation != DCRX_ORIENT_BOTH) break;
     } else {
-      const ScanOut so = scan_long<false, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1, cfg.orientation == DCRX_ORIENT_FORWARD ? gnotes : nullptr);
+      const ScanOut so = scan_long<false, TABLE_LDS>(T, lds_trans, rv, hh, fw, fwk, p1);
       if (p1 || p12) { rec.v = (uint16_t)so.acc; rec.j = (uint16_t)(so.vstate + so.jstate); rec.v_start = (uint16_t)(so.vend + so.jend); rec.j_end = (uint16_t)hh.cnts; status = 254; break; }
       status = dcr_frame<false, TABLE_LDS, false>(T, lds_trans, rv, so, cfg, C, rec, &hh); frame = 1;
     }

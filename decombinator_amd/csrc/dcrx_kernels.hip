@@ -771,8 +771,7 @@ __global__ void zero_counters_kernel(unsigned long long *__restrict__ counters) 
 // one texture-address unit (the launch ran at 0.18 T bases/s), out of LDS a gather over 32 banks.
 template <bool UNIFORM_LEN, bool TABLE_LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void decombine_long_kernel(DevTables T0, BatchDev B, CfgDev cfg, dcrx_record_t *__restrict__ records,
-                                                               unsigned long long *__restrict__ counters, const uint32_t slot_dwords,
-                                                               const uint32_t *__restrict__ notes) {
+                                                               unsigned long long *__restrict__ counters, const uint32_t slot_dwords) {
   extern __shared__ __align__(16) uint32_t smem[];
   uint32_t *lds_counts = smem;
   uint32_t *lds_trans = smem + DCRX_N_COUNTERS;
@@ -791,63 +790,13 @@ __global__ __launch_bounds__(BLOCK) void decombine_long_kernel(DevTables T0, Bat
   __syncthreads();
   const Counters C{lds_counts};
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + tid; r < B.n_reads; r += (uint64_t)gridDim.x * blockDim.x)
-    decombine_long_one<UNIFORM_LEN, TABLE_LDS>(T, lds_trans, B, cfg, r, C, records, slot, (int)slot_dwords, notes ? notes + r * (LONG_GN + 1) : nullptr);
+    decombine_long_one<UNIFORM_LEN, TABLE_LDS>(T, lds_trans, B, cfg, r, C, records, slot, (int)slot_dwords);
   __syncthreads();
   if (tid < DCRX_N_COUNTERS && lds_counts[tid]) atomicAdd(&counters[tid], (unsigned long long)lds_counts[tid]);
 }
-// Pass 1 of the long form as a kernel of its own, on the pair table (alone in LDS): two reads per lane, the flagged words of a read into
-// `notes` (LONG_GN + 1 words per read: long_pass1_pairs); the frame is the call's first (reverse unless `forward`).
-template <bool UNIFORM_LEN, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void long_pass1_kernel(DevTables T0, BatchDev B, CfgDev cfg, uint32_t *__restrict__ notes) {
-  extern __shared__ __align__(64) uint32_t smem[];
-  const int tid = threadIdx.x;
-  const uint32_t lds_addr = dcrx_lds_address(reinterpret_cast<const uint8_t *>(smem));
-  stage_lds<BLOCK>(reinterpret_cast<const uint8_t *>(T0.trans16), smem, T0.dfa16_bytes / 16, T0.dfa16_bytes / 16, lds_addr, tid);
-  DevTables T16 = T0;
-  T16.row16_0 = lds_addr;
-  __syncthreads();
-  const uint64_t pairs = (B.n_reads + 1) / 2;
-  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + tid; p < pairs; p += (uint64_t)gridDim.x * blockDim.x) {
-    ReadView rv[2];
-    bool live[2];
-    uint32_t *out[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const uint64_t r = 2 * p + q;
-      live[q] = r < B.n_reads;
-      long_read_view<UNIFORM_LEN>(T0, B, live[q] ? r : 0, rv[q]);
-      out[q] = notes + (live[q] ? r : 0) * (LONG_GN + 1);
-    }
-    if (cfg.orientation == DCRX_ORIENT_FORWARD) long_pass1_pairs<false, 2>(T16, T0, rv, live, out);
-    else long_pass1_pairs<true, 2>(T16, T0, rv, live, out);
-  }
-}
-
 template <bool TABLE_LDS, int BLOCK>
 static hipError_t launch_long_as(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,
                                  unsigned long long *d_counters, hipStream_t s, const uint32_t grid, const uint32_t lds, const uint32_t slot_dwords) {
-  // pass 1 as a kernel of its own where the handle holds the notes' workspace for this batch and the pair table fits the LDS by itself
-  uint32_t *notes = nullptr;
-  static const bool no_pass1 = dcrx_debug_env("DCRX_DEBUG_LONG_NO_PASS1_KERNEL") != nullptr;      // (A/B)
-  if (TABLE_LDS && !no_pass1 && P.long_notes && P.long_notes_reads >= B.n_reads && T.dfa16_bytes && T.dfa16_bytes <= 150u * 1024u && !(cfg.flags & (DCRX_F_PROFILE_LIST_SCAN_ONLY | DCRX_F_PROFILE_SCAN_ONLY))) {
-    auto p1u = long_pass1_kernel<true, 1024>;
-    auto p1r = long_pass1_kernel<false, 1024>;
-    static bool p1_seen[64];
-    if (first_use_on_device(p1_seen)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(p1u), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(p1r), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attributes_set_on_device(p1_seen);
-    }
-    const uint32_t cus = P.n_cu > P.reserved_cus ? P.n_cu - P.reserved_cus : 1u;
-    const uint32_t g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, ((B.n_reads + 1) / 2 + 1023) / 1024));
-    if (B.lens) hipLaunchKernelGGL(p1r, dim3(g1), dim3(1024), T.dfa16_bytes, s, T, B, cfg, P.long_notes);
-    else hipLaunchKernelGGL(p1u, dim3(g1), dim3(1024), T.dfa16_bytes, s, T, B, cfg, P.long_notes);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    notes = P.long_notes;
-  }
   auto ku = decombine_long_kernel<true, TABLE_LDS, BLOCK>;
   auto kr = decombine_long_kernel<false, TABLE_LDS, BLOCK>;
   static bool attr_seen[64];
@@ -858,8 +807,8 @@ static hipError_t launch_long_as(const LaunchPlan &P, const DevTables &T, const 
     if (e != hipSuccess) return e;
     attributes_set_on_device(attr_seen);
   }
-  if (B.lens) hipExtLaunchKernelGGL(kr, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords, notes);
-  else hipExtLaunchKernelGGL(ku, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords, notes);
+  if (B.lens) hipExtLaunchKernelGGL(kr, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords);
+  else hipExtLaunchKernelGGL(ku, dim3(grid), dim3(BLOCK), lds, s, nullptr, P.ev_step_stop, 0, T, B, cfg, rec, d_counters, slot_dwords);
   return hipGetLastError();
 }
 static hipError_t launch_long(const LaunchPlan &P, const DevTables &T, const BatchDev &B, const CfgDev &cfg, dcrx_record_t *rec,

@@ -103,8 +103,6 @@ struct LaunchPlan {
   // v2 kernels: the per-wave lists between the scan and the finishing kernel (device memory of the tables handle)
   uint4 *v2_tail = nullptr; uint4 *v2_events = nullptr; uint32_t *v2_counts = nullptr;
   uint4 *v2_slow = nullptr;
-  uint32_t *long_notes = nullptr;       // the long form's pass-1 notes (LONG_GN + 1 words per read) for batches of up to long_notes_reads reads
-  uint64_t long_notes_reads = 0;
   uint4 *v2_left = nullptr;             // the finishing launch's left list (V2_LEFT_CAP event entries of the longest shape)
   uint64_t *v2_acc = nullptr;           // the call's tallies (uint64[DCRX_N_COUNTERS]): zero between calls, handed to the caller by the list kernel
   uint64_t v2_tail_rows = 0, v2_event_rows = 0, v2_slow_rows = 0;       // 16-byte rows allocated for each list

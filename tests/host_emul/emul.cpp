@@ -218,27 +218,8 @@ extern "C" int emul_decombine(const dcrx_tagset_t *ts, const dcrx_cfg_t *cfg, co
     if (B.stride > 4 * DCRX_V2_NWLONG) {      // reads of 512 nt and more: the long form (dcrx_kernels.hip, launch_long), every read of the batch
       uint32_t lslot[DCRX_LONG_SLOT_MAX];
       const int sl = (r & 1) ? DCRX_LONG_SLOT_MIN : DCRX_LONG_SLOT_MAX;      // (the launch's choice by the tables' size: both ends of it)
-      // pass 1 as a kernel of its own (long_pass1_pairs: the notes of the call's first frame in a workspace) used for two reads in three; the
-      // third scans inside the long kernel, as a handle without the workspace does
-      // (as the kernel takes them: two reads of a lane side by side — reads 2p and 2p + 1 — where the batch holds both)
-      static uint32_t gn[2][LONG_GN + 1];
-      const uint32_t *notes = nullptr;
-      if ((r & 1) == 0) {
-        ReadView rv2[2];
-        const bool live2[2] = {true, r + 1 < b->n_reads};
-        uint32_t *const out2[2] = {gn[0], gn[1]};
-        for (int q = 0; q < 2; q++) {
-          const uint64_t rr = live2[q] ? r + (uint64_t)q : r;
-          if (b->lens) long_read_view<false>(T, B, rr, rv2[q]); else long_read_view<true>(T, B, rr, rv2[q]);
-        }
-        if (T.dfa16_bytes) {
-          if (C.orientation == DCRX_ORIENT_FORWARD) long_pass1_pairs<false, 2>(T, T, rv2, live2, out2);
-          else long_pass1_pairs<true, 2>(T, T, rv2, live2, out2);
-        }
-      }
-      if (r % 3 != 2 && T.dfa16_bytes) notes = gn[r & 1];
-      if (b->lens) decombine_long_one<false, false>(T, nullptr, B, C, r, CC, records, lslot, sl, notes);
-      else decombine_long_one<true, false>(T, nullptr, B, C, r, CC, records, lslot, sl, notes);
+      if (b->lens) decombine_long_one<false, false>(T, nullptr, B, C, r, CC, records, lslot, sl);
+      else decombine_long_one<true, false>(T, nullptr, B, C, r, CC, records, lslot, sl);
       for (int c = 0; c < DCRX_N_COUNTERS; c++) { counters[c] += counts[c]; counts[c] = 0; }
       continue;
     }
